@@ -1,0 +1,240 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+ctypes access to oracle/liboracle.so (our plain-C restatement of the reference
+algorithms) and, where it was built, oracle/_ref/libquadprog_ref.so (the
+reference's own QuadProg++ compiled from /root/reference).  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+QP_OK, QP_INFEASIBLE, QP_NOT_PD, QP_BAD_DELETE = 0, 1, 2, 3
+
+
+class BalanceParams(C.Structure):
+    _fields_ = [
+        ("kp_trans", C.c_double * 3), ("kd_trans", C.c_double * 3), ("kff_trans", C.c_double * 3),
+        ("kp_rot", C.c_double * 3), ("kd_rot", C.c_double * 3), ("kff_rot", C.c_double * 3),
+        ("force_weights", C.c_double * 6),
+        ("regularizer", C.c_double), ("friction", C.c_double), ("min_normal_force", C.c_double),
+        ("torque_limit", C.c_double), ("torso_mass", C.c_double), ("leg_mass", C.c_double * 4),
+        ("gravity", C.c_double), ("grav_comp_percentage", C.c_double),
+        ("com_in_base", C.c_double * 3), ("hip_in_base", (C.c_double * 3) * 4),
+    ]
+
+
+def build(force=False):
+    """Compile liboracle.so (and _ref when /root/reference exists)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/qp_solver") and not os.path.exists(os.path.join(_HERE, "_ref", "libquadprog_ref.so")):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    return so
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.oracle_solve_quadprog.restype = C.c_int
+        _lib.oracle_leg_potential.restype = C.c_double
+    return _lib
+
+
+def ref_lib():
+    """The reference's own compiled QuadProg++ or None (absent on the GPU box
+    unless the prebuilt oracle/_ref/ travelled with the snapshot)."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(_HERE, "_ref", "libquadprog_ref.so")
+        if not os.path.exists(path):
+            return None
+        _ref = C.CDLL(path)
+        _ref.ref_solve_quadprog.restype = C.c_int
+    return _ref
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def default_params():
+    p = BalanceParams()
+    lib().oracle_balance_default_params(C.byref(p))
+    return p
+
+
+def _qp_args(G, g0, CE, ce0, CI, ci0):
+    G = np.array(G, dtype=np.float64, order="C")
+    n = G.shape[0]
+    g0 = np.ascontiguousarray(g0, dtype=np.float64)
+    CE = np.zeros((n, 0)) if CE is None else np.ascontiguousarray(CE, dtype=np.float64).reshape(n, -1)
+    ce0 = np.zeros(0) if ce0 is None else np.ascontiguousarray(ce0, dtype=np.float64)
+    CI = np.zeros((n, 0)) if CI is None else np.ascontiguousarray(CI, dtype=np.float64).reshape(n, -1)
+    ci0 = np.zeros(0) if ci0 is None else np.ascontiguousarray(ci0, dtype=np.float64)
+    return n, CE.shape[1], CI.shape[1], G, g0, CE, ce0, CI, ci0
+
+
+def solve_quadprog(G, g0, CE=None, ce0=None, CI=None, ci0=None):
+    """min 1/2 x'Gx + g0'x  s.t. CE'x+ce0=0, CI'x+ci0>=0 (QuadProg++.h:11-14).
+    Returns dict(x, f, status, active, iters)."""
+    n, p, m, G, g0, CE, ce0, CI, ci0 = _qp_args(G, g0, CE, ce0, CI, ci0)
+    x = np.zeros(n)
+    f = C.c_double()
+    active = np.zeros(m + p + 1, dtype=np.int32)
+    nact, iters = C.c_int(), C.c_int()
+    st = lib().oracle_solve_quadprog(n, p, m, G.ctypes.data_as(_dp), g0.ctypes.data_as(_dp),
+                                     CE.ctypes.data_as(_dp), ce0.ctypes.data_as(_dp),
+                                     CI.ctypes.data_as(_dp), ci0.ctypes.data_as(_dp),
+                                     x.ctypes.data_as(_dp), C.byref(f), active.ctypes.data_as(_ip),
+                                     C.byref(nact), C.byref(iters))
+    return dict(x=x, f=f.value, status=st, active=active[:nact.value].copy(), iters=iters.value)
+
+
+def ref_solve_quadprog(G, g0, CE=None, ce0=None, CI=None, ci0=None):
+    """Same problem through the reference's own compiled solve_quadprog."""
+    r = ref_lib()
+    if r is None:
+        raise RuntimeError("oracle/_ref/libquadprog_ref.so not built (needs /root/reference)")
+    n, p, m, G, g0, CE, ce0, CI, ci0 = _qp_args(G, g0, CE, ce0, CI, ci0)
+    x = np.zeros(n)
+    f = C.c_double()
+    st = r.ref_solve_quadprog(n, p, m, G.ctypes.data_as(_dp), g0.ctypes.data_as(_dp),
+                              CE.ctypes.data_as(_dp), ce0.ctypes.data_as(_dp),
+                              CI.ctypes.data_as(_dp), ci0.ctypes.data_as(_dp),
+                              x.ctypes.data_as(_dp), C.byref(f))
+    return dict(x=x, f=f.value, status=st)
+
+
+def leg_fk(leg, q):
+    q, qp = _d(q)
+    p = np.zeros(3)
+    R = np.zeros(9)
+    lib().oracle_leg_fk(int(leg), qp, p.ctypes.data_as(_dp), R.ctypes.data_as(_dp))
+    return p, R.reshape(3, 3)
+
+
+def leg_jacobian(leg, q):
+    q, qp = _d(q)
+    J = np.zeros(9)
+    lib().oracle_leg_jacobian(int(leg), qp, J.ctypes.data_as(_dp))
+    return J.reshape(3, 3)
+
+
+def leg_gravity(leg, q, g):
+    q, qp = _d(q)
+    g, gp = _d(g)
+    G = np.zeros(3)
+    lib().oracle_leg_gravity(int(leg), qp, gp, G.ctypes.data_as(_dp))
+    return G
+
+
+def leg_potential(leg, q, g):
+    q, qp = _d(q)
+    g, gp = _d(g)
+    return lib().oracle_leg_potential(int(leg), qp, gp)
+
+
+def quat_to_matrix(q):
+    q, qp = _d(q)
+    R = np.zeros(9)
+    lib().oracle_quat_to_matrix(qp, R.ctypes.data_as(_dp))
+    return R.reshape(3, 3)
+
+
+def quat_box_minus(a, b):
+    a, ap = _d(a)
+    b, bp = _d(b)
+    o = np.zeros(3)
+    lib().oracle_quat_box_minus(ap, bp, o.ctypes.data_as(_dp))
+    return o
+
+
+STATE_FIELDS = (("q", 12), ("base_pos", 3), ("base_quat", 4), ("base_linvel", 3), ("base_angvel", 3),
+                ("des_pos", 3), ("des_quat", 4), ("des_linvel", 3), ("des_angvel", 3))
+
+
+def balance_step(state, i=0, params=None, normals_world=None):
+    """One robot `i` of a state dict (fields [B][k] + 'stance' uint8 [B][4])."""
+    prm = params or default_params()
+    ptrs, keep = [], []
+    for name, k in STATE_FIELDS:
+        a, p = _d(np.asarray(state[name]).reshape(-1, k)[i])
+        keep.append(a)
+        ptrs.append(p)
+    st = np.ascontiguousarray(np.asarray(state["stance"]).reshape(-1, 4)[i], dtype=np.uint8)
+    nw = None
+    if normals_world is not None:
+        nwa, nw = _d(np.asarray(normals_world).reshape(-1, 12)[i])
+        keep.append(nwa)
+    tau, tau_raw, grf, wrench = np.zeros(12), np.zeros(12), np.zeros(12), np.zeros(6)
+    iters, nact = C.c_int(), C.c_int()
+    status = lib().oracle_balance_step(C.byref(prm), *ptrs, st.ctypes.data_as(C.POINTER(C.c_uint8)), nw,
+                                       tau.ctypes.data_as(_dp), tau_raw.ctypes.data_as(_dp),
+                                       grf.ctypes.data_as(_dp), wrench.ctypes.data_as(_dp),
+                                       C.byref(iters), C.byref(nact))
+    return dict(tau=tau, tau_raw=tau_raw, grf=grf, wrench=wrench, status=status,
+                iters=iters.value, n_active=nact.value)
+
+
+def balance_batch(state, params=None, normals_world=None, nthreads=1):
+    """Whole batch; returns tau [B,12], grf [B,12], status [B]."""
+    prm = params or default_params()
+    B = int(np.asarray(state["q"]).reshape(-1, 12).shape[0])
+    ptrs, keep = [], []
+    for name, k in STATE_FIELDS:
+        a, p = _d(np.asarray(state[name]).reshape(B, k))
+        keep.append(a)
+        ptrs.append(p)
+    st = np.ascontiguousarray(np.asarray(state["stance"]).reshape(B, 4), dtype=np.uint8)
+    nw = None
+    if normals_world is not None:
+        nwa, nw = _d(np.asarray(normals_world).reshape(B, 12))
+        keep.append(nwa)
+    tau, grf = np.zeros((B, 12)), np.zeros((B, 12))
+    status = np.zeros(B, dtype=np.int32)
+    lib().oracle_balance_batch(C.byref(prm), C.c_int64(B), *ptrs, st.ctypes.data_as(C.POINTER(C.c_uint8)), nw,
+                               tau.ctypes.data_as(_dp), grf.ctypes.data_as(_dp),
+                               status.ctypes.data_as(C.POINTER(C.c_int32)), int(nthreads))
+    return tau, grf, status
+
+
+def virtual_wrench(state, i=0, params=None):
+    prm = params or default_params()
+    ptrs, keep = [], []
+    for name, k in STATE_FIELDS[1:]:
+        a, p = _d(np.asarray(state[name]).reshape(-1, k)[i])
+        keep.append(a)
+        ptrs.append(p)
+    w = np.zeros(6)
+    lib().oracle_virtual_wrench(C.byref(prm), *ptrs, w.ctypes.data_as(_dp))
+    return w
+
+
+def force_qp_assemble(r_feet, wrench, n_B, t1, t2, params=None):
+    prm = params or default_params()
+    r_feet = np.ascontiguousarray(r_feet, dtype=np.float64).reshape(-1, 3)
+    nS = r_feet.shape[0]
+    n, m = 3 * nS, 5 * nS
+    G, g0, CI, ci0 = np.zeros((n, n)), np.zeros(n), np.zeros((n, m)), np.zeros(m)
+    a = [_d(v) for v in (r_feet, wrench, np.reshape(n_B, (nS, 3)), np.reshape(t1, (nS, 3)), np.reshape(t2, (nS, 3)))]
+    lib().oracle_force_qp_assemble(C.byref(prm), nS, a[0][1], a[1][1], a[2][1], a[3][1], a[4][1],
+                                   G.ctypes.data_as(_dp), g0.ctypes.data_as(_dp),
+                                   CI.ctypes.data_as(_dp), ci0.ctypes.data_as(_dp))
+    return G, g0, CI, ci0

@@ -1,0 +1,114 @@
+"""Seeded synthetic robot states for the balance-controller hot path.
+
+Distributions follow SURVEY.md section 8(d).  The generator is counter based
+(numpy Philox, key = seed): robot i draws the same numbers whatever the batch
+size, so a shard [lo, hi) of a larger batch is reproducible on any rank.
+
+Fields are laid out [B][k] exactly as the C-ABI (include/qlamd.h) takes them,
+mirroring hardware_interface::RobotStateHandle::Data of the reference
+(balance_controller/include/balance_controller/ros_controler/robot_state_interface.hpp:28-65).
+"""
+import numpy as np
+
+SEED = 20261002
+_DRAWS = 64  # uniform draws reserved per robot (fixed so shards line up)
+
+# trot timing, free_gait_ros/test/action_server_test.cpp:183 and
+# free_gait_ros/test/gait_generate_client.cpp:82-117 (diagonal pairs)
+T_SWING = 0.45
+T_STANCE = 0.45
+DOUBLE_SUPPORT_FRACTION = 0.10
+
+
+def _uniform(seed, lo, hi):
+    """[hi-lo, _DRAWS] uniforms in [0,1), robot-index addressed."""
+    bg = np.random.Philox(key=seed)
+    # each Philox counter step yields 4 x 64-bit -> 4 doubles; _DRAWS doubles per robot
+    bg.advance(lo * (_DRAWS // 4))
+    return np.random.Generator(bg).random((hi - lo, _DRAWS))
+
+
+def _quat_mul(a, b):
+    w1, x1, y1, z1 = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    w2, x2, y2, z2 = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2,
+                     w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                     w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], axis=-1)
+
+
+def _quat_axis(axis, ang):
+    q = np.zeros(ang.shape + (4,))
+    q[..., 0] = np.cos(0.5 * ang)
+    q[..., 1 + axis] = np.sin(0.5 * ang)
+    return q
+
+
+def _quat_exp(rv):
+    ang = np.linalg.norm(rv, axis=-1)
+    k = np.where(ang > 1e-12, np.sin(0.5 * ang) / np.maximum(ang, 1e-300), 0.5)
+    return np.concatenate([np.cos(0.5 * ang)[..., None], rv * k[..., None]], axis=-1)
+
+
+def make_states(batch, gait="static", seed=SEED, offset=0):
+    """Return a dict of numpy arrays for robots [offset, offset+batch).
+
+    gait = "static": all four feet in stance (BASELINE configs 1-2).
+    gait = "trot":   diagonal-pair trot with a double-support window and a
+                     horizontal velocity error sized to load the friction
+                     pyramid (BASELINE configs 3-4).
+    """
+    u = _uniform(seed, offset, offset + batch)
+    B = batch
+    sym = lambda c, half: (2.0 * u[:, c] - 1.0) * half  # noqa: E731
+    c = 0
+
+    q_nom = np.tile(np.array([0.0, 0.75, -1.5]), 4)
+    q = q_nom[None, :] + np.stack([sym(c + k, 0.15) for k in range(12)], axis=1)
+    c += 12
+    base_pos = np.array([0.0, 0.0, 0.46])[None, :] + np.stack([sym(c + k, 0.02) for k in range(3)], axis=1)
+    c += 3
+    yaw, roll, pitch = sym(c, np.pi), sym(c + 1, 0.1), sym(c + 2, 0.1)
+    c += 3
+    base_quat = _quat_mul(_quat_mul(_quat_axis(2, yaw), _quat_axis(1, pitch)), _quat_axis(0, roll))
+    base_linvel = np.stack([sym(c + k, 0.1) for k in range(3)], axis=1)
+    c += 3
+    base_angvel = np.stack([sym(c + k, 0.1) for k in range(3)], axis=1)
+    c += 3
+    des_pos = base_pos + np.stack([sym(c + k, 0.02) for k in range(3)], axis=1)
+    c += 3
+    des_quat = _quat_mul(_quat_exp(np.stack([sym(c + k, 0.05) for k in range(3)], axis=1)), base_quat)
+    c += 3
+    des_linvel = np.stack([sym(c + k, 0.1) for k in range(3)], axis=1)
+    c += 3
+    des_angvel = np.stack([sym(c + k, 0.1) for k in range(3)], axis=1)
+    c += 3
+    stance = np.ones((B, 4), dtype=np.uint8)
+
+    if gait == "trot":
+        phase = u[:, c]
+        ratio = 0.2 + 0.7 * u[:, c + 1]
+        theta = 2.0 * np.pi * u[:, c + 2]
+        c += 3
+        # one cycle = swing + stance; pair A = {LF, RH} (legs 0, 2), pair B = {RF, LH} (legs 1, 3)
+        half = DOUBLE_SUPPORT_FRACTION / 2.0
+        dist_to_switch = np.minimum(np.minimum(phase, np.abs(phase - 0.5)), 1.0 - phase)
+        double_support = dist_to_switch < half / 2.0 * 2.0
+        a_stance = phase < 0.5
+        stance[:, 0] = stance[:, 2] = (a_stance | double_support)
+        stance[:, 1] = stance[:, 3] = (~a_stance | double_support)
+        # horizontal force demand |F_xy| / F_z ~ U(0.2, 0.9) through the velocity error
+        # (F_xy ~ kd * e_v, F_z ~ 51 kg * 9.8), zero horizontal position error
+        weight = (27.0 + 4 * 6.0) * 9.8
+        ev = ratio * weight / 5000.0
+        des_pos[:, 0:2] = base_pos[:, 0:2]
+        des_linvel[:, 0] = base_linvel[:, 0] + ev * np.cos(theta)
+        des_linvel[:, 1] = base_linvel[:, 1] + ev * np.sin(theta)
+    elif gait != "static":
+        raise ValueError("gait must be 'static' or 'trot'")
+
+    return dict(q=np.ascontiguousarray(q), base_pos=np.ascontiguousarray(base_pos),
+                base_quat=np.ascontiguousarray(base_quat), base_linvel=base_linvel,
+                base_angvel=base_angvel, des_pos=np.ascontiguousarray(des_pos),
+                des_quat=np.ascontiguousarray(des_quat), des_linvel=np.ascontiguousarray(des_linvel),
+                des_angvel=des_angvel, stance=stance)
