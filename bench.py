@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: control-step QP solves/sec (BASELINE.json `metric`).
+
+One "step" = one balance-controller control tick for every robot of the batch:
+virtual-model wrench -> leg FK -> contact-force-distribution QP -> joint torques
+(clamped), through the C-ABI (qlamd_balance_solve_batch) with all inputs and
+outputs resident in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--gait static|trot] [--batch B]
+
+N = 1: BASELINE configs[1], batch = 4096 robots, static 4-contact stance.
+N > 1: launched by torch.distributed.run, one rank per GPU; every rank solves its
+own shard of `batch` robots (weak scaling: robots are independent, no data-path
+collective) and the joint torques are all-gathered over RCCL/xGMI for result
+collection, as the north star asks.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_STEP = 408   # 304 B state + 4 B stance in, 96 B torques + 4 B status out
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP64_VALU_PEAK_TFLOPS = 78.6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="robots per GPU")
+    ap.add_argument("--gait", default="static", choices=["static", "trot"])
+    ap.add_argument("--rpw", type=int, default=0, help="robots per wavefront (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(state, seconds):
+    """The oracle (plain-C restatement of the reference path) on the host cores of this box,
+    same workload, bounded sample.  Reported next to the GPU number; not the target."""
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    O.balance_batch(state, nthreads=cores)  # warm
+    B = state["q"].shape[0]
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.balance_batch(state, nthreads=cores)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 100000:
+            break
+    return {"value": n * B / dt, "unit": "control-step QP solves/s", "cores": cores, "kind": "port",
+            "sample": "%d passes over the same %d-robot batch (%.1f s), OpenMP over robots, all host cores"
+                      % (n, B, dt)}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from quadruped_locomotion_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+
+    B = args.batch
+    # rank r owns robots [r*B, (r+1)*B) of the global batch (contiguous shards)
+    state = synth.make_states(B, args.gait, offset=rank * B)
+    ctx = capi.Context(device=local_rank)
+    if args.rpw:
+        ctx.set_robots_per_wave(args.rpw)
+    d = capi.to_device(state, dev)
+    tau = [torch.zeros(B, 12, dtype=torch.float64, device=dev) for _ in range(2)]
+    status = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    gathered = [torch.zeros(world * B, 12, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(k, events=None):
+        buf = k & 1
+        if events is not None:
+            events[0].record()
+        ctx.balance_solve_device(d, tau[buf], None, status, stream=stream)
+        if events is not None:
+            events[1].record()
+        if world > 1:
+            # result collection only; overlaps with the next step's solve (double-buffered)
+            return dist.all_gather_into_tensor(gathered[buf], tau[buf], async_op=True)
+        return None
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    pending = []
+    for k in range(args.warmup):
+        w = step(k)
+        if w is not None:
+            w.wait()
+    fence()
+
+    # ---- timed region: exactly K steps -----------------------------------------
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        w = step(k, ev[k])
+        if w is not None:
+            pending.append(w)
+            if len(pending) > 1:
+                pending.pop(0).wait()
+    for w in pending:
+        w.wait()
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    st = status.cpu().numpy()
+    ok = bool((st == 0).all())
+
+    if rank == 0:
+        total = world * B * args.steps
+        value = total / elapsed
+        algo_bytes = ALGO_BYTES_PER_STEP * B
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "control-step QP solves/sec (18-DoF, 4-contact) at 1/2/4/8 MI355X",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "batch=%d robots per GPU, %s, one balance-controller control step "
+                                   "(virtual-model wrench + leg FK + force-distribution QP + torques) per robot"
+                                   % (B, "static 4-contact stance" if args.gait == "static"
+                                      else "trot gait (2<->4 contacts)"),
+                       "robots_per_gpu": B, "gait": args.gait, "seed": synth.SEED,
+                       "result_collection": "rccl all_gather of torques" if world > 1 else "none (single GPU)",
+                       "all_status_ok": ok},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "balance_step_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(state, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,163 @@
+/* qlamd -- C-ABI of the MI355X-native batched balance-controller solve.
+ *
+ * Plain C types only, caller-owned buffers, integer return codes, no
+ * exceptions across the boundary, no hidden globals.
+ * Every entry point names the reference interface it replaces; paths are
+ * relative to the reference tree (ShunyaoWang/quadruped_locomotion).
+ *
+ * The library needs a HIP device (gfx950).  There is NO CPU fallback: without
+ * a usable device qlamd_context_create() fails with QLAMD_ERR_NO_DEVICE.
+ */
+#ifndef QLAMD_H
+#define QLAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QLAMD_VERSION_MAJOR 0
+#define QLAMD_VERSION_MINOR 1
+
+/* ---- return codes of the API calls ------------------------------------- */
+#define QLAMD_OK 0
+#define QLAMD_ERR_INVALID_ARGUMENT (-1)
+#define QLAMD_ERR_NO_DEVICE (-2)      /* no HIP device / wrong architecture   */
+#define QLAMD_ERR_HIP (-3)            /* a HIP runtime call failed            */
+#define QLAMD_ERR_NOT_LOADED (-4)     /* parameters not loaded: the reference's
+                                         checkIfParametersLoaded() == false,
+                                         ContactForceDistribution.cpp:103     */
+#define QLAMD_ERR_OUT_OF_MEMORY (-5)
+
+/* ---- per-robot status words (int32) ------------------------------------ */
+#define QLAMD_STATUS_OK 0
+#define QLAMD_STATUS_INFEASIBLE 1     /* QuadProg++ returns +inf, QuadProg++.cc:339-344 */
+#define QLAMD_STATUS_NOT_PD 2         /* QuadProg++ throws logic_error, QuadProg++.cc:692-699 */
+#define QLAMD_STATUS_MAX_ITER 3       /* iteration guard hit (no reference counterpart) */
+
+/* ---- where caller buffers live ------------------------------------------ */
+#define QLAMD_MEM_DEVICE 0            /* device pointers, used in place, async on `stream` */
+#define QLAMD_MEM_HOST 1              /* host pointers, staged through the context's device
+                                         workspace; the call returns after the copy-back    */
+
+typedef struct qlamd_context qlamd_context;
+
+/* Controller parameters.  Replaces the ROS parameter loads of
+ *   VirtualModelController::loadParameters   balance_controller/src/motion_control/VirtualModelController.cpp:429-548
+ *   ContactForceDistribution::loadParameters balance_controller/src/contact_force_distribution/ContactForceDistribution.cpp:818-886
+ * plus the constants hard-wired in quadruped_model/src/quadruped_state.cpp:26-45,83-97
+ * and the +-300 clamp of ros_balance_controller.cpp:451-454. */
+typedef struct qlamd_balance_params {
+  double kp_trans[3], kd_trans[3], kff_trans[3]; /* heading, lateral, vertical */
+  double kp_rot[3], kd_rot[3], kff_rot[3];       /* roll, pitch, yaw           */
+  double force_weights[6];                       /* S = diag(force xyz, torque xyz) */
+  double regularizer;                            /* W = regularizer * I        */
+  double friction;                               /* mu                          */
+  double min_normal_force;                       /* f_min                       */
+  double torque_limit;                           /* 300                         */
+  double torso_mass;                             /* 27.0                        */
+  double leg_mass[4];                            /* 6.0 each, LF RF RH LH       */
+  double gravity;                                /* 9.8; g_W = (0,0,-gravity)   */
+  double grav_comp_percentage;                   /* 1.0                         */
+  double com_in_base[3];                         /* (0,0,0)                     */
+  double hip_in_base[4][3];                      /* (+-0.42, +-0.075, 0)        */
+} qlamd_balance_params;
+
+/* Fills the values of balance_controller/config/controller_gains.yaml:1-41 and
+ * quadruped_state.cpp:26-45,83-97. */
+void qlamd_balance_default_params(qlamd_balance_params *p);
+
+/* Leg chains base_link -> *_foot_Link (quadrupedkinematics.cpp:67-70): per
+ * [leg][segment] joint origin, fixed rpy, link mass and centre of mass.
+ * Segments 0..2 are revolute about local z, segment 3 is the fixed foot.
+ * Replaces kdl_parser::treeFromFile + tree_.getChain
+ * (quadrupedkinematics.cpp:54-74). */
+typedef struct qlamd_robot_model {
+  double joint_xyz[4][4][3];
+  double joint_rpy[4][4][3];
+  double link_mass[4][4];
+  double link_com[4][4][3];
+} qlamd_robot_model;
+
+/* The reference robot, quadruped_model/urdf/quadruped_model.urdf. */
+void qlamd_default_robot_model(qlamd_robot_model *m);
+
+/* One batch of robot states, every field laid out [batch][k], k fastest.
+ * Field meaning and order mirror hardware_interface::RobotStateHandle::Data
+ * (balance_controller/include/balance_controller/ros_controler/robot_state_interface.hpp:28-65)
+ * and the desired base state that baseCommandCallback stores
+ * (ros_balance_controller.cpp:761-1083, written into State at :384-387).
+ * Joint order LF(0-2) RF(3-5) RH(6-8) LH(9-11) (quadruped_state.cpp:340-343);
+ * quaternions are (w,x,y,z), base -> world. */
+typedef struct qlamd_state_batch {
+  const double *joint_position;       /* [B][12] */
+  const double *base_position;        /* [B][3]  world                        */
+  const double *base_orientation;     /* [B][4]                               */
+  const double *base_linear_velocity; /* [B][3]  world                        */
+  const double *base_angular_velocity;/* [B][3]  base                         */
+  const double *desired_position;     /* [B][3]                               */
+  const double *desired_orientation;  /* [B][4]                               */
+  const double *desired_linear_velocity;  /* [B][3]                           */
+  const double *desired_angular_velocity; /* [B][3]                           */
+  const uint8_t *support_leg;         /* [B][4]  State::isSupportLeg, != 0 = stance */
+  const double *surface_normal;       /* [B][4][3] world, or NULL: the reference's
+                                         update() override n_W = q.rotate(z),
+                                         ros_balance_controller.cpp:378        */
+} qlamd_state_batch;
+
+/* Create / destroy.  `device` is a HIP device ordinal.  `model` may be NULL
+ * (reference robot).  Replaces RosBalanceController::init's construction of
+ * ContactForceDistribution + VirtualModelController + State
+ * (ros_balance_controller.cpp:68-95). */
+int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_model *model,
+                         int device, qlamd_context **out);
+void qlamd_context_destroy(qlamd_context *ctx);
+
+/* Tuning knob: lanes of a wavefront given to robots (64, 16 or 4; 0 = choose
+ * from the batch size).  Fewer robots per wavefront spreads a small batch
+ * over more SIMDs. */
+int qlamd_set_robots_per_wave(qlamd_context *ctx, int robots_per_wave);
+
+/* One control step for `batch` robots: virtual-model wrench -> leg FK ->
+ * contact-force-distribution QP -> joint torques, clamped.
+ * Replaces VirtualModelController::compute() (VirtualModelController.cpp:89-102)
+ * -> ContactForceDistribution::computeForceDistribution() (ContactForceDistribution.cpp:99-136)
+ * and the effort read-out + clamp of RosBalanceController::update
+ * (ros_balance_controller.cpp:441-454).
+ *   joint_effort   [B][12]  out, clamped to +-torque_limit, 0 for non-support legs
+ *   contact_force  [B][12]  out or NULL: QP solution x = ground reaction forces in
+ *                           the base frame (desiredContactForce_ = -x,
+ *                           ContactForceDistribution.cpp:502-503), 0 for non-support legs
+ *   status         [B]      out, QLAMD_STATUS_*
+ *   memory         QLAMD_MEM_DEVICE or QLAMD_MEM_HOST for ALL pointers above
+ *   stream         hipStream_t (NULL = default stream)
+ */
+int qlamd_balance_solve_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch,
+                              double *joint_effort, double *contact_force, int32_t *status,
+                              int memory, void *stream);
+
+/* Virtual wrench only: (F_B, T_B) [B][6].  Replaces
+ * VirtualModelController::computeError/GravityCompensation/VirtualForce/VirtualTorque
+ * (VirtualModelController.cpp:104-268). */
+int qlamd_virtual_wrench_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch,
+                               double *wrench, int memory, void *stream);
+
+/* Leg kinematics for all four legs: foot position [B][4][3], translation
+ * Jacobian [B][4][9] (row-major d p / d q), gravity torque [B][4][3] for the
+ * gravity field g_B = q^-1.rotate((0,0,-gravity)).  Any output may be NULL.
+ * Replaces QuadrupedKinematics::FowardKinematicsSolve / AnalysticJacobian /
+ * getGravityCompensationForLimb (quadrupedkinematics.cpp:143-278,485-552). */
+int qlamd_leg_kinematics_batch(qlamd_context *ctx, const double *joint_position,
+                               const double *base_orientation, int64_t batch,
+                               double *foot_position, double *jacobian, double *gravity_torque,
+                               int memory, void *stream);
+
+const char *qlamd_strerror(int code);
+int qlamd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QLAMD_H */

@@ -1,0 +1,206 @@
+"""ctypes binding of the C-ABI (include/qlamd.h) -- plumbing only.
+
+The arithmetic lives in the HIP kernels of libqlamd.so.  There is no Python or
+CPU fallback: a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libqlamd.so")
+
+OK = 0
+ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_LOADED, ERR_OUT_OF_MEMORY = -1, -2, -3, -4, -5
+STATUS_OK, STATUS_INFEASIBLE, STATUS_NOT_PD, STATUS_MAX_ITER = 0, 1, 2, 3
+MEM_DEVICE, MEM_HOST = 0, 1
+
+EXPORTS = (
+    "qlamd_balance_default_params", "qlamd_default_robot_model", "qlamd_context_create",
+    "qlamd_context_destroy", "qlamd_set_robots_per_wave", "qlamd_balance_solve_batch",
+    "qlamd_virtual_wrench_batch", "qlamd_leg_kinematics_batch", "qlamd_strerror", "qlamd_version",
+)
+
+
+class BalanceParams(C.Structure):
+    _fields_ = [
+        ("kp_trans", C.c_double * 3), ("kd_trans", C.c_double * 3), ("kff_trans", C.c_double * 3),
+        ("kp_rot", C.c_double * 3), ("kd_rot", C.c_double * 3), ("kff_rot", C.c_double * 3),
+        ("force_weights", C.c_double * 6),
+        ("regularizer", C.c_double), ("friction", C.c_double), ("min_normal_force", C.c_double),
+        ("torque_limit", C.c_double), ("torso_mass", C.c_double), ("leg_mass", C.c_double * 4),
+        ("gravity", C.c_double), ("grav_comp_percentage", C.c_double),
+        ("com_in_base", C.c_double * 3), ("hip_in_base", (C.c_double * 3) * 4),
+    ]
+
+
+class RobotModel(C.Structure):
+    _fields_ = [
+        ("joint_xyz", ((C.c_double * 3) * 4) * 4), ("joint_rpy", ((C.c_double * 3) * 4) * 4),
+        ("link_mass", (C.c_double * 4) * 4), ("link_com", ((C.c_double * 3) * 4) * 4),
+    ]
+
+
+class StateBatch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "joint_position", "base_position", "base_orientation", "base_linear_velocity",
+        "base_angular_velocity", "desired_position", "desired_orientation",
+        "desired_linear_velocity", "desired_angular_velocity", "support_leg", "surface_normal")]
+
+
+# state-dict key -> StateBatch field (keys as produced by synth.make_states)
+FIELD_OF_KEY = (
+    ("q", "joint_position", 12), ("base_pos", "base_position", 3), ("base_quat", "base_orientation", 4),
+    ("base_linvel", "base_linear_velocity", 3), ("base_angvel", "base_angular_velocity", 3),
+    ("des_pos", "desired_position", 3), ("des_quat", "desired_orientation", 4),
+    ("des_linvel", "desired_linear_velocity", 3), ("des_angvel", "desired_angular_velocity", 3),
+)
+
+
+class QlamdError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__("%s failed: %s (%d)" % (what, strerror(code), code))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libqlamd.so; raise loudly if the HIP extension was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.qlamd_strerror.restype = C.c_char_p
+        L.qlamd_strerror.argtypes = [C.c_int]
+        L.qlamd_context_create.argtypes = [C.POINTER(BalanceParams), C.POINTER(RobotModel), C.c_int,
+                                           C.POINTER(C.c_void_p)]
+        L.qlamd_context_destroy.argtypes = [C.c_void_p]
+        L.qlamd_context_destroy.restype = None
+        L.qlamd_set_robots_per_wave.argtypes = [C.c_void_p, C.c_int]
+        L.qlamd_balance_solve_batch.argtypes = [C.c_void_p, C.POINTER(StateBatch), C.c_int64, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.qlamd_virtual_wrench_batch.argtypes = [C.c_void_p, C.POINTER(StateBatch), C.c_int64, C.c_void_p,
+                                                 C.c_int, C.c_void_p]
+        L.qlamd_leg_kinematics_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def strerror(code):
+    return lib().qlamd_strerror(int(code)).decode()
+
+
+def default_params():
+    p = BalanceParams()
+    lib().qlamd_balance_default_params(C.byref(p))
+    return p
+
+
+def default_robot_model():
+    m = RobotModel()
+    lib().qlamd_default_robot_model(C.byref(m))
+    return m
+
+
+class Context:
+    """RAII wrapper of qlamd_context."""
+
+    def __init__(self, params=None, model=None, device=0):
+        self._h = C.c_void_p()
+        self.params = params if params is not None else default_params()
+        rc = lib().qlamd_context_create(C.byref(self.params), C.byref(model) if model is not None else None,
+                                        int(device), C.byref(self._h))
+        if rc != OK:
+            raise QlamdError(rc, "qlamd_context_create")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().qlamd_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_robots_per_wave(self, rpw):
+        rc = lib().qlamd_set_robots_per_wave(self._h, int(rpw))
+        if rc != OK:
+            raise QlamdError(rc, "qlamd_set_robots_per_wave")
+
+    # ---- host (numpy) buffers -------------------------------------------------
+    def balance_solve_host(self, state, normals=None, want_forces=True):
+        B = int(np.asarray(state["q"]).reshape(-1, 12).shape[0])
+        sb, keep = StateBatch(), []
+        for key, field, k in FIELD_OF_KEY:
+            a = np.ascontiguousarray(np.asarray(state[key], dtype=np.float64).reshape(B, k))
+            keep.append(a)
+            setattr(sb, field, a.ctypes.data)
+        st = np.ascontiguousarray(np.asarray(state["stance"], dtype=np.uint8).reshape(B, 4))
+        sb.support_leg = st.ctypes.data
+        if normals is not None:
+            nw = np.ascontiguousarray(np.asarray(normals, dtype=np.float64).reshape(B, 12))
+            keep.append(nw)
+            sb.surface_normal = nw.ctypes.data
+        tau = np.zeros((B, 12))
+        grf = np.zeros((B, 12)) if want_forces else None
+        status = np.full(B, -1, dtype=np.int32)
+        rc = lib().qlamd_balance_solve_batch(self._h, C.byref(sb), B, tau.ctypes.data,
+                                             grf.ctypes.data if want_forces else None, status.ctypes.data,
+                                             MEM_HOST, None)
+        if rc != OK:
+            raise QlamdError(rc, "qlamd_balance_solve_batch")
+        return tau, grf, status
+
+    # ---- device (torch) buffers ------------------------------------------------
+    def balance_solve_device(self, dstate, tau, grf, status, stream=None):
+        """dstate: dict of torch CUDA tensors (keys of synth.make_states, plus optional
+        'normals'); tau/grf/status: preallocated CUDA tensors.  Asynchronous."""
+        sb = StateBatch()
+        B = dstate["q"].shape[0]
+        for key, field, _ in FIELD_OF_KEY:
+            setattr(sb, field, dstate[key].data_ptr())
+        sb.support_leg = dstate["stance"].data_ptr()
+        if dstate.get("normals") is not None:
+            sb.surface_normal = dstate["normals"].data_ptr()
+        rc = lib().qlamd_balance_solve_batch(self._h, C.byref(sb), B, tau.data_ptr(),
+                                             grf.data_ptr() if grf is not None else None, status.data_ptr(),
+                                             MEM_DEVICE, C.c_void_p(stream) if stream else None)
+        if rc != OK:
+            raise QlamdError(rc, "qlamd_balance_solve_batch")
+
+    def virtual_wrench_device(self, dstate, wrench, stream=None):
+        sb = StateBatch()
+        for key, field, _ in FIELD_OF_KEY:
+            setattr(sb, field, dstate[key].data_ptr())
+        sb.support_leg = dstate["stance"].data_ptr()
+        rc = lib().qlamd_virtual_wrench_batch(self._h, C.byref(sb), dstate["q"].shape[0], wrench.data_ptr(),
+                                              MEM_DEVICE, C.c_void_p(stream) if stream else None)
+        if rc != OK:
+            raise QlamdError(rc, "qlamd_virtual_wrench_batch")
+
+    def leg_kinematics_device(self, q, quat, foot=None, jac=None, grav=None, stream=None):
+        rc = lib().qlamd_leg_kinematics_batch(
+            self._h, q.data_ptr(), quat.data_ptr(), q.shape[0],
+            foot.data_ptr() if foot is not None else None, jac.data_ptr() if jac is not None else None,
+            grav.data_ptr() if grav is not None else None, MEM_DEVICE, C.c_void_p(stream) if stream else None)
+        if rc != OK:
+            raise QlamdError(rc, "qlamd_leg_kinematics_batch")
+
+
+def to_device(state, device="cuda:0"):
+    """numpy state dict -> dict of torch tensors resident in HBM."""
+    import torch
+    out = {}
+    for k, v in state.items():
+        out[k] = torch.from_numpy(np.ascontiguousarray(v)).to(device)
+    return out

@@ -1,0 +1,359 @@
+// HIP kernels (gfx950) for the batched balance-controller step and the C-ABI
+// of include/qlamd.h.  See DESIGN.md for the data layout and launch geometry.
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <stdio.h>
+#include <string.h>
+
+#include "balance_core.hpp"
+#include "params_build.hpp"
+#include "qlamd.h"
+
+using namespace qlamd;
+
+namespace {
+
+// Per-robot run-time indexed arrays in LDS, [element][robot-in-wave]: a lane's
+// bank depends on the lane only, so divergent element indices never conflict.
+struct LdsScratch {
+  double *base;
+  int stride;
+  __device__ __forceinline__ double &at(int e) { return base[e * stride]; }
+};
+
+struct StatePtrs {
+  const double *q, *pos, *quat, *linvel, *angvel, *dpos, *dquat, *dlinvel, *dangvel;
+  const uint8_t *stance;
+  const double *normals;
+};
+
+__device__ __forceinline__ void load_robot(const StatePtrs &s, int64_t i, RobotIn &in) {
+  // 96-byte (q), 32-byte (quat) and 24-byte records: each lane reads its own
+  // contiguous record; neighbouring lanes share cache lines, every fetched byte is used.
+  const double2 *q2 = reinterpret_cast<const double2 *>(s.q + 12 * i);
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const double2 v = q2[k];
+    in.q[2 * k] = v.x;
+    in.q[2 * k + 1] = v.y;
+  }
+  const double2 *a2 = reinterpret_cast<const double2 *>(s.quat + 4 * i);
+  const double2 *b2 = reinterpret_cast<const double2 *>(s.dquat + 4 * i);
+  double2 v = a2[0]; in.quat[0] = v.x; in.quat[1] = v.y;
+  v = a2[1]; in.quat[2] = v.x; in.quat[3] = v.y;
+  v = b2[0]; in.dquat[0] = v.x; in.dquat[1] = v.y;
+  v = b2[1]; in.dquat[2] = v.x; in.dquat[3] = v.y;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    in.pos[k] = s.pos[3 * i + k];
+    in.linvel[k] = s.linvel[3 * i + k];
+    in.angvel[k] = s.angvel[3 * i + k];
+    in.dpos[k] = s.dpos[3 * i + k];
+    in.dlinvel[k] = s.dlinvel[3 * i + k];
+    in.dangvel[k] = s.dangvel[3 * i + k];
+  }
+  const uint32_t m = *reinterpret_cast<const uint32_t *>(s.stance + 4 * i);
+  in.stance = ((m & 0xFFu) ? 1u : 0u) | ((m & 0xFF00u) ? 2u : 0u) | ((m & 0xFF0000u) ? 4u : 0u) |
+              ((m & 0xFF000000u) ? 8u : 0u);
+}
+
+// One wavefront per workgroup; RPW of its 64 lanes carry a robot each.  A
+// small batch is spread over more SIMDs by lowering RPW (the other lanes
+// idle): the step is latency-bound, not throughput-bound, at 4096 robots.
+template <int RPW, bool kPerLeg>
+__global__ __launch_bounds__(64) void balance_step_kernel(const DeviceParams P, const StatePtrs s, int64_t B,
+                                                          double *__restrict__ tau, double *__restrict__ grf,
+                                                          int32_t *__restrict__ status) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * RPW + lane;
+  if (lane >= RPW || i >= B) return;
+
+  RobotIn in;
+  load_robot(s, i, in);
+  double nw[12];
+  if (kPerLeg) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) nw[k] = s.normals[12 * i + k];
+  }
+  LdsScratch scr{lds + lane, RPW};
+  RobotOut out;
+  balance_robot<kPerLeg>(P, in, nw, scr, out);
+
+  double2 *t2 = reinterpret_cast<double2 *>(tau + 12 * i);
+#pragma unroll
+  for (int k = 0; k < 6; k++) t2[k] = make_double2(out.tau[2 * k], out.tau[2 * k + 1]);
+  if (grf) {
+    double2 *g2 = reinterpret_cast<double2 *>(grf + 12 * i);
+#pragma unroll
+    for (int k = 0; k < 6; k++) g2[k] = make_double2(out.grf[2 * k], out.grf[2 * k + 1]);
+  }
+  status[i] = out.status;
+}
+
+__global__ __launch_bounds__(64) void virtual_wrench_kernel(const DeviceParams P, const StatePtrs s, int64_t B,
+                                                            double *__restrict__ wrench) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= B) return;
+  RobotIn in;
+  load_robot(s, i, in);
+  double Rm[9], gB[3], b[6];
+  quat_to_matrix(in.quat, Rm);
+  const double gW[3] = {0.0, 0.0, -P.grav};
+  irot(Rm, gW, gB);
+  virtual_wrench(P, in, Rm, gB, b);
+#pragma unroll
+  for (int k = 0; k < 6; k++) wrench[6 * i + k] = b[k];
+}
+
+__global__ __launch_bounds__(64) void leg_kinematics_kernel(const DeviceParams P, const double *__restrict__ q,
+                                                            const double *__restrict__ quat, int64_t B,
+                                                            double *__restrict__ foot, double *__restrict__ jac,
+                                                            double *__restrict__ grav) {
+  // one lane per (robot, leg)
+  const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (t >= 4 * B) return;
+  const int64_t i = t >> 2;
+  const int leg = (int)(t & 3);
+  double ql[3] = {q[12 * i + 3 * leg], q[12 * i + 3 * leg + 1], q[12 * i + 3 * leg + 2]};
+  double qq[4] = {quat[4 * i], quat[4 * i + 1], quat[4 * i + 2], quat[4 * i + 3]};
+  double Rm[9], gB[3];
+  quat_to_matrix(qq, Rm);
+  const double gW[3] = {0.0, 0.0, -P.grav};
+  irot(Rm, gW, gB);
+  LegFrames F;
+  double J[9], Gq[3];
+  // `leg` differs between lanes: select the chain with a uniform loop so P stays in SGPRs
+#pragma unroll
+  for (int l = 0; l < 4; l++) {
+    if (l == leg) {
+      leg_frames(P, l, ql, F);
+      leg_jac_grav(P, l, F, gB, J, Gq);
+    }
+  }
+  if (foot) { foot[3 * t] = F.p[3][0]; foot[3 * t + 1] = F.p[3][1]; foot[3 * t + 2] = F.p[3][2]; }
+  if (jac) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) jac[9 * t + k] = J[k];
+  }
+  if (grav) { grav[3 * t] = Gq[0]; grav[3 * t + 1] = Gq[1]; grav[3 * t + 2] = Gq[2]; }
+}
+
+} // namespace
+
+// ------------------------------------------------------------------ C-ABI ---
+
+struct qlamd_context {
+  int device;
+  DeviceParams params;
+  int rpw_override;
+  int num_cu;
+  // HOST-memory mode staging (grown on demand)
+  void *ws;
+  size_t ws_bytes;
+};
+
+namespace {
+
+int pick_rpw(const qlamd_context *ctx, int64_t batch) {
+  if (ctx->rpw_override) return ctx->rpw_override;
+  const int64_t simds = (int64_t)ctx->num_cu * 4;
+  // fill every SIMD with at least one wavefront before packing lanes
+  if (batch <= simds * 4) return 4;
+  if (batch <= simds * 16 * 2) return 16;
+  return 64;
+}
+
+template <int RPW>
+hipError_t launch_balance(const qlamd_context *ctx, const StatePtrs &s, int64_t B, double *tau, double *grf,
+                          int32_t *status, hipStream_t st) {
+  const size_t lds = (size_t)RPW * kScratchDoubles * sizeof(double);
+  const unsigned grid = (unsigned)((B + RPW - 1) / RPW);
+  if (s.normals) {
+    auto k = balance_step_kernel<RPW, true>;
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, ctx->params, s, B, tau, grf, status);
+  } else {
+    auto k = balance_step_kernel<RPW, false>;
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, ctx->params, s, B, tau, grf, status);
+  }
+  return hipGetLastError();
+}
+
+int ensure_ws(qlamd_context *ctx, size_t bytes) {
+  if (ctx->ws_bytes >= bytes) return QLAMD_OK;
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  ctx->ws = nullptr;
+  ctx->ws_bytes = 0;
+  if (hipMalloc(&ctx->ws, bytes) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;
+  ctx->ws_bytes = bytes;
+  return QLAMD_OK;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+} // namespace
+
+extern "C" {
+
+void qlamd_balance_default_params(qlamd_balance_params *p) { if (p) default_balance_params(p); }
+void qlamd_default_robot_model(qlamd_robot_model *m) { if (m) default_robot_model(m); }
+int qlamd_version(void) { return QLAMD_VERSION_MAJOR * 1000 + QLAMD_VERSION_MINOR; }
+
+const char *qlamd_strerror(int code) {
+  switch (code) {
+    case QLAMD_OK: return "ok";
+    case QLAMD_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case QLAMD_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case QLAMD_ERR_HIP: return "HIP runtime error";
+    case QLAMD_ERR_NOT_LOADED: return "parameters not loaded";
+    case QLAMD_ERR_OUT_OF_MEMORY: return "out of device memory";
+    default: return "unknown error";
+  }
+}
+
+int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_model *model, int device,
+                         qlamd_context **out) {
+  if (!out) return QLAMD_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (!params) return QLAMD_ERR_NOT_LOADED;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return QLAMD_ERR_NO_DEVICE;
+  if (device < 0 || device >= count) return QLAMD_ERR_INVALID_ARGUMENT;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return QLAMD_ERR_HIP;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return QLAMD_ERR_NO_DEVICE;
+  qlamd_context *ctx = new (std::nothrow) qlamd_context;
+  if (!ctx) return QLAMD_ERR_OUT_OF_MEMORY;
+  ctx->device = device;
+  ctx->rpw_override = 0;
+  ctx->num_cu = prop.multiProcessorCount;
+  ctx->ws = nullptr;
+  ctx->ws_bytes = 0;
+  qlamd_robot_model m;
+  if (model) m = *model; else default_robot_model(&m);
+  build_device_params(*params, m, &ctx->params);
+  *out = ctx;
+  return QLAMD_OK;
+}
+
+void qlamd_context_destroy(qlamd_context *ctx) {
+  if (!ctx) return;
+  if (ctx->ws) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipFree(ctx->ws);
+  }
+  delete ctx;
+}
+
+int qlamd_set_robots_per_wave(qlamd_context *ctx, int rpw) {
+  if (!ctx || !(rpw == 0 || rpw == 4 || rpw == 16 || rpw == 64)) return QLAMD_ERR_INVALID_ARGUMENT;
+  ctx->rpw_override = rpw;
+  return QLAMD_OK;
+}
+
+int qlamd_balance_solve_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch, double *joint_effort,
+                              double *contact_force, int32_t *status, int memory, void *stream) {
+  if (!ctx || !in || batch < 0 || !joint_effort || !status) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!in->joint_position || !in->base_position || !in->base_orientation || !in->base_linear_velocity ||
+      !in->base_angular_velocity || !in->desired_position || !in->desired_orientation ||
+      !in->desired_linear_velocity || !in->desired_angular_velocity || !in->support_leg)
+    return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+
+  StatePtrs s;
+  double *d_tau = joint_effort, *d_grf = contact_force;
+  int32_t *d_status = status;
+  if (memory == QLAMD_MEM_HOST) {
+    // one staging slab: inputs then outputs, 256-byte aligned pieces
+    const size_t sz[11] = {B * 96, B * 24, B * 32, B * 24, B * 24, B * 24, B * 32, B * 24, B * 24, B * 4,
+                           in->surface_normal ? B * 96 : 0};
+    const void *src[11] = {in->joint_position, in->base_position, in->base_orientation,
+                           in->base_linear_velocity, in->base_angular_velocity, in->desired_position,
+                           in->desired_orientation, in->desired_linear_velocity,
+                           in->desired_angular_velocity, in->support_leg, in->surface_normal};
+    size_t off[14], total = 0;
+    for (int k = 0; k < 11; k++) { off[k] = total; total += align256(sz[k]); }
+    off[11] = total; total += align256(B * 96);
+    off[12] = total; total += align256(B * 96);
+    off[13] = total; total += align256(B * 4);
+    int rc = ensure_ws(ctx, total);
+    if (rc != QLAMD_OK) return rc;
+    char *w = (char *)ctx->ws;
+    for (int k = 0; k < 11; k++)
+      if (sz[k] && hipMemcpyAsync(w + off[k], src[k], sz[k], hipMemcpyHostToDevice, st) != hipSuccess)
+        return QLAMD_ERR_HIP;
+    s = StatePtrs{(const double *)(w + off[0]), (const double *)(w + off[1]), (const double *)(w + off[2]),
+                  (const double *)(w + off[3]), (const double *)(w + off[4]), (const double *)(w + off[5]),
+                  (const double *)(w + off[6]), (const double *)(w + off[7]), (const double *)(w + off[8]),
+                  (const uint8_t *)(w + off[9]), in->surface_normal ? (const double *)(w + off[10]) : nullptr};
+    d_tau = (double *)(w + off[11]);
+    d_grf = contact_force ? (double *)(w + off[12]) : nullptr;
+    d_status = (int32_t *)(w + off[13]);
+  } else {
+    s = StatePtrs{in->joint_position, in->base_position, in->base_orientation, in->base_linear_velocity,
+                  in->base_angular_velocity, in->desired_position, in->desired_orientation,
+                  in->desired_linear_velocity, in->desired_angular_velocity, in->support_leg,
+                  in->surface_normal};
+  }
+
+  hipError_t e;
+  switch (pick_rpw(ctx, batch)) {
+    case 4: e = launch_balance<4>(ctx, s, batch, d_tau, d_grf, d_status, st); break;
+    case 16: e = launch_balance<16>(ctx, s, batch, d_tau, d_grf, d_status, st); break;
+    default: e = launch_balance<64>(ctx, s, batch, d_tau, d_grf, d_status, st); break;
+  }
+  if (e != hipSuccess) return QLAMD_ERR_HIP;
+
+  if (memory == QLAMD_MEM_HOST) {
+    if (hipMemcpyAsync(joint_effort, d_tau, B * 96, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
+    if (contact_force &&
+        hipMemcpyAsync(contact_force, d_grf, B * 96, hipMemcpyDeviceToHost, st) != hipSuccess)
+      return QLAMD_ERR_HIP;
+    if (hipMemcpyAsync(status, d_status, B * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
+  }
+  return QLAMD_OK;
+}
+
+int qlamd_virtual_wrench_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch, double *wrench,
+                               int memory, void *stream) {
+  if (!ctx || !in || batch < 0 || !wrench) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE) return QLAMD_ERR_INVALID_ARGUMENT; // device buffers only
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  StatePtrs s{in->joint_position, in->base_position, in->base_orientation, in->base_linear_velocity,
+              in->base_angular_velocity, in->desired_position, in->desired_orientation,
+              in->desired_linear_velocity, in->desired_angular_velocity, in->support_leg, nullptr};
+  const unsigned grid = (unsigned)((batch + 63) / 64);
+  hipLaunchKernelGGL(virtual_wrench_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, ctx->params, s, batch,
+                     wrench);
+  return hipGetLastError() == hipSuccess ? QLAMD_OK : QLAMD_ERR_HIP;
+}
+
+int qlamd_leg_kinematics_batch(qlamd_context *ctx, const double *joint_position, const double *base_orientation,
+                               int64_t batch, double *foot_position, double *jacobian, double *gravity_torque,
+                               int memory, void *stream) {
+  if (!ctx || !joint_position || !base_orientation || batch < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE) return QLAMD_ERR_INVALID_ARGUMENT; // device buffers only
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  const unsigned grid = (unsigned)((4 * batch + 63) / 64);
+  hipLaunchKernelGGL(leg_kinematics_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, ctx->params,
+                     joint_position, base_orientation, batch, foot_position, jacobian, gravity_torque);
+  return hipGetLastError() == hipSuccess ? QLAMD_OK : QLAMD_ERR_HIP;
+}
+
+} // extern "C"

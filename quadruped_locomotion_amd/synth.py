@@ -60,6 +60,9 @@ def make_states(batch, gait="static", seed=SEED, offset=0):
     """
     u = _uniform(seed, offset, offset + batch)
     B = batch
+    # static stance: a robot holding its pose (small tracking errors, QP constraints mostly
+    # inactive); trot: large tracking errors that load the friction pyramid (active-set churn)
+    e_pos, e_rot, e_twist = (0.004, 0.005, 0.01) if gait == "static" else (0.02, 0.05, 0.1)
     sym = lambda c, half: (2.0 * u[:, c] - 1.0) * half  # noqa: E731
     c = 0
 
@@ -71,17 +74,17 @@ def make_states(batch, gait="static", seed=SEED, offset=0):
     yaw, roll, pitch = sym(c, np.pi), sym(c + 1, 0.1), sym(c + 2, 0.1)
     c += 3
     base_quat = _quat_mul(_quat_mul(_quat_axis(2, yaw), _quat_axis(1, pitch)), _quat_axis(0, roll))
-    base_linvel = np.stack([sym(c + k, 0.1) for k in range(3)], axis=1)
+    base_linvel = np.stack([sym(c + k, e_twist) for k in range(3)], axis=1)
     c += 3
-    base_angvel = np.stack([sym(c + k, 0.1) for k in range(3)], axis=1)
+    base_angvel = np.stack([sym(c + k, e_twist) for k in range(3)], axis=1)
     c += 3
-    des_pos = base_pos + np.stack([sym(c + k, 0.02) for k in range(3)], axis=1)
+    des_pos = base_pos + np.stack([sym(c + k, e_pos) for k in range(3)], axis=1)
     c += 3
-    des_quat = _quat_mul(_quat_exp(np.stack([sym(c + k, 0.05) for k in range(3)], axis=1)), base_quat)
+    des_quat = _quat_mul(_quat_exp(np.stack([sym(c + k, e_rot) for k in range(3)], axis=1)), base_quat)
     c += 3
-    des_linvel = np.stack([sym(c + k, 0.1) for k in range(3)], axis=1)
+    des_linvel = np.stack([sym(c + k, e_twist) for k in range(3)], axis=1)
     c += 3
-    des_angvel = np.stack([sym(c + k, 0.1) for k in range(3)], axis=1)
+    des_angvel = np.stack([sym(c + k, e_twist) for k in range(3)], axis=1)
     c += 3
     stance = np.ones((B, 4), dtype=np.uint8)
 

@@ -1,0 +1,67 @@
+// TEST INFRASTRUCTURE ONLY -- never part of the product library.
+//
+// Compiles the per-robot device arithmetic (csrc/balance_core.hpp) for the
+// HOST with g++, so that CPU-only tests (-m "not gpu") can check the kernel's
+// math against the oracle without a GPU.  The product C-ABI never calls this;
+// it fails with QLAMD_ERR_NO_DEVICE when no GPU is present.
+#include <cstdint>
+
+#include "balance_core.hpp"
+#include "params_build.hpp"
+
+using namespace qlamd;
+
+static void load(RobotIn &in, const double *q, const double *pos, const double *quat, const double *lv,
+                 const double *av, const double *dpos, const double *dquat, const double *dlv, const double *dav,
+                 const uint8_t *stance) {
+  for (int i = 0; i < 12; i++) in.q[i] = q[i];
+  for (int i = 0; i < 3; i++) {
+    in.pos[i] = pos[i]; in.linvel[i] = lv[i]; in.angvel[i] = av[i];
+    in.dpos[i] = dpos[i]; in.dlinvel[i] = dlv[i]; in.dangvel[i] = dav[i];
+  }
+  for (int i = 0; i < 4; i++) { in.quat[i] = quat[i]; in.dquat[i] = dquat[i]; }
+  in.stance = 0;
+  for (int l = 0; l < 4; l++) if (stance[l]) in.stance |= 1u << l;
+}
+
+extern "C" void mirror_balance_batch(const qlamd_balance_params *prm, int64_t B, const double *q,
+                                     const double *pos, const double *quat, const double *lv, const double *av,
+                                     const double *dpos, const double *dquat, const double *dlv,
+                                     const double *dav, const uint8_t *stance, const double *normals,
+                                     double *tau, double *grf, int32_t *status, int32_t *iters,
+                                     int32_t *n_active) {
+  qlamd_robot_model model;
+  default_robot_model(&model);
+  DeviceParams P;
+  build_device_params(*prm, model, &P);
+  for (int64_t i = 0; i < B; i++) {
+    RobotIn in;
+    load(in, q + 12 * i, pos + 3 * i, quat + 4 * i, lv + 3 * i, av + 3 * i, dpos + 3 * i, dquat + 4 * i,
+         dlv + 3 * i, dav + 3 * i, stance + 4 * i);
+    HostScratch scr;
+    RobotOut out;
+    if (normals) balance_robot<true>(P, in, normals + 12 * i, scr, out);
+    else balance_robot<false>(P, in, nullptr, scr, out);
+    for (int k = 0; k < 12; k++) { tau[12 * i + k] = out.tau[k]; if (grf) grf[12 * i + k] = out.grf[k]; }
+    status[i] = out.status;
+    if (iters) iters[i] = out.iters;
+    if (n_active) n_active[i] = out.n_active;
+  }
+}
+
+extern "C" void mirror_leg_kinematics(const double *q3, int leg, const double *g, double *p, double *J,
+                                      double *Gq) {
+  qlamd_balance_params prm;
+  default_balance_params(&prm);
+  qlamd_robot_model model;
+  default_robot_model(&model);
+  DeviceParams P;
+  build_device_params(prm, model, &P);
+  LegFrames F;
+  leg_frames(P, leg, q3, F);
+  for (int i = 0; i < 3; i++) p[i] = F.p[3][i];
+  leg_jac_grav(P, leg, F, g, J, Gq);
+}
+
+extern "C" void mirror_sincos(double x, double *s, double *c) { sincos_reduced(x, *s, *c); }
+extern "C" void mirror_default_params(qlamd_balance_params *p) { default_balance_params(p); }

@@ -1,0 +1,167 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle."""
+import numpy as np
+import pytest
+
+from quadruped_locomotion_amd import synth
+
+pytestmark = pytest.mark.gpu
+TAU_TOL = 1e-6  # BASELINE.json north_star: joint torques within 1e-6 of the reference CPU solve
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    from quadruped_locomotion_amd import capi
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    capi.lib()  # raises if the HIP extension is missing: no silent fallback
+    ctx = capi.Context(device=0)
+    yield capi, ctx, torch
+    ctx.close()
+
+
+def solve_device(gpu, state, normals=None, rpw=0):
+    capi, ctx, torch = gpu
+    ctx.set_robots_per_wave(rpw)
+    B = state["q"].shape[0]
+    d = capi.to_device(state)
+    if normals is not None:
+        d["normals"] = torch.from_numpy(np.ascontiguousarray(normals)).to("cuda:0")
+    tau = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+    grf = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+    status = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+    ctx.balance_solve_device(d, tau, grf, status, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ctx.set_robots_per_wave(0)
+    return tau.cpu().numpy(), grf.cpu().numpy(), status.cpu().numpy()
+
+
+@pytest.mark.parametrize("gait", ["static", "trot"])
+@pytest.mark.parametrize("rpw", [0, 4, 16, 64])
+def test_batch_4096_matches_oracle(gpu, oracle, gait, rpw):
+    """BASELINE configs 2 and 3 at full size, every launch geometry."""
+    s = synth.make_states(4096, gait)
+    tau, grf, status = solve_device(gpu, s, rpw=rpw)
+    t0, g0, s0 = oracle.balance_batch(s, nthreads=8)
+    assert (status == s0).all() and (status == 0).all()
+    err = np.abs(tau - t0).max(axis=1)
+    assert err.max() < TAU_TOL, err.max()
+    assert np.median(err) < 1e-9
+    assert np.abs(grf - g0).max() < 1e-6
+
+
+def test_device_equals_host_mirror(gpu, oracle, mirror):
+    """The same arithmetic compiled for the host: agreement far below the oracle tolerance
+    (differences come only from FMA contraction and libm vs device sqrt/acos)."""
+    s = synth.make_states(2048, "trot")
+    tau, grf, status = solve_device(gpu, s)
+    t1, g1, s1, _, _ = mirror.balance(oracle, s)
+    assert (status == s1).all()
+    assert np.abs(tau - t1).max() < 1e-7
+
+
+def test_contact_subsets_and_ragged_sizes(gpu, oracle):
+    base = synth.make_states(37, "trot")
+    for mask in range(16):
+        s = {k: v.copy() for k, v in base.items()}
+        s["stance"][:] = [(mask >> l) & 1 for l in range(4)]
+        tau, grf, status = solve_device(gpu, s)
+        t0, g0, s0 = oracle.balance_batch(s)
+        assert (status == s0).all()
+        ok = status == 0
+        assert np.abs(tau[ok] - t0[ok]).max(initial=0.0) < TAU_TOL
+        if mask == 0:
+            assert np.all(tau == 0) and np.all(grf == 0)
+    for B in (1, 3, 63, 65, 4097):
+        s = synth.make_states(B, "trot")
+        tau, grf, status = solve_device(gpu, s)
+        t0, _, s0 = oracle.balance_batch(s)
+        assert (status == s0).all() and np.abs(tau - t0).max() < TAU_TOL
+
+
+def test_per_leg_surface_normals(gpu, oracle):
+    s = synth.make_states(512, "trot")
+    rng = np.random.default_rng(5)
+    nw = np.tile(np.array([0, 0, 1.0]), (512, 4, 1)) + 0.15 * rng.normal(size=(512, 4, 3))
+    nw /= np.linalg.norm(nw, axis=2, keepdims=True)
+    tau, grf, status = solve_device(gpu, s, normals=nw.reshape(512, 12))
+    t0, g0, s0 = oracle.balance_batch(s, normals_world=nw.reshape(512, 12))
+    assert (status == s0).all()
+    ok = status == 0
+    assert ok.sum() > 400 and np.abs(tau[ok] - t0[ok]).max() < TAU_TOL
+
+
+def test_host_memory_mode(gpu, oracle):
+    """C1: a single robot with host buffers (the reference's own calling pattern), and a batch."""
+    capi, ctx, torch = gpu
+    for B in (1, 500):
+        s = synth.make_states(B, "static")
+        tau, grf, status = ctx.balance_solve_host(s)
+        t0, g0, s0 = oracle.balance_batch(s)
+        assert (status == 0).all() and np.abs(tau - t0).max() < TAU_TOL and np.abs(grf - g0).max() < 1e-6
+
+
+def test_full_size_properties(gpu):
+    """Size-independent properties at 65536 robots (config 4's global batch): constraints hold,
+    non-support legs are silent, torques are clamped, reruns are bitwise reproducible."""
+    capi, ctx, torch = gpu
+    s = synth.make_states(65536, "trot")
+    tau, grf, status = solve_device(gpu, s)
+    tau2, grf2, status2 = solve_device(gpu, s)
+    assert np.array_equal(tau, tau2) and np.array_equal(grf, grf2)
+    assert (status == 0).all()
+    st = s["stance"].astype(bool)
+    f = grf.reshape(-1, 4, 3)
+    assert np.all(f[~st] == 0) and np.all(tau.reshape(-1, 4, 3)[~st] == 0)
+    assert np.abs(tau).max() <= 300.0
+    fz = f[..., 2][st]
+    assert fz.min() >= 10.0 - 1e-6                                  # minimal normal force
+    # friction pyramid in the base frame: n = z, t1/t2 span the xy plane
+    fxy = np.abs(f[..., :2]).max(axis=2)[st]
+    assert np.all(fxy <= 0.6 * np.sqrt(2) * fz + 1e-6)
+
+
+def test_kkt_optimality_on_sample(gpu, oracle):
+    """The returned forces minimise the QP: stationarity on the active face, checked with the
+    oracle's assembly of the problem (independent of both solvers' iterations)."""
+    s = synth.make_states(256, "trot")
+    tau, grf, status = solve_device(gpu, s)
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    from gen_goldens import force_qp_of_state
+    for i in range(0, 256, 8):
+        legs = [l for l in range(4) if s["stance"][i][l]]
+        G, g0, CI, ci0 = force_qp_of_state(s, i)
+        x = np.concatenate([grf[i][3 * l:3 * l + 3] for l in legs])
+        slack = CI.T @ x + ci0
+        assert slack.min() > -1e-6
+        act = slack < 1e-6
+        grad = G @ x + g0
+        if act.any():
+            u, *_ = np.linalg.lstsq(CI[:, act], grad, rcond=None)
+            assert np.abs(CI[:, act] @ u - grad).max() < 1e-5 * max(1.0, np.abs(grad).max())
+            assert u.min() > -1e-6
+        else:
+            assert np.abs(grad).max() < 1e-6 * max(1.0, np.abs(g0).max())
+
+
+def test_wrench_and_kinematics_kernels(gpu, oracle):
+    capi, ctx, torch = gpu
+    s = synth.make_states(300, "trot")
+    d = capi.to_device(s)
+    w = torch.zeros(300, 6, dtype=torch.float64, device="cuda:0")
+    ctx.virtual_wrench_device(d, w)
+    foot = torch.zeros(300, 4, 3, dtype=torch.float64, device="cuda:0")
+    jac = torch.zeros(300, 4, 9, dtype=torch.float64, device="cuda:0")
+    grav = torch.zeros(300, 4, 3, dtype=torch.float64, device="cuda:0")
+    ctx.leg_kinematics_device(d["q"], d["base_quat"], foot, jac, grav)
+    torch.cuda.synchronize()
+    w, foot, jac, grav = (t.cpu().numpy() for t in (w, foot, jac, grav))
+    for i in range(0, 300, 7):
+        assert np.allclose(w[i], oracle.virtual_wrench(s, i), rtol=1e-12, atol=1e-9)
+        Rm = oracle.quat_to_matrix(s["base_quat"][i])
+        gB = Rm.T @ np.array([0, 0, -9.8])
+        for l in range(4):
+            q = s["q"][i][3 * l:3 * l + 3]
+            assert np.allclose(foot[i, l], oracle.leg_fk(l, q)[0], atol=1e-13)
+            assert np.allclose(jac[i, l].reshape(3, 3), oracle.leg_jacobian(l, q), atol=1e-13)
+            assert np.allclose(grav[i, l], oracle.leg_gravity(l, q, gB), atol=1e-12)

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz with the REFERENCE's own compiled QuadProg++.
+
+Runs only where /root/reference exists (build container).  The reference
+solver is compiled from its sources where they lie (oracle/Makefile target
+`ref` -> oracle/_ref/libquadprog_ref.so); this script feeds it problems and
+stores inputs + outputs.  Nothing of the reference's source text is stored.
+
+  qp_goldens.npz   force-distribution QPs (n=12/m=20 and n=6/m=10) assembled per
+                   ContactForceDistribution.cpp:168-336 from seeded synthetic
+                   states, plus the literals of qp_solver/src/main.cc:46-101
+                   (with and without its dummy equality column)
+                   and qp_solver/src/qp_solve_test.cpp:39-57.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+from quadruped_locomotion_amd import synth  # noqa: E402
+
+
+def force_qp_of_state(s, i):
+    stance = s["stance"][i]
+    legs = [l for l in range(4) if stance[l]]
+    Rm = O.quat_to_matrix(s["base_quat"][i])
+    rf = np.array([O.leg_fk(l, s["q"][i][3 * l:3 * l + 3])[0] for l in legs])
+    yB = Rm.T @ np.array([0.0, 1.0, 0.0])
+    nB = Rm.T @ (Rm @ np.array([0.0, 0.0, 1.0]))
+    t1 = np.cross(nB, yB); t1 /= np.linalg.norm(t1)
+    t2 = np.cross(nB, t1); t2 /= np.linalg.norm(t2)
+    nS = len(legs)
+    w = O.virtual_wrench(s, i)
+    return O.force_qp_assemble(rf, w, np.tile(nB, (nS, 1)), np.tile(t1, (nS, 1)), np.tile(t2, (nS, 1)))
+
+
+def main():
+    assert O.ref_lib() is not None, "build oracle/_ref first: make -C oracle ref"
+    out = {}
+    # ---- force QPs -------------------------------------------------------------
+    trot = synth.make_states(4096, "trot", seed=synth.SEED)
+    static = synth.make_states(512, "static", seed=synth.SEED)
+    four = [("static", i) for i in range(64)] + [("trot", i) for i in range(4096) if trot["stance"][i].sum() == 4][:64]
+    two = [("trot", i) for i in range(4096) if trot["stance"][i].sum() == 2][:128]
+    for name, items, n, m in (("n12", four, 12, 20), ("n6", two, 6, 10)):
+        G = np.zeros((len(items), n, n)); g0 = np.zeros((len(items), n))
+        CI = np.zeros((len(items), n, m)); ci0 = np.zeros((len(items), m))
+        x = np.zeros((len(items), n)); f = np.zeros(len(items)); st = np.zeros(len(items), dtype=np.int32)
+        for k, (src, i) in enumerate(items):
+            s = static if src == "static" else trot
+            G[k], g0[k], CI[k], ci0[k] = force_qp_of_state(s, i)
+            r = O.ref_solve_quadprog(G[k], g0[k], None, None, CI[k], ci0[k])
+            x[k], f[k], st[k] = r["x"], r["f"], r["status"]
+        out.update({name + "_G": G, name + "_g0": g0, name + "_CI": CI, name + "_ci0": ci0,
+                    name + "_x": x, name + "_f": f, name + "_status": st})
+    # ---- literals of the reference's demo programs -----------------------------
+    G = np.array([[1.0, -1.0], [-1.0, 2.0]]); g0 = np.array([-2.0, -6.0])
+    CI = np.array([[-1.0, 1.0, -2.0], [-1.0, -2.0, -1.0]]); ci0 = np.array([2.0, 2.0, 3.0])
+    r_dummy = O.ref_solve_quadprog(G, g0, np.zeros((2, 1)), np.zeros(1), CI, ci0)   # main.cc as shipped
+    r_true = O.ref_solve_quadprog(G, g0, None, None, CI, ci0)
+    out.update(demo_G=G, demo_g0=g0, demo_CI=CI, demo_ci0=ci0, demo_x_dummy_eq=r_dummy["x"],
+               demo_f_dummy_eq=r_dummy["f"], demo_x=r_true["x"], demo_f=r_true["f"])
+    H = np.diag([8.0, 8.0, 10.0]); gq = np.array([-2.6327, -1.4383, 0.5])
+    A = -np.array([[-1.0531, -0.5753, 0.0], [1.4383, -2.6327, 0.0], [-0.3852, 3.2018, 0.0]])
+    b = np.array([1.2, 1.5, 0.3])
+    # A x <= b through the wrapper's sign convention CI = -A', ci0 = b (quadraticproblemsolver.cpp:164)
+    r3 = O.ref_solve_quadprog(H, gq, np.zeros((3, 1)), np.zeros(1), -A.T, b)
+    r3t = O.ref_solve_quadprog(H, gq, None, None, -A.T, b)
+    out.update(t3_H=H, t3_g=gq, t3_A=A, t3_b=b, t3_x_dummy_eq=r3["x"], t3_f_dummy_eq=r3["f"], t3_x=r3t["x"], t3_f=r3t["f"])
+    path = os.path.join(ROOT, "tests", "golden", "qp_goldens.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+    for k in ("n12", "n6"):
+        print(k, "status", np.bincount(out[k + "_status"]), "f range", out[k + "_f"].min(), out[k + "_f"].max())
+    print("demo", r_dummy["x"], r_dummy["f"], r_true["x"], r_true["f"])
+    print("t3", r3["x"], r3["f"], r3t["x"], r3t["f"])
+
+
+if __name__ == "__main__":
+    main()
