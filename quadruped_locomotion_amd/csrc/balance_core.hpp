@@ -8,12 +8,22 @@
 //   joint torques + clamp -> ContactForceDistribution.cpp:516-578,
 //                            ros_balance_controller.cpp:451-454
 //
-// The code is written for one robot per lane: everything a lane indexes with a
-// compile-time constant lives in VGPRs (the 12x12 Cholesky factor of the QP
-// Hessian included); the few arrays that need run-time indices (the Cholesky
-// factor of the active-set Schur complement, the multipliers) go through a
-// `Scratch` object that the kernel maps onto LDS with a [element][lane] layout
-// (bank = lane, so a per-lane index never conflicts).
+// Work split inside a wavefront (see balance_kernel.hip):
+//   phase A  one lane per (robot, leg): FK, translation Jacobian, gravity torque
+//   phase B  one lane per robot: wrench, QP assembly, Cholesky, active-set QP
+//   phase C  one lane per (robot, leg): tau = J'(-f) + G(q), clamp
+// Everything a lane indexes with a compile-time constant lives in VGPRs (the
+// 12x12 Cholesky factor of the QP Hessian included); arrays that need run-time
+// indices and the hand-over between phases go through a `Scratch` object that
+// the kernel maps onto LDS with an [element][robot] layout (bank = robot, so
+// a per-lane index never conflicts).
+//
+// Code size matters as much as flop count here: a wavefront runs this once,
+// so every instruction byte is fetched cold.  The QP is therefore written as
+// a state machine around ONE inlined copy of the 12x12 triangular solves
+// (states X0 / G / Z / POLISH / REBUILD differ only in how the right-hand
+// side is built and consumed); divergent lanes in different states still
+// share the solve's instruction stream.
 //
 // QP method.  The reference solves the force-distribution QP with OOQP; its
 // own dense solver is Goldfarb-Idnani (QuadProg++).  We keep the G-I iteration
@@ -50,13 +60,11 @@ struct DeviceParams {
   double grav;                 // g_W = (0,0,-grav)
   double Fg_scale;             // grav_comp * (torso + sum legs)  : F_g = -Fg_scale * g_B
   double Tg_arm[3];            // sum_l grav_comp*m_l*(hip_l - com) + grav_comp*m_torso*com : T_g = -(Tg_arm x g_B)
-  // leg chains: per [leg][segment] fixed rotation R0 (row-major), origin, mass, mass*com
-  double R0[4][4][9];
-  double xyz[4][4][3];
-  double mass[4][4];
-  double mcom[4][4][3];        // mass * com (link frame)
-  int rot_is_identity[4][4];   // R0 == I exactly (skips a 3x3 product)
+  // leg chains, 64 doubles per leg: R0[4][9] fixed rotations (row-major), xyz[4][3] joint
+  // origins, mass[4], mcom[4][3] = mass * com (link frame); offsets below
+  double legtab[4 * 64];
 };
+constexpr int kTabR0 = 0, kTabXyz = 36, kTabMass = 48, kTabMcom = 52, kTabPerLeg = 64;
 
 struct RobotIn {
   double q[12];
@@ -167,19 +175,44 @@ QL_HD void virtual_wrench(const DeviceParams &P, const RobotIn &in, const double
 
 // ------------------------------------------------------- leg kinematics ----
 
-// Cumulative frames of one leg chain.  Rc[k], pc[k]: pose of link k in base.
-struct LegFrames {
-  double R[4][9];
-  double p[4][3];
+// Scratch element space (doubles per robot), [element][robot] in LDS:
+//   C    91  packed lower Cholesky factor of the active-set Schur complement (12 rows) plus
+//            one more row for the candidate's tentative Schur row (q can reach 12)
+//   U    13  multipliers of the active constraints (+1 for the candidate)
+//   R    13  dual step direction
+//   UO   13  multipliers saved at the start of an outer iteration
+//   XO   12  x saved at the start of an outer iteration
+//   X0   12  unconstrained minimiser (final polish), then the final x for phase C
+//   FEET 12  foot positions in base (phase A -> B)
+//   JAC  36  translation Jacobians, row-major 3x3 per leg (phase A -> C)
+//   GQ   12  gravity torques (phase A -> C)
+//   STATUS 1 per-robot status as a double (phase B -> C)
+constexpr int kScrC = 0, kScrU = 91, kScrR = 104, kScrUo = 117, kScrXo = 130, kScrX0 = 142, kScrFeet = 154,
+              kScrJac = 166, kScrGq = 202, kScrStatus = 214, kScratchDoubles = 215;
+
+struct HostScratch {
+  double a[kScratchDoubles];
+  QL_HD double &at(int e) { return a[e]; }
 };
 
-QL_HD void leg_frames(const DeviceParams &P, int leg, const double q[3], LegFrames &F) {
+// FK + Jacobian + gravity torque of ONE leg (phase A).  `tab` = this leg's 64-double
+// block of DeviceParams::legtab (an LDS copy in the kernel: the leg differs per lane).
+//   T_seg(q) = Trans(xyz) R0 Rz(q)          (kdl_parser placement)
+//   J[:,i]   = z_i x (p_foot - p_i)         (ChainJntToJacSolver, quadrupedkinematics.cpp:214-278)
+//   G_i      = -g . (z_i x sum_{k>=i} m_k (c_k - p_i))   (ChainDynParam::JntToGravity, :485-552)
+template <class Tab>
+QL_HD void leg_kinematics(const Tab &tab, const double q[3], const double g[3], double foot[3], double J[9],
+                          double Gq[3]) {
   double Rc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   double pc[3] = {0, 0, 0};
+  double z[3][3], p[3][3], mc[3] = {0, 0, 0}; // joint axes, joint origins
+  double H[4][3];                              // m_k * c_k per link, base frame
   QL_UNROLL for (int k = 0; k < 4; k++) {
-    const double *R0 = P.R0[leg][k];
-    const double *t = P.xyz[leg][k];
-    double Rs[9]; // segment rotation R0 * Rz(q)
+    double R0[9], t[3], mcom[3];
+    QL_UNROLL for (int i = 0; i < 9; i++) R0[i] = tab[kTabR0 + 9 * k + i];
+    QL_UNROLL for (int i = 0; i < 3; i++) { t[i] = tab[kTabXyz + 3 * k + i]; mcom[i] = tab[kTabMcom + 3 * k + i]; }
+    const double m = tab[kTabMass + k];
+    double Rs[9];
     if (k < 3) {
       double s, c;
       sincos_reduced(q[k], s, c);
@@ -197,51 +230,79 @@ QL_HD void leg_frames(const DeviceParams &P, int leg, const double q[3], LegFram
     QL_UNROLL for (int i = 0; i < 3; i++)
       QL_UNROLL for (int j = 0; j < 3; j++)
         Rn[i * 3 + j] = Rc[i * 3] * Rs[j] + Rc[i * 3 + 1] * Rs[3 + j] + Rc[i * 3 + 2] * Rs[6 + j];
-    QL_UNROLL for (int i = 0; i < 9; i++) { Rc[i] = Rn[i]; F.R[k][i] = Rn[i]; }
-    QL_UNROLL for (int i = 0; i < 3; i++) { pc[i] = pn[i]; F.p[k][i] = pn[i]; }
+    QL_UNROLL for (int i = 0; i < 9; i++) Rc[i] = Rn[i];
+    QL_UNROLL for (int i = 0; i < 3; i++) {
+      pc[i] = pn[i];
+      H[k][i] = m * pn[i] + (Rn[i * 3] * mcom[0] + Rn[i * 3 + 1] * mcom[1] + Rn[i * 3 + 2] * mcom[2]);
+    }
+    if (k < 3) {
+      QL_UNROLL for (int i = 0; i < 3; i++) { z[k][i] = Rn[i * 3 + 2]; p[k][i] = pn[i]; }
+    }
+  }
+  (void)mc;
+  foot[0] = pc[0]; foot[1] = pc[1]; foot[2] = pc[2];
+  double Hs[3] = {H[3][0], H[3][1], H[3][2]};
+  double M = tab[kTabMass + 3];
+  QL_UNROLL for (int i = 2; i >= 0; i--) {
+    QL_UNROLL for (int a = 0; a < 3; a++) Hs[a] += H[i][a];
+    M += tab[kTabMass + i];
+    const double d[3] = {pc[0] - p[i][0], pc[1] - p[i][1], pc[2] - p[i][2]};
+    double v[3];
+    cross3(z[i], d, v);
+    J[0 * 3 + i] = v[0]; J[1 * 3 + i] = v[1]; J[2 * 3 + i] = v[2];
+    const double h[3] = {Hs[0] - M * p[i][0], Hs[1] - M * p[i][1], Hs[2] - M * p[i][2]};
+    double zh[3];
+    cross3(z[i], h, zh);
+    Gq[i] = -dot3(g, zh);
   }
 }
 
-// Translation Jacobian (column i = z_i x (p_foot - p_i)) and gravity torque
-// G_i = -g . (z_i x sum_{k>=i} m_k (c_k - p_i))  from the frames.
-QL_HD void leg_jac_grav(const DeviceParams &P, int leg, const LegFrames &F, const double g[3],
-                        double J[9], double Gq[3]) {
-  // mass-weighted COM offsets of the links in base coordinates
-  double mc[4][3];
-  QL_UNROLL for (int k = 0; k < 4; k++) {
-    const double *c = P.mcom[leg][k];
-    const double m = P.mass[leg][k];
-    QL_UNROLL for (int i = 0; i < 3; i++)
-      mc[k][i] = m * F.p[k][i] + (F.R[k][i * 3] * c[0] + F.R[k][i * 3 + 1] * c[1] + F.R[k][i * 3 + 2] * c[2]);
+// Phase A for one (robot, leg): results into the robot's scratch.
+template <class Tab, class Scratch>
+QL_HD void phase_a_leg(const Tab &tab, int leg, bool support, const double q[3], const double quat[4], double grav,
+                       Scratch &scr) {
+  double foot[3] = {0, 0, 0}, J[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Gq[3] = {0, 0, 0};
+  if (support) {
+    double Rm[9], gB[3];
+    quat_to_matrix(quat, Rm);
+    const double gW[3] = {0.0, 0.0, -grav};
+    irot(Rm, gW, gB); // ContactForceDistribution.cpp:518-519
+    leg_kinematics(tab, q, gB, foot, J, Gq);
   }
-  // suffix sums over distal links: M_i = sum_{k>=i} m_k, H_i = sum_{k>=i} m_k c_k
-  double H[3] = {mc[3][0], mc[3][1], mc[3][2]};
-  double M = P.mass[leg][3];
-  QL_UNROLL for (int i = 2; i >= 0; i--) {
-    QL_UNROLL for (int a = 0; a < 3; a++) H[a] += mc[i][a];
-    M += P.mass[leg][i];
-    const double z[3] = {F.R[i][2], F.R[i][5], F.R[i][8]};
-    const double d[3] = {F.p[3][0] - F.p[i][0], F.p[3][1] - F.p[i][1], F.p[3][2] - F.p[i][2]};
-    double v[3];
-    cross3(z, d, v);
-    J[0 * 3 + i] = v[0]; J[1 * 3 + i] = v[1]; J[2 * 3 + i] = v[2];
-    const double h[3] = {H[0] - M * F.p[i][0], H[1] - M * F.p[i][1], H[2] - M * F.p[i][2]};
-    double zh[3];
-    cross3(z, h, zh);
-    Gq[i] = -dot3(g, zh);
+  QL_UNROLL for (int a = 0; a < 3; a++) {
+    scr.at(kScrFeet + 3 * leg + a) = foot[a];
+    scr.at(kScrGq + 3 * leg + a) = Gq[a];
+  }
+  QL_UNROLL for (int a = 0; a < 9; a++) scr.at(kScrJac + 9 * leg + a) = J[a];
+}
+
+// Phase C for one (robot, leg): tau = J'(-x_leg) + G(q), clamped
+// (ContactForceDistribution.cpp:516-578, ros_balance_controller.cpp:451-454).
+template <class Scratch>
+QL_HD void phase_c_leg(int leg, bool live, double tau_max, Scratch &scr, double tau[3], double grf[3]) {
+  QL_UNROLL for (int j = 0; j < 3; j++) { tau[j] = 0.0; grf[j] = 0.0; }
+  if (!live) return;
+  double x[3], J[9];
+  QL_UNROLL for (int a = 0; a < 3; a++) x[a] = scr.at(kScrX0 + 3 * leg + a);
+  QL_UNROLL for (int a = 0; a < 9; a++) J[a] = scr.at(kScrJac + 9 * leg + a);
+  QL_UNROLL for (int j = 0; j < 3; j++) {
+    double t = (J[j] * -x[0] + J[3 + j] * -x[1] + J[6 + j] * -x[2]) + scr.at(kScrGq + 3 * leg + j);
+    t = t > tau_max ? tau_max : t;
+    t = t < -tau_max ? -tau_max : t;
+    tau[j] = t;
+    grf[j] = x[j];
   }
 }
 
 // -------------------------------------------------------------- the QP -----
 
-// Packed lower-triangular index.
 QL_HD constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 
 // Constraint ids: id = 5*leg + t;  t = 0: n.f >= f_min;  t = 1..4: (mu n +- t1/t2).f >= 0
 // in the reference's row order +t1, -t1, +t2, -t2 (ContactForceDistribution.cpp:314-325).
 QL_HD int id_leg(int id) { return (id * 13) >> 6; } // id / 5 for id < 20
 
-struct Pyramid { // friction pyramid directions in the base frame (one set; see kernel for per-leg normals)
+struct Pyramid { // friction pyramid directions in the base frame
   double n[3], t1[3], t2[3];
 };
 
@@ -254,44 +315,6 @@ QL_HD void constraint_normal(const Pyramid &py, double mu, int t, double nv[3]) 
   }
 }
 
-// y = L^-1 b, then x = L^-T y.  L packed lower, inv_d[i] = 1 / L_ii.
-QL_HD void chol_solve12(const double L[78], const double inv_d[12], const double b[12], double x[12]) {
-  double y[12];
-  QL_UNROLL for (int i = 0; i < 12; i++) {
-    double acc = b[i];
-    QL_UNROLL for (int j = 0; j < i; j++) acc -= L[tri(i, j)] * y[j];
-    y[i] = acc * inv_d[i];
-  }
-  QL_UNROLL for (int i = 11; i >= 0; i--) {
-    double acc = y[i];
-    QL_UNROLL for (int j = i + 1; j < 12; j++) acc -= L[tri(j, i)] * x[j];
-    x[i] = acc * inv_d[i];
-  }
-}
-
-// Scratch: run-time indexed per-robot arrays.  Layout of the element space:
-//   [0,78)    C   packed lower Cholesky factor of the Schur complement
-//   [78,91)   u   multipliers of the active constraints (+1 slot for the candidate)
-//   [91,104)  r   dual step direction
-//   [104,117) uo  multipliers saved at the start of an outer iteration
-//   [117,129) xo  x saved at the start of an outer iteration
-//   [129,141) x0  unconstrained minimiser (kept for the final polish)
-constexpr int kScrC = 0, kScrU = 78, kScrR = 91, kScrUo = 104, kScrXo = 117, kScrX0 = 129, kScratchDoubles = 141;
-
-struct HostScratch {
-  double a[kScratchDoubles];
-  QL_HD double &at(int e) { return a[e]; }
-};
-
-struct QpResult {
-  int status;
-  int iters;
-  int n_active;
-};
-
-// Solve  min 1/2 x'Gx + g0'x  s.t. the pyramid / minimum-force constraints of
-// the stance legs.  G (packed lower, 12x12, legs outside `stance` decoupled as
-// w*I) is overwritten by its Cholesky factor.
 template <bool kPerLeg>
 QL_HD Pyramid pick_pyramid(const Pyramid (&py)[4], int leg) {
   if (!kPerLeg) return py[0];
@@ -304,28 +327,47 @@ QL_HD Pyramid pick_pyramid(const Pyramid (&py)[4], int leg) {
   return o;
 }
 
+QL_HD void leg_part(const double v[12], int leg, double o[3]) {
+  QL_UNROLL for (int a = 0; a < 3; a++) o[a] = leg == 0 ? v[a] : leg == 1 ? v[3 + a] : leg == 2 ? v[6 + a] : v[9 + a];
+}
+
+// v (12) (+)= coef * nv placed in leg block `leg`
+QL_HD void leg_axpy(double v[12], int leg, double coef, const double nv[3]) {
+  QL_UNROLL for (int l = 0; l < 4; l++) {
+    const double c = (l == leg) ? coef : 0.0;
+    QL_UNROLL for (int a = 0; a < 3; a++) v[3 * l + a] += c * nv[a];
+  }
+}
+
+struct QpResult {
+  int status;
+  int iters;
+  int n_active;
+};
+
+// Solve  min 1/2 x'Gx + g0'x  s.t. the pyramid / minimum-force constraints of the stance
+// legs.  G: packed lower 12x12 (legs outside `stance` decoupled as w*I), overwritten by its
+// Cholesky factor with the RECIPROCAL diagonal stored on the diagonal.  The final x is left
+// in scratch [kScrX0, kScrX0+12).
 template <bool kPerLeg, class Scratch>
-QL_HD QpResult force_qp_solve(double G[78], const double g0[12], const Pyramid (&py)[4],
-                              double mu, double f_min, unsigned stance, int nS, Scratch &scr, double x[12]) {
+QL_HD QpResult force_qp_solve(double G[78], const double g0[12], const Pyramid (&py)[4], double mu, double f_min,
+                              unsigned stance, int nS, Scratch &scr) {
   QpResult res = {kStatusOk, 0, 0};
   const double eps = 2.220446049250313e-16;
   const double inf = INFINITY;
 
-  // --- Cholesky G = L L' (in place), c1 = trace(G), c2 = trace(L^-1) over the stance block
+  // --- Cholesky G = L L' (in place); c1 = trace(G), c2 = trace(L^-1) over the stance block
   double c1 = 0.0, c2 = 0.0;
-  double inv_d[12];
   bool not_pd = false;
-  QL_UNROLL for (int i = 0; i < 12; i++)
-    if ((stance >> (i / 3)) & 1u) c1 += G[tri(i, i)];
   QL_UNROLL for (int j = 0; j < 12; j++) {
+    const bool on = (stance >> (j / 3)) & 1u;
+    if (on) c1 += G[tri(j, j)];
     double d = G[tri(j, j)];
     QL_UNROLL for (int k = 0; k < j; k++) d -= G[tri(j, k)] * G[tri(j, k)];
     if (!(d > 0.0)) not_pd = true;
-    const double ljj = sqrt(d);
-    const double inv = 1.0 / ljj;
-    G[tri(j, j)] = ljj;
-    inv_d[j] = inv;
-    if ((stance >> (j / 3)) & 1u) c2 += inv;
+    const double inv = 1.0 / sqrt(d);
+    G[tri(j, j)] = inv;
+    if (on) c2 += inv;
     QL_UNROLL for (int i = j + 1; i < 12; i++) {
       double acc = G[tri(i, j)];
       QL_UNROLL for (int k = 0; k < j; k++) acc -= G[tri(i, k)] * G[tri(j, k)];
@@ -335,293 +377,100 @@ QL_HD QpResult force_qp_solve(double G[78], const double g0[12], const Pyramid (
   if (not_pd) { res.status = kStatusNotPd; return res; }
   const double *L = G;
 
-  // --- unconstrained minimiser x = -G^-1 g0
-  {
-    double ng[12];
-    QL_UNROLL for (int i = 0; i < 12; i++) ng[i] = -g0[i];
-    chol_solve12(L, inv_d, ng, x);
-    QL_UNROLL for (int i = 0; i < 12; i++) scr.at(kScrX0 + i) = x[i];
-  }
-
   const int m = 5 * nS;
   const double psi_tol = (double)m * eps * c1 * c2 * 100.0; // QuadProg++.cc:246
-  uint64_t act = 0;      // active ids, 5 bits each, position k at bits [5k, 5k+5)
-  unsigned act_mask = 0; // bit id set <=> active
-  int q = 0;
+  uint64_t act = 0, act_old = 0; // active ids, 5 bits each, position k at bits [5k, 5k+5)
+  unsigned act_mask = 0, excl = 0;
+  int q = 0, q_old = 0;
   double rnorm = 1.0;
 
   const auto leg_pyr = [&](int leg) -> Pyramid { return pick_pyramid<kPerLeg>(py, leg); };
-
-  // slack of constraint (leg, t) at x
-  const auto slack = [&](int leg, int t, const double xx[12]) -> double {
-    double xl[3];
-    QL_UNROLL for (int a = 0; a < 3; a++)
-      xl[a] = leg == 0 ? xx[a] : leg == 1 ? xx[3 + a] : leg == 2 ? xx[6 + a] : xx[9 + a];
-    double nv[3];
+  const auto act_id = [&](int k) -> int { return (int)((act >> (5 * k)) & 31u); };
+  const auto slack = [&](int id, const double xx[12]) -> double {
+    const int leg = id_leg(id), t = id - 5 * leg;
+    double xl[3], nv[3];
+    leg_part(xx, leg, xl);
     constraint_normal(leg_pyr(leg), mu, t, nv);
     return dot3(nv, xl) - (t == 0 ? f_min : 0.0);
   };
 
-  for (int outer = 0; outer < kMaxOuter; outer++) {
-    res.iters++;
-    // ---- step 1: slacks of the inactive constraints, sum of infeasibilities
-    double psi = 0.0, ss = 0.0;
-    int ip = -1;
-    unsigned excl = 0;
-    // reference order: all minimum-force rows first, then the friction rows leg by leg
-    QL_UNROLL for (int pass = 0; pass < 2; pass++) {
-      QL_UNROLL for (int leg = 0; leg < 4; leg++) {
-        if (!((stance >> leg) & 1u)) continue;
-        const Pyramid &pl = py[kPerLeg ? leg : 0];
-        const double dn = pl.n[0] * x[3 * leg] + pl.n[1] * x[3 * leg + 1] + pl.n[2] * x[3 * leg + 2];
-        if (pass == 0) {
-          const double s = dn - f_min;
-          psi += fmin(0.0, s);
-          if (s < ss && !((act_mask >> (5 * leg)) & 1u)) { ss = s; ip = 5 * leg; }
-        } else {
-          const double d1 = pl.t1[0] * x[3 * leg] + pl.t1[1] * x[3 * leg + 1] + pl.t1[2] * x[3 * leg + 2];
-          const double d2 = pl.t2[0] * x[3 * leg] + pl.t2[1] * x[3 * leg + 1] + pl.t2[2] * x[3 * leg + 2];
-          const double sv[4] = {mu * dn + d1, mu * dn - d1, mu * dn + d2, mu * dn - d2};
-          QL_UNROLL for (int t = 1; t <= 4; t++) {
-            const double s = sv[t - 1];
+  enum { kX0, kSelect, kG, kZ, kPolish, kRebuild, kDone };
+  int state = kX0;
+  bool fresh = true;        // kSelect: start of an outer iteration (label l1) vs. re-selection (l2)
+  int ip = -1, pleg = 0, pt = 0, pass = 0, kk = 0;
+  double x[12], v[12], npv[3] = {0, 0, 0};
+  double sp = 0.0, ss = 0.0, dd = 0.0;
+  QL_UNROLL for (int i = 0; i < 12; i++) { x[i] = 0.0; v[i] = 0.0; }
+
+  for (int tick = 0; tick < 40 * kMaxOuter; tick++) {
+    // ------------------------------------------------ pre: choose a candidate
+    if (state == kSelect) {
+      if (fresh) { res.iters++; excl = 0; }
+      double psi = 0.0;
+      ss = 0.0; ip = -1;
+      const unsigned blocked = act_mask | excl;
+      // reference row order: all minimum-force rows, then the friction rows leg by leg
+      QL_UNROLL for (int ps = 0; ps < 2; ps++) {
+        QL_UNROLL for (int leg = 0; leg < 4; leg++) {
+          if (!((stance >> leg) & 1u)) continue;
+          const Pyramid &pl = py[kPerLeg ? leg : 0];
+          const double dn = pl.n[0] * x[3 * leg] + pl.n[1] * x[3 * leg + 1] + pl.n[2] * x[3 * leg + 2];
+          if (ps == 0) {
+            const double s = dn - f_min;
             psi += fmin(0.0, s);
-            if (s < ss && !((act_mask >> (5 * leg + t)) & 1u)) { ss = s; ip = 5 * leg + t; }
+            if (s < ss && !((blocked >> (5 * leg)) & 1u)) { ss = s; ip = 5 * leg; }
+          } else {
+            const double d1 = pl.t1[0] * x[3 * leg] + pl.t1[1] * x[3 * leg + 1] + pl.t1[2] * x[3 * leg + 2];
+            const double d2 = pl.t2[0] * x[3 * leg] + pl.t2[1] * x[3 * leg + 1] + pl.t2[2] * x[3 * leg + 2];
+            const double sv[4] = {mu * dn + d1, mu * dn - d1, mu * dn + d2, mu * dn - d2};
+            QL_UNROLL for (int t = 1; t <= 4; t++) {
+              const double s = sv[t - 1];
+              psi += fmin(0.0, s);
+              if (s < ss && !((blocked >> (5 * leg + t)) & 1u)) { ss = s; ip = 5 * leg + t; }
+            }
           }
         }
       }
+      const bool feasible = fresh && (fabs(psi) <= psi_tol); // QuadProg++.cc:246-250
+      if (feasible || ip < 0 || res.iters > kMaxOuter) {      // :271-274
+        if (res.iters > kMaxOuter) res.status = kStatusMaxIter;
+        state = (q > 0 && res.status == kStatusOk) ? kPolish : kDone;
+        pass = 0;
+        if (state == kDone) {
+          QL_UNROLL for (int i = 0; i < 12; i++) scr.at(kScrX0 + i) = x[i];
+        }
+      } else {
+        if (fresh) { // save for the degenerate rollback, QuadProg++.cc:252-260
+          act_old = act; q_old = q;
+          for (int k = 0; k < q; k++) scr.at(kScrUo + k) = scr.at(kScrU + k);
+          QL_UNROLL for (int i = 0; i < 12; i++) scr.at(kScrXo + i) = x[i];
+        }
+        pleg = id_leg(ip); pt = ip - 5 * pleg;
+        constraint_normal(leg_pyr(pleg), mu, pt, npv);
+        sp = ss;
+        scr.at(kScrU + q) = 0.0;
+        state = kG;
+      }
     }
-    if (fabs(psi) <= psi_tol) break; // numerically feasible, QuadProg++.cc:246-250
-    if (ip < 0) break;               // nothing violated among the inactive rows, :271-274
+    if (state == kDone) break;
 
-    // save state for the (rare) degenerate rollback, QuadProg++.cc:252-260
-    const uint64_t act_old = act;
-    const int q_old = q;
-    for (int k = 0; k < q; k++) scr.at(kScrUo + k) = scr.at(kScrU + k);
-    QL_UNROLL for (int i = 0; i < 12; i++) scr.at(kScrXo + i) = x[i];
-
-    bool next_outer = false;
-    while (!next_outer) { // ---- step 2: a candidate ip
-      const int pleg = id_leg(ip), pt = ip - 5 * pleg;
-      double npv[3];
-      constraint_normal(leg_pyr(pleg), mu, pt, npv);
-      double sp = ss;
-      scr.at(kScrU + q) = 0.0;
-
-      bool stepping = true;
-      int guard = 0;
-      while (stepping) { // ---- step 2a: direction; 2b: step length; 2c: step
-        if (++guard > 64) { res.status = kStatusMaxIter; return res; }
-        // g = G^-1 n_p
-        double np12[12], g[12];
-        QL_UNROLL for (int l = 0; l < 4; l++)
-          QL_UNROLL for (int a = 0; a < 3; a++) np12[3 * l + a] = (l == pleg) ? npv[a] : 0.0;
-        chol_solve12(L, inv_d, np12, g);
-        // Schur column c = N' g; solve C y = c; r = C^-T y; v = n_p - N r
-        double v[12];
-        QL_UNROLL for (int i = 0; i < 12; i++) v[i] = np12[i];
-        double z[12];
-        if (q > 0) {
-          for (int k = 0; k < q; k++) {
-            const int id = (int)((act >> (5 * k)) & 31u);
-            const int leg = id_leg(id), t = id - 5 * leg;
-            double nk[3], gl[3];
-            constraint_normal(leg_pyr(leg), mu, t, nk);
-            QL_UNROLL for (int a = 0; a < 3; a++)
-              gl[a] = leg == 0 ? g[a] : leg == 1 ? g[3 + a] : leg == 2 ? g[6 + a] : g[9 + a];
-            double acc = dot3(nk, gl);
-            for (int j = 0; j < k; j++) acc -= scr.at(kScrC + tri(k, j)) * scr.at(kScrR + j);
-            scr.at(kScrR + k) = acc / scr.at(kScrC + tri(k, k)); // y_k (kept in r)
-          }
-          for (int k = q - 1; k >= 0; k--) {
-            double acc = scr.at(kScrR + k);
-            for (int j = k + 1; j < q; j++) acc -= scr.at(kScrC + tri(j, k)) * scr.at(kScrR + j);
-            const double rk = acc / scr.at(kScrC + tri(k, k));
-            scr.at(kScrR + k) = rk;
-            const int id = (int)((act >> (5 * k)) & 31u);
-            const int leg = id_leg(id), t = id - 5 * leg;
-            double nk[3];
-            constraint_normal(leg_pyr(leg), mu, t, nk);
-            QL_UNROLL for (int l = 0; l < 4; l++) {
-              const double coef = (l == leg) ? rk : 0.0;
-              QL_UNROLL for (int a = 0; a < 3; a++) v[3 * l + a] -= coef * nk[a];
-            }
-          }
-          chol_solve12(L, inv_d, v, z);
-        } else {
-          QL_UNROLL for (int i = 0; i < 12; i++) z[i] = g[i];
-        }
-        double zl[3];
-        QL_UNROLL for (int a = 0; a < 3; a++)
-          zl[a] = pleg == 0 ? z[a] : pleg == 1 ? z[3 + a] : pleg == 2 ? z[6 + a] : z[9 + a];
-        const double zn = dot3(zl, npv);
-        double zz = 0.0;
-        QL_UNROLL for (int i = 0; i < 12; i++) zz += z[i] * z[i];
-
-        // step lengths, QuadProg++.cc:304-331
-        double t1 = inf;
-        int lpos = -1;
-        for (int k = 0; k < q; k++) {
-          const double rk = scr.at(kScrR + k);
-          if (rk > 0.0) {
-            const double ratio = scr.at(kScrU + k) / rk;
-            if (ratio < t1) { t1 = ratio; lpos = k; }
-          }
-        }
-        double t2 = inf;
-        if (fabs(zz) > eps) {
-          t2 = -sp / zn;
-          if (t2 < 0.0) t2 = inf;
-        }
-        const double t = fmin(t1, t2);
-        if (t >= inf) { res.status = kStatusInfeasible; return res; } // :339-344
-
-        const bool dual_only = (t2 >= inf);
-        if (!dual_only) {
-          QL_UNROLL for (int i = 0; i < 12; i++) x[i] += t * z[i];
-        }
-        for (int k = 0; k < q; k++) scr.at(kScrU + k) -= t * scr.at(kScrR + k);
-        scr.at(kScrU + q) += t;
-
-        if (!dual_only && fabs(t - t2) < eps) {
-          // ---- full step: constraint ip becomes active, :384-421
-          // new Schur row: [y', delta], y = C^-1 N'g, delta^2 = n_p'g - y'y  ( = z'n_p )
-          double gl[3];
-          QL_UNROLL for (int a = 0; a < 3; a++)
-            gl[a] = pleg == 0 ? g[a] : pleg == 1 ? g[3 + a] : pleg == 2 ? g[6 + a] : g[9 + a];
-          double dd = dot3(npv, gl);
-          for (int k = 0; k < q; k++) {
-            const int id = (int)((act >> (5 * k)) & 31u);
-            const int leg = id_leg(id), tt = id - 5 * leg;
-            double nk[3], gk[3];
-            constraint_normal(leg_pyr(leg), mu, tt, nk);
-            QL_UNROLL for (int a = 0; a < 3; a++)
-              gk[a] = leg == 0 ? g[a] : leg == 1 ? g[3 + a] : leg == 2 ? g[6 + a] : g[9 + a];
-            double acc = dot3(nk, gk);
-            for (int j = 0; j < k; j++) acc -= scr.at(kScrC + tri(k, j)) * scr.at(kScrC + tri(q, j));
-            const double yk = acc / scr.at(kScrC + tri(k, k));
-            scr.at(kScrC + tri(q, k)) = yk;
-            dd -= yk * yk;
-          }
-          const double delta = dd > 0.0 ? sqrt(dd) : 0.0;
-          if (delta <= eps * rnorm) {
-            // degenerate: exclude ip, restore the state saved at step 1, pick another, :392-412
-            excl |= 1u << ip;
-            act = act_old; q = q_old;
-            act_mask = 0;
-            for (int k = 0; k < q; k++) {
-              act_mask |= 1u << (int)((act >> (5 * k)) & 31u);
-              scr.at(kScrU + k) = scr.at(kScrUo + k);
-            }
-            QL_UNROLL for (int i = 0; i < 12; i++) x[i] = scr.at(kScrXo + i);
-            // rebuild the Schur factor of the restored working set
-            for (int kk = 0; kk < q; kk++) {
-              const int idn = (int)((act >> (5 * kk)) & 31u);
-              const int legn = id_leg(idn), tn = idn - 5 * legn;
-              double nn[3], nn12[12], gn[12];
-              constraint_normal(leg_pyr(legn), mu, tn, nn);
-              QL_UNROLL for (int l = 0; l < 4; l++)
-                QL_UNROLL for (int a = 0; a < 3; a++) nn12[3 * l + a] = (l == legn) ? nn[a] : 0.0;
-              chol_solve12(L, inv_d, nn12, gn);
-              double d2 = 0.0;
-              for (int k = 0; k <= kk; k++) {
-                const int id = (int)((act >> (5 * k)) & 31u);
-                const int leg = id_leg(id), tt = id - 5 * leg;
-                double nk[3], gk[3];
-                constraint_normal(leg_pyr(leg), mu, tt, nk);
-                QL_UNROLL for (int a = 0; a < 3; a++)
-                  gk[a] = leg == 0 ? gn[a] : leg == 1 ? gn[3 + a] : leg == 2 ? gn[6 + a] : gn[9 + a];
-                double acc = dot3(nk, gk);
-                for (int j = 0; j < k; j++) acc -= scr.at(kScrC + tri(k, j)) * scr.at(kScrC + tri(kk, j));
-                if (k < kk) {
-                  const double yk = acc / scr.at(kScrC + tri(k, k));
-                  scr.at(kScrC + tri(kk, k)) = yk;
-                } else {
-                  d2 = acc;
-                }
-              }
-              scr.at(kScrC + tri(kk, kk)) = sqrt(fmax(d2, 0.0));
-            }
-            // choose the next most violated admissible row at the restored x (label l2)
-            ss = 0.0; ip = -1;
-            QL_UNROLL for (int pass = 0; pass < 2; pass++)
-              QL_UNROLL for (int leg = 0; leg < 4; leg++) {
-                if (!((stance >> leg) & 1u)) continue;
-                QL_UNROLL for (int tt = (pass ? 1 : 0); tt <= (pass ? 4 : 0); tt++) {
-                  const int id = 5 * leg + tt;
-                  if (((act_mask | excl) >> id) & 1u) continue;
-                  const double s = slack(leg, tt, x);
-                  if (s < ss) { ss = s; ip = id; }
-                }
-              }
-            if (ip < 0) return res.n_active = q, res; // :271-274
-            stepping = false; // back to step 2 with the new ip
-          } else {
-            scr.at(kScrC + tri(q, q)) = delta;
-            rnorm = fmax(rnorm, delta);
-            act |= (uint64_t)ip << (5 * q);
-            act_mask |= 1u << ip;
-            q++;
-            stepping = false;
-            next_outer = true;
-          }
-        } else {
-          // ---- partial step (or dual-only step): drop the blocking constraint, :346-362, :423-445
-          // Remove row lpos of C (C C' = N'G^-1 N) and restore the triangle.  Work in the OLD
-          // index space: for the column pair (c, c+1), c = lpos .. q-2, a rotation computed from
-          // old row c+1 zeroes its overhang; rows below are rotated; finally rows move up by one.
-          {
-            for (int c = lpos; c < q - 1; c++) {
-              // rotation from old row c+1: (C[c+1][c], C[c+1][c+1]) -> (h, 0)
-              const double a0 = scr.at(kScrC + tri(c + 1, c));
-              const double b0 = scr.at(kScrC + tri(c + 1, c + 1));
-              const double h = sqrt(a0 * a0 + b0 * b0);
-              const double cs = h > 0.0 ? a0 / h : 1.0, sn = h > 0.0 ? b0 / h : 0.0;
-              // rows below: i = c+2 .. q-1 : (C[i][c], C[i][c+1]) -> (cs*a + sn*b, -sn*a + cs*b)
-              for (int i = c + 2; i < q; i++) {
-                const double a = scr.at(kScrC + tri(i, c));
-                const double b = scr.at(kScrC + tri(i, c + 1));
-                scr.at(kScrC + tri(i, c)) = cs * a + sn * b;
-                scr.at(kScrC + tri(i, c + 1)) = -sn * a + cs * b;
-              }
-              scr.at(kScrC + tri(c + 1, c)) = h;
-              scr.at(kScrC + tri(c + 1, c + 1)) = 0.0;
-            }
-            // now shift rows lpos+1 .. q-1 up by one (row i -> i-1, columns 0 .. i-1)
-            for (int i = lpos + 1; i < q; i++)
-              for (int j = 0; j < i; j++) scr.at(kScrC + tri(i - 1, j)) = scr.at(kScrC + tri(i, j));
-          }
-          // drop from the lists (u[q] is the candidate's multiplier and moves down too)
-          const int id_drop = (int)((act >> (5 * lpos)) & 31u);
-          act_mask &= ~(1u << id_drop);
-          for (int k = lpos; k < q; k++) scr.at(kScrU + k) = scr.at(kScrU + k + 1);
-          {
-            const uint64_t low = act & ((1ull << (5 * lpos)) - 1ull);
-            const uint64_t high = (act >> (5 * (lpos + 1))) << (5 * lpos);
-            act = low | high;
-          }
-          q--;
-          if (!dual_only) sp = slack(pleg, pt, x); // :436-440
-        }
-      } // step 2a loop
-    }   // step 2 loop
-  }     // outer
-  if (res.iters >= kMaxOuter) res.status = kStatusMaxIter;
-  res.n_active = q;
-
-  // ---- final polish.  The Schur factor C carries cond(N'G^-1 N) ~ 1/w, so the iterates sit on
-  // the active rows only to ~1e-7.  With the working set known, recompute x from the unconstrained
-  // minimiser by the corrected semi-normal equations: u = M^-1 (b_A - N'x0), x1 = x0 + G^-1 N u,
-  // then one correction with the residual of the active rows at x1.
-  if (q > 0) {
-    QL_UNROLL for (int i = 0; i < 12; i++) x[i] = scr.at(kScrX0 + i);
-    QL_UNROLL for (int pass = 0; pass < 2; pass++) {
-      double v[12], dx[12];
-      QL_UNROLL for (int i = 0; i < 12; i++) v[i] = 0.0;
-      // rhs_k = b_k - n_k'x ; forward solve in place (kept in r)
+    // ------------------------------------------------ right-hand side by state
+    double rhs[12];
+    if (state == kX0) {
+      QL_UNROLL for (int i = 0; i < 12; i++) rhs[i] = -g0[i];
+    } else if (state == kG) {
+      QL_UNROLL for (int i = 0; i < 12; i++) rhs[i] = 0.0;
+      leg_axpy(rhs, pleg, 1.0, npv);
+    } else if (state == kZ) {
+      QL_UNROLL for (int i = 0; i < 12; i++) rhs[i] = v[i];
+    } else if (state == kPolish) {
+      // u = M^-1 (b_A - N'x), rhs = N u      (corrected semi-normal equations)
+      if (pass == 0) {
+        QL_UNROLL for (int i = 0; i < 12; i++) x[i] = scr.at(kScrX0 + i);
+      }
+      QL_UNROLL for (int i = 0; i < 12; i++) rhs[i] = 0.0;
       for (int k = 0; k < q; k++) {
-        const int id = (int)((act >> (5 * k)) & 31u);
-        const int leg = id_leg(id), t = id - 5 * leg;
-        double acc = -slack(leg, t, x);
+        double acc = -slack(act_id(k), x);
         for (int j = 0; j < k; j++) acc -= scr.at(kScrC + tri(k, j)) * scr.at(kScrR + j);
         scr.at(kScrR + k) = acc / scr.at(kScrC + tri(k, k));
       }
@@ -630,34 +479,193 @@ QL_HD QpResult force_qp_solve(double G[78], const double g0[12], const Pyramid (
         for (int j = k + 1; j < q; j++) acc -= scr.at(kScrC + tri(j, k)) * scr.at(kScrR + j);
         const double uk = acc / scr.at(kScrC + tri(k, k));
         scr.at(kScrR + k) = uk;
-        const int id = (int)((act >> (5 * k)) & 31u);
-        const int leg = id_leg(id), t = id - 5 * leg;
+        const int id = act_id(k), leg = id_leg(id);
         double nk[3];
-        constraint_normal(leg_pyr(leg), mu, t, nk);
-        QL_UNROLL for (int l = 0; l < 4; l++) {
-          const double coef = (l == leg) ? uk : 0.0;
-          QL_UNROLL for (int a = 0; a < 3; a++) v[3 * l + a] += coef * nk[a];
+        constraint_normal(leg_pyr(leg), mu, id - 5 * leg, nk);
+        leg_axpy(rhs, leg, uk, nk);
+      }
+    } else { // kRebuild: row kk of the Schur factor of the restored working set
+      const int id = act_id(kk), leg = id_leg(id);
+      double nk[3];
+      constraint_normal(leg_pyr(leg), mu, id - 5 * leg, nk);
+      QL_UNROLL for (int i = 0; i < 12; i++) rhs[i] = 0.0;
+      leg_axpy(rhs, leg, 1.0, nk);
+    }
+
+    // ------------------------------------------------ sol = G^-1 rhs  (the one copy)
+    double sol[12];
+    {
+      double y[12];
+      QL_UNROLL for (int i = 0; i < 12; i++) {
+        double acc = rhs[i];
+        QL_UNROLL for (int j = 0; j < i; j++) acc -= L[tri(i, j)] * y[j];
+        y[i] = acc * L[tri(i, i)];
+      }
+      QL_UNROLL for (int i = 11; i >= 0; i--) {
+        double acc = y[i];
+        QL_UNROLL for (int j = i + 1; j < 12; j++) acc -= L[tri(j, i)] * sol[j];
+        sol[i] = acc * L[tri(i, i)];
+      }
+    }
+
+    // ------------------------------------------------ consume by state
+    bool have_z = false;
+    if (state == kX0) {
+      QL_UNROLL for (int i = 0; i < 12; i++) { x[i] = sol[i]; scr.at(kScrX0 + i) = sol[i]; }
+      state = kSelect; fresh = true;
+    } else if (state == kPolish) {
+      QL_UNROLL for (int i = 0; i < 12; i++) x[i] += sol[i];
+      if (++pass == 2) {
+        QL_UNROLL for (int i = 0; i < 12; i++) scr.at(kScrX0 + i) = x[i];
+        state = kDone;
+      }
+    } else if (state == kRebuild) {
+      double d2 = 0.0;
+      for (int k = 0; k <= kk; k++) {
+        const int id = act_id(k), leg = id_leg(id);
+        double nk[3], gk[3];
+        constraint_normal(leg_pyr(leg), mu, id - 5 * leg, nk);
+        leg_part(sol, leg, gk);
+        double acc = dot3(nk, gk);
+        for (int j = 0; j < k; j++) acc -= scr.at(kScrC + tri(k, j)) * scr.at(kScrC + tri(kk, j));
+        if (k < kk) scr.at(kScrC + tri(kk, k)) = acc / scr.at(kScrC + tri(k, k));
+        else d2 = acc;
+      }
+      scr.at(kScrC + tri(kk, kk)) = sqrt(fmax(d2, 0.0));
+      if (++kk >= q) { state = kSelect; fresh = false; }
+    } else if (state == kG) {
+      // g = sol.  Tentative Schur row y = C^-1 N'g into row q of C, dd = n_p'g - y'y,
+      // r = C^-T y, v = n_p - N r
+      double gl[3];
+      leg_part(sol, pleg, gl);
+      dd = dot3(npv, gl);
+      for (int k = 0; k < q; k++) {
+        const int id = act_id(k), leg = id_leg(id);
+        double nk[3], gk[3];
+        constraint_normal(leg_pyr(leg), mu, id - 5 * leg, nk);
+        leg_part(sol, leg, gk);
+        double acc = dot3(nk, gk);
+        for (int j = 0; j < k; j++) acc -= scr.at(kScrC + tri(k, j)) * scr.at(kScrC + tri(q, j));
+        const double yk = acc / scr.at(kScrC + tri(k, k));
+        scr.at(kScrC + tri(q, k)) = yk;
+        dd -= yk * yk;
+      }
+      if (q > 0) {
+        QL_UNROLL for (int i = 0; i < 12; i++) v[i] = 0.0;
+        leg_axpy(v, pleg, 1.0, npv);
+        for (int k = q - 1; k >= 0; k--) {
+          double acc = scr.at(kScrC + tri(q, k));
+          for (int j = k + 1; j < q; j++) acc -= scr.at(kScrC + tri(j, k)) * scr.at(kScrR + j);
+          const double rk = acc / scr.at(kScrC + tri(k, k));
+          scr.at(kScrR + k) = rk;
+          const int id = act_id(k), leg = id_leg(id);
+          double nk[3];
+          constraint_normal(leg_pyr(leg), mu, id - 5 * leg, nk);
+          leg_axpy(v, leg, -rk, nk);
+        }
+        state = kZ;
+      } else {
+        have_z = true; // z = g
+      }
+    } else { // kZ
+      have_z = true;
+    }
+
+    // ------------------------------------------------ step (QuadProg++.cc:304-445), z = sol
+    if (have_z) {
+      double zl[3];
+      leg_part(sol, pleg, zl);
+      const double zn = dot3(zl, npv);
+      double zz = 0.0;
+      QL_UNROLL for (int i = 0; i < 12; i++) zz += sol[i] * sol[i];
+      double t1 = inf;
+      int lpos = -1;
+      for (int k = 0; k < q; k++) {
+        const double rk = scr.at(kScrR + k);
+        if (rk > 0.0) {
+          const double ratio = scr.at(kScrU + k) / rk;
+          if (ratio < t1) { t1 = ratio; lpos = k; }
         }
       }
-      chol_solve12(L, inv_d, v, dx);
-      QL_UNROLL for (int i = 0; i < 12; i++) x[i] += dx[i];
+      double t2 = inf;
+      if (fabs(zz) > eps) {
+        t2 = -sp / zn;
+        if (t2 < 0.0) t2 = inf;
+      }
+      const double t = fmin(t1, t2);
+      if (t >= inf) { res.status = kStatusInfeasible; state = kDone; break; } // :339-344
+      const bool dual_only = (t2 >= inf);
+      if (!dual_only) {
+        QL_UNROLL for (int i = 0; i < 12; i++) x[i] += t * sol[i];
+      }
+      for (int k = 0; k < q; k++) scr.at(kScrU + k) -= t * scr.at(kScrR + k);
+      scr.at(kScrU + q) += t;
+
+      if (!dual_only && fabs(t - t2) < eps) {
+        // full step: ip becomes active (:384-421); its Schur row is already in row q of C
+        const double delta = dd > 0.0 ? sqrt(dd) : 0.0;
+        if (delta <= eps * rnorm) {
+          // degenerate: exclude ip, restore the state saved at the start of the outer iteration
+          excl |= 1u << ip;
+          act = act_old; q = q_old;
+          act_mask = 0;
+          for (int k = 0; k < q; k++) {
+            act_mask |= 1u << act_id(k);
+            scr.at(kScrU + k) = scr.at(kScrUo + k);
+          }
+          QL_UNROLL for (int i = 0; i < 12; i++) x[i] = scr.at(kScrXo + i);
+          kk = 0;
+          if (q > 0) state = kRebuild; else { state = kSelect; fresh = false; }
+        } else {
+          scr.at(kScrC + tri(q, q)) = delta;
+          rnorm = fmax(rnorm, delta);
+          act |= (uint64_t)ip << (5 * q);
+          act_mask |= 1u << ip;
+          q++;
+          state = kSelect; fresh = true;
+        }
+      } else {
+        // partial or dual-only step: drop the blocking constraint at position lpos (:346-362, :423-445).
+        // Remove row lpos of C (C C' = N'G^-1 N) and restore the triangle, working in the OLD index
+        // space: for the column pair (c, c+1) a rotation computed from old row c+1 zeroes its
+        // overhang, rows below are rotated, finally the rows move up by one.
+        for (int c = lpos; c < q - 1; c++) {
+          const double a0 = scr.at(kScrC + tri(c + 1, c));
+          const double b0 = scr.at(kScrC + tri(c + 1, c + 1));
+          const double h = sqrt(a0 * a0 + b0 * b0);
+          const double cs = h > 0.0 ? a0 / h : 1.0, sn = h > 0.0 ? b0 / h : 0.0;
+          for (int i = c + 2; i < q; i++) {
+            const double a = scr.at(kScrC + tri(i, c));
+            const double b = scr.at(kScrC + tri(i, c + 1));
+            scr.at(kScrC + tri(i, c)) = cs * a + sn * b;
+            scr.at(kScrC + tri(i, c + 1)) = -sn * a + cs * b;
+          }
+          scr.at(kScrC + tri(c + 1, c)) = h;
+          scr.at(kScrC + tri(c + 1, c + 1)) = 0.0;
+        }
+        for (int i = lpos + 1; i < q; i++)
+          for (int j = 0; j < i; j++) scr.at(kScrC + tri(i - 1, j)) = scr.at(kScrC + tri(i, j));
+        act_mask &= ~(1u << act_id(lpos));
+        for (int k = lpos; k < q; k++) scr.at(kScrU + k) = scr.at(kScrU + k + 1);
+        {
+          const uint64_t low = act & ((1ull << (5 * lpos)) - 1ull);
+          const uint64_t high = (act >> (5 * (lpos + 1))) << (5 * lpos);
+          act = low | high;
+        }
+        q--;
+        if (!dual_only) sp = slack(ip, x); // :436-440
+        state = kG;
+      }
     }
   }
+  if (state != kDone && res.status == kStatusOk) res.status = kStatusMaxIter;
+  res.n_active = q;
   return res;
 }
 
+// ------------------------------------------------------ phase B: one robot ---
 
-// ------------------------------------------------------ one control step ---
-
-struct RobotOut {
-  double tau[12]; // clamped joint efforts, 0 for non-support legs
-  double grf[12]; // QP solution x (ground reaction forces, base frame)
-  int status;
-  int iters;
-  int n_active;
-};
-
-// QP Hessian block (leg l, leg m), l >= m:  S_f + X_l' S_t X_m  with X = skew(r)
+// QP Hessian block (leg l, leg m):  X_l' S_t X_m  with X = skew(r)
 QL_HD void hessian_block(const double St[3], const double r[3], const double rp[3], double E[9]) {
   const double x = r[0], y = r[1], z = r[2], xp = rp[0], yp = rp[1], zp = rp[2];
   E[0] = St[1] * z * zp + St[2] * y * yp; E[1] = -St[2] * y * xp;                 E[2] = -St[1] * z * xp;
@@ -665,34 +673,25 @@ QL_HD void hessian_block(const double St[3], const double r[3], const double rp[
   E[6] = -St[1] * x * zp;                 E[7] = -St[0] * y * zp;                 E[8] = St[0] * y * yp + St[1] * x * xp;
 }
 
+// Wrench, pyramids, QP assembly and solve.  Foot positions come from scratch (phase A); the
+// solution x is left in scratch [kScrX0, +12) for phase C.
 // normals_w: per-leg surface normals in the world frame ([4][3]) when kPerLeg, else ignored.
 template <bool kPerLeg, class Scratch>
-QL_HD void balance_robot(const DeviceParams &P, const RobotIn &in, const double *normals_w, Scratch &scr,
-                         RobotOut &out) {
+QL_HD QpResult phase_b_robot(const DeviceParams &P, const RobotIn &in, const double *normals_w, Scratch &scr) {
+  QpResult none = {kStatusOk, 0, 0};
+  const unsigned stance = in.stance & 0xFu;
+  const int nS = (int)((stance & 1u) + ((stance >> 1) & 1u) + ((stance >> 2) & 1u) + ((stance >> 3) & 1u));
+  if (nS == 0) { // ContactForceDistribution.cpp:127-132
+    QL_UNROLL for (int i = 0; i < 12; i++) scr.at(kScrX0 + i) = 0.0;
+    return none;
+  }
   double Rm[9], gB[3], b[6];
   quat_to_matrix(in.quat, Rm);
   {
     const double gW[3] = {0.0, 0.0, -P.grav};
-    irot(Rm, gW, gB); // VirtualModelController.cpp:165-166, ContactForceDistribution.cpp:518-519
+    irot(Rm, gW, gB); // VirtualModelController.cpp:165-166
   }
   virtual_wrench(P, in, Rm, gB, b);
-
-  QL_UNROLL for (int i = 0; i < 12; i++) { out.tau[i] = 0.0; out.grf[i] = 0.0; }
-  out.status = kStatusOk; out.iters = 0; out.n_active = 0;
-  const unsigned stance = in.stance & 0xFu;
-  const int nS = (int)((stance & 1u) + ((stance >> 1) & 1u) + ((stance >> 2) & 1u) + ((stance >> 3) & 1u));
-  if (nS == 0) return; // ContactForceDistribution.cpp:127-132
-
-  // foot positions of the support legs (prepareOptimization, :189-199)
-  double r[4][3];
-  QL_UNROLL for (int l = 0; l < 4; l++) {
-    r[l][0] = r[l][1] = r[l][2] = 0.0;
-    if ((stance >> l) & 1u) {
-      LegFrames F;
-      leg_frames(P, l, &in.q[3 * l], F);
-      r[l][0] = F.p[3][0]; r[l][1] = F.p[3][1]; r[l][2] = F.p[3][2];
-    }
-  }
 
   // friction pyramids (addMinimalForceConstraints :223-237, addFrictionConstraints :272-309)
   Pyramid py[4];
@@ -714,17 +713,19 @@ QL_HD void balance_robot(const DeviceParams &P, const RobotIn &in, const double 
     }
   }
 
-  // QP data: G = A'SA + W (packed lower), g0 = -A'Sb, legs outside the stance set decoupled
-  double G[78], g0[12], x[12];
+  // QP data: G = A'SA + W (packed lower), g0 = -A'Sb  (prepareOptimization :168-206, objective :388)
+  double G[78], g0[12];
   {
+    double r[4][3];
+    QL_UNROLL for (int l = 0; l < 4; l++)
+      QL_UNROLL for (int a = 0; a < 3; a++) r[l][a] = scr.at(kScrFeet + 3 * l + a);
     const double Sf[3] = {P.S[0], P.S[1], P.S[2]}, St[3] = {P.S[3], P.S[4], P.S[5]};
     const double SF[3] = {Sf[0] * b[0], Sf[1] * b[1], Sf[2] * b[2]};
     const double ST[3] = {St[0] * b[3], St[1] * b[4], St[2] * b[5]};
     QL_UNROLL for (int l = 0; l < 4; l++) {
       const bool on_l = (stance >> l) & 1u;
-      // X' y = y x r
       double c[3];
-      cross3(ST, r[l], c);
+      cross3(ST, r[l], c); // X' y = y x r
       QL_UNROLL for (int a = 0; a < 3; a++) g0[3 * l + a] = on_l ? -(SF[a] + c[a]) : 0.0;
       QL_UNROLL for (int mm = 0; mm <= l; mm++) {
         const bool on = on_l && ((stance >> mm) & 1u);
@@ -734,34 +735,14 @@ QL_HD void balance_robot(const DeviceParams &P, const RobotIn &in, const double 
           QL_UNROLL for (int bb = 0; bb < 3; bb++) {
             const int i = 3 * l + a, j = 3 * mm + bb;
             if (j > i) continue;
-            double v = on ? (E[a * 3 + bb] + (a == bb ? Sf[a] : 0.0)) : 0.0;
-            if (i == j) v += P.w_reg;
-            G[tri(i, j)] = v;
+            double val = on ? (E[a * 3 + bb] + (a == bb ? Sf[a] : 0.0)) : 0.0;
+            if (i == j) val += P.w_reg;
+            G[tri(i, j)] = val;
           }
       }
     }
   }
-
-  const QpResult qr = force_qp_solve<kPerLeg>(G, g0, py, P.mu, P.f_min, stance, nS, scr, x);
-  out.status = qr.status; out.iters = qr.iters; out.n_active = qr.n_active;
-  if (qr.status != kStatusOk) return; // efforts stay untouched in the reference; we report zeros + status
-
-  // computeJointTorques, ContactForceDistribution.cpp:516-578, then the clamp
-  QL_UNROLL for (int l = 0; l < 4; l++) {
-    if (!((stance >> l) & 1u)) continue;
-    LegFrames F;
-    leg_frames(P, l, &in.q[3 * l], F);
-    double J[9], Gq[3];
-    leg_jac_grav(P, l, F, gB, J, Gq);
-    const double fc[3] = {-x[3 * l], -x[3 * l + 1], -x[3 * l + 2]};
-    QL_UNROLL for (int j = 0; j < 3; j++) {
-      double t = (J[j] * fc[0] + J[3 + j] * fc[1] + J[6 + j] * fc[2]) + Gq[j];
-      t = t > P.tau_max ? P.tau_max : t;
-      t = t < -P.tau_max ? -P.tau_max : t;
-      out.tau[3 * l + j] = t;
-      out.grf[3 * l + j] = x[3 * l + j];
-    }
-  }
+  return force_qp_solve<kPerLeg>(G, g0, py, P.mu, P.f_min, stance, nS, scr);
 }
 
 } // namespace qlamd

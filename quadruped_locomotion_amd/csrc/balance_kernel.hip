@@ -58,42 +58,92 @@ __device__ __forceinline__ void load_robot(const StatePtrs &s, int64_t i, RobotI
               ((m & 0xFF000000u) ? 8u : 0u);
 }
 
-// One wavefront per workgroup; RPW of its 64 lanes carry a robot each.  A
-// small batch is spread over more SIMDs by lowering RPW (the other lanes
-// idle): the step is latency-bound, not throughput-bound, at 4096 robots.
+struct LdsTab { // one leg's 64-double block of the model table, staged in LDS
+  const double *p;
+  __device__ __forceinline__ double operator[](int i) const { return p[i]; }
+};
+
+// One wavefront per workgroup, RPW robots per wavefront (64, 16 or 4).  A small batch is spread
+// over more SIMDs by lowering RPW: at 4096 robots the step is latency-bound, not throughput-bound.
+//   phase A  lanes = (robot, leg) pairs: FK + Jacobian + gravity torque       -> LDS
+//   phase B  lanes = robots: wrench, QP assembly, Cholesky, active-set QP      -> LDS
+//   phase C  lanes = (robot, leg) pairs: tau = J'(-f) + G(q), clamp            -> HBM
+// Loads and stores of phases A and C are contiguous across lanes (24-byte records in
+// (robot, leg) order); phase B reads its 26 base-state doubles as per-robot records.
 template <int RPW, bool kPerLeg>
-__global__ __launch_bounds__(64) void balance_step_kernel(const DeviceParams P, const StatePtrs s, int64_t B,
-                                                          double *__restrict__ tau, double *__restrict__ grf,
-                                                          int32_t *__restrict__ status) {
+__global__ __launch_bounds__(64) void balance_step_kernel(const DeviceParams *__restrict__ Pp, const StatePtrs s,
+                                                          int64_t B, double *__restrict__ tau,
+                                                          double *__restrict__ grf, int32_t *__restrict__ status) {
   extern __shared__ double lds[];
+  double *tab = lds;                 // 256 doubles: leg model table
+  double *scratch = lds + 4 * kTabPerLeg; // [kScratchDoubles][RPW]
+  const DeviceParams &P = *Pp;
   const int lane = threadIdx.x;
-  const int64_t i = (int64_t)blockIdx.x * RPW + lane;
-  if (lane >= RPW || i >= B) return;
+  const int64_t base = (int64_t)blockIdx.x * RPW;
 
-  RobotIn in;
-  load_robot(s, i, in);
-  double nw[12];
-  if (kPerLeg) {
 #pragma unroll
-    for (int k = 0; k < 12; k++) nw[k] = s.normals[12 * i + k];
-  }
-  LdsScratch scr{lds + lane, RPW};
-  RobotOut out;
-  balance_robot<kPerLeg>(P, in, nw, scr, out);
+  for (int i = lane; i < 4 * kTabPerLeg; i += 64) tab[i] = P.legtab[i];
+  __syncthreads();
 
-  double2 *t2 = reinterpret_cast<double2 *>(tau + 12 * i);
-#pragma unroll
-  for (int k = 0; k < 6; k++) t2[k] = make_double2(out.tau[2 * k], out.tau[2 * k + 1]);
-  if (grf) {
-    double2 *g2 = reinterpret_cast<double2 *>(grf + 12 * i);
-#pragma unroll
-    for (int k = 0; k < 6; k++) g2[k] = make_double2(out.grf[2 * k], out.grf[2 * k + 1]);
+  // ---- phase A
+#pragma unroll 1
+  for (int item = lane; item < 4 * RPW; item += 64) {
+    const int rb = item >> 2, leg = item & 3;
+    const int64_t i = base + rb;
+    if (i < B) {
+      const bool support = s.stance[4 * i + leg] != 0;
+      const double q3[3] = {s.q[12 * i + 3 * leg], s.q[12 * i + 3 * leg + 1], s.q[12 * i + 3 * leg + 2]};
+      const double2 *a2 = reinterpret_cast<const double2 *>(s.quat + 4 * i);
+      const double2 v0 = a2[0], v1 = a2[1];
+      const double quat[4] = {v0.x, v0.y, v1.x, v1.y};
+      LdsScratch scr{scratch + rb, RPW};
+      phase_a_leg(LdsTab{tab + kTabPerLeg * leg}, leg, support, q3, quat, P.grav, scr);
+    }
   }
-  status[i] = out.status;
+  __syncthreads();
+
+  // ---- phase B
+  {
+    const int64_t i = base + lane;
+    if (lane < RPW && i < B) {
+      RobotIn in;
+      load_robot(s, i, in);
+      double nw[12];
+      if (kPerLeg) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) nw[k] = s.normals[12 * i + k];
+      }
+      LdsScratch scr{scratch + lane, RPW};
+      const QpResult r = phase_b_robot<kPerLeg>(P, in, nw, scr);
+      scr.at(kScrStatus) = (double)r.status;
+      status[i] = r.status;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase C
+#pragma unroll 1
+  for (int item = lane; item < 4 * RPW; item += 64) {
+    const int rb = item >> 2, leg = item & 3;
+    const int64_t i = base + rb;
+    if (i < B) {
+      LdsScratch scr{scratch + rb, RPW};
+      const bool live = (s.stance[4 * i + leg] != 0) && (scr.at(kScrStatus) == 0.0);
+      double t[3], f[3];
+      phase_c_leg(leg, live, P.tau_max, scr, t, f);
+      double *to = tau + 12 * i + 3 * leg;
+      to[0] = t[0]; to[1] = t[1]; to[2] = t[2];
+      if (grf) {
+        double *go = grf + 12 * i + 3 * leg;
+        go[0] = f[0]; go[1] = f[1]; go[2] = f[2];
+      }
+    }
+  }
 }
 
-__global__ __launch_bounds__(64) void virtual_wrench_kernel(const DeviceParams P, const StatePtrs s, int64_t B,
-                                                            double *__restrict__ wrench) {
+__global__ __launch_bounds__(64) void virtual_wrench_kernel(const DeviceParams *__restrict__ Pp, const StatePtrs s,
+                                                            int64_t B, double *__restrict__ wrench) {
+  const DeviceParams &P = *Pp;
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= B) return;
   RobotIn in;
@@ -107,32 +157,31 @@ __global__ __launch_bounds__(64) void virtual_wrench_kernel(const DeviceParams P
   for (int k = 0; k < 6; k++) wrench[6 * i + k] = b[k];
 }
 
-__global__ __launch_bounds__(64) void leg_kinematics_kernel(const DeviceParams P, const double *__restrict__ q,
+struct GlobalTab {
+  const double *p;
+  __device__ __forceinline__ double operator[](int i) const { return p[i]; }
+};
+
+__global__ __launch_bounds__(64) void leg_kinematics_kernel(const DeviceParams *__restrict__ Pp,
+                                                            const double *__restrict__ q,
                                                             const double *__restrict__ quat, int64_t B,
                                                             double *__restrict__ foot, double *__restrict__ jac,
                                                             double *__restrict__ grav) {
   // one lane per (robot, leg)
+  const DeviceParams &P = *Pp;
   const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (t >= 4 * B) return;
   const int64_t i = t >> 2;
   const int leg = (int)(t & 3);
-  double ql[3] = {q[12 * i + 3 * leg], q[12 * i + 3 * leg + 1], q[12 * i + 3 * leg + 2]};
-  double qq[4] = {quat[4 * i], quat[4 * i + 1], quat[4 * i + 2], quat[4 * i + 3]};
+  const double ql[3] = {q[12 * i + 3 * leg], q[12 * i + 3 * leg + 1], q[12 * i + 3 * leg + 2]};
+  const double qq[4] = {quat[4 * i], quat[4 * i + 1], quat[4 * i + 2], quat[4 * i + 3]};
   double Rm[9], gB[3];
   quat_to_matrix(qq, Rm);
   const double gW[3] = {0.0, 0.0, -P.grav};
   irot(Rm, gW, gB);
-  LegFrames F;
-  double J[9], Gq[3];
-  // `leg` differs between lanes: select the chain with a uniform loop so P stays in SGPRs
-#pragma unroll
-  for (int l = 0; l < 4; l++) {
-    if (l == leg) {
-      leg_frames(P, l, ql, F);
-      leg_jac_grav(P, l, F, gB, J, Gq);
-    }
-  }
-  if (foot) { foot[3 * t] = F.p[3][0]; foot[3 * t + 1] = F.p[3][1]; foot[3 * t + 2] = F.p[3][2]; }
+  double F[3], J[9], Gq[3];
+  leg_kinematics(GlobalTab{P.legtab + kTabPerLeg * leg}, ql, gB, F, J, Gq);
+  if (foot) { foot[3 * t] = F[0]; foot[3 * t + 1] = F[1]; foot[3 * t + 2] = F[2]; }
   if (jac) {
 #pragma unroll
     for (int k = 0; k < 9; k++) jac[9 * t + k] = J[k];
@@ -147,6 +196,7 @@ __global__ __launch_bounds__(64) void leg_kinematics_kernel(const DeviceParams P
 struct qlamd_context {
   int device;
   DeviceParams params;
+  DeviceParams *d_params; // device copy, read through scalar loads
   int rpw_override;
   int num_cu;
   // HOST-memory mode staging (grown on demand)
@@ -168,7 +218,7 @@ int pick_rpw(const qlamd_context *ctx, int64_t batch) {
 template <int RPW>
 hipError_t launch_balance(const qlamd_context *ctx, const StatePtrs &s, int64_t B, double *tau, double *grf,
                           int32_t *status, hipStream_t st) {
-  const size_t lds = (size_t)RPW * kScratchDoubles * sizeof(double);
+  const size_t lds = ((size_t)RPW * kScratchDoubles + 4 * kTabPerLeg) * sizeof(double);
   const unsigned grid = (unsigned)((B + RPW - 1) / RPW);
   if (s.normals) {
     auto k = balance_step_kernel<RPW, true>;
@@ -176,14 +226,14 @@ hipError_t launch_balance(const qlamd_context *ctx, const StatePtrs &s, int64_t 
       hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, ctx->params, s, B, tau, grf, status);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, ctx->d_params, s, B, tau, grf, status);
   } else {
     auto k = balance_step_kernel<RPW, false>;
     if (lds > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, ctx->params, s, B, tau, grf, status);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, ctx->d_params, s, B, tau, grf, status);
   }
   return hipGetLastError();
 }
@@ -241,16 +291,22 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
   qlamd_robot_model m;
   if (model) m = *model; else default_robot_model(&m);
   build_device_params(*params, m, &ctx->params);
+  ctx->d_params = nullptr;
+  if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&ctx->d_params, sizeof(DeviceParams)) != hipSuccess ||
+      hipMemcpy(ctx->d_params, &ctx->params, sizeof(DeviceParams), hipMemcpyHostToDevice) != hipSuccess) {
+    if (ctx->d_params) (void)hipFree(ctx->d_params);
+    delete ctx;
+    return QLAMD_ERR_HIP;
+  }
   *out = ctx;
   return QLAMD_OK;
 }
 
 void qlamd_context_destroy(qlamd_context *ctx) {
   if (!ctx) return;
-  if (ctx->ws) {
-    (void)hipSetDevice(ctx->device);
-    (void)hipFree(ctx->ws);
-  }
+  (void)hipSetDevice(ctx->device);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->d_params) (void)hipFree(ctx->d_params);
   delete ctx;
 }
 
@@ -338,7 +394,7 @@ int qlamd_virtual_wrench_batch(qlamd_context *ctx, const qlamd_state_batch *in, 
               in->base_angular_velocity, in->desired_position, in->desired_orientation,
               in->desired_linear_velocity, in->desired_angular_velocity, in->support_leg, nullptr};
   const unsigned grid = (unsigned)((batch + 63) / 64);
-  hipLaunchKernelGGL(virtual_wrench_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, ctx->params, s, batch,
+  hipLaunchKernelGGL(virtual_wrench_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, ctx->d_params, s, batch,
                      wrench);
   return hipGetLastError() == hipSuccess ? QLAMD_OK : QLAMD_ERR_HIP;
 }
@@ -351,7 +407,7 @@ int qlamd_leg_kinematics_batch(qlamd_context *ctx, const double *joint_position,
   if (batch == 0) return QLAMD_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   const unsigned grid = (unsigned)((4 * batch + 63) / 64);
-  hipLaunchKernelGGL(leg_kinematics_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, ctx->params,
+  hipLaunchKernelGGL(leg_kinematics_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, ctx->d_params,
                      joint_position, base_orientation, batch, foot_position, jacobian, gravity_torque);
   return hipGetLastError() == hipSuccess ? QLAMD_OK : QLAMD_ERR_HIP;
 }

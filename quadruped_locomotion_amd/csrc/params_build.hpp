@@ -67,18 +67,17 @@ inline void build_device_params(const qlamd_balance_params &p, const qlamd_robot
   }
   d->Fg_scale = p.grav_comp_percentage * mass;
   for (int i = 0; i < 3; i++) d->Tg_arm[i] = p.grav_comp_percentage * arm[i];
-  for (int l = 0; l < 4; l++)
+  for (int l = 0; l < 4; l++) {
+    double *tab = d->legtab + kTabPerLeg * l;
     for (int k = 0; k < 4; k++) {
-      rpy_to_matrix(m.joint_rpy[l][k], d->R0[l][k]);
-      const double *R = d->R0[l][k];
-      d->rot_is_identity[l][k] = (R[0] == 1.0 && R[4] == 1.0 && R[8] == 1.0 && R[1] == 0.0 && R[2] == 0.0 &&
-                                  R[3] == 0.0 && R[5] == 0.0 && R[6] == 0.0 && R[7] == 0.0);
-      d->mass[l][k] = m.link_mass[l][k];
+      rpy_to_matrix(m.joint_rpy[l][k], tab + kTabR0 + 9 * k);
+      tab[kTabMass + k] = m.link_mass[l][k];
       for (int i = 0; i < 3; i++) {
-        d->xyz[l][k][i] = m.joint_xyz[l][k][i];
-        d->mcom[l][k][i] = m.link_mass[l][k] * m.link_com[l][k][i];
+        tab[kTabXyz + 3 * k + i] = m.joint_xyz[l][k][i];
+        tab[kTabMcom + 3 * k + i] = m.link_mass[l][k] * m.link_com[l][k][i];
       }
     }
+  }
 }
 
 } // namespace qlamd

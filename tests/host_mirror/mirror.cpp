@@ -39,13 +39,18 @@ extern "C" void mirror_balance_batch(const qlamd_balance_params *prm, int64_t B,
     load(in, q + 12 * i, pos + 3 * i, quat + 4 * i, lv + 3 * i, av + 3 * i, dpos + 3 * i, dquat + 4 * i,
          dlv + 3 * i, dav + 3 * i, stance + 4 * i);
     HostScratch scr;
-    RobotOut out;
-    if (normals) balance_robot<true>(P, in, normals + 12 * i, scr, out);
-    else balance_robot<false>(P, in, nullptr, scr, out);
-    for (int k = 0; k < 12; k++) { tau[12 * i + k] = out.tau[k]; if (grf) grf[12 * i + k] = out.grf[k]; }
-    status[i] = out.status;
-    if (iters) iters[i] = out.iters;
-    if (n_active) n_active[i] = out.n_active;
+    for (int l = 0; l < 4; l++) // phase A
+      phase_a_leg(P.legtab + kTabPerLeg * l, l, (in.stance >> l) & 1u, in.q + 3 * l, in.quat, P.grav, scr);
+    const QpResult r = normals ? phase_b_robot<true>(P, in, normals + 12 * i, scr)
+                               : phase_b_robot<false>(P, in, nullptr, scr);
+    for (int l = 0; l < 4; l++) { // phase C
+      double t[3], f[3];
+      phase_c_leg(l, ((in.stance >> l) & 1u) && r.status == kStatusOk, P.tau_max, scr, t, f);
+      for (int a = 0; a < 3; a++) { tau[12 * i + 3 * l + a] = t[a]; if (grf) grf[12 * i + 3 * l + a] = f[a]; }
+    }
+    status[i] = r.status;
+    if (iters) iters[i] = r.iters;
+    if (n_active) n_active[i] = r.n_active;
   }
 }
 
@@ -57,10 +62,7 @@ extern "C" void mirror_leg_kinematics(const double *q3, int leg, const double *g
   default_robot_model(&model);
   DeviceParams P;
   build_device_params(prm, model, &P);
-  LegFrames F;
-  leg_frames(P, leg, q3, F);
-  for (int i = 0; i < 3; i++) p[i] = F.p[3][i];
-  leg_jac_grav(P, leg, F, g, J, Gq);
+  leg_kinematics(P.legtab + kTabPerLeg * leg, q3, g, p, J, Gq);
 }
 
 extern "C" void mirror_sincos(double x, double *s, double *c) { sincos_reduced(x, *s, *c); }

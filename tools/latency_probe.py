@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""GPU probe: kernel time vs. per-robot QP iteration count and vs. batch size (tuning aid)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from quadruped_locomotion_amd import capi, synth
+from oracle import oracle as O
+
+def timeit(ctx, state, rpw, reps=50):
+    d = capi.to_device(state); B = state["q"].shape[0]
+    tau = torch.zeros(B, 12, dtype=torch.float64, device="cuda:0"); st = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    ctx.set_robots_per_wave(rpw)
+    for _ in range(5): ctx.balance_solve_device(d, tau, None, st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): ctx.balance_solve_device(d, tau, None, st)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+ctx = capi.Context()
+s = synth.make_states(4096, "trot")
+its = np.array([O.balance_step(s, i)["iters"] for i in range(4096)])
+print("iters histogram", np.bincount(its))
+for target in sorted(set([1, 2, 4, 8, 12, 16, int(its.max())])):
+    idx = np.where(its == target)[0]
+    if len(idx) == 0: continue
+    rep = {k: np.repeat(v[idx[:1]], 4096, axis=0) for k, v in s.items()}
+    print("all robots = %2d outer iterations: rpw4 %.1f us  rpw16 %.1f us  rpw64 %.1f us" % (
+        target, timeit(ctx, rep, 4), timeit(ctx, rep, 16), timeit(ctx, rep, 64)))
+for B in (4096, 16384, 65536, 262144, 1048576):
+    st = synth.make_states(B, "static")
+    for rpw in (16, 64):
+        t = timeit(ctx, st, rpw, reps=10)
+        print("static B=%7d rpw=%2d: %.1f us  -> %.1f M solves/s" % (B, rpw, t, B / t))

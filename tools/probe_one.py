@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Run ONE configuration a few times (for rocprofv3): probe_one.py <gait> <batch> <rpw> [iters_filter]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from quadruped_locomotion_amd import capi, synth
+gait, B, rpw = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+filt = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+s = synth.make_states(B, gait)
+if filt:
+    from oracle import oracle as O
+    its = np.array([O.balance_step(s, i)["iters"] for i in range(min(B, 4096))])
+    idx = np.where(its == filt)[0][:1]
+    s = {k: np.repeat(v[idx], B, axis=0) for k, v in s.items()}
+ctx = capi.Context(); ctx.set_robots_per_wave(rpw)
+d = capi.to_device(s)
+tau = torch.zeros(B, 12, dtype=torch.float64, device="cuda:0"); st = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+for _ in range(5): ctx.balance_solve_device(d, tau, None, st)
+torch.cuda.synchronize()
+print("done", int((st != 0).sum()))
