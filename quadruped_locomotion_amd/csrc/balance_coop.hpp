@@ -1,0 +1,577 @@
+// Lane-cooperative ("latency") form of the balance-controller step: 16 lanes per robot,
+// 4 robots per wavefront.  Device-only (DPP cross-lane moves); included by balance_kernel.hip.
+//
+// Why: with a few thousand robots the chip runs ~1 wavefront per SIMD and a control step
+// lasts as long as the slowest robot's SERIAL instruction stream.  Spreading one robot over a
+// 16-lane DPP row turns every 12x12 product into 12 broadcasts + 12 FMAs per lane and every
+// search over the 20 constraints into one DPP reduction.
+//
+// Lane r = 4*leg + c of a row: c = 0,1,2 carries component c of leg `leg` of every 12-vector
+// (x, z, g0 ...) and row i = 3*leg + c of every 12x12 matrix (G, H); c = 3 is a spare lane.
+// Lane k (0..11) also carries slot k of the active set: id_k, multiplier u_k, row k of N*.
+// Per-robot scalars are replicated on the 16 lanes; control flow is uniform inside a row.
+//
+// QP method: Goldfarb-Idnani with the operators of the original paper kept EXPLICITLY,
+//   H  = G^-1 - G^-1 N (N'G^-1 N)^-1 N'G^-1      (12x12, row per lane)
+//   N* = (N'G^-1 N)^-1 N'G^-1                     (q x 12, row per slot lane)
+// so that z = H n_p and r = N* n_p are one broadcast pass, and adding / dropping a
+// constraint is a rank-one update:
+//   add n+:  H -= z z'/d,  N* <- [N* - r z'/d ; z'/d],          d = z'n+
+//   drop k:  H += n~ n~'/e, N* <- rows!=k of (N* - (N* G n~) n~'/e), n~ = row k of N*, e = n~'G n~
+// Same pivot rule, step lengths and termination test as QuadProg++ (QuadProg++.cc:216-445).
+// The explicit operators drift by ~1e-9 per update; a final refinement on the known working
+// set (constraint residual through N*', reduced gradient through H) removes the drift.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "balance_core.hpp"
+
+namespace qlamd {
+namespace coop {
+
+template <int CTRL>
+__device__ __forceinline__ double dpp(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dppi(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, false);
+}
+// broadcast from lane J of the 16-lane row (one v_mov_b64_dpp row_newbcast)
+template <int J>
+__device__ __forceinline__ double bc(double x) {
+  return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + J, 0xF, 0xF, false);
+}
+template <int J>
+__device__ __forceinline__ int bci(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, 0x150 + J, 0xF, 0xF, false);
+}
+// lane that carries variable index j (0..11)
+__host__ __device__ constexpr int lane_of(int j) { return 4 * (j / 3) + (j % 3); }
+template <int j>
+__device__ __forceinline__ double bcv(double x) { return bc<lane_of(j)>(x); }
+
+__device__ __forceinline__ double row_sum(double x) {
+  x += dpp<0x128>(x); // row_ror:8
+  x += dpp<0x124>(x);
+  x += dpp<0x122>(x);
+  x += dpp<0x121>(x);
+  return x;
+}
+__device__ __forceinline__ double quad_sum(double x) {
+  x += dpp<0xB1>(x); // quad_perm [1,0,3,2]
+  x += dpp<0x4E>(x); // quad_perm [2,3,0,1]
+  return x;
+}
+template <int K>
+__device__ __forceinline__ double quad_bc(double x) { return dpp<K * 85>(x); } // quad_perm [K,K,K,K]
+
+// (value, key) minimum over the row; ties -> smaller key.  Invalid lanes pass +inf.
+__device__ __forceinline__ void row_argmin(double &v, int &key) {
+#define QL_ARGMIN_STEP(CTRL)                                        \
+  {                                                                 \
+    const double ov = dpp<CTRL>(v);                                 \
+    const int ok = dppi<CTRL>(key);                                 \
+    const bool take = (ov < v) || (ov == v && ok < key);            \
+    v = take ? ov : v;                                              \
+    key = take ? ok : key;                                          \
+  }
+  QL_ARGMIN_STEP(0x128) QL_ARGMIN_STEP(0x124) QL_ARGMIN_STEP(0x122) QL_ARGMIN_STEP(0x121)
+#undef QL_ARGMIN_STEP
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_impl(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_impl<I + 1, N>(f);
+  }
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl<0, N>(f); }
+
+// 1/x and 1/sqrt(x): hardware seed + two Newton steps (1-2 ulp)
+__device__ __forceinline__ double rcp_nr(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y + y * (1.0 - x * y);
+  y = y + y * (1.0 - x * y);
+  return y;
+}
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y + y * (0.5 - 0.5 * x * y * y);
+  y = y + y * (0.5 - 0.5 * x * y * y);
+  return y;
+}
+
+// element c (0..2) of a replicated 3-vector; 0 for the spare lane
+__device__ __forceinline__ double pick3(const double v[3], int c) {
+  return c == 0 ? v[0] : c == 1 ? v[1] : c == 2 ? v[2] : 0.0;
+}
+
+struct CoopTab { // one leg's model block in LDS
+  const double *p;
+  __device__ __forceinline__ double operator[](int i) const { return p[i]; }
+};
+
+struct CoopPtrs {
+  const double *q, *pos, *quat, *linvel, *angvel, *dpos, *dquat, *dlinvel, *dangvel;
+  const uint8_t *stance;
+  const double *normals;
+};
+
+// One robot per 16-lane row.  lds_tab: 256-double model table; lds_row: this robot's private
+// LDS block of kCoopLdsDoubles doubles (N* export for the refinement, row export for drops).
+constexpr int kCoopLdsDoubles = 12 * 12 + 12;
+
+template <bool kPerLeg>
+__device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs &s, int64_t irobot, bool robot_live,
+                                           const double *lds_tab, double *lds_row, double *__restrict__ tau_out,
+                                           double *__restrict__ grf_out, int32_t *__restrict__ status_out) {
+  const int lr = threadIdx.x & 15;   // lane in row
+  const int leg = lr >> 2, c = lr & 3;
+  const bool comp = c < 3;           // carries a variable / matrix row
+  const int myidx = 3 * leg + c;     // valid when comp
+  const double eps = 2.220446049250313e-16;
+  const double inf = INFINITY;
+
+  // ---------------------------------------------------------------- load
+  const int64_t i = irobot;
+  double quat[4], dquat[4], pos[3], linvel[3], angvel[3], dpos[3], dlinvel[3], dangvel[3];
+  {
+    const double2 *a2 = reinterpret_cast<const double2 *>(s.quat + 4 * i);
+    const double2 *b2 = reinterpret_cast<const double2 *>(s.dquat + 4 * i);
+    double2 v = a2[0]; quat[0] = v.x; quat[1] = v.y;
+    v = a2[1]; quat[2] = v.x; quat[3] = v.y;
+    v = b2[0]; dquat[0] = v.x; dquat[1] = v.y;
+    v = b2[1]; dquat[2] = v.x; dquat[3] = v.y;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      pos[k] = s.pos[3 * i + k]; linvel[k] = s.linvel[3 * i + k]; angvel[k] = s.angvel[3 * i + k];
+      dpos[k] = s.dpos[3 * i + k]; dlinvel[k] = s.dlinvel[3 * i + k]; dangvel[k] = s.dangvel[3 * i + k];
+    }
+  }
+  const uint32_t sm = *reinterpret_cast<const uint32_t *>(s.stance + 4 * i);
+  const unsigned stance = robot_live ? (((sm & 0xFFu) ? 1u : 0u) | ((sm & 0xFF00u) ? 2u : 0u) |
+                                        ((sm & 0xFF0000u) ? 4u : 0u) | ((sm & 0xFF000000u) ? 8u : 0u))
+                                     : 0u;
+  const int nS = __popc(stance);
+  const bool on = ((stance >> leg) & 1u) != 0; // my leg supports
+  const double qj = comp ? s.q[12 * i + myidx] : 0.0;
+
+  // ---------------------------------------------------------------- wrench (replicated)
+  double Rm[9], gB[3], b[6];
+  quat_to_matrix(quat, Rm);
+  {
+    const double gW[3] = {0.0, 0.0, -P.grav};
+    irot(Rm, gW, gB);
+    RobotIn in;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      in.pos[k] = pos[k]; in.linvel[k] = linvel[k]; in.angvel[k] = angvel[k];
+      in.dpos[k] = dpos[k]; in.dlinvel[k] = dlinvel[k]; in.dangvel[k] = dangvel[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { in.quat[k] = quat[k]; in.dquat[k] = dquat[k]; }
+    virtual_wrench(P, in, Rm, gB, b);
+  }
+
+  // ---------------------------------------------------------------- leg kinematics, 4 lanes per leg
+  // lane c holds row c of the cumulative rotation and component c of every position
+  const CoopTab tab{lds_tab + kTabPerLeg * leg};
+  double sj, cj;
+  sincos_reduced(qj, sj, cj);
+  double Rc[3] = {c == 0 ? 1.0 : 0.0, c == 1 ? 1.0 : 0.0, c == 2 ? 1.0 : 0.0};
+  double pc = 0.0;
+  double zax[3], pj[3], Hk[4]; // component c of joint axes, joint origins, m_k * com_k
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    double R0[9], t[3], mcom[3];
+#pragma unroll
+    for (int a = 0; a < 9; a++) R0[a] = tab[kTabR0 + 9 * k + a];
+#pragma unroll
+    for (int a = 0; a < 3; a++) { t[a] = tab[kTabXyz + 3 * k + a]; mcom[a] = tab[kTabMcom + 3 * k + a]; }
+    const double m = tab[kTabMass + k];
+    double Rs[9];
+    if (k < 3) {
+      const double sk = k == 0 ? quad_bc<0>(sj) : k == 1 ? quad_bc<1>(sj) : quad_bc<2>(sj);
+      const double ck = k == 0 ? quad_bc<0>(cj) : k == 1 ? quad_bc<1>(cj) : quad_bc<2>(cj);
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        Rs[a * 3 + 0] = R0[a * 3 + 0] * ck + R0[a * 3 + 1] * sk;
+        Rs[a * 3 + 1] = R0[a * 3 + 1] * ck - R0[a * 3 + 0] * sk;
+        Rs[a * 3 + 2] = R0[a * 3 + 2];
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 9; a++) Rs[a] = R0[a];
+    }
+    pc += Rc[0] * t[0] + Rc[1] * t[1] + Rc[2] * t[2];
+    double Rn[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) Rn[a] = Rc[0] * Rs[a] + Rc[1] * Rs[3 + a] + Rc[2] * Rs[6 + a];
+    Rc[0] = Rn[0]; Rc[1] = Rn[1]; Rc[2] = Rn[2];
+    Hk[k] = m * pc + (Rn[0] * mcom[0] + Rn[1] * mcom[1] + Rn[2] * mcom[2]);
+    if (k < 3) { zax[k] = Rn[2]; pj[k] = pc; }
+  }
+  const double foot = (comp && on) ? pc : 0.0; // component c of my leg's foot position
+  // cross product component c of (a x b) for quad-distributed a, b: a_{c+1} b_{c+2} - a_{c+2} b_{c+1}
+  const auto qcross = [&](double a, double bq) -> double {
+    const double a1 = dpp<0xC9>(a), a2 = dpp<0xD2>(a);   // quad_perm [1,2,0,3], [2,0,1,3]
+    const double b1 = dpp<0xC9>(bq), b2 = dpp<0xD2>(bq);
+    return a1 * b2 - a2 * b1;
+  };
+  double Jrow[3], Gq[3]; // Jrow[i] = J[c][i];  Gq[i] replicated in the quad
+  {
+    const double my_g = pick3(gB, c);
+    double Hs = Hk[3];
+    double M = tab[kTabMass + 3];
+#pragma unroll
+    for (int k = 2; k >= 0; k--) {
+      Hs += Hk[k];
+      M += tab[kTabMass + k];
+      const double d = pc - pj[k];
+      Jrow[k] = comp ? qcross(zax[k], d) : 0.0;
+      const double h = Hs - M * pj[k];
+      const double zh = qcross(zax[k], h);
+      Gq[k] = -quad_sum(comp ? my_g * zh : 0.0);
+    }
+  }
+
+  // ---------------------------------------------------------------- friction pyramid of my leg
+  double myn = 0.0, myt1 = 0.0, myt2 = 0.0; // component c of n, t1, t2 (base frame)
+  {
+    const double ey[3] = {0.0, 1.0, 0.0}, ez[3] = {0.0, 0.0, 1.0};
+    double yB[3], nW[3], nb[3], t1[3], t2[3];
+    irot(Rm, ey, yB);
+    if (kPerLeg) { nW[0] = s.normals[12 * i + 3 * leg]; nW[1] = s.normals[12 * i + 3 * leg + 1]; nW[2] = s.normals[12 * i + 3 * leg + 2]; }
+    else rot(Rm, ez, nW);
+    irot(Rm, nW, nb);
+    cross3(nb, yB, t1);
+    double nn = rsqrt_nr(dot3(t1, t1));
+    t1[0] *= nn; t1[1] *= nn; t1[2] *= nn;
+    cross3(nb, t1, t2);
+    nn = rsqrt_nr(dot3(t2, t2));
+    t2[0] *= nn; t2[1] *= nn; t2[2] *= nn;
+    myn = pick3(nb, c); myt1 = pick3(t1, c); myt2 = pick3(t2, c);
+  }
+  const double mu = P.mu, f_min = P.f_min;
+
+  // ---------------------------------------------------------------- G row, g0, H = G^-1 (Gauss-Jordan)
+  double Gm[12], H[12], g0;
+  double c1 = 0.0, c2 = 0.0;
+  {
+    // foot positions of all legs, replicated
+    double r[4][3];
+    static_for<12>([&](auto J) { constexpr int j = J; r[j / 3][j % 3] = bcv<j>(foot); });
+    const double rl[3] = {quad_bc<0>(foot), quad_bc<1>(foot), quad_bc<2>(foot)};
+    // a = r_leg x e_c  (column c of skew(r_leg))
+    const double a[3] = {c == 1 ? -rl[2] : c == 2 ? rl[1] : 0.0, c == 0 ? rl[2] : c == 2 ? -rl[0] : 0.0,
+                         c == 0 ? -rl[1] : c == 1 ? rl[0] : 0.0};
+    const double sa[3] = {P.S[3] * a[0], P.S[4] * a[1], P.S[5] * a[2]};
+    const double Sfc = pick3(P.S, c);
+    const bool row_on = comp && on;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const bool both = row_on && ((stance >> m) & 1u);
+      const double xp = r[m][0], yp = r[m][1], zp = r[m][2];
+      // (r_m x e_b) for b = 0,1,2: (0,z',-y'), (-z',0,x'), (y',-x',0)
+      const double e0 = sa[1] * zp - sa[2] * yp;
+      const double e1 = -sa[0] * zp + sa[2] * xp;
+      const double e2 = sa[0] * yp - sa[1] * xp;
+      Gm[3 * m + 0] = both ? e0 + (c == 0 ? Sfc : 0.0) : 0.0;
+      Gm[3 * m + 1] = both ? e1 + (c == 1 ? Sfc : 0.0) : 0.0;
+      Gm[3 * m + 2] = both ? e2 + (c == 2 ? Sfc : 0.0) : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 12; j++)
+      if (comp && j == myidx) Gm[j] += P.w_reg;
+    const double Fc = pick3(b, c);
+    const double ST[3] = {P.S[3] * b[3], P.S[4] * b[4], P.S[5] * b[5]};
+    g0 = row_on ? -(Sfc * Fc + (a[0] * ST[0] + a[1] * ST[1] + a[2] * ST[2])) : 0.0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) H[j] = Gm[j];
+    // trace(G) over the stance block
+    {
+      double diag = 0.0;
+#pragma unroll
+      for (int j = 0; j < 12; j++) diag = (j == myidx) ? Gm[j] : diag;
+      c1 = row_sum(row_on ? diag : 0.0);
+    }
+    // in-place Gauss-Jordan inversion, row per lane; pivot k = L_kk^2 of the Cholesky factor
+    bool bad = false;
+    static_for<12>([&](auto K) {
+      constexpr int k = K;
+      double Pk[12];
+      static_for<12>([&](auto J) { constexpr int j = J; Pk[j] = bcv<k>(H[j]); });
+      const double d = Pk[k];
+      bad = bad || !(d > 0.0);
+      const double sinv = rsqrt_nr(d);
+      const double p = sinv * sinv;
+      if ((stance >> (k / 3)) & 1u) c2 += sinv;
+      const bool piv = comp && (myidx == k);
+      const double f = piv ? (1.0 - p) : H[k] * p;
+#pragma unroll
+      for (int j = 0; j < 12; j++)
+        if (j != k) H[j] -= f * Pk[j];
+      H[k] = piv ? p : -f;
+    });
+    if (bad && nS > 0) {
+      if (lr == 0 && robot_live) status_out[i] = kStatusNotPd;
+      if (comp && robot_live) { tau_out[12 * i + myidx] = 0.0; if (grf_out) grf_out[12 * i + myidx] = 0.0; }
+      return;
+    }
+  }
+
+  // ---------------------------------------------------------------- x0 = -H g0
+  double x = 0.0;
+  static_for<12>([&](auto J) { constexpr int j = J; x -= H[j] * bcv<j>(g0); });
+  x = comp ? x : 0.0;
+
+  // ---------------------------------------------------------------- active-set loop
+  double Ns[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) Ns[j] = 0.0;
+  double u = 0.0;      // multiplier of slot lr
+  int idk = 0;         // constraint id of slot lr
+  int q = 0, iters = 0, status = kStatusOk;
+  unsigned act_mask = 0, excl = 0;
+  const double psi_tol = (double)(5 * nS) * eps * c1 * c2 * 100.0;
+  double rnorm = 1.0;
+  bool done = (nS == 0), need_select = true, fresh = true;
+  int ip = -1, pleg = 0, pt = 0;
+  double sp = 0.0, ucand = 0.0;
+  // per-lane constraint coefficients: lane c of a quad evaluates friction row t = c+1
+  const double fa = c == 0 ? 1.0 : c == 1 ? -1.0 : 0.0, fb = c == 2 ? 1.0 : c == 3 ? -1.0 : 0.0;
+
+  // slacks at the current x: s_min (replicated in the quad) and this lane's friction row
+  const auto slacks = [&](double xx, double &s_min, double &s_fric) {
+    const double dn = quad_sum(myn * xx), d1 = quad_sum(myt1 * xx), d2 = quad_sum(myt2 * xx);
+    s_min = dn - f_min;
+    s_fric = mu * dn + fa * d1 + fb * d2;
+  };
+  // component c of the normal of constraint type t on my leg
+  const auto my_normal = [&](int t) -> double {
+    return t == 0 ? myn : (mu * myn + (t == 1 ? myt1 : t == 2 ? -myt1 : t == 3 ? myt2 : -myt2));
+  };
+
+  for (int tick = 0; tick < 40 * kMaxOuter; tick++) {
+    if (__all(done)) break;
+    if (!done && need_select) {
+      if (fresh) { iters++; excl = 0; }
+      double s_min, s_fric;
+      slacks(x, s_min, s_fric);
+      const double psi = row_sum(on ? (fmin(0.0, s_fric) + (c == 0 ? fmin(0.0, s_min) : 0.0)) : 0.0);
+      const unsigned blocked = act_mask | excl;
+      // candidates of this lane: friction row 5*leg + c + 1, and (lane c == 0) the minimum-force row 5*leg.
+      // key = row index in the reference's ordering (minimum-force rows first) for tie breaks
+      double v = inf;
+      int key = 1 << 20;
+      if (on) {
+        const int idf = 5 * leg + c + 1;
+        if (!((blocked >> idf) & 1u) && s_fric < 0.0) { v = s_fric; key = (4 + 4 * leg + c) * 32 + idf; }
+        const int idm = 5 * leg;
+        if (c == 0 && !((blocked >> idm) & 1u) && s_min < 0.0 && (s_min < v || (s_min == v))) {
+          v = s_min; key = leg * 32 + idm;
+        }
+      }
+      row_argmin(v, key);
+      const bool feasible = fresh && (fabs(psi) <= psi_tol); // QuadProg++.cc:246-250
+      if (feasible || !(v < 0.0) || iters > kMaxOuter) {      // :271-274
+        if (iters > kMaxOuter) status = kStatusMaxIter;
+        done = true;
+      } else {
+        ip = key & 31;
+        pleg = id_leg(ip); pt = ip - 5 * pleg;
+        sp = v;
+        ucand = 0.0;
+        need_select = false;
+      }
+    }
+    if (!done) {
+      // ---- directions: z = H n_p (lane i), r = N* n_p (slot lane k)
+      const double npj = (comp && leg == pleg) ? my_normal(pt) : 0.0;
+      double z = 0.0, r = 0.0;
+      static_for<12>([&](auto J) {
+        constexpr int j = J;
+        const double nj = bcv<j>(npj);
+        z += H[j] * nj;
+        r += Ns[j] * nj;
+      });
+      z = comp ? z : 0.0;
+      const bool slot = lr < q;
+      r = slot ? r : 0.0;
+      const double zn = row_sum(z * npj);
+      const double zz = row_sum(z * z);
+      // ---- step lengths, QuadProg++.cc:304-331
+      double ratio = inf;
+      int lkey = 1 << 20;
+      if (slot && r > 0.0) { ratio = u * rcp_nr(r); lkey = lr; }
+      row_argmin(ratio, lkey);
+      const double t1 = ratio;
+      const int lpos = lkey;
+      double t2 = inf;
+      if (fabs(zz) > eps) {
+        t2 = -sp * rcp_nr(zn);
+        if (t2 < 0.0) t2 = inf;
+      }
+      const double t = fmin(t1, t2);
+      if (t >= inf) { // :339-344
+        status = kStatusInfeasible;
+        done = true;
+      } else {
+        const bool dual_only = (t2 >= inf);
+        if (!dual_only) x += t * z;
+        if (slot) u -= t * r;
+        ucand += t;
+        if (!dual_only && t2 <= t1) {
+          // ---- full step: add ip (rank-one updates of H and N*)
+          const double delta = zn > 0.0 ? sqrt(zn) : 0.0;
+          if (delta <= eps * rnorm) {
+            // numerically dependent normal: undo the step, exclude ip, select again
+            x -= t * z;
+            if (slot) u += t * r;
+            excl |= 1u << ip;
+            need_select = true; fresh = false;
+          } else {
+            rnorm = fmax(rnorm, delta);
+            const double dinv = rcp_nr(zn);
+            const double wz = z * dinv;          // w_i = z_i / d on lane i
+            const bool newslot = (lr == q);
+            static_for<12>([&](auto J) {
+              constexpr int j = J;
+              const double wj = bcv<j>(wz);
+              H[j] -= z * wj;
+              Ns[j] = newslot ? wj : (Ns[j] - r * wj);
+            });
+            if (newslot) { u = ucand; idk = ip; }
+            act_mask |= 1u << ip;
+            q++;
+            need_select = true; fresh = true;
+          }
+        } else {
+          // ---- partial / dual-only step: drop the constraint in slot lpos (:346-362, :423-445)
+          // export row lpos of N* through LDS so that every lane gets all of it and its own element
+          if (lr == lpos) {
+#pragma unroll
+            for (int j = 0; j < 12; j++) lds_row[144 + j] = Ns[j];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+          double nt[12];
+#pragma unroll
+          for (int j = 0; j < 12; j++) nt[j] = lds_row[144 + j];
+          const double nt_me = comp ? lds_row[144 + myidx] : 0.0;
+          // Gn = G n~ (lane i), e = n~' G n~
+          double Gn = 0.0;
+#pragma unroll
+          for (int j = 0; j < 12; j++) Gn += Gm[j] * nt[j];
+          Gn = comp ? Gn : 0.0;
+          const double e = row_sum(nt_me * Gn);
+          const double einv = rcp_nr(e);
+          // coef_k = (N*_k . G n~) / e on slot lanes; H += n~ n~'/e
+          double coef = 0.0;
+          static_for<12>([&](auto J) {
+            constexpr int j = J;
+            coef += Ns[j] * bcv<j>(Gn);
+          });
+          coef *= einv;
+          const double hme = nt_me * einv;
+#pragma unroll
+          for (int j = 0; j < 12; j++) {
+            H[j] += hme * nt[j];
+            Ns[j] -= coef * nt[j];
+          }
+          // close the gap: slots above lpos move down one lane
+          const int drop_id = __shfl(idk, lpos, 16);
+          {
+            const bool mv = (lr >= lpos);
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+              const double up = dpp<0x101>(Ns[j]); // row_shl:1 : lane k <- lane k+1
+              Ns[j] = mv ? up : Ns[j];
+            }
+            const double uu = dpp<0x101>(u);
+            const int ii = dppi<0x101>(idk);
+            u = mv ? uu : u;
+            idk = mv ? ii : idk;
+          }
+          act_mask &= ~(1u << drop_id);
+          q--;
+          if (lr >= q) {
+#pragma unroll
+            for (int j = 0; j < 12; j++) Ns[j] = 0.0;
+            u = 0.0;
+          }
+          if (!dual_only) { // :436-440
+            double s_min, s_fric;
+            slacks(x, s_min, s_fric);
+            const int src = 4 * pleg + (pt == 0 ? 0 : pt - 1);
+            const double vm = __shfl(s_min, src, 16), vf = __shfl(s_fric, src, 16);
+            sp = pt == 0 ? vm : vf;
+          }
+        }
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- refinement on the final working set
+  if (!done) status = kStatusMaxIter;
+  if (status == kStatusOk && q > 0) {
+    // export N* through LDS once: lane (leg,c) needs column myidx of N*
+    if (lr < 12) {
+#pragma unroll
+      for (int j = 0; j < 12; j++) lds_row[12 * lr + j] = Ns[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    double NsT[12]; // N*[k][myidx], k = 0..11
+#pragma unroll
+    for (int k = 0; k < 12; k++) NsT[k] = comp ? lds_row[12 * k + myidx] : 0.0;
+    const int lg = id_leg(idk), tt = idk - 5 * lg;
+    const int src = (lr < q) ? (4 * lg + (tt == 0 ? 0 : tt - 1)) : 0;
+    for (int pass = 0; pass < P.refine_passes; pass++) {
+      // (1) reduced gradient: x -= H (G x + g0)
+      double grad = g0;
+      static_for<12>([&](auto J) { constexpr int j = J; grad += Gm[j] * bcv<j>(x); });
+      grad = comp ? grad : 0.0;
+      double corr = 0.0;
+      static_for<12>([&](auto J) { constexpr int j = J; corr += H[j] * bcv<j>(grad); });
+      x -= comp ? corr : 0.0;
+      // (2) constraint residuals rho_k = b_k - n_k'x on slot lanes; x += N*' rho
+      double s_min, s_fric;
+      slacks(x, s_min, s_fric);
+      const double vm = __shfl(s_min, src, 16), vf = __shfl(s_fric, src, 16);
+      const double rho = (lr < q) ? -(tt == 0 ? vm : vf) : 0.0;
+      double dx = 0.0;
+      static_for<12>([&](auto K) { constexpr int k = K; dx += NsT[k] * bc<k>(rho); });
+      x += comp ? dx : 0.0;
+    }
+  }
+
+  // ---------------------------------------------------------------- torques (phase C)
+  {
+    const bool live = on && status == kStatusOk;
+    const double fx = live ? -x : 0.0;
+    const double t0 = quad_sum(comp ? Jrow[0] * fx : 0.0) + Gq[0];
+    const double t1 = quad_sum(comp ? Jrow[1] * fx : 0.0) + Gq[1];
+    const double t2 = quad_sum(comp ? Jrow[2] * fx : 0.0) + Gq[2];
+    double t = c == 0 ? t0 : c == 1 ? t1 : t2;
+    t = t > P.tau_max ? P.tau_max : t;
+    t = t < -P.tau_max ? -P.tau_max : t;
+    if (comp && robot_live) {
+      tau_out[12 * i + myidx] = live ? t : 0.0;
+      if (grf_out) grf_out[12 * i + myidx] = live ? x : 0.0;
+    }
+    if (lr == 0 && robot_live) status_out[i] = status;
+  }
+}
+
+} // namespace coop
+} // namespace qlamd

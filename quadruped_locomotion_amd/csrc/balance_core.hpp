@@ -63,6 +63,7 @@ struct DeviceParams {
   // leg chains, 64 doubles per leg: R0[4][9] fixed rotations (row-major), xyz[4][3] joint
   // origins, mass[4], mcom[4][3] = mass * com (link frame); offsets below
   double legtab[4 * 64];
+  int refine_passes;           // lane-cooperative kernel: refinement passes on the final working set
 };
 constexpr int kTabR0 = 0, kTabXyz = 36, kTabMass = 48, kTabMcom = 52, kTabPerLeg = 64;
 

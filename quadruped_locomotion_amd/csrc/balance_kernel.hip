@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include "balance_coop.hpp"
 #include "balance_core.hpp"
 #include "params_build.hpp"
 #include "qlamd.h"
@@ -139,6 +140,26 @@ __global__ __launch_bounds__(64) void balance_step_kernel(const DeviceParams *__
       }
     }
   }
+}
+
+// Latency form: 16 lanes per robot, 4 robots per wavefront (balance_coop.hpp).
+template <bool kPerLeg>
+__global__ __launch_bounds__(64) void balance_coop_kernel(const DeviceParams *__restrict__ Pp, const StatePtrs s,
+                                                          int64_t B, double *__restrict__ tau,
+                                                          double *__restrict__ grf, int32_t *__restrict__ status) {
+  __shared__ double tab[4 * kTabPerLeg];
+  __shared__ double rows[4 * coop::kCoopLdsDoubles];
+  const DeviceParams &P = *Pp;
+#pragma unroll
+  for (int i = threadIdx.x; i < 4 * kTabPerLeg; i += 64) tab[i] = P.legtab[i];
+  __syncthreads();
+  const int row = threadIdx.x >> 4;
+  int64_t i = (int64_t)blockIdx.x * 4 + row;
+  const bool live = i < B;
+  if (!live) i = B - 1;
+  const coop::CoopPtrs cp{s.q, s.pos, s.quat, s.linvel, s.angvel, s.dpos, s.dquat, s.dlinvel, s.dangvel, s.stance,
+                          s.normals};
+  coop::coop_robot<kPerLeg>(P, cp, i, live, tab, rows + row * coop::kCoopLdsDoubles, tau, grf, status);
 }
 
 __global__ __launch_bounds__(64) void virtual_wrench_kernel(const DeviceParams *__restrict__ Pp, const StatePtrs s,
@@ -367,7 +388,17 @@ int qlamd_balance_solve_batch(qlamd_context *ctx, const qlamd_state_batch *in, i
 
   hipError_t e;
   switch (pick_rpw(ctx, batch)) {
-    case 4: e = launch_balance<4>(ctx, s, batch, d_tau, d_grf, d_status, st); break;
+    case 4: {
+      const unsigned grid = (unsigned)((batch + 3) / 4);
+      if (s.normals)
+        hipLaunchKernelGGL(balance_coop_kernel<true>, dim3(grid), dim3(64), 0, st, ctx->d_params, s, batch, d_tau,
+                           d_grf, d_status);
+      else
+        hipLaunchKernelGGL(balance_coop_kernel<false>, dim3(grid), dim3(64), 0, st, ctx->d_params, s, batch, d_tau,
+                           d_grf, d_status);
+      e = hipGetLastError();
+      break;
+    }
     case 16: e = launch_balance<16>(ctx, s, batch, d_tau, d_grf, d_status, st); break;
     default: e = launch_balance<64>(ctx, s, batch, d_tau, d_grf, d_status, st); break;
   }

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "balance_core.hpp"
@@ -59,6 +60,8 @@ inline void build_device_params(const qlamd_balance_params &p, const qlamd_robot
   for (int i = 0; i < 6; i++) d->S[i] = p.force_weights[i];
   d->w_reg = p.regularizer; d->mu = p.friction; d->f_min = p.min_normal_force; d->tau_max = p.torque_limit;
   d->grav = p.gravity;
+  d->refine_passes = 1;
+  if (const char *e = getenv("QLAMD_REFINE_PASSES")) d->refine_passes = atoi(e);
   double mass = p.torso_mass;
   double arm[3] = {p.torso_mass * p.com_in_base[0], p.torso_mass * p.com_in_base[1], p.torso_mass * p.com_in_base[2]};
   for (int l = 0; l < 4; l++) {
