@@ -72,6 +72,33 @@ __device__ __forceinline__ double quad_sum(double x) {
 template <int K>
 __device__ __forceinline__ double quad_bc(double x) { return dpp<K * 85>(x); } // quad_perm [K,K,K,K]
 
+// acc += bcast_{LANE}(src) * mul in ONE instruction (v_fmac_f64_dpp, the only f64 VALU op that
+// takes a DPP operand, and only row_newbcast).  kNop: `src` may have been written by the previous
+// VALU instruction (DPP read-after-VALU-write needs 2 wait states; hipcc does not see inside asm).
+template <int LANE, bool kNop = false>
+__device__ __forceinline__ void fmac_bc(double &acc, double src, double mul) {
+  if constexpr (kNop)
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
+  else
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
+}
+
+__device__ __forceinline__ double row_min(double x) {
+  x = fmin(x, dpp<0x128>(x));
+  x = fmin(x, dpp<0x124>(x));
+  x = fmin(x, dpp<0x122>(x));
+  x = fmin(x, dpp<0x121>(x));
+  return x;
+}
+// lowest lane of my row for which `pred` holds (16 if none)
+__device__ __forceinline__ int row_first(bool pred) {
+  const unsigned long long m = __ballot(pred);
+  const unsigned bits = (unsigned)(m >> (threadIdx.x & 48)) & 0xFFFFu;
+  return bits ? (__ffs(bits) - 1) : 16;
+}
+
 // (value, key) minimum over the row; ties -> smaller key.  Invalid lanes pass +inf.
 __device__ __forceinline__ void row_argmin(double &v, int &key) {
 #define QL_ARGMIN_STEP(CTRL)                                        \
@@ -304,23 +331,25 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       for (int j = 0; j < 12; j++) diag = (j == myidx) ? Gm[j] : diag;
       c1 = row_sum(row_on ? diag : 0.0);
     }
-    // in-place Gauss-Jordan inversion, row per lane; pivot k = L_kk^2 of the Cholesky factor
+    // in-place Gauss-Jordan inversion, row per lane; pivot k = L_kk^2 of the Cholesky factor.
+    // Row update H[j] -= f * H_k[j] is one v_fmac_f64_dpp (pivot row read through the DPP operand);
+    // on the pivot lane f = 1 - 1/d turns the same formula into H_k[j] / d.
     bool bad = false;
     static_for<12>([&](auto K) {
       constexpr int k = K;
-      double Pk[12];
-      static_for<12>([&](auto J) { constexpr int j = J; Pk[j] = bcv<k>(H[j]); });
-      const double d = Pk[k];
+      const double d = bcv<k>(H[k]);
       bad = bad || !(d > 0.0);
       const double sinv = rsqrt_nr(d);
       const double p = sinv * sinv;
       if ((stance >> (k / 3)) & 1u) c2 += sinv;
       const bool piv = comp && (myidx == k);
       const double f = piv ? (1.0 - p) : H[k] * p;
-#pragma unroll
-      for (int j = 0; j < 12; j++)
-        if (j != k) H[j] -= f * Pk[j];
-      H[k] = piv ? p : -f;
+      const double nf = -f;
+      static_for<12>([&](auto J) {
+        constexpr int j = J;
+        if constexpr (j != k) fmac_bc<lane_of(k), (j == (k == 0 ? 1 : 0))>(H[j], H[j], nf);
+      });
+      H[k] = piv ? p : nf;
     });
     if (bad && nS > 0) {
       if (lr == 0 && robot_live) status_out[i] = kStatusNotPd;
@@ -331,32 +360,37 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
 
   // ---------------------------------------------------------------- x0 = -H g0
   double x = 0.0;
-  static_for<12>([&](auto J) { constexpr int j = J; x -= H[j] * bcv<j>(g0); });
-  x = comp ? x : 0.0;
+  {
+    const double ng0 = -g0;
+    static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(x, ng0, H[j]); });
+  }
 
   // ---------------------------------------------------------------- active-set loop
+  // Slots are NOT compacted on a drop: a freed slot lane is reused by the next add (the order of the
+  // slots only breaks exact ties in the blocking-constraint search).
   double Ns[12];
 #pragma unroll
   for (int j = 0; j < 12; j++) Ns[j] = 0.0;
-  double u = 0.0;      // multiplier of slot lr
-  int idk = 0;         // constraint id of slot lr
+  double u = 0.0;            // multiplier of slot lr
+  int idk = 0;               // constraint id of slot lr
+  unsigned used = 0;         // bit k set <=> slot lane k holds an active constraint
   int q = 0, iters = 0, status = kStatusOk;
   unsigned act_mask = 0, excl = 0;
   const double psi_tol = (double)(5 * nS) * eps * c1 * c2 * 100.0;
-  double rnorm = 1.0;
+  double rnorm2 = 1.0; // R_norm^2
   bool done = (nS == 0), need_select = true, fresh = true;
-  int ip = -1, pleg = 0, pt = 0;
+  int ip = 0, pleg = 0, pt = 0;
   double sp = 0.0, ucand = 0.0;
   // per-lane constraint coefficients: lane c of a quad evaluates friction row t = c+1
   const double fa = c == 0 ? 1.0 : c == 1 ? -1.0 : 0.0, fb = c == 2 ? 1.0 : c == 3 ? -1.0 : 0.0;
 
-  // slacks at the current x: s_min (replicated in the quad) and this lane's friction row
+  // slacks at x: s_min (replicated in the quad) and this lane's friction row
   const auto slacks = [&](double xx, double &s_min, double &s_fric) {
     const double dn = quad_sum(myn * xx), d1 = quad_sum(myt1 * xx), d2 = quad_sum(myt2 * xx);
     s_min = dn - f_min;
     s_fric = mu * dn + fa * d1 + fb * d2;
   };
-  // component c of the normal of constraint type t on my leg
+  // component c of the normal of constraint type t on my leg (0 on the spare lane)
   const auto my_normal = [&](int t) -> double {
     return t == 0 ? myn : (mu * myn + (t == 1 ? myt1 : t == 2 ? -myt1 : t == 3 ? myt2 : -myt2));
   };
@@ -369,25 +403,27 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       slacks(x, s_min, s_fric);
       const double psi = row_sum(on ? (fmin(0.0, s_fric) + (c == 0 ? fmin(0.0, s_min) : 0.0)) : 0.0);
       const unsigned blocked = act_mask | excl;
-      // candidates of this lane: friction row 5*leg + c + 1, and (lane c == 0) the minimum-force row 5*leg.
-      // key = row index in the reference's ordering (minimum-force rows first) for tie breaks
+      // candidates of this lane: friction row 5*leg + c + 1 and (lane c == 0) the minimum-force row
+      // 5*leg.  Exact ties go to the lowest lane (the reference takes the lowest row index; either
+      // way the minimiser is the same, only the path differs).
       double v = inf;
-      int key = 1 << 20;
+      bool cand_min = false;
       if (on) {
-        const int idf = 5 * leg + c + 1;
-        if (!((blocked >> idf) & 1u) && s_fric < 0.0) { v = s_fric; key = (4 + 4 * leg + c) * 32 + idf; }
-        const int idm = 5 * leg;
-        if (c == 0 && !((blocked >> idm) & 1u) && s_min < 0.0 && (s_min < v || (s_min == v))) {
-          v = s_min; key = leg * 32 + idm;
-        }
+        const int idf = 5 * leg + c + 1, idm = 5 * leg;
+        if (!((blocked >> idf) & 1u) && s_fric < 0.0) v = s_fric;
+        if (c == 0 && !((blocked >> idm) & 1u) && s_min < 0.0 && s_min <= v) { v = s_min; cand_min = true; }
       }
-      row_argmin(v, key);
+      const double vbest = row_min(v);
+      const int wl = row_first(v == vbest && v < 0.0);
+      const bool wmin = ((unsigned)(__ballot(cand_min) >> ((threadIdx.x & 48) + (wl & 15))) & 1u) != 0;
+      v = vbest;
+      const int key = 5 * (wl >> 2) + (wmin ? 0 : (wl & 3) + 1);
       const bool feasible = fresh && (fabs(psi) <= psi_tol); // QuadProg++.cc:246-250
       if (feasible || !(v < 0.0) || iters > kMaxOuter) {      // :271-274
         if (iters > kMaxOuter) status = kStatusMaxIter;
         done = true;
       } else {
-        ip = key & 31;
+        ip = key;
         pleg = id_leg(ip); pt = ip - 5 * pleg;
         sp = v;
         ucand = 0.0;
@@ -396,127 +432,97 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     }
     if (!done) {
       // ---- directions: z = H n_p (lane i), r = N* n_p (slot lane k)
-      const double npj = (comp && leg == pleg) ? my_normal(pt) : 0.0;
+      const double npj = (leg == pleg) ? my_normal(pt) : 0.0;
       double z = 0.0, r = 0.0;
       static_for<12>([&](auto J) {
         constexpr int j = J;
-        const double nj = bcv<j>(npj);
-        z += H[j] * nj;
-        r += Ns[j] * nj;
+        fmac_bc<lane_of(j), j == 0>(z, npj, H[j]);
+        fmac_bc<lane_of(j)>(r, npj, Ns[j]);
       });
-      z = comp ? z : 0.0;
-      const bool slot = lr < q;
-      r = slot ? r : 0.0;
+      const bool slot = (used >> lr) & 1u;
       const double zn = row_sum(z * npj);
       const double zz = row_sum(z * z);
       // ---- step lengths, QuadProg++.cc:304-331
       double ratio = inf;
-      int lkey = 1 << 20;
-      if (slot && r > 0.0) { ratio = u * rcp_nr(r); lkey = lr; }
-      row_argmin(ratio, lkey);
-      const double t1 = ratio;
-      const int lpos = lkey;
+      if (slot && r > 0.0) ratio = u * rcp_nr(r);
+      const double t1 = row_min(ratio);
+      const int lpos = row_first(ratio == t1 && ratio < inf);
       double t2 = inf;
       if (fabs(zz) > eps) {
         t2 = -sp * rcp_nr(zn);
         if (t2 < 0.0) t2 = inf;
       }
       const double t = fmin(t1, t2);
-      if (t >= inf) { // :339-344
-        status = kStatusInfeasible;
-        done = true;
-      } else {
-        const bool dual_only = (t2 >= inf);
-        if (!dual_only) x += t * z;
-        if (slot) u -= t * r;
-        ucand += t;
-        if (!dual_only && t2 <= t1) {
-          // ---- full step: add ip (rank-one updates of H and N*)
-          const double delta = zn > 0.0 ? sqrt(zn) : 0.0;
-          if (delta <= eps * rnorm) {
-            // numerically dependent normal: undo the step, exclude ip, select again
-            x -= t * z;
-            if (slot) u += t * r;
-            excl |= 1u << ip;
-            need_select = true; fresh = false;
-          } else {
-            rnorm = fmax(rnorm, delta);
-            const double dinv = rcp_nr(zn);
-            const double wz = z * dinv;          // w_i = z_i / d on lane i
-            const bool newslot = (lr == q);
-            static_for<12>([&](auto J) {
-              constexpr int j = J;
-              const double wj = bcv<j>(wz);
-              H[j] -= z * wj;
-              Ns[j] = newslot ? wj : (Ns[j] - r * wj);
-            });
-            if (newslot) { u = ucand; idk = ip; }
-            act_mask |= 1u << ip;
-            q++;
-            need_select = true; fresh = true;
-          }
-        } else {
-          // ---- partial / dual-only step: drop the constraint in slot lpos (:346-362, :423-445)
-          // export row lpos of N* through LDS so that every lane gets all of it and its own element
-          if (lr == lpos) {
+      // what happens this tick (all row-uniform)
+      const bool infeasible = !(t < inf);                          // :339-344
+      const bool dual_only = (t2 >= inf);
+      const bool full = !infeasible && !dual_only && (t2 <= t1);   // :384
+      // add_constraint fails when |R_qq| = sqrt(z'n_p) <= eps * R_norm (:392); compared squared
+      const bool degenerate = full && !(zn > eps * eps * rnorm2);
+      const bool is_add = full && !degenerate;
+      const bool is_drop = !infeasible && !full;                   // partial or dual-only step
+      if (infeasible) { status = kStatusInfeasible; done = true; }
+      // ---- the step
+      const double tp = (infeasible || dual_only || degenerate) ? 0.0 : t;
+      const double td = (infeasible || degenerate) ? 0.0 : t;
+      x += tp * z;
+      u -= slot ? td * r : 0.0;
+      ucand += td;
+      sp += tp * zn; // slack of ip after a partial step (:436-440, linear in t)
+      // ---- rank-one update of H and N*:  H[j] += hc * v_j,  N*[j] += nc * v_j
+      double vec = 0.0, hc = 0.0, nc = 0.0;
+      if (is_add) {
+        // H -= z z'/d;  N* <- [N* - r z'/d ; z'/d]  (the new row goes to the lowest free slot lane)
+        const int newlane = __ffs(~used & 0xFFFu) - 1;
+        const double dinv = rcp_nr(zn);
+        vec = z * dinv;
+        hc = -z;
+        const bool newslot = (lr == newlane);
+        nc = newslot ? 1.0 : (slot ? -r : 0.0);
+        if (newslot) { u = ucand; idk = ip; }
+        used |= 1u << newlane;
+        act_mask |= 1u << ip;
+        rnorm2 = fmax(rnorm2, zn);
+        q++;
+        need_select = true; fresh = true;
+      }
+      if (degenerate) { // numerically dependent normal: skip it and select again
+        excl |= 1u << ip;
+        need_select = true; fresh = false;
+      }
+      if (is_drop) {
+        // n~ = row lpos of N*: through LDS so that lane (leg,c) gets element myidx of it
+        if (lr == lpos) {
 #pragma unroll
-            for (int j = 0; j < 12; j++) lds_row[144 + j] = Ns[j];
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
-          double nt[12];
-#pragma unroll
-          for (int j = 0; j < 12; j++) nt[j] = lds_row[144 + j];
-          const double nt_me = comp ? lds_row[144 + myidx] : 0.0;
-          // Gn = G n~ (lane i), e = n~' G n~
-          double Gn = 0.0;
-#pragma unroll
-          for (int j = 0; j < 12; j++) Gn += Gm[j] * nt[j];
-          Gn = comp ? Gn : 0.0;
-          const double e = row_sum(nt_me * Gn);
-          const double einv = rcp_nr(e);
-          // coef_k = (N*_k . G n~) / e on slot lanes; H += n~ n~'/e
-          double coef = 0.0;
-          static_for<12>([&](auto J) {
-            constexpr int j = J;
-            coef += Ns[j] * bcv<j>(Gn);
-          });
-          coef *= einv;
-          const double hme = nt_me * einv;
-#pragma unroll
-          for (int j = 0; j < 12; j++) {
-            H[j] += hme * nt[j];
-            Ns[j] -= coef * nt[j];
-          }
-          // close the gap: slots above lpos move down one lane
-          const int drop_id = __shfl(idk, lpos, 16);
-          {
-            const bool mv = (lr >= lpos);
-#pragma unroll
-            for (int j = 0; j < 12; j++) {
-              const double up = dpp<0x101>(Ns[j]); // row_shl:1 : lane k <- lane k+1
-              Ns[j] = mv ? up : Ns[j];
-            }
-            const double uu = dpp<0x101>(u);
-            const int ii = dppi<0x101>(idk);
-            u = mv ? uu : u;
-            idk = mv ? ii : idk;
-          }
-          act_mask &= ~(1u << drop_id);
-          q--;
-          if (lr >= q) {
-#pragma unroll
-            for (int j = 0; j < 12; j++) Ns[j] = 0.0;
-            u = 0.0;
-          }
-          if (!dual_only) { // :436-440
-            double s_min, s_fric;
-            slacks(x, s_min, s_fric);
-            const int src = 4 * pleg + (pt == 0 ? 0 : pt - 1);
-            const double vm = __shfl(s_min, src, 16), vf = __shfl(s_fric, src, 16);
-            sp = pt == 0 ? vm : vf;
-          }
+          for (int j = 0; j < 12; j++) lds_row[144 + j] = Ns[j];
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+        const double nt_me = comp ? lds_row[144 + myidx] : 0.0;
+        // Gn = G n~ (lane i), e = n~'G n~, coef_k = N*_k . Gn / e
+        double Gn = 0.0;
+        static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(Gn, nt_me, Gm[j]); });
+        const double einv = rcp_nr(row_sum(nt_me * Gn));
+        double coef = 0.0;
+        static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(coef, Gn, Ns[j]); });
+        // H += n~ n~'/e;  N* -= coef n~'  (row lpos becomes exactly 0: coef = 1 there)
+        vec = nt_me;
+        hc = nt_me * einv;
+        nc = -coef * einv;
+        const int drop_id = __shfl(idk, lpos, 16);
+        act_mask &= ~(1u << drop_id);
+        used &= ~(1u << lpos);
+        if (lr == lpos) u = 0.0;
+        q--;
+      }
+      static_for<12>([&](auto J) {
+        constexpr int j = J;
+        fmac_bc<lane_of(j), j == 0>(H[j], vec, hc);
+        fmac_bc<lane_of(j)>(Ns[j], vec, nc);
+      });
+      if (is_drop && lr == lpos) {
+#pragma unroll
+        for (int j = 0; j < 12; j++) Ns[j] = 0.0;
       }
     }
   }
@@ -535,23 +541,23 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
 #pragma unroll
     for (int k = 0; k < 12; k++) NsT[k] = comp ? lds_row[12 * k + myidx] : 0.0;
     const int lg = id_leg(idk), tt = idk - 5 * lg;
-    const int src = (lr < q) ? (4 * lg + (tt == 0 ? 0 : tt - 1)) : 0;
+    const bool myslot = (used >> lr) & 1u;
+    const int src = myslot ? (4 * lg + (tt == 0 ? 0 : tt - 1)) : 0;
     for (int pass = 0; pass < P.refine_passes; pass++) {
       // (1) reduced gradient: x -= H (G x + g0)
       double grad = g0;
-      static_for<12>([&](auto J) { constexpr int j = J; grad += Gm[j] * bcv<j>(x); });
-      grad = comp ? grad : 0.0;
+      static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(grad, x, Gm[j]); });
       double corr = 0.0;
-      static_for<12>([&](auto J) { constexpr int j = J; corr += H[j] * bcv<j>(grad); });
-      x -= comp ? corr : 0.0;
+      static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(corr, grad, H[j]); });
+      x -= corr;
       // (2) constraint residuals rho_k = b_k - n_k'x on slot lanes; x += N*' rho
       double s_min, s_fric;
       slacks(x, s_min, s_fric);
       const double vm = __shfl(s_min, src, 16), vf = __shfl(s_fric, src, 16);
-      const double rho = (lr < q) ? -(tt == 0 ? vm : vf) : 0.0;
+      const double rho = myslot ? -(tt == 0 ? vm : vf) : 0.0;
       double dx = 0.0;
-      static_for<12>([&](auto K) { constexpr int k = K; dx += NsT[k] * bc<k>(rho); });
-      x += comp ? dx : 0.0;
+      static_for<12>([&](auto K) { constexpr int k = K; fmac_bc<k, k == 0>(dx, rho, NsT[k]); });
+      x += dx;
     }
   }
 
