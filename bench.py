@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=4096, help="robots per GPU")
     ap.add_argument("--gait", default="static", choices=["static", "trot"])
     ap.add_argument("--rpw", type=int, default=0, help="robots per wavefront (0 = auto)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph of K steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -136,17 +137,46 @@ def main():
     fence()
 
     # ---- timed region: exactly K steps -----------------------------------------
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # Single GPU: the K launches are captured once into a hipGraph and replayed (the step is a few
+    # tens of microseconds, comparable to an eager launch from Python).  The graph is built outside
+    # the timed region; the timed region is one replay = K control steps.  Multi-GPU keeps eager
+    # launches so that the all-gather of step k overlaps the solve of step k+1.
+    use_graph = (world == 1) and not args.no_graph
+    graph = None
+    if use_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    cap = torch.cuda.current_stream().cuda_stream
+                    for k in range(args.steps):
+                        ctx.balance_solve_device(d, tau[k & 1], None, status, stream=cap)
+            torch.cuda.current_stream().wait_stream(side)
+            graph.replay()  # one untimed replay (instantiation / upload)
+            fence()
+        except Exception as e:  # pragma: no cover - fall back to eager launches
+            sys.stderr.write("hipGraph capture failed (%s); eager launches\n" % e)
+            graph = None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev = []
     fence()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        w = step(k, ev[k])
-        if w is not None:
-            pending.append(w)
-            if len(pending) > 1:
-                pending.pop(0).wait()
-    for w in pending:
-        w.wait()
+    if graph is not None:
+        e0.record()
+        graph.replay()
+        e1.record()
+    else:
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for k in range(args.steps):
+            w = step(k, ev[k])
+            if w is not None:
+                pending.append(w)
+                if len(pending) > 1:
+                    pending.pop(0).wait()
+        for w in pending:
+            w.wait()
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -155,7 +185,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if graph is not None:
+        # HIP events around the replay: K kernels back to back, so this average includes the
+        # ~1.5 us kernel-to-kernel boundary (an upper bound of the pure kernel duration; the
+        # rocprofv3 summary under profiles/ has the exact figure)
+        kernel_ms = e0.elapsed_time(e1) / args.steps
+    else:
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     st = status.cpu().numpy()
     ok = bool((st == 0).all())
 
@@ -175,6 +211,7 @@ def main():
                                       else "trot gait (2<->4 contacts)"),
                        "robots_per_gpu": B, "gait": args.gait, "seed": synth.SEED,
                        "result_collection": "rccl all_gather of torques" if world > 1 else "none (single GPU)",
+                       "launch": "hipGraph of K steps" if graph is not None else "eager",
                        "all_status_ok": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": MEASURED_TRAFFIC_BYTES.get((B, args.gait)),

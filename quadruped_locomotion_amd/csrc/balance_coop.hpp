@@ -32,25 +32,43 @@
 namespace qlamd {
 namespace coop {
 
+// Diagnostic build only (-DQLAMD_STAMPS): s_memtime at segment boundaries of wave 0, read back
+// through qlamd_debug_stamps.  Never compiled into the shipped library.
+#ifdef QLAMD_STAMPS
+__device__ unsigned long long g_stamps[64];
+#define QL_STAMP(k)                                                                         \
+  do {                                                                                      \
+    unsigned long long t_;                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[k] = t_;                              \
+  } while (0)
+#else
+#define QL_STAMP(k)
+#endif
+
 template <int CTRL>
 __device__ __forceinline__ double dpp(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  // mov_dpp (no `old` operand to initialise): one v_mov_b32_dpp per half; bound_ctrl -> 0 for
+  // lanes whose source is outside the row (row_shl/shr), never the case for ror / quad_perm
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 template <int CTRL>
 __device__ __forceinline__ int dppi(int x) {
-  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, false);
+  return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, true);
 }
 // broadcast from lane J of the 16-lane row (one v_mov_b64_dpp row_newbcast)
 template <int J>
 __device__ __forceinline__ double bc(double x) {
-  return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + J, 0xF, 0xF, false);
+  return __builtin_amdgcn_mov_dpp(x, 0x150 + J, 0xF, 0xF, true);
 }
 template <int J>
 __device__ __forceinline__ int bci(int x) {
-  return __builtin_amdgcn_update_dpp(0, x, 0x150 + J, 0xF, 0xF, false);
+  return __builtin_amdgcn_mov_dpp(x, 0x150 + J, 0xF, 0xF, true);
 }
 // lane that carries variable index j (0..11)
 __host__ __device__ constexpr int lane_of(int j) { return 4 * (j / 3) + (j % 3); }
@@ -168,6 +186,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   const double eps = 2.220446049250313e-16;
   const double inf = INFINITY;
 
+  QL_STAMP(0);
   // ---------------------------------------------------------------- load
   const int64_t i = irobot;
   double quat[4], dquat[4], pos[3], linvel[3], angvel[3], dpos[3], dlinvel[3], dangvel[3];
@@ -192,6 +211,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   const bool on = ((stance >> leg) & 1u) != 0; // my leg supports
   const double qj = comp ? s.q[12 * i + myidx] : 0.0;
 
+  QL_STAMP(1);
   // ---------------------------------------------------------------- wrench (replicated)
   double Rm[9], gB[3], b[6];
   quat_to_matrix(quat, Rm);
@@ -209,6 +229,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     virtual_wrench(P, in, Rm, gB, b);
   }
 
+  QL_STAMP(2);
   // ---------------------------------------------------------------- leg kinematics, 4 lanes per leg
   // lane c holds row c of the cumulative rotation and component c of every position
   const CoopTab tab{lds_tab + kTabPerLeg * leg};
@@ -271,6 +292,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     }
   }
 
+  QL_STAMP(3);
   // ---------------------------------------------------------------- friction pyramid of my leg
   double myn = 0.0, myt1 = 0.0, myt2 = 0.0; // component c of n, t1, t2 (base frame)
   {
@@ -290,6 +312,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   }
   const double mu = P.mu, f_min = P.f_min;
 
+  QL_STAMP(4);
   // ---------------------------------------------------------------- G row, g0, H = G^-1 (Gauss-Jordan)
   double Gm[12], H[12], g0;
   double c1 = 0.0, c2 = 0.0;
@@ -339,9 +362,8 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       constexpr int k = K;
       const double d = bcv<k>(H[k]);
       bad = bad || !(d > 0.0);
-      const double sinv = rsqrt_nr(d);
-      const double p = sinv * sinv;
-      if ((stance >> (k / 3)) & 1u) c2 += sinv;
+      const double p = rcp_nr(d);
+      if ((stance >> (k / 3)) & 1u) c2 += rsqrt_nr(d); // only feeds the termination tolerance
       const bool piv = comp && (myidx == k);
       const double f = piv ? (1.0 - p) : H[k] * p;
       const double nf = -f;
@@ -358,13 +380,17 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     }
   }
 
+  QL_STAMP(5);
   // ---------------------------------------------------------------- x0 = -H g0
   double x = 0.0;
   {
     const double ng0 = -g0;
-    static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(x, ng0, H[j]); });
+    double xa[3] = {0.0, 0.0, 0.0};
+    static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(xa[j % 3], ng0, H[j]); });
+    x = (xa[0] + xa[1]) + xa[2];
   }
 
+  QL_STAMP(6);
   // ---------------------------------------------------------------- active-set loop
   // Slots are NOT compacted on a drop: a freed slot lane is reused by the next add (the order of the
   // slots only breaks exact ties in the blocking-constraint search).
@@ -433,12 +459,14 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     if (!done) {
       // ---- directions: z = H n_p (lane i), r = N* n_p (slot lane k)
       const double npj = (leg == pleg) ? my_normal(pt) : 0.0;
-      double z = 0.0, r = 0.0;
+      // three partial sums per product: consecutive dependent FMAs are 6 instructions apart
+      double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
       static_for<12>([&](auto J) {
         constexpr int j = J;
-        fmac_bc<lane_of(j), j == 0>(z, npj, H[j]);
-        fmac_bc<lane_of(j)>(r, npj, Ns[j]);
+        fmac_bc<lane_of(j), j == 0>(za[j % 3], npj, H[j]);
+        fmac_bc<lane_of(j)>(ra[j % 3], npj, Ns[j]);
       });
+      const double z = (za[0] + za[1]) + za[2], r = (ra[0] + ra[1]) + ra[2];
       const bool slot = (used >> lr) & 1u;
       const double zn = row_sum(z * npj);
       const double zz = row_sum(z * z);
@@ -527,6 +555,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     }
   }
 
+  QL_STAMP(7);
   // ---------------------------------------------------------------- refinement on the final working set
   if (!done) status = kStatusMaxIter;
   if (status == kStatusOk && q > 0) {
@@ -561,6 +590,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     }
   }
 
+  QL_STAMP(8);
   // ---------------------------------------------------------------- torques (phase C)
   {
     const bool live = on && status == kStatusOk;
@@ -577,6 +607,8 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     }
     if (lr == 0 && robot_live) status_out[i] = status;
   }
+  QL_STAMP(9);
+  QL_STAMP(10);
 }
 
 } // namespace coop

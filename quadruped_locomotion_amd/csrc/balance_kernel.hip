@@ -159,6 +159,10 @@ __global__ __launch_bounds__(64) void balance_coop_kernel(const DeviceParams *__
   if (!live) i = B - 1;
   const coop::CoopPtrs cp{s.q, s.pos, s.quat, s.linvel, s.angvel, s.dpos, s.dquat, s.dlinvel, s.dangvel, s.stance,
                           s.normals};
+#ifdef QLAMD_STAMPS
+#pragma unroll 1
+  for (int rep = 0; rep < 2; rep++) // second pass runs with a warm instruction cache
+#endif
   coop::coop_robot<kPerLeg>(P, cp, i, live, tab, rows + row * coop::kCoopLdsDoubles, tau, grf, status);
 }
 
@@ -278,6 +282,12 @@ extern "C" {
 void qlamd_balance_default_params(qlamd_balance_params *p) { if (p) default_balance_params(p); }
 void qlamd_default_robot_model(qlamd_robot_model *m) { if (m) default_robot_model(m); }
 int qlamd_version(void) { return QLAMD_VERSION_MAJOR * 1000 + QLAMD_VERSION_MINOR; }
+
+#ifdef QLAMD_STAMPS
+int qlamd_debug_stamps(unsigned long long *out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(qlamd::coop::g_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
 
 const char *qlamd_strerror(int code) {
   switch (code) {
