@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="robots per GPU")
     ap.add_argument("--gait", default="static", choices=["static", "trot"])
+    ap.add_argument("--workload", default="balance", choices=["balance", "pose_sqp"],
+                    help="pose_sqp = BASELINE config 5 (reported separately; single GPU)")
     ap.add_argument("--rpw", type=int, default=0, help="robots per wavefront (0 = auto)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph of K steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -77,8 +79,49 @@ def cpu_baseline(state, seconds):
                       "(fastest of %s)" % (n, B, dt, best, cands)}
 
 
+def bench_pose_sqp(args):
+    """BASELINE configs[4]: batch pose optimisation, exactly 5 SQP iterations x inner QP per problem."""
+    import torch
+    from quadruped_locomotion_amd import capi, synth
+    B = args.batch
+    pb = synth.make_pose_problems(B)
+    ctx = capi.Context(device=0)
+    prm = capi.default_pose_params()
+    prm.tolerance, prm.max_iterations = 0.0, 5
+    d = {k: torch.from_numpy(v).to("cuda:0") for k, v in pb.items()}
+    out = (torch.zeros(B, 7, dtype=torch.float64, device="cuda:0"), torch.zeros(B, dtype=torch.int32, device="cuda:0"),
+           torch.zeros(B, dtype=torch.int32, device="cuda:0"))
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(args.warmup):
+        capi.pose_sqp(ctx, d, prm, memory=capi.MEM_DEVICE, out=out, stream=stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        capi.pose_sqp(ctx, d, prm, memory=capi.MEM_DEVICE, out=out, stream=stream)
+    e1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = e0.elapsed_time(e1) / args.steps
+    algo = 424 * B  # SURVEY.md 8(d): 46 doubles in + 7 out per pose-SQP solve
+    achieved = algo / (kernel_ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "pose-SQP solves/sec (config 5, reported separately from the headline metric)",
+        "value": B * args.steps / elapsed, "unit": "solves/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "batch=%d pose optimisations, 5 SQP iterations x inner Goldfarb-Idnani QP "
+                               "(n=6, m=8, dummy equality)" % B, "all_status_ok": bool((out[2] == 0).all().item())},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "pose_sqp_kernel", "kernel_ms": kernel_ms,
+                     "algorithmic_bytes_per_launch": algo}}), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "pose_sqp":
+        return bench_pose_sqp(args)
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -154,6 +154,58 @@ int qlamd_leg_kinematics_batch(qlamd_context *ctx, const double *joint_position,
                                double *foot_position, double *jacobian, double *gravity_torque,
                                int memory, void *stream);
 
+/* ---- dense QP batch -------------------------------------------------
+ * min 1/2 x'Gx + g0'x  s.t.  CE'x + ce0 = 0,  CI'x + ci0 >= 0, one problem per batch entry, all
+ * of the same shape (n <= 12, p <= 2, m <= 24), row-major, one constraint per COLUMN of CE / CI as
+ * in quadprogpp::solve_quadprog(G, g0, CE, ce0, CI, ci0, x) (qp_solver/include/qp_solver/QuadProg++.h:69-72),
+ * which this replaces together with qp_solver::QuadraticProblemSolver::minimize
+ * (qp_solver/src/quadraticproblemsolver.cpp:65-97; its wrapper passes CI = -A', ci0 = b for A x <= b,
+ * :164).  The Goldfarb-Idnani iteration is the reference's, including its treatment of an all-zero
+ * equality column.  G is not modified.
+ *   G [B][n][n], g0 [B][n], CE [B][n][p] (NULL if p = 0), ce0 [B][p], CI [B][n][m], ci0 [B][m]
+ *   x [B][n] out, objective [B] out or NULL (+inf when infeasible), status [B] out (QLAMD_STATUS_*)
+ */
+int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *G, const double *g0,
+                         const double *CE, const double *ce0, const double *CI, const double *ci0,
+                         int64_t batch, double *x, double *objective, int32_t *status, int memory,
+                         void *stream);
+
+/* ---- pose optimisation batch (BASELINE config 5) ----------------------
+ * Replaces free_gait::PoseOptimizationSQP::optimize(Pose&) with its setters
+ * (free_gait_core/include/free_gait_core/pose_optimization/PoseOptimizationSQP.hpp:36-54,
+ *  free_gait_core/src/pose_optimization/PoseOptimizationSQP.cpp:58-111,
+ *  free_gait_core/src/pose_optimization/PoseOptimizationBase.cpp:21-50). */
+typedef struct qlamd_pose_params {
+  double hip_in_base[4][3];   /* adapter.getPositionBaseToHipInBaseFrame, limb order LF RF RH LH    */
+  double com_weight;          /* 2.0, PoseOptimizationObjectiveFunction.cpp:17                      */
+  double tolerance;           /* 0.05, PoseOptimizationSQP.cpp:99 (stop when |dp| < tolerance)      */
+  int max_iterations;         /* 30                                                                  */
+  int dummy_equality;         /* 1 = pass the all-zero equality column like the reference (Q1)      */
+  int leg_order[4];           /* iteration order of the reference's unordered_map Stance (Q6);
+                                 limbs missing from a problem's stance_mask are skipped             */
+} qlamd_pose_params;
+
+/* Reference defaults: hips (+-0.42, +-0.075, 0) (free_gait_core/test/AdapterDummy.cpp:111-125),
+ * leg_order = libstdc++ order of a Stance filled LF, RF, LH, RH = {RH, LH, RF, LF}. */
+void qlamd_pose_default_params(qlamd_pose_params *p);
+
+typedef struct qlamd_pose_batch {
+  const double *stance;          /* [B][4][3] foot positions, world           (setStance)               */
+  const uint8_t *stance_mask;    /* [B][4] or NULL (= all four limbs)                                   */
+  const double *nominal_stance;  /* [B][4][3] base frame                      (setNominalStance)        */
+  const double *support_polygon; /* [B][4][2] counter-clockwise vertices      (setSupportRegion)        */
+  const int32_t *n_vertices;     /* [B] or NULL (= 4); 3 or 4                                           */
+  const double *center_of_mass;  /* [B][3] in base or NULL (= 0, every shipped adapter)                 */
+  const double *max_limb_length; /* [B][4]                                    (setLimbLengthConstraints) */
+  const double *pose;            /* [B][7] initial pose (x,y,z,qw,qx,qy,qz)   (optimize's in/out Pose)   */
+} qlamd_pose_batch;
+
+/* pose_out [B][7]; iterations [B] (SQP iterations taken) or NULL; status [B] QLAMD_STATUS_*
+ * (a failed inner QP stops that problem, like the uncaught exception would in the reference). */
+int qlamd_pose_sqp_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
+                         int64_t batch, double *pose_out, int32_t *iterations, int32_t *status, int memory,
+                         void *stream);
+
 const char *qlamd_strerror(int code);
 int qlamd_version(void);
 

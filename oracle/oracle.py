@@ -238,3 +238,51 @@ def force_qp_assemble(r_feet, wrench, n_B, t1, t2, params=None):
                                    G.ctypes.data_as(_dp), g0.ctypes.data_as(_dp),
                                    CI.ctypes.data_as(_dp), ci0.ctypes.data_as(_dp))
     return G, g0, CI, ci0
+
+
+# ---- pose optimisation (config 5) ---------------------------------------------------------------
+class PoseProblem(C.Structure):
+    _fields_ = [("n_legs", C.c_int), ("leg_order", C.c_int * 4), ("stance", (C.c_double * 3) * 4),
+                ("nominal", (C.c_double * 3) * 4), ("hips", (C.c_double * 3) * 4), ("max_len", C.c_double * 4),
+                ("n_vertices", C.c_int), ("polygon", (C.c_double * 2) * 4), ("r_com", C.c_double * 3),
+                ("com_weight", C.c_double)]
+
+
+def pose_problem(pb, i, hips, leg_order, com_weight=2.0):
+    """Problem i of a batch dict (synth.make_pose_problems layout)."""
+    p = PoseProblem()
+    mask = pb["stance_mask"][i]
+    legs = [l for l in leg_order if mask[l]]
+    p.n_legs = len(legs)
+    for k, l in enumerate(legs):
+        p.leg_order[k] = int(l)
+    for l in range(4):
+        for a in range(3):
+            p.stance[l][a] = pb["stance"][i][l][a]
+            p.nominal[l][a] = pb["nominal"][i][l][a]
+            p.hips[l][a] = hips[l][a]
+        p.max_len[l] = pb["max_len"][i][l]
+        p.polygon[l][0], p.polygon[l][1] = pb["polygon"][i][l]
+    p.n_vertices = int(pb["n_vertices"][i])
+    for a in range(3):
+        p.r_com[a] = pb["r_com"][i][a]
+    p.com_weight = com_weight
+    return p
+
+
+def pose_sqp(pb, i, hips, leg_order, tol=0.05, max_iter=30, dummy_equality=1, com_weight=2.0):
+    lib().oracle_pose_cost.restype = C.c_double
+    p = pose_problem(pb, i, hips, leg_order, com_weight)
+    pose_in = (C.c_double * 7)(*pb["pose"][i])
+    out = (C.c_double * 7)()
+    it, cost = C.c_int(), C.c_double()
+    hist = np.zeros((max(max_iter, 1), 6))
+    st = lib().oracle_pose_sqp(C.byref(p), pose_in, C.c_double(tol), int(max_iter), int(dummy_equality), out,
+                               C.byref(it), C.byref(cost), hist.ctypes.data_as(_dp))
+    return dict(pose=np.array(out[:]), iters=it.value, cost=cost.value, status=st, dp=hist[:it.value].copy())
+
+
+def pose_cost(pb, i, pose, hips, leg_order, com_weight=2.0):
+    lib().oracle_pose_cost.restype = C.c_double
+    p = pose_problem(pb, i, hips, leg_order, com_weight)
+    return lib().oracle_pose_cost(C.byref(p), (C.c_double * 7)(*pose))

@@ -20,6 +20,7 @@ EXPORTS = (
     "qlamd_balance_default_params", "qlamd_default_robot_model", "qlamd_context_create",
     "qlamd_context_destroy", "qlamd_set_robots_per_wave", "qlamd_balance_solve_batch",
     "qlamd_virtual_wrench_batch", "qlamd_leg_kinematics_batch", "qlamd_strerror", "qlamd_version",
+    "qlamd_qp_solve_batch", "qlamd_pose_default_params", "qlamd_pose_sqp_batch",
 )
 
 
@@ -47,6 +48,22 @@ class StateBatch(C.Structure):
         "joint_position", "base_position", "base_orientation", "base_linear_velocity",
         "base_angular_velocity", "desired_position", "desired_orientation",
         "desired_linear_velocity", "desired_angular_velocity", "support_leg", "surface_normal")]
+
+
+class PoseParams(C.Structure):
+    _fields_ = [("hip_in_base", (C.c_double * 3) * 4), ("com_weight", C.c_double), ("tolerance", C.c_double),
+                ("max_iterations", C.c_int), ("dummy_equality", C.c_int), ("leg_order", C.c_int * 4)]
+
+
+class PoseBatch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("stance", "stance_mask", "nominal_stance", "support_polygon",
+                                           "n_vertices", "center_of_mass", "max_limb_length", "pose")]
+
+
+# problem-dict key (synth.make_pose_problems) -> PoseBatch field
+POSE_FIELD_OF_KEY = (("stance", "stance"), ("stance_mask", "stance_mask"), ("nominal", "nominal_stance"),
+                     ("polygon", "support_polygon"), ("n_vertices", "n_vertices"), ("r_com", "center_of_mass"),
+                     ("max_len", "max_limb_length"), ("pose", "pose"))
 
 
 # state-dict key -> StateBatch field (keys as produced by synth.make_states)
@@ -89,6 +106,10 @@ def lib():
                                                  C.c_int, C.c_void_p]
         L.qlamd_leg_kinematics_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.qlamd_qp_solve_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 + [
+            C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.qlamd_pose_sqp_batch.argtypes = [C.c_void_p, C.POINTER(PoseParams), C.POINTER(PoseBatch), C.c_int64,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -100,6 +121,12 @@ def strerror(code):
 def default_params():
     p = BalanceParams()
     lib().qlamd_balance_default_params(C.byref(p))
+    return p
+
+
+def default_pose_params():
+    p = PoseParams()
+    lib().qlamd_pose_default_params(C.byref(p))
     return p
 
 
@@ -195,6 +222,57 @@ class Context:
             grav.data_ptr() if grav is not None else None, MEM_DEVICE, C.c_void_p(stream) if stream else None)
         if rc != OK:
             raise QlamdError(rc, "qlamd_leg_kinematics_batch")
+
+
+def _ptr(a):
+    """data pointer of a numpy array or a torch tensor (None -> NULL)."""
+    if a is None:
+        return None
+    return a.data_ptr() if hasattr(a, "data_ptr") else a.ctypes.data
+
+
+def pose_sqp(ctx, problems, params=None, memory=MEM_HOST, out=None, stream=None):
+    """problems: dict as synth.make_pose_problems (numpy for MEM_HOST, torch CUDA tensors for
+    MEM_DEVICE).  Returns (pose [B,7], iterations [B], status [B]) -- numpy arrays for host
+    memory; for device memory the preallocated tensors passed in `out`."""
+    prm = params if params is not None else default_pose_params()
+    B = int(problems["pose"].shape[0])
+    pb = PoseBatch()
+    keep = []
+    for key, field in POSE_FIELD_OF_KEY:
+        a = problems.get(key)
+        if a is not None and memory == MEM_HOST:
+            a = np.ascontiguousarray(a)
+            keep.append(a)
+        setattr(pb, field, _ptr(a))
+    if memory == MEM_HOST:
+        pose = np.zeros((B, 7)); it = np.zeros(B, dtype=np.int32); st = np.full(B, -1, dtype=np.int32)
+    else:
+        pose, it, st = out
+    rc = lib().qlamd_pose_sqp_batch(ctx._h, C.byref(prm), C.byref(pb), B, _ptr(pose), _ptr(it), _ptr(st), memory,
+                                    C.c_void_p(stream) if stream else None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_pose_sqp_batch")
+    return pose, it, st
+
+
+def qp_solve(ctx, G, g0, CE, ce0, CI, ci0):
+    """Batch of dense QPs with host (numpy) buffers: G [B,n,n], g0 [B,n], CE [B,n,p] or None, CI [B,n,m]."""
+    G = np.ascontiguousarray(G, dtype=np.float64)
+    B, n = G.shape[0], G.shape[1]
+    g0 = np.ascontiguousarray(g0, dtype=np.float64)
+    p = 0 if CE is None else int(np.asarray(CE).shape[2])
+    m = 0 if CI is None else int(np.asarray(CI).shape[2])
+    CE = None if p == 0 else np.ascontiguousarray(CE, dtype=np.float64)
+    ce0 = None if p == 0 else np.ascontiguousarray(ce0, dtype=np.float64)
+    CI = None if m == 0 else np.ascontiguousarray(CI, dtype=np.float64)
+    ci0 = None if m == 0 else np.ascontiguousarray(ci0, dtype=np.float64)
+    x = np.zeros((B, n)); f = np.zeros(B); st = np.full(B, -1, dtype=np.int32)
+    rc = lib().qlamd_qp_solve_batch(ctx._h, n, p, m, _ptr(G), _ptr(g0), _ptr(CE), _ptr(ce0), _ptr(CI), _ptr(ci0), B,
+                                    _ptr(x), _ptr(f), _ptr(st), MEM_HOST, None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_qp_solve_batch")
+    return x, f, st
 
 
 def to_device(state, device="cuda:0"):

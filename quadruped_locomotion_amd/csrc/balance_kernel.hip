@@ -9,6 +9,7 @@
 #include "balance_coop.hpp"
 #include "balance_core.hpp"
 #include "params_build.hpp"
+#include "pose_core.hpp"
 #include "qlamd.h"
 
 using namespace qlamd;
@@ -214,6 +215,80 @@ __global__ __launch_bounds__(64) void leg_kinematics_kernel(const DeviceParams *
   if (grav) { grav[3 * t] = Gq[0]; grav[3 * t + 1] = Gq[1]; grav[3 * t + 2] = Gq[2]; }
 }
 
+// ---- config 5: one pose-optimisation problem per lane, 16 problems per wavefront --------------
+struct PosePtrs {
+  const double *stance, *nominal, *polygon, *rcom, *maxlen, *pose;
+  const uint8_t *mask;
+  const int32_t *nverts;
+};
+constexpr int kPosePerWave = 16;
+
+__global__ __launch_bounds__(64) void pose_sqp_kernel(const PoseParamsDev P, const PosePtrs s, int64_t B,
+                                                      double *__restrict__ pose_out, int32_t *__restrict__ iters,
+                                                      int32_t *__restrict__ status) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * kPosePerWave + lane;
+  if (lane >= kPosePerWave || i >= B) return;
+  PoseProblem pb;
+#pragma unroll
+  for (int l = 0; l < 4; l++) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      pb.stance[l][a] = s.stance[12 * i + 3 * l + a];
+      pb.nominal[l][a] = s.nominal[12 * i + 3 * l + a];
+    }
+    pb.max_len[l] = s.maxlen[4 * i + l];
+    pb.polygon[l][0] = s.polygon[8 * i + 2 * l];
+    pb.polygon[l][1] = s.polygon[8 * i + 2 * l + 1];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) pb.r_com[a] = s.rcom ? s.rcom[3 * i + a] : 0.0;
+  pb.n_vertices = s.nverts ? s.nverts[i] : 4;
+  pb.stance_mask = 0;
+#pragma unroll
+  for (int l = 0; l < 4; l++)
+    if (!s.mask || s.mask[4 * i + l]) pb.stance_mask |= 1u << l;
+  double pose[7];
+#pragma unroll
+  for (int a = 0; a < 7; a++) pose[a] = s.pose[7 * i + a];
+  LdsScratch scr{lds + lane, kPosePerWave};
+  int it = 0;
+  const int st = pose_sqp(P, pb, scr, pose, &it);
+#pragma unroll
+  for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
+  if (iters) iters[i] = it;
+  status[i] = st;
+}
+
+// ---- dense QP batch: one problem per lane, 8 problems per wavefront, arrays in LDS ------------
+typedef GiLayout<12, 2, 24> QpGi;
+constexpr int kQpPerWave = 8;
+
+__global__ __launch_bounds__(64) void qp_solve_kernel(int n, int p, int m, const double *__restrict__ G,
+                                                      const double *__restrict__ g0, const double *__restrict__ CE,
+                                                      const double *__restrict__ ce0, const double *__restrict__ CI,
+                                                      const double *__restrict__ ci0, int64_t B,
+                                                      double *__restrict__ x, double *__restrict__ obj,
+                                                      int32_t *__restrict__ status) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * kQpPerWave + lane;
+  if (lane >= kQpPerWave || i >= B) return;
+  LdsScratch s{lds + lane, kQpPerWave};
+  for (int k = 0; k < n * n; k++) s.at(QpGi::G + k) = G[(size_t)i * n * n + k];
+  for (int k = 0; k < n; k++) s.at(QpGi::G0 + k) = g0[(size_t)i * n + k];
+  for (int k = 0; k < n * p; k++) s.at(QpGi::CE + k) = CE[(size_t)i * n * p + k];
+  for (int k = 0; k < p; k++) s.at(QpGi::CE0 + k) = ce0[(size_t)i * p + k];
+  for (int k = 0; k < n * m; k++) s.at(QpGi::CI + k) = CI[(size_t)i * n * m + k];
+  for (int k = 0; k < m; k++) s.at(QpGi::CI0 + k) = ci0[(size_t)i * m + k];
+  double f;
+  const int st = gi_solve<12, 2, 24>(s, n, p, m, &f, nullptr);
+  for (int k = 0; k < n; k++) x[(size_t)i * n + k] = s.at(QpGi::X + k);
+  if (obj) obj[i] = f;
+  status[i] = st;
+}
+
 } // namespace
 
 // ------------------------------------------------------------------ C-ABI ---
@@ -282,6 +357,132 @@ extern "C" {
 void qlamd_balance_default_params(qlamd_balance_params *p) { if (p) default_balance_params(p); }
 void qlamd_default_robot_model(qlamd_robot_model *m) { if (m) default_robot_model(m); }
 int qlamd_version(void) { return QLAMD_VERSION_MAJOR * 1000 + QLAMD_VERSION_MINOR; }
+
+void qlamd_pose_default_params(qlamd_pose_params *p) {
+  if (!p) return;
+  // free_gait_core/test/AdapterDummy.cpp:111-125 (same values as quadruped_state.cpp:83-97), LF RF RH LH
+  const double hips[4][3] = {{0.42, 0.075, 0.0}, {0.42, -0.075, 0.0}, {-0.42, -0.075, 0.0}, {-0.42, 0.075, 0.0}};
+  memcpy(p->hip_in_base, hips, sizeof(hips));
+  p->com_weight = 2.0;     // PoseOptimizationObjectiveFunction.cpp:17
+  p->tolerance = 0.05;     // PoseOptimizationSQP.cpp:99
+  p->max_iterations = 30;
+  p->dummy_equality = 1;   // sequencequadraticproblemsolver.cpp:25-26
+  p->leg_order[0] = 2; p->leg_order[1] = 3; p->leg_order[2] = 1; p->leg_order[3] = 0;
+}
+
+int qlamd_pose_sqp_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
+                         int64_t batch, double *pose_out, int32_t *iterations, int32_t *status, int memory,
+                         void *stream) {
+  if (!ctx || !in || batch < 0 || !pose_out || !status) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!params) return QLAMD_ERR_NOT_LOADED;
+  if (!in->stance || !in->nominal_stance || !in->support_polygon || !in->max_limb_length || !in->pose)
+    return QLAMD_ERR_INVALID_ARGUMENT;
+  if (params->max_iterations < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+  for (int k = 0; k < 4; k++)
+    if (params->leg_order[k] < 0 || params->leg_order[k] > 3) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+  PoseParamsDev P;
+  memcpy(P.hips, params->hip_in_base, sizeof(P.hips));
+  P.com_weight = params->com_weight; P.tol = params->tolerance; P.max_iter = params->max_iterations;
+  P.dummy_equality = params->dummy_equality;
+  for (int k = 0; k < 4; k++) P.leg_order[k] = params->leg_order[k];
+
+  PosePtrs s{in->stance, in->nominal_stance, in->support_polygon, in->center_of_mass, in->max_limb_length,
+             in->pose, in->stance_mask, in->n_vertices};
+  double *d_out = pose_out;
+  int32_t *d_it = iterations, *d_st = status;
+  if (memory == QLAMD_MEM_HOST) {
+    const size_t sz[8] = {B * 96, B * 96, B * 64, in->center_of_mass ? B * 24 : 0, B * 32, B * 56,
+                          in->stance_mask ? B * 4 : 0, in->n_vertices ? B * 4 : 0};
+    const void *src[8] = {in->stance, in->nominal_stance, in->support_polygon, in->center_of_mass,
+                          in->max_limb_length, in->pose, in->stance_mask, in->n_vertices};
+    size_t off[11], total = 0;
+    for (int k = 0; k < 8; k++) { off[k] = total; total += align256(sz[k]); }
+    off[8] = total; total += align256(B * 56);
+    off[9] = total; total += align256(B * 4);
+    off[10] = total; total += align256(B * 4);
+    int rc = ensure_ws(ctx, total);
+    if (rc != QLAMD_OK) return rc;
+    char *w = (char *)ctx->ws;
+    for (int k = 0; k < 8; k++)
+      if (sz[k] && hipMemcpyAsync(w + off[k], src[k], sz[k], hipMemcpyHostToDevice, st) != hipSuccess)
+        return QLAMD_ERR_HIP;
+    s = PosePtrs{(const double *)(w + off[0]), (const double *)(w + off[1]), (const double *)(w + off[2]),
+                 in->center_of_mass ? (const double *)(w + off[3]) : nullptr, (const double *)(w + off[4]),
+                 (const double *)(w + off[5]), in->stance_mask ? (const uint8_t *)(w + off[6]) : nullptr,
+                 in->n_vertices ? (const int32_t *)(w + off[7]) : nullptr};
+    d_out = (double *)(w + off[8]);
+    d_it = (int32_t *)(w + off[9]);
+    d_st = (int32_t *)(w + off[10]);
+  }
+  const size_t lds = (size_t)kPosePerWave * PoseGi::kTotal * sizeof(double);
+  const unsigned grid = (unsigned)((batch + kPosePerWave - 1) / kPosePerWave);
+  hipLaunchKernelGGL(pose_sqp_kernel, dim3(grid), dim3(64), lds, st, P, s, batch, d_out, d_it, d_st);
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  if (memory == QLAMD_MEM_HOST) {
+    if (hipMemcpyAsync(pose_out, d_out, B * 56, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
+    if (iterations && hipMemcpyAsync(iterations, d_it, B * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+      return QLAMD_ERR_HIP;
+    if (hipMemcpyAsync(status, d_st, B * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
+  }
+  return QLAMD_OK;
+}
+
+int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *G, const double *g0,
+                         const double *CE, const double *ce0, const double *CI, const double *ci0,
+                         int64_t batch, double *x, double *objective, int32_t *status, int memory,
+                         void *stream) {
+  if (!ctx || batch < 0 || !G || !g0 || !x || !status) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (n < 1 || n > 12 || p < 0 || p > 2 || m < 0 || m > 24) return QLAMD_ERR_INVALID_ARGUMENT;
+  if ((p > 0 && (!CE || !ce0)) || (m > 0 && (!CI || !ci0))) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+  const double *dG = G, *dg0 = g0, *dCE = CE, *dce0 = ce0, *dCI = CI, *dci0 = ci0;
+  double *dx = x, *dobj = objective;
+  int32_t *dst = status;
+  if (memory == QLAMD_MEM_HOST) {
+    const size_t sz[6] = {B * n * n * 8, B * n * 8, B * n * p * 8, B * p * 8, B * n * m * 8, B * m * 8};
+    const void *src[6] = {G, g0, CE, ce0, CI, ci0};
+    size_t off[9], total = 0;
+    for (int k = 0; k < 6; k++) { off[k] = total; total += align256(sz[k]); }
+    off[6] = total; total += align256(B * n * 8);
+    off[7] = total; total += align256(B * 8);
+    off[8] = total; total += align256(B * 4);
+    int rc = ensure_ws(ctx, total);
+    if (rc != QLAMD_OK) return rc;
+    char *w = (char *)ctx->ws;
+    for (int k = 0; k < 6; k++)
+      if (sz[k] && hipMemcpyAsync(w + off[k], src[k], sz[k], hipMemcpyHostToDevice, st) != hipSuccess)
+        return QLAMD_ERR_HIP;
+    dG = (const double *)(w + off[0]); dg0 = (const double *)(w + off[1]); dCE = (const double *)(w + off[2]);
+    dce0 = (const double *)(w + off[3]); dCI = (const double *)(w + off[4]); dci0 = (const double *)(w + off[5]);
+    dx = (double *)(w + off[6]); dobj = objective ? (double *)(w + off[7]) : nullptr; dst = (int32_t *)(w + off[8]);
+  }
+  const size_t lds = (size_t)kQpPerWave * QpGi::kTotal * sizeof(double);
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute((const void *)qp_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return QLAMD_ERR_HIP;
+  const unsigned grid = (unsigned)((batch + kQpPerWave - 1) / kQpPerWave);
+  hipLaunchKernelGGL(qp_solve_kernel, dim3(grid), dim3(64), lds, st, n, p, m, dG, dg0, dCE, dce0, dCI, dci0, batch,
+                     dx, dobj, dst);
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  if (memory == QLAMD_MEM_HOST) {
+    if (hipMemcpyAsync(x, dx, B * n * 8, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
+    if (objective && hipMemcpyAsync(objective, dobj, B * 8, hipMemcpyDeviceToHost, st) != hipSuccess)
+      return QLAMD_ERR_HIP;
+    if (hipMemcpyAsync(status, dst, B * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
+  }
+  return QLAMD_OK;
+}
 
 #ifdef QLAMD_STAMPS
 int qlamd_debug_stamps(unsigned long long *out, int n) {

@@ -1,0 +1,216 @@
+// Per-problem arithmetic of the batched pose optimisation (BASELINE config 5), host/device.
+//
+// Replaces free_gait::PoseOptimizationSQP::optimize
+// (free_gait_core/src/pose_optimization/PoseOptimizationSQP.cpp:58-111):
+//   objective gradient / Hessian  PoseOptimizationObjectiveFunction.cpp:150-248
+//   constraint values / Jacobian  PoseOptimizationFunctionConstraints.cpp:95-194
+//   SQP loop                      qp_solver/src/sequencequadraticproblemsolver.cpp:18-102
+//   params (+) dp                 poseparameterization.cpp:37-51
+// Inner QP: gi_core.hpp (n = 6, m <= 8, one all-zero equality column as the reference passes).
+#pragma once
+
+#include "gi_core.hpp"
+
+namespace qlamd {
+
+struct PoseParamsDev {
+  double hips[4][3];   // base -> hip in base (adapter.getPositionBaseToHipInBaseFrame)
+  double com_weight;   // 2.0, PoseOptimizationObjectiveFunction.cpp:17
+  double tol;          // 0.05, PoseOptimizationSQP.cpp:99
+  int max_iter;        // 30
+  int dummy_equality;  // 1 = reference behaviour
+  int leg_order[4];    // iteration order of the reference's unordered_map Stance
+};
+
+struct PoseProblem { // one problem, indexed by limb id
+  double stance[4][3], nominal[4][3], max_len[4], polygon[4][2], r_com[3], pose[7];
+  int n_vertices;
+  unsigned stance_mask;
+};
+
+typedef GiLayout<6, 1, 8> PoseGi;
+
+QL_HD void skew3(const double r[3], double S[9]) {
+  S[0] = 0;     S[1] = -r[2]; S[2] = r[1];
+  S[3] = r[2];  S[4] = 0;     S[5] = -r[0];
+  S[6] = -r[1]; S[7] = r[0];  S[8] = 0;
+}
+QL_HD void mm3(const double A[9], const double B[9], double C[9]) {
+  QL_UNROLL for (int i = 0; i < 3; i++)
+    QL_UNROLL for (int j = 0; j < 3; j++)
+      C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+// grid_map::Polygon::getCentroid (grid_map_core, restated; vertices counter-clockwise)
+QL_HD void polygon_centroid(int nv, const double poly[4][2], double c[2]) {
+  double area = 0.0;
+  c[0] = c[1] = 0.0;
+  for (int i = 0; i < nv; i++) {
+    const int k = (i + 1 == nv) ? 0 : i + 1;
+    const double cr = poly[i][0] * poly[k][1] - poly[k][0] * poly[i][1];
+    area += cr;
+    c[0] += cr * (poly[i][0] + poly[k][0]);
+    c[1] += cr * (poly[i][1] + poly[k][1]);
+  }
+  area *= 0.5;
+  c[0] /= (6.0 * area);
+  c[1] /= (6.0 * area);
+}
+
+// grid_map::Polygon::convertToInequalityConstraints: A x <= b, one row per non-degenerate edge
+QL_HD int polygon_halfspaces(int nv, const double poly[4][2], double A[4][2], double b[4]) {
+  double c[2] = {0, 0};
+  for (int i = 0; i < nv; i++) { c[0] += poly[i][0]; c[1] += poly[i][1]; }
+  c[0] /= nv; c[1] /= nv;
+  int rows = 0;
+  for (int i = 0; i < nv; i++) {
+    const int k = (i + 1 == nv) ? 0 : i + 1;
+    const double x1 = poly[i][0] - c[0], y1 = poly[i][1] - c[1];
+    const double x2 = poly[k][0] - c[0], y2 = poly[k][1] - c[1];
+    const double det = x1 * y2 - x2 * y1;
+    if (fabs(det) <= 1e-12 * (fabs(x1 * y2) + fabs(x2 * y1) + 1e-300)) continue;
+    const double a0 = (y2 - y1) / det, a1 = (x1 - x2) / det;
+    A[rows][0] = a0; A[rows][1] = a1;
+    b[rows] = 1.0 + (a0 * c[0] + a1 * c[1]);
+    rows++;
+  }
+  return rows;
+}
+
+// q.boxPlus(d) = exp(d) * q   (kindr exp map)
+QL_HD void quat_box_plus(const double q[4], const double d[3], double out[4]) {
+  const double v = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  double e[4];
+  if (v < 1e-12) {
+    e[0] = 1.0; e[1] = 0.5 * d[0]; e[2] = 0.5 * d[1]; e[3] = 0.5 * d[2];
+  } else {
+    const double a = 0.5 * v, sn = sin(a) / v;
+    e[0] = cos(a); e[1] = sn * d[0]; e[2] = sn * d[1]; e[3] = sn * d[2];
+  }
+  out[0] = e[0] * q[0] - e[1] * q[1] - e[2] * q[2] - e[3] * q[3];
+  out[1] = e[0] * q[1] + e[1] * q[0] + e[2] * q[3] - e[3] * q[2];
+  out[2] = e[0] * q[2] - e[1] * q[3] + e[2] * q[0] + e[3] * q[1];
+  out[3] = e[0] * q[3] + e[1] * q[2] - e[2] * q[1] + e[3] * q[0];
+}
+
+// Linearise at `pose` straight into the QP scratch: G = H, G0 = g, CI = -A', CI0 = vmax - val,
+// CE = 0, CE0 = 0.  Returns m.
+template <class Scr>
+QL_HD int pose_linearise(const PoseParamsDev &P, const PoseProblem &pb, const double centroid[2], int nsp,
+                         const double GA[4][2], const double gb[4], const double pose[7], Scr &s) {
+  typedef PoseGi Ly;
+  double R[9], ps[9];
+  const double *p = pose;
+  quat_to_matrix(pose + 3, R);
+  skew3(p, ps);
+  double g[6] = {0, 0, 0, 0, 0, 0}, H[36];
+  for (int i = 0; i < 36; i++) H[i] = 0.0;
+  int nl = 0;
+  for (int k = 0; k < 4; k++) {
+    const int l = P.leg_order[k];
+    if (!((pb.stance_mask >> l) & 1u)) continue;
+    nl++;
+    const double *f = pb.stance[l];
+    double Pd[3], D[9], F[9], Dp[3], Df[3], T1[9], T2[9], T3[9], T4[9];
+    rot(R, pb.nominal[l], Pd);
+    skew3(Pd, D); skew3(f, F);
+    rot(D, p, Dp); rot(D, f, Df);
+    for (int i = 0; i < 3; i++) { g[i] += p[i] + Pd[i] - f[i]; g[3 + i] += Dp[i] - Df[i]; }
+    mm3(ps, D, T1); mm3(D, ps, T2); mm3(F, D, T3); mm3(D, F, T4);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        H[6 * i + j] += (i == j) ? 1.0 : 0.0;
+        H[6 * i + 3 + j] += -D[3 * i + j];
+        H[6 * (3 + i) + j] += D[3 * i + j];
+        H[6 * (3 + i) + 3 + j] += 0.5 * (T1[3 * i + j] + T2[3 * i + j] - T3[3 * i + j] - T4[3 * i + j]);
+      }
+  }
+  double Pr3[3], Rr3[9]; // full Phi r_com (constraints use it with its z component)
+  rot(R, pb.r_com, Pr3);
+  skew3(Pr3, Rr3);
+  {
+    const double w = P.com_weight;
+    const double pbar[3] = {p[0], p[1], 0.0};
+    const double Pr[3] = {Pr3[0], Pr3[1], 0.0};
+    const double rc[3] = {centroid[0], centroid[1], 0.0};
+    double Rr[9], C[9], a[3], b[3], T1[9], T2[9], T3[9], T4[9];
+    skew3(Pr, Rr); skew3(rc, C);
+    rot(Rr, pbar, a); rot(Rr, rc, b);
+    for (int i = 0; i < 3; i++) { g[i] += w * (pbar[i] - rc[i] + Pr[i]); g[3 + i] += w * (a[i] - b[i]); }
+    mm3(ps, Rr, T1); mm3(Rr, ps, T2); mm3(C, Rr, T3); mm3(Rr, C, T4);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        H[6 * i + j] += w * ((i == j && i < 2) ? 1.0 : 0.0);
+        H[6 * i + 3 + j] += -w * Rr[3 * i + j];
+        H[6 * (3 + i) + j] += w * Rr[3 * i + j];
+        H[6 * (3 + i) + 3 + j] += 0.5 * w * (T1[3 * i + j] + T2[3 * i + j] - T3[3 * i + j] - T4[3 * i + j]);
+      }
+  }
+  for (int i = 0; i < 6; i++) s.at(Ly::G0 + i) = 2.0 * g[i];
+  for (int i = 0; i < 36; i++) s.at(Ly::G + i) = 2.0 * H[i];
+
+  const int m = nsp + nl;
+  const double cw[2] = {p[0] + Pr3[0], p[1] + Pr3[1]};
+  for (int i = 0; i < nsp; i++) {
+    const double val = GA[i][0] * cw[0] + GA[i][1] * cw[1];
+    s.at(Ly::CI0 + i) = gb[i] - val;
+    const double G3[3] = {GA[i][0], GA[i][1], 0.0};
+    for (int j = 0; j < 3; j++) {
+      s.at(Ly::CI + j * m + i) = -G3[j];
+      s.at(Ly::CI + (3 + j) * m + i) = (G3[0] * Rr3[j] + G3[1] * Rr3[3 + j] + G3[2] * Rr3[6 + j]);
+    }
+  }
+  int row = nsp;
+  for (int k = 0; k < 4; k++) {
+    const int l = P.leg_order[k];
+    if (!((pb.stance_mask >> l) & 1u)) continue;
+    const double *f = pb.stance[l];
+    const double df[3] = {f[0] - p[0], f[1] - p[1], f[2] - p[2]};
+    double bf[3], Ph[3], Hs[9];
+    irot(R, df, bf);
+    const double e[3] = {bf[0] - P.hips[l][0], bf[1] - P.hips[l][1], bf[2] - P.hips[l][2]};
+    const double len = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    s.at(Ly::CI0 + row) = pb.max_len[l] - len;
+    rot(R, P.hips[l], Ph);
+    skew3(Ph, Hs);
+    double ln[3] = {p[0] + Ph[0] - f[0], p[1] + Ph[1] - f[1], p[2] + Ph[2] - f[2]};
+    const double nn = sqrt(ln[0] * ln[0] + ln[1] * ln[1] + ln[2] * ln[2]);
+    ln[0] /= nn; ln[1] /= nn; ln[2] /= nn;
+    for (int j = 0; j < 3; j++) {
+      s.at(Ly::CI + j * m + row) = -ln[j];
+      s.at(Ly::CI + (3 + j) * m + row) = (ln[0] * Hs[j] + ln[1] * Hs[3 + j] + ln[2] * Hs[6 + j]);
+    }
+    row++;
+  }
+  for (int j = 0; j < 6; j++) s.at(Ly::CE + j) = 0.0;
+  s.at(Ly::CE0) = 0.0;
+  return m;
+}
+
+// The SQP loop of sequencequadraticproblemsolver.cpp:18-102.  pose is updated in place.
+template <class Scr>
+QL_HD int pose_sqp(const PoseParamsDev &P, const PoseProblem &pb, Scr &s, double pose[7], int *iters_out) {
+  double centroid[2], GA[4][2], gb[4];
+  polygon_centroid(pb.n_vertices, pb.polygon, centroid);
+  const int nsp = polygon_halfspaces(pb.n_vertices, pb.polygon, GA, gb);
+  int k = 0, status = kStatusOk;
+  while (k < P.max_iter) {
+    const int m = pose_linearise(P, pb, centroid, nsp, GA, gb, pose, s);
+    k++;
+    double f;
+    status = gi_solve<6, 1, 8>(s, 6, P.dummy_equality ? 1 : 0, m, &f, nullptr);
+    if (status != kStatusOk) break;
+    double dp[6];
+    for (int i = 0; i < 6; i++) dp[i] = s.at(PoseGi::X + i);
+    for (int i = 0; i < 3; i++) pose[i] += dp[i];
+    double qn[4];
+    quat_box_plus(pose + 3, dp + 3, qn);
+    for (int i = 0; i < 4; i++) pose[3 + i] = qn[i];
+    const double nrm = sqrt(dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2] + dp[3] * dp[3] + dp[4] * dp[4] + dp[5] * dp[5]);
+    if (nrm < P.tol) break; // :72-76
+  }
+  if (iters_out) *iters_out = k;
+  return status;
+}
+
+} // namespace qlamd

@@ -115,3 +115,40 @@ def make_states(batch, gait="static", seed=SEED, offset=0):
                 base_angvel=base_angvel, des_pos=np.ascontiguousarray(des_pos),
                 des_quat=np.ascontiguousarray(des_quat), des_linvel=np.ascontiguousarray(des_linvel),
                 des_angvel=des_angvel, stance=stance)
+
+
+# ---------------------------------------------------------------------------------------------
+# Pose-optimisation problems (BASELINE config 5), SURVEY.md section 8(d):
+# the SquareUp family of free_gait_core/test/PoseOptimizationSQPTest.cpp:111-199 with seeded
+# perturbations.  Limb ids LF, RF, RH, LH = 0..3.
+POSE_NOMINAL = np.array([[0.3, 0.2, -0.4], [0.3, -0.2, -0.4], [-0.3, -0.2, -0.4], [-0.3, 0.2, -0.4]])
+POSE_FEET = np.array([[0.3, 0.2, -0.1], [0.3, -0.2, -0.1], [-0.3, -0.2, -0.1], [-0.3, 0.2, -0.1]])
+POSE_HIPS = np.array([[0.42, 0.075, 0.0], [0.42, -0.075, 0.0], [-0.42, -0.075, 0.0], [-0.42, 0.075, 0.0]])
+POSE_MAX_LEN = 0.565          # PoseOptimizationSQPTest.cpp:141
+# iteration order of the reference's unordered_map `Stance` when filled LF, RF, LH, RH
+# (libstdc++: reverse insertion order), SURVEY.md Q6
+POSE_LEG_ORDER = (2, 3, 1, 0)
+# counter-clockwise footprint LF, LH, RH, RF (getFootholdsCounterClockwiseOrdered)
+_CCW = (0, 3, 2, 1)
+
+
+def make_pose_problems(batch, seed=SEED + 5, offset=0):
+    u = _uniform(seed, offset, offset + batch)
+    B = batch
+    yaw = np.deg2rad(40.0) * u[:, 0]
+    trans = (2.0 * u[:, 1:3] - 1.0) * 0.3
+    noise = (2.0 * u[:, 3:15].reshape(B, 4, 3) - 1.0) * 0.05
+    c, s = np.cos(yaw), np.sin(yaw)
+    Rz = np.zeros((B, 3, 3))
+    Rz[:, 0, 0], Rz[:, 0, 1], Rz[:, 1, 0], Rz[:, 1, 1], Rz[:, 2, 2] = c, -s, s, c, 1.0
+    stance = np.einsum("bij,lj->bli", Rz, POSE_FEET) + noise
+    stance[:, :, 0:2] += trans[:, None, :]
+    polygon = stance[:, _CCW, 0:2]
+    pose = np.zeros((B, 7))
+    pose[:, 0:2] = trans
+    pose[:, 2] = 0.3
+    pose[:, 3] = 1.0
+    return dict(stance=np.ascontiguousarray(stance), stance_mask=np.ones((B, 4), dtype=np.uint8),
+                nominal=np.ascontiguousarray(np.tile(POSE_NOMINAL, (B, 1, 1))),
+                polygon=np.ascontiguousarray(polygon), n_vertices=np.full(B, 4, dtype=np.int32),
+                r_com=np.zeros((B, 3)), max_len=np.full((B, 4), POSE_MAX_LEN), pose=pose)

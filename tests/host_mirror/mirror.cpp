@@ -67,3 +67,53 @@ extern "C" void mirror_leg_kinematics(const double *q3, int leg, const double *g
 
 extern "C" void mirror_sincos(double x, double *s, double *c) { sincos_reduced(x, *s, *c); }
 extern "C" void mirror_default_params(qlamd_balance_params *p) { default_balance_params(p); }
+
+// ---- pose optimisation / dense QP (config 5), host build of gi_core.hpp + pose_core.hpp ----
+#include "pose_core.hpp"
+
+template <int N>
+struct HostScr {
+  double a[N];
+  double &at(int e) { return a[e]; }
+};
+
+extern "C" int mirror_qp_solve(int n, int p, int m, const double *G, const double *g0, const double *CE,
+                               const double *ce0, const double *CI, const double *ci0, double *x, double *f) {
+  typedef GiLayout<12, 2, 24> Ly;
+  if (n > 12 || p > 2 || m > 24) return -1;
+  static HostScr<Ly::kTotal> s;
+  for (int i = 0; i < n * n; i++) s.at(Ly::G + i) = G[i];
+  for (int i = 0; i < n; i++) s.at(Ly::G0 + i) = g0[i];
+  for (int i = 0; i < n * p; i++) s.at(Ly::CE + i) = CE[i];
+  for (int i = 0; i < p; i++) s.at(Ly::CE0 + i) = ce0[i];
+  for (int i = 0; i < n * m; i++) s.at(Ly::CI + i) = CI[i];
+  for (int i = 0; i < m; i++) s.at(Ly::CI0 + i) = ci0[i];
+  const int st = gi_solve<12, 2, 24>(s, n, p, m, f, nullptr);
+  for (int i = 0; i < n; i++) x[i] = s.at(Ly::X + i);
+  return st;
+}
+
+extern "C" void mirror_pose_sqp_batch(const PoseParamsDev *P, int64_t B, const double *stance,
+                                      const uint8_t *mask, const double *nominal, const double *polygon,
+                                      const int32_t *nverts, const double *rcom, const double *maxlen,
+                                      const double *pose_in, double *pose_out, int32_t *iters, int32_t *status) {
+  for (int64_t i = 0; i < B; i++) {
+    PoseProblem pb;
+    for (int l = 0; l < 4; l++) {
+      for (int a = 0; a < 3; a++) { pb.stance[l][a] = stance[12 * i + 3 * l + a]; pb.nominal[l][a] = nominal[12 * i + 3 * l + a]; }
+      pb.max_len[l] = maxlen[4 * i + l];
+      pb.polygon[l][0] = polygon[8 * i + 2 * l]; pb.polygon[l][1] = polygon[8 * i + 2 * l + 1];
+    }
+    for (int a = 0; a < 3; a++) pb.r_com[a] = rcom ? rcom[3 * i + a] : 0.0;
+    pb.n_vertices = nverts ? nverts[i] : 4;
+    pb.stance_mask = 0;
+    for (int l = 0; l < 4; l++) if (!mask || mask[4 * i + l]) pb.stance_mask |= 1u << l;
+    double pose[7];
+    for (int a = 0; a < 7; a++) pose[a] = pose_in[7 * i + a];
+    HostScr<PoseGi::kTotal> s;
+    int it = 0;
+    status[i] = pose_sqp(*P, pb, s, pose, &it);
+    if (iters) iters[i] = it;
+    for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
+  }
+}
