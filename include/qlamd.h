@@ -115,9 +115,8 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
                          int device, qlamd_context **out);
 void qlamd_context_destroy(qlamd_context *ctx);
 
-/* Tuning knob: lanes of a wavefront given to robots (64, 16 or 4; 0 = choose
- * from the batch size).  Fewer robots per wavefront spreads a small batch
- * over more SIMDs. */
+/* Tuning knob: robots per wavefront.  4 = lane-cooperative latency kernel (16 lanes per robot);
+ * 16 / 64 = one lane per robot (throughput kernel); 0 = choose from the batch size. */
 int qlamd_set_robots_per_wave(qlamd_context *ctx, int robots_per_wave);
 
 /* One control step for `batch` robots: virtual-model wrench -> leg FK ->
@@ -137,6 +136,16 @@ int qlamd_set_robots_per_wave(qlamd_context *ctx, int robots_per_wave);
 int qlamd_balance_solve_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch,
                               double *joint_effort, double *contact_force, int32_t *status,
                               int memory, void *stream);
+
+/* Force distribution only, with the virtual wrench supplied by the caller:
+ * replaces bool ContactForceDistributionBase::computeForceDistribution(const Force& F_B, const Torque& T_B)
+ * (balance_controller/include/balance_controller/contact_force_distribution/ContactForceDistributionBase.hpp:97-98,
+ *  ContactForceDistribution.cpp:99-136) including computeJointTorques (:516-578) and the +-limit clamp.
+ *   virtual_wrench [B][6] = (F_B, T_B) in the base frame; other arguments as qlamd_balance_solve_batch. */
+int qlamd_force_distribution_batch(qlamd_context *ctx, const double *joint_position, const double *base_orientation,
+                                   const uint8_t *support_leg, const double *surface_normal,
+                                   const double *virtual_wrench, int64_t batch, double *joint_effort,
+                                   double *contact_force, int32_t *status, int memory, void *stream);
 
 /* Virtual wrench only: (F_B, T_B) [B][6].  Replaces
  * VirtualModelController::computeError/GravityCompensation/VirtualForce/VirtualTorque

@@ -21,6 +21,7 @@ EXPORTS = (
     "qlamd_context_destroy", "qlamd_set_robots_per_wave", "qlamd_balance_solve_batch",
     "qlamd_virtual_wrench_batch", "qlamd_leg_kinematics_batch", "qlamd_strerror", "qlamd_version",
     "qlamd_qp_solve_batch", "qlamd_pose_default_params", "qlamd_pose_sqp_batch",
+    "qlamd_force_distribution_batch",
 )
 
 
@@ -108,6 +109,8 @@ def lib():
                                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_qp_solve_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 + [
             C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.qlamd_force_distribution_batch.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_pose_sqp_batch.argtypes = [C.c_void_p, C.POINTER(PoseParams), C.POINTER(PoseBatch), C.c_int64,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
@@ -229,6 +232,20 @@ def _ptr(a):
     if a is None:
         return None
     return a.data_ptr() if hasattr(a, "data_ptr") else a.ctypes.data
+
+
+def force_distribution(ctx, q, quat, support, wrench, normals=None, memory=MEM_HOST):
+    """qlamd_force_distribution_batch with host (numpy) buffers -> (tau, grf, status)."""
+    q = np.ascontiguousarray(q, dtype=np.float64); quat = np.ascontiguousarray(quat, dtype=np.float64)
+    support = np.ascontiguousarray(support, dtype=np.uint8); wrench = np.ascontiguousarray(wrench, dtype=np.float64)
+    normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float64)
+    B = q.shape[0]
+    tau = np.zeros((B, 12)); grf = np.zeros((B, 12)); st = np.full(B, -1, dtype=np.int32)
+    rc = lib().qlamd_force_distribution_batch(ctx._h, _ptr(q), _ptr(quat), _ptr(support), _ptr(normals), _ptr(wrench), B,
+                                              _ptr(tau), _ptr(grf), _ptr(st), memory, None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_force_distribution_batch")
+    return tau, grf, st
 
 
 def pose_sqp(ctx, problems, params=None, memory=MEM_HOST, out=None, stream=None):

@@ -169,6 +169,7 @@ struct CoopPtrs {
   const double *q, *pos, *quat, *linvel, *angvel, *dpos, *dquat, *dlinvel, *dangvel;
   const uint8_t *stance;
   const double *normals;
+  const double *wrench; // [B][6] or NULL: externally supplied (F_B, T_B)
 };
 
 // One robot per 16-lane row.  lds_tab: 256-double model table; lds_row: this robot's private
@@ -226,7 +227,13 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) { in.quat[k] = quat[k]; in.dquat[k] = dquat[k]; }
-    virtual_wrench(P, in, Rm, gB, b);
+    if (s.wrench) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) b[k] = s.wrench[6 * i + k];
+    } else {
+      in.has_wrench = false;
+      virtual_wrench(P, in, Rm, gB, b);
+    }
   }
 
   QL_STAMP(2);

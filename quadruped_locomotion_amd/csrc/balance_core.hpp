@@ -72,6 +72,8 @@ struct RobotIn {
   double pos[3], quat[4], linvel[3], angvel[3];
   double dpos[3], dquat[4], dlinvel[3], dangvel[3];
   unsigned stance; // bit l = leg l supports
+  bool has_wrench;  // true: use `wrench` (computeForceDistribution's arguments) instead of the VMC
+  double wrench[6]; // (F_B, T_B)
 };
 
 // ------------------------------------------------------------ small math ---
@@ -692,7 +694,11 @@ QL_HD QpResult phase_b_robot(const DeviceParams &P, const RobotIn &in, const dou
     const double gW[3] = {0.0, 0.0, -P.grav};
     irot(Rm, gW, gB); // VirtualModelController.cpp:165-166
   }
-  virtual_wrench(P, in, Rm, gB, b);
+  if (in.has_wrench) {
+    QL_UNROLL for (int k = 0; k < 6; k++) b[k] = in.wrench[k];
+  } else {
+    virtual_wrench(P, in, Rm, gB, b);
+  }
 
   // friction pyramids (addMinimalForceConstraints :223-237, addFrictionConstraints :272-309)
   Pyramid py[4];

@@ -28,6 +28,7 @@ struct StatePtrs {
   const double *q, *pos, *quat, *linvel, *angvel, *dpos, *dquat, *dlinvel, *dangvel;
   const uint8_t *stance;
   const double *normals;
+  const double *wrench; // [B][6] or NULL
 };
 
 __device__ __forceinline__ void load_robot(const StatePtrs &s, int64_t i, RobotIn &in) {
@@ -58,6 +59,11 @@ __device__ __forceinline__ void load_robot(const StatePtrs &s, int64_t i, RobotI
   const uint32_t m = *reinterpret_cast<const uint32_t *>(s.stance + 4 * i);
   in.stance = ((m & 0xFFu) ? 1u : 0u) | ((m & 0xFF00u) ? 2u : 0u) | ((m & 0xFF0000u) ? 4u : 0u) |
               ((m & 0xFF000000u) ? 8u : 0u);
+  in.has_wrench = s.wrench != nullptr;
+  if (in.has_wrench) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) in.wrench[k] = s.wrench[6 * i + k];
+  }
 }
 
 struct LdsTab { // one leg's 64-double block of the model table, staged in LDS
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(64) void balance_coop_kernel(const DeviceParams *__
   const bool live = i < B;
   if (!live) i = B - 1;
   const coop::CoopPtrs cp{s.q, s.pos, s.quat, s.linvel, s.angvel, s.dpos, s.dquat, s.dlinvel, s.dangvel, s.stance,
-                          s.normals};
+                          s.normals, s.wrench};
 #ifdef QLAMD_STAMPS
 #pragma unroll 1
   for (int rep = 0; rep < 2; rep++) // second pass runs with a warm instruction cache
@@ -548,13 +554,23 @@ int qlamd_set_robots_per_wave(qlamd_context *ctx, int rpw) {
   return QLAMD_OK;
 }
 
-int qlamd_balance_solve_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch, double *joint_effort,
-                              double *contact_force, int32_t *status, int memory, void *stream) {
-  if (!ctx || !in || batch < 0 || !joint_effort || !status) return QLAMD_ERR_INVALID_ARGUMENT;
-  if (!in->joint_position || !in->base_position || !in->base_orientation || !in->base_linear_velocity ||
-      !in->base_angular_velocity || !in->desired_position || !in->desired_orientation ||
-      !in->desired_linear_velocity || !in->desired_angular_velocity || !in->support_leg)
+static int balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, const double *wrench, int64_t batch,
+                        double *joint_effort, double *contact_force, int32_t *status, int memory, void *stream) {
+  if (!ctx || !in_user || batch < 0 || !joint_effort || !status) return QLAMD_ERR_INVALID_ARGUMENT;
+  qlamd_state_batch filled = *in_user;
+  const qlamd_state_batch *in = &filled;
+  if (!filled.joint_position || !filled.base_orientation || !filled.support_leg) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (wrench) {
+    // force distribution only: the base pose / twist fields are not read for arithmetic; point
+    // them at valid memory of sufficient size (joint_position is [B][12])
+    filled.base_position = filled.base_linear_velocity = filled.base_angular_velocity = filled.joint_position;
+    filled.desired_position = filled.desired_linear_velocity = filled.desired_angular_velocity = filled.joint_position;
+    filled.desired_orientation = filled.base_orientation;
+  } else if (!filled.base_position || !filled.base_linear_velocity || !filled.base_angular_velocity ||
+             !filled.desired_position || !filled.desired_orientation || !filled.desired_linear_velocity ||
+             !filled.desired_angular_velocity) {
     return QLAMD_ERR_INVALID_ARGUMENT;
+  }
   if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
   if (batch == 0) return QLAMD_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
@@ -566,35 +582,38 @@ int qlamd_balance_solve_batch(qlamd_context *ctx, const qlamd_state_batch *in, i
   int32_t *d_status = status;
   if (memory == QLAMD_MEM_HOST) {
     // one staging slab: inputs then outputs, 256-byte aligned pieces
-    const size_t sz[11] = {B * 96, B * 24, B * 32, B * 24, B * 24, B * 24, B * 32, B * 24, B * 24, B * 4,
-                           in->surface_normal ? B * 96 : 0};
-    const void *src[11] = {in->joint_position, in->base_position, in->base_orientation,
+    // (with an external wrench the pose / twist fields alias the head of joint_position)
+    const size_t rec = 24, qrec = 32;
+    const size_t sz[12] = {B * 96, B * rec, B * qrec, B * rec, B * rec, B * rec, B * qrec, B * rec, B * rec, B * 4,
+                           in->surface_normal ? B * 96 : 0, wrench ? B * 48 : 0};
+    const void *src[12] = {in->joint_position, in->base_position, in->base_orientation,
                            in->base_linear_velocity, in->base_angular_velocity, in->desired_position,
                            in->desired_orientation, in->desired_linear_velocity,
-                           in->desired_angular_velocity, in->support_leg, in->surface_normal};
-    size_t off[14], total = 0;
-    for (int k = 0; k < 11; k++) { off[k] = total; total += align256(sz[k]); }
-    off[11] = total; total += align256(B * 96);
+                           in->desired_angular_velocity, in->support_leg, in->surface_normal, wrench};
+    size_t off[15], total = 0;
+    for (int k = 0; k < 12; k++) { off[k] = total; total += align256(sz[k]); }
     off[12] = total; total += align256(B * 96);
-    off[13] = total; total += align256(B * 4);
+    off[13] = total; total += align256(B * 96);
+    off[14] = total; total += align256(B * 4);
     int rc = ensure_ws(ctx, total);
     if (rc != QLAMD_OK) return rc;
     char *w = (char *)ctx->ws;
-    for (int k = 0; k < 11; k++)
+    for (int k = 0; k < 12; k++)
       if (sz[k] && hipMemcpyAsync(w + off[k], src[k], sz[k], hipMemcpyHostToDevice, st) != hipSuccess)
         return QLAMD_ERR_HIP;
     s = StatePtrs{(const double *)(w + off[0]), (const double *)(w + off[1]), (const double *)(w + off[2]),
                   (const double *)(w + off[3]), (const double *)(w + off[4]), (const double *)(w + off[5]),
                   (const double *)(w + off[6]), (const double *)(w + off[7]), (const double *)(w + off[8]),
-                  (const uint8_t *)(w + off[9]), in->surface_normal ? (const double *)(w + off[10]) : nullptr};
-    d_tau = (double *)(w + off[11]);
-    d_grf = contact_force ? (double *)(w + off[12]) : nullptr;
-    d_status = (int32_t *)(w + off[13]);
+                  (const uint8_t *)(w + off[9]), in->surface_normal ? (const double *)(w + off[10]) : nullptr,
+                  wrench ? (const double *)(w + off[11]) : nullptr};
+    d_tau = (double *)(w + off[12]);
+    d_grf = contact_force ? (double *)(w + off[13]) : nullptr;
+    d_status = (int32_t *)(w + off[14]);
   } else {
     s = StatePtrs{in->joint_position, in->base_position, in->base_orientation, in->base_linear_velocity,
                   in->base_angular_velocity, in->desired_position, in->desired_orientation,
                   in->desired_linear_velocity, in->desired_angular_velocity, in->support_leg,
-                  in->surface_normal};
+                  in->surface_normal, wrench};
   }
 
   hipError_t e;
@@ -626,6 +645,25 @@ int qlamd_balance_solve_batch(qlamd_context *ctx, const qlamd_state_batch *in, i
   return QLAMD_OK;
 }
 
+int qlamd_balance_solve_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch, double *joint_effort,
+                              double *contact_force, int32_t *status, int memory, void *stream) {
+  return balance_impl(ctx, in, nullptr, batch, joint_effort, contact_force, status, memory, stream);
+}
+
+int qlamd_force_distribution_batch(qlamd_context *ctx, const double *joint_position, const double *base_orientation,
+                                   const uint8_t *support_leg, const double *surface_normal,
+                                   const double *virtual_wrench, int64_t batch, double *joint_effort,
+                                   double *contact_force, int32_t *status, int memory, void *stream) {
+  if (!virtual_wrench) return QLAMD_ERR_INVALID_ARGUMENT;
+  qlamd_state_batch in;
+  memset(&in, 0, sizeof(in));
+  in.joint_position = joint_position;
+  in.base_orientation = base_orientation;
+  in.support_leg = support_leg;
+  in.surface_normal = surface_normal;
+  return balance_impl(ctx, &in, virtual_wrench, batch, joint_effort, contact_force, status, memory, stream);
+}
+
 int qlamd_virtual_wrench_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch, double *wrench,
                                int memory, void *stream) {
   if (!ctx || !in || batch < 0 || !wrench) return QLAMD_ERR_INVALID_ARGUMENT;
@@ -634,7 +672,7 @@ int qlamd_virtual_wrench_batch(qlamd_context *ctx, const qlamd_state_batch *in, 
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   StatePtrs s{in->joint_position, in->base_position, in->base_orientation, in->base_linear_velocity,
               in->base_angular_velocity, in->desired_position, in->desired_orientation,
-              in->desired_linear_velocity, in->desired_angular_velocity, in->support_leg, nullptr};
+              in->desired_linear_velocity, in->desired_angular_velocity, in->support_leg, nullptr, nullptr};
   const unsigned grid = (unsigned)((batch + 63) / 64);
   hipLaunchKernelGGL(virtual_wrench_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, ctx->d_params, s, batch,
                      wrench);

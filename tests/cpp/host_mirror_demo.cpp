@@ -1,0 +1,89 @@
+// Drives the C++ mirror of the reference interface (quadruped_locomotion_amd/host/) end to end:
+//   1. the stance scenario of balance_controller/test/test.cpp:57-130 (yaw 0.5 rad, desired height
+//      0.1 above the measured one), through RosBalanceController::{init,update} and through
+//      VirtualModelController + ContactForceDistribution::computeForceDistribution(F_B, T_B);
+//   2. the SquareUp case of free_gait_core/test/PoseOptimizationSQPTest.cpp:111-150 through
+//      PoseOptimizationSQP::optimize;
+//   3. the demo QP of qp_solver/src/main.cc:46-101 through QuadraticProblemSolver::minimize.
+// Prints "key v0 v1 ..." lines that tests/test_cpp_mirror.py compares with the oracle.
+// Exit code 3 when no GPU is present (init() returns false: there is no CPU fallback).
+#include <cmath>
+#include <cstdio>
+
+#include "balance_controller/RosBalanceController.hpp"
+#include "free_gait_core/PoseOptimizationSQP.hpp"
+#include "qp_solver/quadraticproblemsolver.hpp"
+
+int main() {
+  qlamd_balance_params params;
+  qlamd_balance_default_params(&params);
+
+  // ---- 1. balance controller ------------------------------------------------------------------
+  double q[12], effort[12] = {0};
+  for (int l = 0; l < 4; ++l) { q[3 * l] = 0.05 * (l - 1.5); q[3 * l + 1] = 0.75; q[3 * l + 2] = -1.5; }
+  const double yaw = 0.5;
+  const double orientation[4] = {std::cos(yaw / 2), 0.0, 0.0, std::sin(yaw / 2)};
+  const double position[3] = {0.0, 0.0, 0.2}, linvel[3] = {0.01, -0.02, 0.0}, angvel[3] = {0.0, 0.01, 0.02};
+  bool contact[4] = {true, true, true, true};
+  balance_controller::RobotStateHandleData hw;
+  hw.orientation = orientation; hw.position = position; hw.linear_velocity = linvel; hw.angular_velocity = angvel;
+  hw.joint_position_read = q; hw.joint_effort_write = effort; hw.foot_contact = contact;
+
+  balance_controller::RosBalanceController controller;
+  if (!controller.init(hw, params, 0)) { std::printf("init_failed 1\n"); return 3; }
+  balance_controller::BaseCommand cmd;
+  cmd.position = qlamd::Position(0.0, 0.0, 0.3);                      // 0.1 above the measured height
+  cmd.orientation = qlamd::RotationQuaternion(orientation[0], 0, 0, orientation[3]);
+  controller.setCommand(cmd);
+  if (!controller.update()) { std::printf("update_failed 1\n"); return 4; }
+  std::printf("state"); for (int i = 0; i < 12; ++i) std::printf(" %.17g", q[i]); std::printf("\n");
+  std::printf("effort"); for (int i = 0; i < 12; ++i) std::printf(" %.17g", effort[i]); std::printf("\n");
+  std::printf("grf"); for (double v : controller.vmc().getContactForces()) std::printf(" %.17g", v); std::printf("\n");
+
+  // the inner boundary: computeForceDistribution(F_B, T_B) with a hand-made wrench
+  auto ctx = std::make_shared<qlamd::Context>(params, 0);
+  auto state = std::make_shared<free_gait::State>();
+  std::array<double, 12> qa; for (int i = 0; i < 12; ++i) qa[i] = q[i];
+  state->setCurrentLimbJoints(qa);
+  state->setPoseBaseToWorld(qlamd::Pose(qlamd::Position(0, 0, 0.2), qlamd::RotationQuaternion(orientation[0], 0, 0, orientation[3])));
+  balance_controller::ContactForceDistribution cfd(ctx, state);
+  if (cfd.computeForceDistribution(qlamd::Force(0, 0, 500), qlamd::Torque(0, 0, 0))) { std::printf("unloaded_accepted 1\n"); return 5; }
+  cfd.loadParameters();
+  if (!cfd.computeForceDistribution(qlamd::Force(120.0, -40.0, 520.0), qlamd::Torque(10.0, -20.0, 5.0))) return 6;
+  std::printf("cfd_effort"); for (double v : state->getAllJointEfforts()) std::printf(" %.17g", v); std::printf("\n");
+  qlamd::Force f_lf; cfd.getForceForLeg(qlamd::LimbEnum::LF_LEG, f_lf);
+  std::printf("cfd_force_lf %.17g %.17g %.17g\n", f_lf(0), f_lf(1), f_lf(2));
+
+  // ---- 2. pose optimisation ---------------------------------------------------------------------
+  free_gait::PoseOptimizationSQP optimization(ctx);
+  free_gait::Stance nominal, stance;
+  const double sx[4] = {0.3, 0.3, -0.3, -0.3}, sy[4] = {0.2, -0.2, 0.2, -0.2};
+  const qlamd::LimbEnum order[4] = {qlamd::LimbEnum::LF_LEG, qlamd::LimbEnum::RF_LEG, qlamd::LimbEnum::LH_LEG, qlamd::LimbEnum::RH_LEG};
+  for (int k = 0; k < 4; ++k) { nominal[order[k]] = qlamd::Position(sx[k], sy[k], -0.4); stance[order[k]] = qlamd::Position(sx[k], sy[k], -0.1); }
+  optimization.setNominalStance(nominal);
+  optimization.setStance(stance);
+  optimization.setSupportStance(stance);
+  optimization.setSupportRegion({{0.3, 0.2}, {-0.3, 0.2}, {-0.3, -0.2}, {0.3, -0.2}}); // counter-clockwise
+  optimization.setLimbLengthConstraints({0.2, 0.2, 0.2, 0.2}, {0.565, 0.565, 0.565, 0.565});
+  qlamd::Pose result(qlamd::Position(0.0, 0.0, 0.3), qlamd::RotationQuaternion());
+  if (!optimization.optimize(result)) return 7;
+  std::printf("pose %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", result.position(0), result.position(1), result.position(2),
+              result.rotation.q[0], result.rotation.q[1], result.rotation.q[2], result.rotation.q[3]);
+
+  // ---- 3. the QuadProg++ demo problem -----------------------------------------------------------
+  qp_solver::QuadraticObjectiveFunction cost;
+  qp_solver::LinearFunctionConstraints cons;
+  qp_solver::Matrix G(2, 2); G(0, 0) = 1; G(0, 1) = -1; G(1, 0) = -1; G(1, 1) = 2;
+  cost.setGlobalHessian(G); cost.setLinearTerm({-2.0, -6.0});
+  qp_solver::Matrix A(3, 2); // A x <= b  <=>  CI = -A'
+  A(0, 0) = 1; A(0, 1) = 1; A(1, 0) = -1; A(1, 1) = 2; A(2, 0) = 2; A(2, 1) = 1;
+  cons.setGlobalInequalityConstraintJacobian(A); cons.setInequalityConstraintMaxValues({2.0, 2.0, 3.0});
+  qp_solver::QuadraticProblemSolver solver(ctx);
+  qp_solver::Vector x;
+  if (!solver.minimize(cost, cons, x)) return 8;
+  std::printf("qp %.17g %.17g %.17g\n", x[0], x[1], solver.lastObjective());
+  qp_solver::Matrix Aeq(2, 1); cons.setGlobalEqualityConstraintJacobian(Aeq); cons.setEqualityConstraintMaxValues({0.0});
+  if (!solver.minimize(cost, cons, x)) return 9;
+  std::printf("qp_dummy_eq %.17g %.17g %.17g\n", x[0], x[1], solver.lastObjective());
+  return 0;
+}

@@ -22,6 +22,7 @@ static void load(RobotIn &in, const double *q, const double *pos, const double *
   for (int i = 0; i < 4; i++) { in.quat[i] = quat[i]; in.dquat[i] = dquat[i]; }
   in.stance = 0;
   for (int l = 0; l < 4; l++) if (stance[l]) in.stance |= 1u << l;
+  in.has_wrench = false;
 }
 
 extern "C" void mirror_balance_batch(const qlamd_balance_params *prm, int64_t B, const double *q,
