@@ -43,6 +43,8 @@ def parse():
                     help="pose_sqp = BASELINE config 5 (reported separately; single GPU)")
     ap.add_argument("--rpw", type=int, default=0, help="robots per wavefront (0 = auto)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph of K steps")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the multi-GPU code path (process group + all-gather) even with one rank (self-test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -138,8 +140,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback in the product path)")
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
 
     B = args.batch
@@ -151,7 +155,7 @@ def main():
     d = capi.to_device(state, dev)
     tau = [torch.zeros(B, 12, dtype=torch.float64, device=dev) for _ in range(2)]
     status = torch.full((B,), -1, dtype=torch.int32, device=dev)
-    gathered = [torch.zeros(world * B, 12, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    gathered = [torch.zeros(world * B, 12, dtype=torch.float64, device=dev) for _ in range(2)] if collective else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(k, events=None):
@@ -161,14 +165,14 @@ def main():
         ctx.balance_solve_device(d, tau[buf], None, status, stream=stream)
         if events is not None:
             events[1].record()
-        if world > 1:
+        if collective:
             # result collection only; overlaps with the next step's solve (double-buffered)
             return dist.all_gather_into_tensor(gathered[buf], tau[buf], async_op=True)
         return None
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -180,11 +184,12 @@ def main():
     fence()
 
     # ---- timed region: exactly K steps -----------------------------------------
-    # Single GPU: the K launches are captured once into a hipGraph and replayed (the step is a few
-    # tens of microseconds, comparable to an eager launch from Python).  The graph is built outside
-    # the timed region; the timed region is one replay = K control steps.  Multi-GPU keeps eager
-    # launches so that the all-gather of step k overlaps the solve of step k+1.
-    use_graph = (world == 1) and not args.no_graph
+    # The K steps (solve, plus the all-gather of the torques when there are several ranks) are
+    # captured once into a hipGraph and replayed: a step is a few tens of microseconds, comparable
+    # to one eager launch from Python.  The graph is built outside the timed region; the timed
+    # region is one replay = K control steps.  If capture fails the steps are launched eagerly,
+    # the all-gather of step k then overlapping the solve of step k+1.
+    use_graph = not args.no_graph
     graph = None
     if use_graph:
         try:
@@ -196,12 +201,21 @@ def main():
                     cap = torch.cuda.current_stream().cuda_stream
                     for k in range(args.steps):
                         ctx.balance_solve_device(d, tau[k & 1], None, status, stream=cap)
+                        if collective:  # RCCL collectives are capturable; they replay from the graph
+                            dist.all_gather_into_tensor(gathered[k & 1], tau[k & 1])
             torch.cuda.current_stream().wait_stream(side)
-            graph.replay()  # one untimed replay (instantiation / upload)
-            fence()
         except Exception as e:  # pragma: no cover - fall back to eager launches
             sys.stderr.write("hipGraph capture failed (%s); eager launches\n" % e)
             graph = None
+        if collective:
+            # every rank must take the same path, or the collectives would not match up
+            okflag = torch.tensor([1 if graph is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(okflag, op=dist.ReduceOp.MIN)
+            if int(okflag.item()) == 0:
+                graph = None
+        if graph is not None:
+            graph.replay()  # one untimed replay (instantiation / upload)
+            fence()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev = []
     fence()
@@ -223,10 +237,13 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
+    if collective:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if rank == 0 and args.steps > 0:  # the gathered buffer holds every rank's torques in rank order
+            last = (args.steps - 1) & 1
+            assert torch.equal(gathered[last][:B], tau[last]), "all-gather layout"
 
     if graph is not None:
         # HIP events around the replay: K kernels back to back, so this average includes the
@@ -253,7 +270,7 @@ def main():
                                    % (B, "static 4-contact stance" if args.gait == "static"
                                       else "trot gait (2<->4 contacts)"),
                        "robots_per_gpu": B, "gait": args.gait, "seed": synth.SEED,
-                       "result_collection": "rccl all_gather of torques" if world > 1 else "none (single GPU)",
+                       "result_collection": "rccl all_gather of torques" if collective else "none (single GPU)",
                        "launch": "hipGraph of K steps" if graph is not None else "eager",
                        "all_status_ok": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -265,7 +282,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(state, args.cpu_seconds)
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

@@ -313,12 +313,11 @@ struct qlamd_context {
 namespace {
 
 int pick_rpw(const qlamd_context *ctx, int64_t batch) {
-  if (ctx->rpw_override) return ctx->rpw_override;
-  const int64_t simds = (int64_t)ctx->num_cu * 4;
-  // fill every SIMD with at least one wavefront before packing lanes
-  if (batch <= simds * 4) return 4;
-  if (batch <= simds * 16 * 2) return 16;
-  return 64;
+  // The lane-cooperative kernel wins at every batch size measured (1 K ... 1 M robots, static and
+  // trot: tools/batch_sweep.py); the one-lane-per-robot kernels stay selectable as an independent
+  // second implementation (different QP linear algebra) for cross-checks.
+  (void)batch;
+  return ctx->rpw_override ? ctx->rpw_override : 4;
 }
 
 template <int RPW>
