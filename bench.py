@@ -28,8 +28,8 @@ ALGO_BYTES_PER_STEP = 408   # 304 B state + 4 B stance in, 96 B 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP64_VALU_PEAK_TFLOPS = 78.6
 # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), see
-# profiles/r1/hbm_traffic_pmc_bench_static_b4096.json; None for configurations not profiled.
-MEASURED_TRAFFIC_BYTES = {(4096, "static"): int((1250.0 + 416.0) * 1024)}
+# profiles/r1/hbm_traffic_and_sq_pmc_bench_static_b4096_coop.json; None for configurations not profiled.
+MEASURED_TRAFFIC_BYTES = {(4096, "static"): int((1116.58 + 416.0) * 1024)}
 
 
 def parse():
@@ -275,7 +275,7 @@ def main():
                        "all_status_ok": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": MEASURED_TRAFFIC_BYTES.get((B, args.gait)),
-                         "kernel": "balance_step_kernel", "kernel_ms": kernel_ms,
+                         "kernel": "balance_coop_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
         if not args.no_cpu_baseline and world == 1:
