@@ -79,6 +79,7 @@ typedef struct qlamd_robot_model {
   double joint_rpy[4][4][3];
   double link_mass[4][4];
   double link_com[4][4][3];
+  double link_inertia[4][4][6]; /* about the com, link frame: ixx ixy ixz iyy iyz izz (swing-leg dynamics) */
 } qlamd_robot_model;
 
 /* The reference robot, quadruped_model/urdf/quadruped_model.urdf. */
@@ -146,6 +147,39 @@ int qlamd_force_distribution_batch(qlamd_context *ctx, const double *joint_posit
                                    const uint8_t *support_leg, const double *surface_normal,
                                    const double *virtual_wrench, int64_t batch, double *joint_effort,
                                    double *contact_force, int32_t *status, int memory, void *stream);
+
+/* ---- swing-leg torque ----------------------------------------------------
+ * Replaces MyRobotSolver::update (single_leg_test/lib/model_test_header.cpp:412-503) for the legs
+ * that are NOT support legs:
+ *   qdd = accel_scale * (qd - qd_oldest) / (accel_window * period)
+ *   tau = InverseDynamics(leg, q_id, qd, qdd; gravity (0,0,-gravity) in the base frame)
+ *       + J(q)' (kp o (p_des - FK(q)) + kd o (v_des - J(q) qd))
+ * with the gains of balance_controller/config/controller_gains.yaml:42-51. */
+typedef struct qlamd_swing_params {
+  double kp[3], kd[3];      /* 300 / 20 per axis                                               */
+  double period;            /* control period, 0.0025 s (balance_controller_manager.cpp:48)    */
+  double accel_window;      /* 10  (Time_derta = period * 10, model_test_header.cpp:418)       */
+  double accel_scale;       /* 0.5 (model_test_header.cpp:460)                                 */
+  double gravity;           /* 9.81 (RBDL leg models)                                          */
+} qlamd_swing_params;
+void qlamd_swing_default_params(qlamd_swing_params *p);
+
+typedef struct qlamd_swing_batch {
+  const double *joint_position;        /* [B][12] current joints (FK, Jacobian)                 */
+  const double *joint_velocity;        /* [B][12] newest entry of the velocity queue            */
+  const double *joint_velocity_oldest; /* [B][12] oldest entry of the 11-deep velocity queue    */
+  const double *target_foot_position;  /* [B][4][3] base frame (State::getTargetFootPositionInBaseForLimb) */
+  const double *target_foot_velocity;  /* [B][4][3] base frame                                  */
+  const uint8_t *support_leg;          /* [B][4]; torques are produced for legs with 0 here     */
+  const double *id_joint_position;     /* [B][12] joints fed to the inverse dynamics, or NULL = joint_position.
+                                          The reference feeds every limb the LAST stored limb's joints
+                                          (model_test_header.cpp:106-112; ros_balance_controller.cpp:239);
+                                          pass that here to reproduce it. */
+} qlamd_swing_batch;
+
+/* joint_effort [B][12]: swing legs written, support legs set to 0. */
+int qlamd_swing_leg_torque_batch(qlamd_context *ctx, const qlamd_swing_params *params, const qlamd_swing_batch *in,
+                                 int64_t batch, double *joint_effort, int memory, void *stream);
 
 /* Virtual wrench only: (F_B, T_B) [B][6].  Replaces
  * VirtualModelController::computeError/GravityCompensation/VirtualForce/VirtualTorque

@@ -286,3 +286,44 @@ def pose_cost(pb, i, pose, hips, leg_order, com_weight=2.0):
     lib().oracle_pose_cost.restype = C.c_double
     p = pose_problem(pb, i, hips, leg_order, com_weight)
     return lib().oracle_pose_cost(C.byref(p), (C.c_double * 7)(*pose))
+
+
+# ---- swing-leg torque (row a18) ---------------------------------------------------------------
+class SwingParams(C.Structure):
+    _fields_ = [("kp", C.c_double * 3), ("kd", C.c_double * 3), ("period", C.c_double), ("accel_window", C.c_double),
+                ("accel_scale", C.c_double), ("gravity", C.c_double)]
+
+
+def default_swing_params():
+    p = SwingParams()
+    lib().oracle_swing_default_params(C.byref(p))
+    return p
+
+
+def leg_rnea(leg, q, qd, qdd, g):
+    a = [_d(v) for v in (q, qd, qdd, g)]
+    tau = np.zeros(3)
+    lib().oracle_leg_rnea(int(leg), a[0][1], a[1][1], a[2][1], a[3][1], tau.ctypes.data_as(_dp))
+    return tau
+
+
+def swing_leg_torque(leg, q_id, q, qd, qd_oldest, target_pos, target_vel, params=None):
+    prm = params or default_swing_params()
+    a = [_d(v) for v in (q_id, q, qd, qd_oldest, target_pos, target_vel)]
+    tau = np.zeros(3)
+    lib().oracle_swing_leg_torque(C.byref(prm), int(leg), *[x[1] for x in a], tau.ctypes.data_as(_dp))
+    return tau
+
+
+def swing_batch(q, qd, qd_oldest, target_pos, target_vel, support, q_id=None, params=None):
+    """[B,12] arrays; returns tau [B,12] (0 for support legs)."""
+    B = q.shape[0]
+    tau = np.zeros((B, 12))
+    qi = q if q_id is None else q_id
+    for i in range(B):
+        for l in range(4):
+            if not support[i][l]:
+                sl = slice(3 * l, 3 * l + 3)
+                tau[i, sl] = swing_leg_torque(l, qi[i, sl], q[i, sl], qd[i, sl], qd_oldest[i, sl], target_pos[i, sl],
+                                              target_vel[i, sl], params)
+    return tau

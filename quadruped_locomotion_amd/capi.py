@@ -21,7 +21,7 @@ EXPORTS = (
     "qlamd_context_destroy", "qlamd_set_robots_per_wave", "qlamd_balance_solve_batch",
     "qlamd_virtual_wrench_batch", "qlamd_leg_kinematics_batch", "qlamd_strerror", "qlamd_version",
     "qlamd_qp_solve_batch", "qlamd_pose_default_params", "qlamd_pose_sqp_batch",
-    "qlamd_force_distribution_batch",
+    "qlamd_force_distribution_batch", "qlamd_swing_default_params", "qlamd_swing_leg_torque_batch",
 )
 
 
@@ -41,7 +41,19 @@ class RobotModel(C.Structure):
     _fields_ = [
         ("joint_xyz", ((C.c_double * 3) * 4) * 4), ("joint_rpy", ((C.c_double * 3) * 4) * 4),
         ("link_mass", (C.c_double * 4) * 4), ("link_com", ((C.c_double * 3) * 4) * 4),
+        ("link_inertia", ((C.c_double * 6) * 4) * 4),
     ]
+
+
+class SwingParams(C.Structure):
+    _fields_ = [("kp", C.c_double * 3), ("kd", C.c_double * 3), ("period", C.c_double), ("accel_window", C.c_double),
+                ("accel_scale", C.c_double), ("gravity", C.c_double)]
+
+
+class SwingBatch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("joint_position", "joint_velocity", "joint_velocity_oldest",
+                                           "target_foot_position", "target_foot_velocity", "support_leg",
+                                           "id_joint_position")]
 
 
 class StateBatch(C.Structure):
@@ -111,6 +123,8 @@ def lib():
             C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_force_distribution_batch.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_int, C.c_void_p]
+        L.qlamd_swing_leg_torque_batch.argtypes = [C.c_void_p, C.POINTER(SwingParams), C.POINTER(SwingBatch), C.c_int64,
+                                                   C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_pose_sqp_batch.argtypes = [C.c_void_p, C.POINTER(PoseParams), C.POINTER(PoseBatch), C.c_int64,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
@@ -246,6 +260,29 @@ def force_distribution(ctx, q, quat, support, wrench, normals=None, memory=MEM_H
     if rc != OK:
         raise QlamdError(rc, "qlamd_force_distribution_batch")
     return tau, grf, st
+
+
+def default_swing_params():
+    p = SwingParams()
+    lib().qlamd_swing_default_params(C.byref(p))
+    return p
+
+
+def swing_leg_torque(ctx, q, qd, qd_oldest, target_pos, target_vel, support, q_id=None, params=None, memory=MEM_HOST,
+                     out=None, stream=None):
+    """qlamd_swing_leg_torque_batch; numpy arrays for MEM_HOST (returns tau [B,12]), torch tensors + out for MEM_DEVICE."""
+    prm = params if params is not None else default_swing_params()
+    arrs = [q, qd, qd_oldest, target_pos, target_vel, support, q_id]
+    if memory == MEM_HOST:
+        arrs = [None if a is None else np.ascontiguousarray(a) for a in arrs]
+    sb = SwingBatch(*[_ptr(a) for a in arrs])
+    B = int(arrs[0].shape[0])
+    tau = np.zeros((B, 12)) if memory == MEM_HOST else out
+    rc = lib().qlamd_swing_leg_torque_batch(ctx._h, C.byref(prm), C.byref(sb), B, _ptr(tau), memory,
+                                            C.c_void_p(stream) if stream else None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_swing_leg_torque_batch")
+    return tau
 
 
 def pose_sqp(ctx, problems, params=None, memory=MEM_HOST, out=None, stream=None):

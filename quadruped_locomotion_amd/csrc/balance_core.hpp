@@ -60,12 +60,13 @@ struct DeviceParams {
   double grav;                 // g_W = (0,0,-grav)
   double Fg_scale;             // grav_comp * (torso + sum legs)  : F_g = -Fg_scale * g_B
   double Tg_arm[3];            // sum_l grav_comp*m_l*(hip_l - com) + grav_comp*m_torso*com : T_g = -(Tg_arm x g_B)
-  // leg chains, 64 doubles per leg: R0[4][9] fixed rotations (row-major), xyz[4][3] joint
-  // origins, mass[4], mcom[4][3] = mass * com (link frame); offsets below
-  double legtab[4 * 64];
+  // leg chains, 88 doubles per leg: R0[4][9] fixed rotations (row-major), xyz[4][3] joint
+  // origins, mass[4], mcom[4][3] = mass * com (link frame), inertia[4][6] about the com
+  // (ixx ixy ixz iyy iyz izz, link frame); offsets below
+  double legtab[4 * 88];
   int refine_passes;           // lane-cooperative kernel: refinement passes on the final working set
 };
-constexpr int kTabR0 = 0, kTabXyz = 36, kTabMass = 48, kTabMcom = 52, kTabPerLeg = 64;
+constexpr int kTabR0 = 0, kTabXyz = 36, kTabMass = 48, kTabMcom = 52, kTabInertia = 64, kTabPerLeg = 88;
 
 struct RobotIn {
   double q[12];

@@ -10,6 +10,7 @@
 #include "balance_core.hpp"
 #include "params_build.hpp"
 #include "pose_core.hpp"
+#include "swing_core.hpp"
 #include "qlamd.h"
 
 using namespace qlamd;
@@ -221,6 +222,32 @@ __global__ __launch_bounds__(64) void leg_kinematics_kernel(const DeviceParams *
   if (grav) { grav[3 * t] = Gq[0]; grav[3 * t + 1] = Gq[1]; grav[3 * t + 2] = Gq[2]; }
 }
 
+// ---- row a18: swing-leg torque, one lane per (robot, leg) -------------------------------------
+struct SwingPtrs {
+  const double *q, *qd, *qd_old, *tpos, *tvel, *q_id;
+  const uint8_t *support;
+};
+
+__global__ __launch_bounds__(64) void swing_leg_kernel(const DeviceParams *__restrict__ Pp, const SwingParamsDev SP,
+                                                       const SwingPtrs s, int64_t B, double *__restrict__ tau) {
+  const DeviceParams &P = *Pp;
+  const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (t >= 4 * B) return;
+  const int leg = (int)(t & 3);
+  double out[3] = {0.0, 0.0, 0.0};
+  if (!s.support[t]) {
+    const double q[3] = {s.q[3 * t], s.q[3 * t + 1], s.q[3 * t + 2]};
+    const double qd[3] = {s.qd[3 * t], s.qd[3 * t + 1], s.qd[3 * t + 2]};
+    const double qo[3] = {s.qd_old[3 * t], s.qd_old[3 * t + 1], s.qd_old[3 * t + 2]};
+    const double tp[3] = {s.tpos[3 * t], s.tpos[3 * t + 1], s.tpos[3 * t + 2]};
+    const double tv[3] = {s.tvel[3 * t], s.tvel[3 * t + 1], s.tvel[3 * t + 2]};
+    double qi[3] = {q[0], q[1], q[2]};
+    if (s.q_id) { qi[0] = s.q_id[3 * t]; qi[1] = s.q_id[3 * t + 1]; qi[2] = s.q_id[3 * t + 2]; }
+    swing_leg_torque(GlobalTab{P.legtab + kTabPerLeg * leg}, SP, qi, q, qd, qo, tp, tv, out);
+  }
+  tau[3 * t] = out[0]; tau[3 * t + 1] = out[1]; tau[3 * t + 2] = out[2];
+}
+
 // ---- config 5: one pose-optimisation problem per lane, 16 problems per wavefront --------------
 struct PosePtrs {
   const double *stance, *nominal, *polygon, *rcom, *maxlen, *pose;
@@ -362,6 +389,63 @@ extern "C" {
 void qlamd_balance_default_params(qlamd_balance_params *p) { if (p) default_balance_params(p); }
 void qlamd_default_robot_model(qlamd_robot_model *m) { if (m) default_robot_model(m); }
 int qlamd_version(void) { return QLAMD_VERSION_MAJOR * 1000 + QLAMD_VERSION_MINOR; }
+
+void qlamd_swing_default_params(qlamd_swing_params *p) {
+  if (!p) return;
+  for (int i = 0; i < 3; i++) { p->kp[i] = 300.0; p->kd[i] = 20.0; } // controller_gains.yaml:42-51
+  p->period = 0.0025;      // balance_controller_manager.cpp:48
+  p->accel_window = 10.0;  // model_test_header.cpp:418
+  p->accel_scale = 0.5;    // model_test_header.cpp:460
+  p->gravity = 9.81;
+}
+
+int qlamd_swing_leg_torque_batch(qlamd_context *ctx, const qlamd_swing_params *params, const qlamd_swing_batch *in,
+                                 int64_t batch, double *joint_effort, int memory, void *stream) {
+  if (!ctx || !in || batch < 0 || !joint_effort) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!params) return QLAMD_ERR_NOT_LOADED;
+  if (!in->joint_position || !in->joint_velocity || !in->joint_velocity_oldest || !in->target_foot_position ||
+      !in->target_foot_velocity || !in->support_leg)
+    return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!(params->period > 0.0) || !(params->accel_window > 0.0)) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+  SwingParamsDev SP;
+  for (int i = 0; i < 3; i++) { SP.kp[i] = params->kp[i]; SP.kd[i] = params->kd[i]; }
+  SP.period = params->period; SP.accel_window = params->accel_window; SP.accel_scale = params->accel_scale;
+  SP.gravity = params->gravity;
+  SwingPtrs s{in->joint_position, in->joint_velocity, in->joint_velocity_oldest, in->target_foot_position,
+              in->target_foot_velocity, in->id_joint_position, in->support_leg};
+  double *d_tau = joint_effort;
+  if (memory == QLAMD_MEM_HOST) {
+    const size_t sz[7] = {B * 96, B * 96, B * 96, B * 96, B * 96, in->id_joint_position ? B * 96 : 0, B * 4};
+    const void *src[7] = {in->joint_position, in->joint_velocity, in->joint_velocity_oldest,
+                          in->target_foot_position, in->target_foot_velocity, in->id_joint_position, in->support_leg};
+    size_t off[8], total = 0;
+    for (int k = 0; k < 7; k++) { off[k] = total; total += align256(sz[k]); }
+    off[7] = total; total += align256(B * 96);
+    int rc = ensure_ws(ctx, total);
+    if (rc != QLAMD_OK) return rc;
+    char *w = (char *)ctx->ws;
+    for (int k = 0; k < 7; k++)
+      if (sz[k] && hipMemcpyAsync(w + off[k], src[k], sz[k], hipMemcpyHostToDevice, st) != hipSuccess)
+        return QLAMD_ERR_HIP;
+    s = SwingPtrs{(const double *)(w + off[0]), (const double *)(w + off[1]), (const double *)(w + off[2]),
+                  (const double *)(w + off[3]), (const double *)(w + off[4]),
+                  in->id_joint_position ? (const double *)(w + off[5]) : nullptr, (const uint8_t *)(w + off[6])};
+    d_tau = (double *)(w + off[7]);
+  }
+  const unsigned grid = (unsigned)((4 * batch + 63) / 64);
+  hipLaunchKernelGGL(swing_leg_kernel, dim3(grid), dim3(64), 0, st, ctx->d_params, SP, s, batch, d_tau);
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  if (memory == QLAMD_MEM_HOST) {
+    if (hipMemcpyAsync(joint_effort, d_tau, B * 96, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
+  }
+  return QLAMD_OK;
+}
 
 void qlamd_pose_default_params(qlamd_pose_params *p) {
   if (!p) return;

@@ -39,6 +39,7 @@ inline void default_robot_model(qlamd_robot_model *m) {
   memcpy(m->joint_rpy, QLAMD_JOINT_RPY, sizeof(m->joint_rpy));
   memcpy(m->link_mass, QLAMD_LINK_MASS, sizeof(m->link_mass));
   memcpy(m->link_com, QLAMD_LINK_COM, sizeof(m->link_com));
+  memcpy(m->link_inertia, QLAMD_LINK_INERTIA, sizeof(m->link_inertia));
 }
 
 // URDF fixed-axis rpy: R = Rz(yaw) Ry(pitch) Rx(roll)  (kdl_parser)
@@ -79,6 +80,7 @@ inline void build_device_params(const qlamd_balance_params &p, const qlamd_robot
         tab[kTabXyz + 3 * k + i] = m.joint_xyz[l][k][i];
         tab[kTabMcom + 3 * k + i] = m.link_mass[l][k] * m.link_com[l][k][i];
       }
+      for (int i = 0; i < 6; i++) tab[kTabInertia + 6 * k + i] = m.link_inertia[l][k][i];
     }
   }
 }

@@ -152,3 +152,16 @@ def make_pose_problems(batch, seed=SEED + 5, offset=0):
                 nominal=np.ascontiguousarray(np.tile(POSE_NOMINAL, (B, 1, 1))),
                 polygon=np.ascontiguousarray(polygon), n_vertices=np.full(B, 4, dtype=np.int32),
                 r_com=np.zeros((B, 3)), max_len=np.full((B, 4), POSE_MAX_LEN), pose=pose)
+
+
+def make_swing_inputs(batch, seed=SEED + 9, offset=0):
+    """Swing-leg inputs on top of a trot state batch: newest / oldest joint velocities of the 11-deep
+    queue and Cartesian foot targets near the current foot position (row a18)."""
+    st = make_states(batch, "trot", offset=offset)
+    u = _uniform(seed, offset, offset + batch)
+    qd = (2.0 * u[:, 0:12] - 1.0) * 1.5
+    qd_old = qd + (2.0 * u[:, 12:24] - 1.0) * 0.2
+    dpos = (2.0 * u[:, 24:36] - 1.0) * 0.03
+    tvel = (2.0 * u[:, 36:48] - 1.0) * 0.5
+    return dict(q=st["q"], qd=np.ascontiguousarray(qd), qd_old=np.ascontiguousarray(qd_old), dpos=np.ascontiguousarray(dpos),
+                tvel=np.ascontiguousarray(tvel), support=st["stance"])

@@ -118,3 +118,16 @@ extern "C" void mirror_pose_sqp_batch(const PoseParamsDev *P, int64_t B, const d
     for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
   }
 }
+
+// ---- swing-leg torque (row a18) ----
+#include "swing_core.hpp"
+extern "C" void mirror_swing_leg(int leg, const SwingParamsDev *SP, const double *q_id, const double *q, const double *qd,
+                                 const double *qd_old, const double *tp, const double *tv, double *tau) {
+  qlamd_balance_params prm;
+  default_balance_params(&prm);
+  qlamd_robot_model model;
+  default_robot_model(&model);
+  DeviceParams P;
+  build_device_params(prm, model, &P);
+  swing_leg_torque(P.legtab + kTabPerLeg * leg, *SP, q_id, q, qd, qd_old, tp, tv, tau);
+}
