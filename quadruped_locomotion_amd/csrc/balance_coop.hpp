@@ -424,8 +424,12 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     s_fric = mu * dn + fa * d1 + fb * d2;
   };
   // component c of the normal of constraint type t on my leg (0 on the spare lane)
+  // the five normals of my leg, component c: a table + selects keeps this branch-free
+  const double nrm0 = myn, nrm1 = mu * myn + myt1, nrm2 = mu * myn - myt1, nrm3 = mu * myn + myt2, nrm4 = mu * myn - myt2;
   const auto my_normal = [&](int t) -> double {
-    return t == 0 ? myn : (mu * myn + (t == 1 ? myt1 : t == 2 ? -myt1 : t == 3 ? myt2 : -myt2));
+    const double a = (t & 1) ? nrm1 : nrm2, b = (t & 1) ? nrm3 : nrm4;
+    const double f = (t <= 2) ? a : b;
+    return t == 0 ? nrm0 : f;
   };
 
   for (int tick = 0; tick < 40 * kMaxOuter; tick++) {
@@ -505,26 +509,22 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       ucand += td;
       sp += tp * zn; // slack of ip after a partial step (:436-440, linear in t)
       // ---- rank-one update of H and N*:  H[j] += hc * v_j,  N*[j] += nc * v_j
-      double vec = 0.0, hc = 0.0, nc = 0.0;
-      if (is_add) {
-        // H -= z z'/d;  N* <- [N* - r z'/d ; z'/d]  (the new row goes to the lowest free slot lane)
-        const int newlane = __ffs(~used & 0xFFFu) - 1;
-        const double dinv = rcp_nr(zn);
-        vec = z * dinv;
-        hc = -z;
-        const bool newslot = (lr == newlane);
-        nc = newslot ? 1.0 : (slot ? -r : 0.0);
-        if (newslot) { u = ucand; idk = ip; }
-        used |= 1u << newlane;
-        act_mask |= 1u << ip;
-        rnorm2 = fmax(rnorm2, zn);
-        q++;
-        need_select = true; fresh = true;
-      }
-      if (degenerate) { // numerically dependent normal: skip it and select again
-        excl |= 1u << ip;
-        need_select = true; fresh = false;
-      }
+      // add (predicated, no branch):  H -= z z'/d;  N* <- [N* - r z'/d ; z'/d], the new row goes to the
+      // lowest free slot lane.  A numerically dependent normal is skipped and selection repeated.
+      const int newlane = __ffs(~used & 0xFFFu) - 1;
+      const bool newslot = is_add && (lr == newlane);
+      double vec = is_add ? z * rcp_nr(zn) : 0.0;
+      double hc = is_add ? -z : 0.0;
+      double nc = newslot ? 1.0 : ((is_add && slot) ? -r : 0.0);
+      u = newslot ? ucand : u;
+      idk = newslot ? ip : idk;
+      used |= is_add ? (1u << newlane) : 0u;
+      act_mask |= is_add ? (1u << ip) : 0u;
+      rnorm2 = is_add ? fmax(rnorm2, zn) : rnorm2;
+      q += is_add ? 1 : 0;
+      excl |= degenerate ? (1u << ip) : 0u;
+      need_select = need_select || full;
+      fresh = is_add ? true : (degenerate ? false : fresh);
       if (is_drop) {
         // n~ = row lpos of N*: through LDS so that lane (leg,c) gets element myidx of it
         if (lr == lpos) {

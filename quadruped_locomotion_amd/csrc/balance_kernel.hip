@@ -264,30 +264,27 @@ __global__ __launch_bounds__(64) void pose_sqp_kernel(const PoseParamsDev P, con
   const int64_t i = (int64_t)blockIdx.x * kPosePerWave + lane;
   if (lane >= kPosePerWave || i >= B) return;
   PoseProblem pb;
+  unsigned limb_mask = 0;
+#pragma unroll
+  for (int l = 0; l < 4; l++)
+    if (!s.mask || s.mask[4 * i + l]) limb_mask |= 1u << l;
+  pose_problem_load_legs(
+      P, pb, [&](int l, int a) { return s.stance[12 * i + 3 * l + a]; },
+      [&](int l, int a) { return s.nominal[12 * i + 3 * l + a]; }, [&](int l) { return s.maxlen[4 * i + l]; }, limb_mask);
 #pragma unroll
   for (int l = 0; l < 4; l++) {
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      pb.stance[l][a] = s.stance[12 * i + 3 * l + a];
-      pb.nominal[l][a] = s.nominal[12 * i + 3 * l + a];
-    }
-    pb.max_len[l] = s.maxlen[4 * i + l];
     pb.polygon[l][0] = s.polygon[8 * i + 2 * l];
     pb.polygon[l][1] = s.polygon[8 * i + 2 * l + 1];
   }
 #pragma unroll
   for (int a = 0; a < 3; a++) pb.r_com[a] = s.rcom ? s.rcom[3 * i + a] : 0.0;
   pb.n_vertices = s.nverts ? s.nverts[i] : 4;
-  pb.stance_mask = 0;
-#pragma unroll
-  for (int l = 0; l < 4; l++)
-    if (!s.mask || s.mask[4 * i + l]) pb.stance_mask |= 1u << l;
   double pose[7];
 #pragma unroll
   for (int a = 0; a < 7; a++) pose[a] = s.pose[7 * i + a];
   LdsScratch scr{lds + lane, kPosePerWave};
   int it = 0;
-  const int st = pose_sqp(P, pb, scr, pose, &it);
+  const int st = pose_sqp6(P, pb, scr, pose, &it); // register-resident inner QP (gi6_core.hpp)
 #pragma unroll
   for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
   if (iters) iters[i] = it;
@@ -508,7 +505,7 @@ int qlamd_pose_sqp_batch(qlamd_context *ctx, const qlamd_pose_params *params, co
     d_it = (int32_t *)(w + off[9]);
     d_st = (int32_t *)(w + off[10]);
   }
-  const size_t lds = (size_t)kPosePerWave * PoseGi::kTotal * sizeof(double);
+  const size_t lds = (size_t)kPosePerWave * Gi6Layout::kTotal * sizeof(double);
   const unsigned grid = (unsigned)((batch + kPosePerWave - 1) / kPosePerWave);
   hipLaunchKernelGGL(pose_sqp_kernel, dim3(grid), dim3(64), lds, st, P, s, batch, d_out, d_it, d_st);
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;

@@ -9,6 +9,7 @@
 // Inner QP: gi_core.hpp (n = 6, m <= 8, one all-zero equality column as the reference passes).
 #pragma once
 
+#include "gi6_core.hpp"
 #include "gi_core.hpp"
 
 namespace qlamd {
@@ -22,11 +23,30 @@ struct PoseParamsDev {
   int leg_order[4];    // iteration order of the reference's unordered_map Stance
 };
 
-struct PoseProblem { // one problem, indexed by limb id
-  double stance[4][3], nominal[4][3], max_len[4], polygon[4][2], r_com[3], pose[7];
+// One problem.  The per-leg arrays are stored in ITERATION order (slot k holds limb leg_order[k]),
+// permuted once at load time, so that every later index is a compile-time constant (a run-time
+// limb index into a register array would send the whole struct to scratch memory).
+struct PoseProblem {
+  double stance[4][3], nominal[4][3], hips[4][3], max_len[4], polygon[4][2], r_com[3], pose[7];
   int n_vertices;
-  unsigned stance_mask;
+  unsigned present; // bit k: slot k is part of the stance
 };
+
+// Fill slot k from limb-indexed batch arrays (get(l, a) style accessors keep this usable on host and device).
+template <class FS, class FN, class F1>
+QL_HD void pose_problem_load_legs(const PoseParamsDev &P, PoseProblem &pb, FS stance, FN nominal, F1 maxlen, unsigned limb_mask) {
+  pb.present = 0;
+  QL_UNROLL for (int k = 0; k < 4; k++) {
+    const int l = P.leg_order[k];
+    if ((limb_mask >> l) & 1u) pb.present |= 1u << k;
+    QL_UNROLL for (int a = 0; a < 3; a++) {
+      pb.stance[k][a] = stance(l, a);
+      pb.nominal[k][a] = nominal(l, a);
+      pb.hips[k][a] = P.hips[l][a];
+    }
+    pb.max_len[k] = maxlen(l);
+  }
+}
 
 typedef GiLayout<6, 1, 8> PoseGi;
 
@@ -93,12 +113,13 @@ QL_HD void quat_box_plus(const double q[4], const double d[3], double out[4]) {
   out[3] = e[0] * q[3] + e[1] * q[2] - e[2] * q[1] + e[3] * q[0];
 }
 
-// Linearise at `pose` straight into the QP scratch: G = H, G0 = g, CI = -A', CI0 = vmax - val,
-// CE = 0, CE0 = 0.  Returns m.
-template <class Scr>
-QL_HD int pose_linearise(const PoseParamsDev &P, const PoseProblem &pb, const double centroid[2], int nsp,
-                         const double GA[4][2], const double gb[4], const double pose[7], Scr &s) {
-  typedef PoseGi Ly;
+// Linearise at `pose`: Hessian / gradient through `put_G(i, v)` / `put_g0(i, v)`, constraints into
+// the scratch at offsets (kCI, kCI0): CI = -A' (stride m), CI0 = vmax - val.  Returns m.
+template <int kCI, int kCI0, class Scr, class PutG, class PutG0>
+QL_HD int pose_linearise_to(const PoseParamsDev &P, const PoseProblem &pb, const double centroid[2], int nsp,
+                            const double GA[4][2], const double gb[4], const double pose[7], Scr &s, PutG put_G,
+                            PutG0 put_g0) {
+  struct Ly { enum { CI = kCI, CI0 = kCI0 }; };
   double R[9], ps[9];
   const double *p = pose;
   quat_to_matrix(pose + 3, R);
@@ -106,13 +127,12 @@ QL_HD int pose_linearise(const PoseParamsDev &P, const PoseProblem &pb, const do
   double g[6] = {0, 0, 0, 0, 0, 0}, H[36];
   for (int i = 0; i < 36; i++) H[i] = 0.0;
   int nl = 0;
-  for (int k = 0; k < 4; k++) {
-    const int l = P.leg_order[k];
-    if (!((pb.stance_mask >> l) & 1u)) continue;
+  QL_UNROLL for (int k = 0; k < 4; k++) {
+    if (!((pb.present >> k) & 1u)) continue;
     nl++;
-    const double *f = pb.stance[l];
+    const double *f = pb.stance[k];
     double Pd[3], D[9], F[9], Dp[3], Df[3], T1[9], T2[9], T3[9], T4[9];
-    rot(R, pb.nominal[l], Pd);
+    rot(R, pb.nominal[k], Pd);
     skew3(Pd, D); skew3(f, F);
     rot(D, p, Dp); rot(D, f, Df);
     for (int i = 0; i < 3; i++) { g[i] += p[i] + Pd[i] - f[i]; g[3 + i] += Dp[i] - Df[i]; }
@@ -146,8 +166,8 @@ QL_HD int pose_linearise(const PoseParamsDev &P, const PoseProblem &pb, const do
         H[6 * (3 + i) + 3 + j] += 0.5 * w * (T1[3 * i + j] + T2[3 * i + j] - T3[3 * i + j] - T4[3 * i + j]);
       }
   }
-  for (int i = 0; i < 6; i++) s.at(Ly::G0 + i) = 2.0 * g[i];
-  for (int i = 0; i < 36; i++) s.at(Ly::G + i) = 2.0 * H[i];
+  for (int i = 0; i < 6; i++) put_g0(i, 2.0 * g[i]);
+  for (int i = 0; i < 36; i++) put_G(i, 2.0 * H[i]);
 
   const int m = nsp + nl;
   const double cw[2] = {p[0] + Pr3[0], p[1] + Pr3[1]};
@@ -161,17 +181,16 @@ QL_HD int pose_linearise(const PoseParamsDev &P, const PoseProblem &pb, const do
     }
   }
   int row = nsp;
-  for (int k = 0; k < 4; k++) {
-    const int l = P.leg_order[k];
-    if (!((pb.stance_mask >> l) & 1u)) continue;
-    const double *f = pb.stance[l];
+  QL_UNROLL for (int k = 0; k < 4; k++) {
+    if (!((pb.present >> k) & 1u)) continue;
+    const double *f = pb.stance[k];
     const double df[3] = {f[0] - p[0], f[1] - p[1], f[2] - p[2]};
     double bf[3], Ph[3], Hs[9];
     irot(R, df, bf);
-    const double e[3] = {bf[0] - P.hips[l][0], bf[1] - P.hips[l][1], bf[2] - P.hips[l][2]};
+    const double e[3] = {bf[0] - pb.hips[k][0], bf[1] - pb.hips[k][1], bf[2] - pb.hips[k][2]};
     const double len = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
-    s.at(Ly::CI0 + row) = pb.max_len[l] - len;
-    rot(R, P.hips[l], Ph);
+    s.at(Ly::CI0 + row) = pb.max_len[k] - len;
+    rot(R, pb.hips[k], Ph);
     skew3(Ph, Hs);
     double ln[3] = {p[0] + Ph[0] - f[0], p[1] + Ph[1] - f[1], p[2] + Ph[2] - f[2]};
     const double nn = sqrt(ln[0] * ln[0] + ln[1] * ln[1] + ln[2] * ln[2]);
@@ -182,8 +201,18 @@ QL_HD int pose_linearise(const PoseParamsDev &P, const PoseProblem &pb, const do
     }
     row++;
   }
-  for (int j = 0; j < 6; j++) s.at(Ly::CE + j) = 0.0;
-  s.at(Ly::CE0) = 0.0;
+  return m;
+}
+
+// LDS-resident variant (gi_core.hpp layout): everything into the scratch, CE = 0, CE0 = 0.
+template <class Scr>
+QL_HD int pose_linearise(const PoseParamsDev &P, const PoseProblem &pb, const double centroid[2], int nsp,
+                         const double GA[4][2], const double gb[4], const double pose[7], Scr &s) {
+  const int m = pose_linearise_to<PoseGi::CI, PoseGi::CI0>(
+      P, pb, centroid, nsp, GA, gb, pose, s, [&](int i, double v) { s.at(PoseGi::G + i) = v; },
+      [&](int i, double v) { s.at(PoseGi::G0 + i) = v; });
+  for (int j = 0; j < 6; j++) s.at(PoseGi::CE + j) = 0.0;
+  s.at(PoseGi::CE0) = 0.0;
   return m;
 }
 
@@ -202,6 +231,33 @@ QL_HD int pose_sqp(const PoseParamsDev &P, const PoseProblem &pb, Scr &s, double
     if (status != kStatusOk) break;
     double dp[6];
     for (int i = 0; i < 6; i++) dp[i] = s.at(PoseGi::X + i);
+    for (int i = 0; i < 3; i++) pose[i] += dp[i];
+    double qn[4];
+    quat_box_plus(pose + 3, dp + 3, qn);
+    for (int i = 0; i < 4; i++) pose[3 + i] = qn[i];
+    const double nrm = sqrt(dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2] + dp[3] * dp[3] + dp[4] * dp[4] + dp[5] * dp[5]);
+    if (nrm < P.tol) break; // :72-76
+  }
+  if (iters_out) *iters_out = k;
+  return status;
+}
+
+
+// Register-resident variant (gi6_core.hpp): the one the kernel runs.
+template <class Scr>
+QL_HD int pose_sqp6(const PoseParamsDev &P, const PoseProblem &pb, Scr &s, double pose[7], int *iters_out) {
+  double centroid[2], GA[4][2], gb[4];
+  polygon_centroid(pb.n_vertices, pb.polygon, centroid);
+  const int nsp = polygon_halfspaces(pb.n_vertices, pb.polygon, GA, gb);
+  int k = 0, status = kStatusOk;
+  while (k < P.max_iter) {
+    double G[36], g0[6], dp[6], f;
+    const double CE[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const int m = pose_linearise_to<Gi6Layout::CI, Gi6Layout::CI0>(
+        P, pb, centroid, nsp, GA, gb, pose, s, [&](int i, double v) { G[i] = v; }, [&](int i, double v) { g0[i] = v; });
+    k++;
+    status = gi6_solve(s, G, g0, CE, 0.0, P.dummy_equality ? 1 : 0, m, dp, &f);
+    if (status != kStatusOk) break;
     for (int i = 0; i < 3; i++) pose[i] += dp[i];
     double qn[4];
     quat_box_plus(pose + 3, dp + 3, qn);

@@ -94,26 +94,27 @@ extern "C" int mirror_qp_solve(int n, int p, int m, const double *G, const doubl
   return st;
 }
 
+extern "C" { int g_mirror_pose_variant = 6; } // 6 = register GI (the kernel's), 0 = LDS-layout GI
+
 extern "C" void mirror_pose_sqp_batch(const PoseParamsDev *P, int64_t B, const double *stance,
                                       const uint8_t *mask, const double *nominal, const double *polygon,
                                       const int32_t *nverts, const double *rcom, const double *maxlen,
                                       const double *pose_in, double *pose_out, int32_t *iters, int32_t *status) {
   for (int64_t i = 0; i < B; i++) {
     PoseProblem pb;
-    for (int l = 0; l < 4; l++) {
-      for (int a = 0; a < 3; a++) { pb.stance[l][a] = stance[12 * i + 3 * l + a]; pb.nominal[l][a] = nominal[12 * i + 3 * l + a]; }
-      pb.max_len[l] = maxlen[4 * i + l];
-      pb.polygon[l][0] = polygon[8 * i + 2 * l]; pb.polygon[l][1] = polygon[8 * i + 2 * l + 1];
-    }
+    unsigned limb_mask = 0;
+    for (int l = 0; l < 4; l++) if (!mask || mask[4 * i + l]) limb_mask |= 1u << l;
+    pose_problem_load_legs(
+        *P, pb, [&](int l, int a) { return stance[12 * i + 3 * l + a]; },
+        [&](int l, int a) { return nominal[12 * i + 3 * l + a]; }, [&](int l) { return maxlen[4 * i + l]; }, limb_mask);
+    for (int l = 0; l < 4; l++) { pb.polygon[l][0] = polygon[8 * i + 2 * l]; pb.polygon[l][1] = polygon[8 * i + 2 * l + 1]; }
     for (int a = 0; a < 3; a++) pb.r_com[a] = rcom ? rcom[3 * i + a] : 0.0;
     pb.n_vertices = nverts ? nverts[i] : 4;
-    pb.stance_mask = 0;
-    for (int l = 0; l < 4; l++) if (!mask || mask[4 * i + l]) pb.stance_mask |= 1u << l;
     double pose[7];
     for (int a = 0; a < 7; a++) pose[a] = pose_in[7 * i + a];
     HostScr<PoseGi::kTotal> s;
     int it = 0;
-    status[i] = pose_sqp(*P, pb, s, pose, &it);
+    status[i] = g_mirror_pose_variant == 6 ? pose_sqp6(*P, pb, s, pose, &it) : pose_sqp(*P, pb, s, pose, &it);
     if (iters) iters[i] = it;
     for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
   }
@@ -130,4 +131,17 @@ extern "C" void mirror_swing_leg(int leg, const SwingParamsDev *SP, const double
   DeviceParams P;
   build_device_params(prm, model, &P);
   swing_leg_torque(P.legtab + kTabPerLeg * leg, *SP, q_id, q, qd, qd_old, tp, tv, tau);
+}
+
+extern "C" int mirror_qp6_solve(int p, int m, const double *G, const double *g0, const double *CE, double ce0,
+                                const double *CI, const double *ci0, double *x, double *f) {
+  HostScr<Gi6Layout::kTotal> s;
+  double Gr[36], g[6], ce[6], xx[6];
+  for (int i = 0; i < 36; i++) Gr[i] = G[i];
+  for (int i = 0; i < 6; i++) { g[i] = g0[i]; ce[i] = p ? CE[i] : 0.0; }
+  for (int i = 0; i < 6 * m; i++) s.at(Gi6Layout::CI + i) = CI[i];
+  for (int i = 0; i < m; i++) s.at(Gi6Layout::CI0 + i) = ci0[i];
+  const int st = gi6_solve(s, Gr, g, ce, ce0, p, m, xx, f);
+  for (int i = 0; i < 6; i++) x[i] = xx[i];
+  return st;
 }
