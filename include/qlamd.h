@@ -249,6 +249,20 @@ int qlamd_pose_sqp_batch(qlamd_context *ctx, const qlamd_pose_params *params, co
                          int64_t batch, double *pose_out, int32_t *iterations, int32_t *status, int memory,
                          void *stream);
 
+/* PoseOptimizationQP::optimize (free_gait_core/src/pose_optimization/PoseOptimizationQP.cpp:42-140): the step before
+ * the SQP in BaseAuto::optimizePose (BaseAuto.cpp:394-400).  Position only (orientation of `pose` kept):
+ * min sum |x + R d_i - f_i|^2  s.t. the support-region half-spaces on (x + R r_com)_xy, solved with the same dense
+ * QP (n = 3) and the same all-zero equality column as the reference. */
+int qlamd_pose_qp_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in, int64_t batch,
+                        double *pose_out, int32_t *status, int memory, void *stream);
+
+/* PoseConstraintsChecker::check (free_gait_core/src/pose_optimization/PoseConstraintsChecker.cpp:29-64) for the
+ * poses in in->pose: ok[b] = 1 when the centre of mass lies inside the support region and every limb length is
+ * within [min - tol, max + tol].  min_limb_length [B][4] or NULL (= 0). */
+int qlamd_pose_check_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
+                           const double *min_limb_length, double leg_length_tolerance, int64_t batch, uint8_t *ok,
+                           int memory, void *stream);
+
 const char *qlamd_strerror(int code);
 int qlamd_version(void);
 

@@ -327,3 +327,15 @@ def swing_batch(q, qd, qd_oldest, target_pos, target_vel, support, q_id=None, pa
                 tau[i, sl] = swing_leg_torque(l, qi[i, sl], q[i, sl], qd[i, sl], qd_oldest[i, sl], target_pos[i, sl],
                                               target_vel[i, sl], params)
     return tau
+
+
+def pose_qp(pb, i, hips, leg_order, dummy_equality=1):
+    p = pose_problem(pb, i, hips, leg_order)
+    out = (C.c_double * 7)()
+    st = lib().oracle_pose_qp(C.byref(p), (C.c_double * 7)(*pb["pose"][i]), int(dummy_equality), out)
+    return dict(pose=np.array(out[:]), status=st)
+
+
+def pose_check(pb, i, pose, hips, leg_order, min_len=(0.2, 0.2, 0.2, 0.2), leg_tol=0.0):
+    p = pose_problem(pb, i, hips, leg_order)
+    return int(lib().oracle_pose_check(C.byref(p), (C.c_double * 7)(*pose), (C.c_double * 4)(*min_len), C.c_double(leg_tol)))

@@ -255,3 +255,60 @@ int oracle_pose_sqp(const oracle_pose_problem *pb, const double pose_in[7], doub
   if (cost_out) *cost_out = oracle_pose_cost(pb, pose);
   return status;
 }
+
+/* ------------------------------------------------------------------ PoseOptimizationQP, PoseConstraintsChecker */
+
+int oracle_pose_qp(const oracle_pose_problem *pb, const double pose_in[7], int dummy_equality, double pose_out[7]) {
+  double R[9], G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, q[3] = {0, 0, 0};
+  quat_to_mat(pose_in + 3, R);
+  /* P = 2 A'A = 2 nFeet I;  q = -2 A'b,  b_i = f_i - R d_i  (:57-66, :83-84) */
+  for (int k = 0; k < pb->n_legs; k++) {
+    const int l = pb->leg_order[k];
+    double Rd[3];
+    mv(R, pb->nominal[l], Rd);
+    for (int i = 0; i < 3; i++) q[i] += -2.0 * (pb->stance[l][i] - Rd[i]);
+  }
+  for (int i = 0; i < 3; i++) G[4 * i] = 2.0 * pb->n_legs;
+  /* G x <= h,  h = hp - G (R r_com)_xy;  z column zero  (:73-81) */
+  double GA[8], gb[4], Rr[3], CI[12], ci0[4], CE[3] = {0, 0, 0}, ce0[1] = {0}, x[3], f;
+  const int m = oracle_polygon_halfspaces(pb->n_vertices, &pb->polygon[0][0], GA, gb);
+  mv(R, pb->r_com, Rr);
+  for (int i = 0; i < m; i++) {
+    ci0[i] = gb[i] - (GA[2 * i] * Rr[0] + GA[2 * i + 1] * Rr[1]);
+    CI[0 * m + i] = -GA[2 * i];
+    CI[1 * m + i] = -GA[2 * i + 1];
+    CI[2 * m + i] = -0.0;
+  }
+  const int st = oracle_solve_quadprog(3, dummy_equality ? 1 : 0, m, G, q, CE, ce0, CI, ci0, x, &f, NULL, NULL, NULL);
+  memcpy(pose_out, pose_in, 7 * sizeof(double));
+  if (st == ORACLE_QP_OK) memcpy(pose_out, x, sizeof(x));
+  return st;
+}
+
+/* grid_map::Polygon::isInside (crossing number) */
+int oracle_polygon_is_inside(int nv, const double *v, const double pt[2]) {
+  int cross = 0;
+  for (int i = 0, j = nv - 1; i < nv; j = i++) {
+    const double xi = v[2 * i], yi = v[2 * i + 1], xj = v[2 * j], yj = v[2 * j + 1];
+    if (((yi > pt[1]) != (yj > pt[1])) && (pt[0] < (xj - xi) * (pt[1] - yi) / (yj - yi) + xi)) cross++;
+  }
+  return cross % 2;
+}
+
+int oracle_pose_check(const oracle_pose_problem *pb, const double pose[7], const double min_len[4], double leg_tol) {
+  double R[9], Pr[3];
+  quat_to_mat(pose + 3, R);
+  mv(R, pb->r_com, Pr);
+  const double com[2] = {pose[0] + Pr[0], pose[1] + Pr[1]};
+  if (!oracle_polygon_is_inside(pb->n_vertices, &pb->polygon[0][0], com)) return 0;
+  for (int k = 0; k < pb->n_legs; k++) {
+    const int l = pb->leg_order[k];
+    const double df[3] = {pb->stance[l][0] - pose[0], pb->stance[l][1] - pose[1], pb->stance[l][2] - pose[2]};
+    double bf[3];
+    mtv(R, df, bf);
+    const double e[3] = {bf[0] - pb->hips[l][0], bf[1] - pb->hips[l][1], bf[2] - pb->hips[l][2]};
+    const double len = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    if (len < min_len[l] - leg_tol || len > pb->max_len[l] + leg_tol) return 0;
+  }
+  return 1;
+}

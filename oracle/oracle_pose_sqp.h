@@ -35,6 +35,16 @@ int oracle_pose_constraints(const oracle_pose_problem *pb, const double pose[7],
 int oracle_pose_sqp(const oracle_pose_problem *pb, const double pose_in[7], double tol, int max_iter,
                     int dummy_equality, double pose_out[7], int *iters_out, double *cost_out, double *dp_hist);
 
+/* PoseOptimizationQP::optimize (free_gait_core/src/pose_optimization/PoseOptimizationQP.cpp:42-140): position only,
+ * orientation kept; min sum |x + R d_i - f_i|^2  s.t.  G (x + R r_com)_xy <= h, plus the dummy equality. */
+int oracle_pose_qp(const oracle_pose_problem *pb, const double pose_in[7], int dummy_equality, double pose_out[7]);
+
+/* PoseConstraintsChecker::check (PoseConstraintsChecker.cpp:29-64): centre of mass inside the support region
+ * (grid_map::Polygon::isInside; the inward-offset copy is built but not used there) and every limb length within
+ * [min - tol, max + tol].  Returns 1 when the pose passes. */
+int oracle_pose_check(const oracle_pose_problem *pb, const double pose[7], const double min_len[4], double leg_tol);
+int oracle_polygon_is_inside(int nv, const double *v, const double pt[2]);
+
 #ifdef __cplusplus
 }
 #endif

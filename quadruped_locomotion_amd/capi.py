@@ -22,6 +22,7 @@ EXPORTS = (
     "qlamd_virtual_wrench_batch", "qlamd_leg_kinematics_batch", "qlamd_strerror", "qlamd_version",
     "qlamd_qp_solve_batch", "qlamd_pose_default_params", "qlamd_pose_sqp_batch",
     "qlamd_force_distribution_batch", "qlamd_swing_default_params", "qlamd_swing_leg_torque_batch",
+    "qlamd_pose_qp_batch", "qlamd_pose_check_batch",
 )
 
 
@@ -123,6 +124,10 @@ def lib():
             C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_force_distribution_batch.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_int, C.c_void_p]
+        L.qlamd_pose_qp_batch.argtypes = [C.c_void_p, C.POINTER(PoseParams), C.POINTER(PoseBatch), C.c_int64, C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_void_p]
+        L.qlamd_pose_check_batch.argtypes = [C.c_void_p, C.POINTER(PoseParams), C.POINTER(PoseBatch), C.c_void_p, C.c_double,
+                                             C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_swing_leg_torque_batch.argtypes = [C.c_void_p, C.POINTER(SwingParams), C.POINTER(SwingBatch), C.c_int64,
                                                    C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_pose_sqp_batch.argtypes = [C.c_void_p, C.POINTER(PoseParams), C.POINTER(PoseBatch), C.c_int64,
@@ -308,6 +313,42 @@ def pose_sqp(ctx, problems, params=None, memory=MEM_HOST, out=None, stream=None)
     if rc != OK:
         raise QlamdError(rc, "qlamd_pose_sqp_batch")
     return pose, it, st
+
+
+def _pose_batch(problems, memory):
+    pb, keep = PoseBatch(), []
+    for key, field in POSE_FIELD_OF_KEY:
+        a = problems.get(key)
+        if a is not None and memory == MEM_HOST:
+            a = np.ascontiguousarray(a)
+            keep.append(a)
+        setattr(pb, field, _ptr(a))
+    return pb, keep
+
+
+def pose_qp(ctx, problems, params=None):
+    """qlamd_pose_qp_batch, host buffers -> (pose [B,7], status [B])."""
+    prm = params if params is not None else default_pose_params()
+    B = int(problems["pose"].shape[0])
+    pb, keep = _pose_batch(problems, MEM_HOST)
+    pose = np.zeros((B, 7)); st = np.full(B, -1, dtype=np.int32)
+    rc = lib().qlamd_pose_qp_batch(ctx._h, C.byref(prm), C.byref(pb), B, _ptr(pose), _ptr(st), MEM_HOST, None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_pose_qp_batch")
+    return pose, st
+
+
+def pose_check(ctx, problems, min_len=None, leg_tol=0.0, params=None):
+    """qlamd_pose_check_batch for the poses in problems['pose'], host buffers -> ok [B] uint8."""
+    prm = params if params is not None else default_pose_params()
+    B = int(problems["pose"].shape[0])
+    pb, keep = _pose_batch(problems, MEM_HOST)
+    mn = None if min_len is None else np.ascontiguousarray(min_len, dtype=np.float64)
+    ok = np.zeros(B, dtype=np.uint8)
+    rc = lib().qlamd_pose_check_batch(ctx._h, C.byref(prm), C.byref(pb), _ptr(mn), float(leg_tol), B, _ptr(ok), MEM_HOST, None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_pose_check_batch")
+    return ok
 
 
 def qp_solve(ctx, G, g0, CE, ce0, CI, ci0):

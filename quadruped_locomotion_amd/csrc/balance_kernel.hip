@@ -256,14 +256,8 @@ struct PosePtrs {
 };
 constexpr int kPosePerWave = 16;
 
-__global__ __launch_bounds__(64) void pose_sqp_kernel(const PoseParamsDev P, const PosePtrs s, int64_t B,
-                                                      double *__restrict__ pose_out, int32_t *__restrict__ iters,
-                                                      int32_t *__restrict__ status) {
-  extern __shared__ double lds[];
-  const int lane = threadIdx.x;
-  const int64_t i = (int64_t)blockIdx.x * kPosePerWave + lane;
-  if (lane >= kPosePerWave || i >= B) return;
-  PoseProblem pb;
+__device__ __forceinline__ void load_pose_problem(const PoseParamsDev &P, const PosePtrs &s, int64_t i, PoseProblem &pb,
+                                                  double pose[7]) {
   unsigned limb_mask = 0;
 #pragma unroll
   for (int l = 0; l < 4; l++)
@@ -279,9 +273,20 @@ __global__ __launch_bounds__(64) void pose_sqp_kernel(const PoseParamsDev P, con
 #pragma unroll
   for (int a = 0; a < 3; a++) pb.r_com[a] = s.rcom ? s.rcom[3 * i + a] : 0.0;
   pb.n_vertices = s.nverts ? s.nverts[i] : 4;
-  double pose[7];
 #pragma unroll
   for (int a = 0; a < 7; a++) pose[a] = s.pose[7 * i + a];
+}
+
+__global__ __launch_bounds__(64) void pose_sqp_kernel(const PoseParamsDev P, const PosePtrs s, int64_t B,
+                                                      double *__restrict__ pose_out, int32_t *__restrict__ iters,
+                                                      int32_t *__restrict__ status) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * kPosePerWave + lane;
+  if (lane >= kPosePerWave || i >= B) return;
+  PoseProblem pb;
+  double pose[7];
+  load_pose_problem(P, s, i, pb, pose);
   LdsScratch scr{lds + lane, kPosePerWave};
   int it = 0;
   const int st = pose_sqp6(P, pb, scr, pose, &it); // register-resident inner QP (gi6_core.hpp)
@@ -289,6 +294,36 @@ __global__ __launch_bounds__(64) void pose_sqp_kernel(const PoseParamsDev P, con
   for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
   if (iters) iters[i] = it;
   status[i] = st;
+}
+
+// PoseOptimizationQP (position only) and PoseConstraintsChecker, same problem layout
+__global__ __launch_bounds__(64) void pose_qp_kernel(const PoseParamsDev P, const PosePtrs s, int64_t B,
+                                                     double *__restrict__ pose_out, int32_t *__restrict__ status) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * kPosePerWave + lane;
+  if (lane >= kPosePerWave || i >= B) return;
+  PoseProblem pb;
+  double pose[7];
+  load_pose_problem(P, s, i, pb, pose);
+  LdsScratch scr{lds + lane, kPosePerWave};
+  const int st = pose_qp(P, pb, scr, pose);
+#pragma unroll
+  for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
+  status[i] = st;
+}
+
+__global__ __launch_bounds__(64) void pose_check_kernel(const PoseParamsDev P, const PosePtrs s,
+                                                        const double *__restrict__ min_len, double leg_tol, int64_t B,
+                                                        uint8_t *__restrict__ ok) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= B) return;
+  PoseProblem pb;
+  double pose[7], mn[4];
+  load_pose_problem(P, s, i, pb, pose);
+#pragma unroll
+  for (int k = 0; k < 4; k++) mn[k] = min_len ? min_len[4 * i + P.leg_order[k]] : 0.0;
+  ok[i] = pose_check(pb, pose, mn, leg_tol) ? 1 : 0;
 }
 
 // ---- dense QP batch: one problem per lane, 8 problems per wavefront, arrays in LDS ------------
@@ -456,10 +491,12 @@ void qlamd_pose_default_params(qlamd_pose_params *p) {
   p->leg_order[0] = 2; p->leg_order[1] = 3; p->leg_order[2] = 1; p->leg_order[3] = 0;
 }
 
-int qlamd_pose_sqp_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
-                         int64_t batch, double *pose_out, int32_t *iterations, int32_t *status, int memory,
-                         void *stream) {
-  if (!ctx || !in || batch < 0 || !pose_out || !status) return QLAMD_ERR_INVALID_ARGUMENT;
+// mode 0: SQP, 1: QP (position only), 2: constraints check (ok flags through `ok`)
+static int pose_impl(int mode, qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
+                     int64_t batch, double *pose_out, int32_t *iterations, int32_t *status, const double *min_len,
+                     double leg_tol, uint8_t *ok, int memory, void *stream) {
+  if (!ctx || !in || batch < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (mode == 2 ? !ok : (!pose_out || !status)) return QLAMD_ERR_INVALID_ARGUMENT;
   if (!params) return QLAMD_ERR_NOT_LOADED;
   if (!in->stance || !in->nominal_stance || !in->support_polygon || !in->max_limb_length || !in->pose)
     return QLAMD_ERR_INVALID_ARGUMENT;
@@ -481,42 +518,77 @@ int qlamd_pose_sqp_batch(qlamd_context *ctx, const qlamd_pose_params *params, co
              in->pose, in->stance_mask, in->n_vertices};
   double *d_out = pose_out;
   int32_t *d_it = iterations, *d_st = status;
+  const double *d_min = min_len;
+  uint8_t *d_ok = ok;
   if (memory == QLAMD_MEM_HOST) {
-    const size_t sz[8] = {B * 96, B * 96, B * 64, in->center_of_mass ? B * 24 : 0, B * 32, B * 56,
-                          in->stance_mask ? B * 4 : 0, in->n_vertices ? B * 4 : 0};
-    const void *src[8] = {in->stance, in->nominal_stance, in->support_polygon, in->center_of_mass,
-                          in->max_limb_length, in->pose, in->stance_mask, in->n_vertices};
-    size_t off[11], total = 0;
-    for (int k = 0; k < 8; k++) { off[k] = total; total += align256(sz[k]); }
-    off[8] = total; total += align256(B * 56);
-    off[9] = total; total += align256(B * 4);
+    const size_t sz[9] = {B * 96, B * 96, B * 64, in->center_of_mass ? B * 24 : 0, B * 32, B * 56,
+                          in->stance_mask ? B * 4 : 0, in->n_vertices ? B * 4 : 0, min_len ? B * 32 : 0};
+    const void *src[9] = {in->stance, in->nominal_stance, in->support_polygon, in->center_of_mass,
+                          in->max_limb_length, in->pose, in->stance_mask, in->n_vertices, min_len};
+    size_t off[13], total = 0;
+    for (int k = 0; k < 9; k++) { off[k] = total; total += align256(sz[k]); }
+    off[9] = total; total += align256(B * 56);
     off[10] = total; total += align256(B * 4);
+    off[11] = total; total += align256(B * 4);
+    off[12] = total; total += align256(B);
     int rc = ensure_ws(ctx, total);
     if (rc != QLAMD_OK) return rc;
     char *w = (char *)ctx->ws;
-    for (int k = 0; k < 8; k++)
+    for (int k = 0; k < 9; k++)
       if (sz[k] && hipMemcpyAsync(w + off[k], src[k], sz[k], hipMemcpyHostToDevice, st) != hipSuccess)
         return QLAMD_ERR_HIP;
     s = PosePtrs{(const double *)(w + off[0]), (const double *)(w + off[1]), (const double *)(w + off[2]),
                  in->center_of_mass ? (const double *)(w + off[3]) : nullptr, (const double *)(w + off[4]),
                  (const double *)(w + off[5]), in->stance_mask ? (const uint8_t *)(w + off[6]) : nullptr,
                  in->n_vertices ? (const int32_t *)(w + off[7]) : nullptr};
-    d_out = (double *)(w + off[8]);
-    d_it = (int32_t *)(w + off[9]);
-    d_st = (int32_t *)(w + off[10]);
+    d_out = (double *)(w + off[9]);
+    d_it = (int32_t *)(w + off[10]);
+    d_st = (int32_t *)(w + off[11]);
+    d_min = min_len ? (const double *)(w + off[8]) : nullptr;
+    d_ok = (uint8_t *)(w + off[12]);
   }
-  const size_t lds = (size_t)kPosePerWave * Gi6Layout::kTotal * sizeof(double);
   const unsigned grid = (unsigned)((batch + kPosePerWave - 1) / kPosePerWave);
-  hipLaunchKernelGGL(pose_sqp_kernel, dim3(grid), dim3(64), lds, st, P, s, batch, d_out, d_it, d_st);
+  if (mode == 0) {
+    const size_t lds = (size_t)kPosePerWave * Gi6Layout::kTotal * sizeof(double);
+    hipLaunchKernelGGL(pose_sqp_kernel, dim3(grid), dim3(64), lds, st, P, s, batch, d_out, d_it, d_st);
+  } else if (mode == 1) {
+    const size_t lds = (size_t)kPosePerWave * PoseQpGi::kTotal * sizeof(double);
+    hipLaunchKernelGGL(pose_qp_kernel, dim3(grid), dim3(64), lds, st, P, s, batch, d_out, d_st);
+  } else {
+    hipLaunchKernelGGL(pose_check_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, P, s, d_min, leg_tol,
+                       batch, d_ok);
+  }
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   if (memory == QLAMD_MEM_HOST) {
-    if (hipMemcpyAsync(pose_out, d_out, B * 56, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
-    if (iterations && hipMemcpyAsync(iterations, d_it, B * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+    if (mode != 2) {
+      if (hipMemcpyAsync(pose_out, d_out, B * 56, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
+      if (iterations && mode == 0 && hipMemcpyAsync(iterations, d_it, B * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+        return QLAMD_ERR_HIP;
+      if (hipMemcpyAsync(status, d_st, B * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
+    } else if (hipMemcpyAsync(ok, d_ok, B, hipMemcpyDeviceToHost, st) != hipSuccess) {
       return QLAMD_ERR_HIP;
-    if (hipMemcpyAsync(status, d_st, B * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
+    }
     if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
   }
   return QLAMD_OK;
+}
+
+int qlamd_pose_sqp_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
+                         int64_t batch, double *pose_out, int32_t *iterations, int32_t *status, int memory,
+                         void *stream) {
+  return pose_impl(0, ctx, params, in, batch, pose_out, iterations, status, nullptr, 0.0, nullptr, memory, stream);
+}
+
+int qlamd_pose_qp_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in, int64_t batch,
+                        double *pose_out, int32_t *status, int memory, void *stream) {
+  return pose_impl(1, ctx, params, in, batch, pose_out, nullptr, status, nullptr, 0.0, nullptr, memory, stream);
+}
+
+int qlamd_pose_check_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
+                           const double *min_limb_length, double leg_length_tolerance, int64_t batch, uint8_t *ok,
+                           int memory, void *stream) {
+  return pose_impl(2, ctx, params, in, batch, nullptr, nullptr, nullptr, min_limb_length, leg_length_tolerance, ok,
+                   memory, stream);
 }
 
 int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *G, const double *g0,

@@ -243,6 +243,69 @@ QL_HD int pose_sqp(const PoseParamsDev &P, const PoseProblem &pb, Scr &s, double
 }
 
 
+// ---- PoseOptimizationQP::optimize (PoseOptimizationQP.cpp:42-140): position only ------------------
+typedef GiLayout<3, 1, 4> PoseQpGi;
+
+template <class Scr>
+QL_HD int pose_qp(const PoseParamsDev &P, const PoseProblem &pb, Scr &s, double pose[7]) {
+  typedef PoseQpGi Ly;
+  double R[9], q[3] = {0, 0, 0};
+  quat_to_matrix(pose + 3, R);
+  int nl = 0;
+  QL_UNROLL for (int k = 0; k < 4; k++) {
+    if (!((pb.present >> k) & 1u)) continue;
+    nl++;
+    double Rd[3];
+    rot(R, pb.nominal[k], Rd);
+    for (int i = 0; i < 3; i++) q[i] += -2.0 * (pb.stance[k][i] - Rd[i]);
+  }
+  for (int i = 0; i < 9; i++) s.at(Ly::G + i) = 0.0;
+  for (int i = 0; i < 3; i++) { s.at(Ly::G + 4 * i) = 2.0 * nl; s.at(Ly::G0 + i) = q[i]; s.at(Ly::CE + i) = 0.0; }
+  s.at(Ly::CE0) = 0.0;
+  double GA[4][2], gb[4], Rr[3];
+  const int m = polygon_halfspaces(pb.n_vertices, pb.polygon, GA, gb);
+  rot(R, pb.r_com, Rr);
+  for (int i = 0; i < m; i++) {
+    s.at(Ly::CI0 + i) = gb[i] - (GA[i][0] * Rr[0] + GA[i][1] * Rr[1]);
+    s.at(Ly::CI + 0 * m + i) = -GA[i][0];
+    s.at(Ly::CI + 1 * m + i) = -GA[i][1];
+    s.at(Ly::CI + 2 * m + i) = -0.0;
+  }
+  double f;
+  const int st = gi_solve<3, 1, 4>(s, 3, P.dummy_equality ? 1 : 0, m, &f, nullptr);
+  if (st == kStatusOk)
+    for (int i = 0; i < 3; i++) pose[i] = s.at(Ly::X + i);
+  return st;
+}
+
+// ---- PoseConstraintsChecker::check (PoseConstraintsChecker.cpp:29-64) --------------------------------
+QL_HD bool polygon_is_inside(int nv, const double poly[4][2], const double pt[2]) { // grid_map crossing number
+  int cross = 0;
+  for (int i = 0, j = nv - 1; i < nv; j = i++) {
+    const double xi = poly[i][0], yi = poly[i][1], xj = poly[j][0], yj = poly[j][1];
+    if (((yi > pt[1]) != (yj > pt[1])) && (pt[0] < (xj - xi) * (pt[1] - yi) / (yj - yi) + xi)) cross++;
+  }
+  return (cross & 1) != 0;
+}
+
+QL_HD bool pose_check(const PoseProblem &pb, const double pose[7], const double min_len[4], double leg_tol) {
+  double R[9], Pr[3];
+  quat_to_matrix(pose + 3, R);
+  rot(R, pb.r_com, Pr);
+  const double com[2] = {pose[0] + Pr[0], pose[1] + Pr[1]};
+  bool ok = polygon_is_inside(pb.n_vertices, pb.polygon, com);
+  QL_UNROLL for (int k = 0; k < 4; k++) {
+    if (!((pb.present >> k) & 1u)) continue;
+    const double df[3] = {pb.stance[k][0] - pose[0], pb.stance[k][1] - pose[1], pb.stance[k][2] - pose[2]};
+    double bf[3];
+    irot(R, df, bf);
+    const double e[3] = {bf[0] - pb.hips[k][0], bf[1] - pb.hips[k][1], bf[2] - pb.hips[k][2]};
+    const double len = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    if (len < min_len[k] - leg_tol || len > pb.max_len[k] + leg_tol) ok = false;
+  }
+  return ok;
+}
+
 // Register-resident variant (gi6_core.hpp): the one the kernel runs.
 template <class Scr>
 QL_HD int pose_sqp6(const PoseParamsDev &P, const PoseProblem &pb, Scr &s, double pose[7], int *iters_out) {

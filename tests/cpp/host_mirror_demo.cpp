@@ -11,6 +11,8 @@
 #include <cstdio>
 
 #include "balance_controller/RosBalanceController.hpp"
+#include "free_gait_core/PoseConstraintsChecker.hpp"
+#include "free_gait_core/PoseOptimizationQP.hpp"
 #include "free_gait_core/PoseOptimizationSQP.hpp"
 #include "qp_solver/quadraticproblemsolver.hpp"
 
@@ -69,6 +71,24 @@ int main() {
   if (!optimization.optimize(result)) return 7;
   std::printf("pose %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", result.position(0), result.position(1), result.position(2),
               result.rotation.q[0], result.rotation.q[1], result.rotation.q[2], result.rotation.q[3]);
+
+  // BaseAuto::optimizePose order (BaseAuto.cpp:394-400): QP, then the checker, then the SQP.
+  // quadrupedSymmetricUnconstrained of PoseOptimizationQpTest.cpp:20-52 with the same stances.
+  free_gait::PoseOptimizationQP qp(ctx);
+  qp.setNominalStance(nominal); qp.setStance(stance); qp.setSupportStance(stance);
+  qp.setSupportRegion({{0.3, 0.2}, {-0.3, 0.2}, {-0.3, -0.2}, {0.3, -0.2}});
+  qlamd::Pose qp_result;
+  if (!qp.optimize(qp_result)) return 10;
+  std::printf("pose_qp %.17g %.17g %.17g\n", qp_result.position(0), qp_result.position(1), qp_result.position(2));
+  free_gait::PoseConstraintsChecker checker(ctx);
+  checker.setNominalStance(nominal); checker.setStance(stance); checker.setSupportStance(stance);
+  checker.setSupportRegion({{0.3, 0.2}, {-0.3, 0.2}, {-0.3, -0.2}, {0.3, -0.2}});
+  checker.setLimbLengthConstraints({0.2, 0.2, 0.2, 0.2}, {0.565, 0.565, 0.565, 0.565});
+  checker.setTolerances(0.02, 0.0);                                    // BaseAuto.cpp:156
+  const bool ok_in = checker.check(qp_result);
+  qlamd::Pose far(qlamd::Position(0.5, 0.0, 0.3), qlamd::RotationQuaternion());  // CoM outside the footprint
+  const bool ok_out = checker.check(far);
+  std::printf("pose_check %d %d\n", ok_in ? 1 : 0, ok_out ? 1 : 0);
 
   // ---- 3. the QuadProg++ demo problem -----------------------------------------------------------
   qp_solver::QuadraticObjectiveFunction cost;

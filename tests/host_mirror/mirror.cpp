@@ -120,6 +120,36 @@ extern "C" void mirror_pose_sqp_batch(const PoseParamsDev *P, int64_t B, const d
   }
 }
 
+// PoseOptimizationQP / PoseConstraintsChecker (row f3): mode 1 = QP (pose_out, status), 2 = check (ok)
+extern "C" void mirror_pose_aux_batch(int mode, const PoseParamsDev *P, int64_t B, const double *stance,
+                                      const uint8_t *mask, const double *nominal, const double *polygon,
+                                      const int32_t *nverts, const double *rcom, const double *maxlen,
+                                      const double *pose_in, const double *min_len, double leg_tol, double *pose_out,
+                                      int32_t *status, uint8_t *ok) {
+  for (int64_t i = 0; i < B; i++) {
+    PoseProblem pb;
+    unsigned limb_mask = 0;
+    for (int l = 0; l < 4; l++) if (!mask || mask[4 * i + l]) limb_mask |= 1u << l;
+    pose_problem_load_legs(
+        *P, pb, [&](int l, int a) { return stance[12 * i + 3 * l + a]; },
+        [&](int l, int a) { return nominal[12 * i + 3 * l + a]; }, [&](int l) { return maxlen[4 * i + l]; }, limb_mask);
+    for (int l = 0; l < 4; l++) { pb.polygon[l][0] = polygon[8 * i + 2 * l]; pb.polygon[l][1] = polygon[8 * i + 2 * l + 1]; }
+    for (int a = 0; a < 3; a++) pb.r_com[a] = rcom ? rcom[3 * i + a] : 0.0;
+    pb.n_vertices = nverts ? nverts[i] : 4;
+    double pose[7];
+    for (int a = 0; a < 7; a++) pose[a] = pose_in[7 * i + a];
+    if (mode == 1) {
+      HostScr<PoseQpGi::kTotal> s;
+      status[i] = pose_qp(*P, pb, s, pose);
+      for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
+    } else {
+      double mn[4];
+      for (int k = 0; k < 4; k++) mn[k] = min_len ? min_len[4 * i + P->leg_order[k]] : 0.0;
+      ok[i] = pose_check(pb, pose, mn, leg_tol) ? 1 : 0;
+    }
+  }
+}
+
 // ---- swing-leg torque (row a18) ----
 #include "swing_core.hpp"
 extern "C" void mirror_swing_leg(int leg, const SwingParamsDev *SP, const double *q_id, const double *q, const double *qd,
