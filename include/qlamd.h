@@ -263,6 +263,24 @@ int qlamd_pose_check_batch(qlamd_context *ctx, const qlamd_pose_params *params, 
                            const double *min_limb_length, double leg_length_tolerance, int64_t batch, uint8_t *ok,
                            int memory, void *stream);
 
+/* PoseOptimizationGeometric::optimize (free_gait_core/src/pose_optimization/PoseOptimizationGeometric.cpp:34-105):
+ * position = centroid of the support region + mean height offset; orientation = the closed-form least-squares
+ * rotation between nominal and actual stance (4x4 eigen-problem), re-headed along the fore/hind mid-point line
+ * with 70 % of its roll/pitch.  stance_for_orientation [B][12] by limb id (setStanceForOrientation) or NULL
+ * (= in->stance; all four limbs are read).  in->pose is not read. */
+int qlamd_pose_geometric_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
+                               const double *stance_for_orientation, int64_t batch, double *pose_out, int memory,
+                               void *stream);
+
+/* BaseAuto::optimizePose (free_gait_core/src/base_motion/BaseAuto.cpp:394-400) in one launch: geometric -> QP ->
+ * constraints check -> SQP for the problems the check rejects.  stage [B] (nullable): 2 = QP result accepted,
+ * 3 = SQP ran; iterations [B] (nullable): SQP iterations (0 when it did not run); status [B] as the failing
+ * solver reported it (the reference returns false).  in->pose is not read. */
+int qlamd_base_auto_optimize_pose_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
+                                        const double *stance_for_orientation, const double *min_limb_length,
+                                        double leg_length_tolerance, int64_t batch, double *pose_out, int32_t *stage,
+                                        int32_t *iterations, int32_t *status, int memory, void *stream);
+
 const char *qlamd_strerror(int code);
 int qlamd_version(void);
 

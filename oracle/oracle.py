@@ -336,6 +336,33 @@ def pose_qp(pb, i, hips, leg_order, dummy_equality=1):
     return dict(pose=np.array(out[:]), status=st)
 
 
+def pose_geometric(pb, i, hips, leg_order, stance_for_orientation=None):
+    """PoseOptimizationGeometric::optimize; stance_for_orientation [4][3] by limb id (default: the stance)."""
+    p = pose_problem(pb, i, hips, leg_order)
+    sfo = np.ascontiguousarray(pb["stance"][i] if stance_for_orientation is None else stance_for_orientation, dtype=np.float64)
+    out, qp = (C.c_double * 7)(), (C.c_double * 4)()
+    st = lib().oracle_pose_geometric(C.byref(p), sfo.ctypes.data_as(_dp), out, qp)
+    return dict(pose=np.array(out[:]), q_procrustes=np.array(qp[:]), status=st)
+
+
+def base_auto_optimize_pose(pb, i, hips, leg_order, stance_for_orientation=None, min_len=(0.1, 0.1, 0.1, 0.1), leg_tol=0.0,
+                            tol=0.05, max_iter=30, dummy_equality=1):
+    """BaseAuto::optimizePose: geometric -> QP -> check -> SQP.  Returns dict(pose, stage, status)."""
+    p = pose_problem(pb, i, hips, leg_order)
+    sfo = np.ascontiguousarray(pb["stance"][i] if stance_for_orientation is None else stance_for_orientation, dtype=np.float64)
+    out, stage = (C.c_double * 7)(), C.c_int()
+    st = lib().oracle_base_auto_optimize_pose(C.byref(p), sfo.ctypes.data_as(_dp), (C.c_double * 4)(*min_len), C.c_double(leg_tol),
+                                              C.c_double(tol), int(max_iter), int(dummy_equality), out, C.byref(stage))
+    return dict(pose=np.array(out[:]), stage=stage.value, status=st)
+
+
+def sym4_eigen(Cm):
+    Cm = np.ascontiguousarray(Cm, dtype=np.float64)
+    w, V = np.zeros(4), np.zeros((4, 4))
+    lib().oracle_sym4_eigen(Cm.ctypes.data_as(_dp), w.ctypes.data_as(_dp), V.ctypes.data_as(_dp))
+    return w, V
+
+
 def pose_check(pb, i, pose, hips, leg_order, min_len=(0.2, 0.2, 0.2, 0.2), leg_tol=0.0):
     p = pose_problem(pb, i, hips, leg_order)
     return int(lib().oracle_pose_check(C.byref(p), (C.c_double * 7)(*pose), (C.c_double * 4)(*min_len), C.c_double(leg_tol)))

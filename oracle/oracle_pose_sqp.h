@@ -45,6 +45,14 @@ int oracle_pose_qp(const oracle_pose_problem *pb, const double pose_in[7], int d
 int oracle_pose_check(const oracle_pose_problem *pb, const double pose[7], const double min_len[4], double leg_tol);
 int oracle_polygon_is_inside(int nv, const double *v, const double pt[2]);
 
+/* PoseOptimizationGeometric::optimize and BaseAuto::optimizePose (oracle_pose_geometric.c) */
+void oracle_sym4_eigen(const double C[16], double w[4], double V[16]);
+int oracle_pose_geometric(const oracle_pose_problem *pb, const double stance_for_orientation[4][3], double pose_out[7],
+                          double q_procrustes[4]);
+int oracle_base_auto_optimize_pose(const oracle_pose_problem *pb, const double stance_for_orientation[4][3],
+                                   const double min_len[4], double leg_tol, double sqp_tol, int sqp_max_iter,
+                                   int dummy_equality, double pose_out[7], int *stage_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,7 +22,8 @@ EXPORTS = (
     "qlamd_virtual_wrench_batch", "qlamd_leg_kinematics_batch", "qlamd_strerror", "qlamd_version",
     "qlamd_qp_solve_batch", "qlamd_pose_default_params", "qlamd_pose_sqp_batch",
     "qlamd_force_distribution_batch", "qlamd_swing_default_params", "qlamd_swing_leg_torque_batch",
-    "qlamd_pose_qp_batch", "qlamd_pose_check_batch",
+    "qlamd_pose_qp_batch", "qlamd_pose_check_batch", "qlamd_pose_geometric_batch",
+    "qlamd_base_auto_optimize_pose_batch",
 )
 
 
@@ -128,6 +129,11 @@ def lib():
                                           C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_pose_check_batch.argtypes = [C.c_void_p, C.POINTER(PoseParams), C.POINTER(PoseBatch), C.c_void_p, C.c_double,
                                              C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+        L.qlamd_pose_geometric_batch.argtypes = [C.c_void_p, C.POINTER(PoseParams), C.POINTER(PoseBatch), C.c_void_p, C.c_int64,
+                                                 C.c_void_p, C.c_int, C.c_void_p]
+        L.qlamd_base_auto_optimize_pose_batch.argtypes = [C.c_void_p, C.POINTER(PoseParams), C.POINTER(PoseBatch), C.c_void_p,
+                                                          C.c_void_p, C.c_double, C.c_int64, C.c_void_p, C.c_void_p,
+                                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_swing_leg_torque_batch.argtypes = [C.c_void_p, C.POINTER(SwingParams), C.POINTER(SwingBatch), C.c_int64,
                                                    C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_pose_sqp_batch.argtypes = [C.c_void_p, C.POINTER(PoseParams), C.POINTER(PoseBatch), C.c_int64,
@@ -349,6 +355,41 @@ def pose_check(ctx, problems, min_len=None, leg_tol=0.0, params=None):
     if rc != OK:
         raise QlamdError(rc, "qlamd_pose_check_batch")
     return ok
+
+
+def pose_geometric(ctx, problems, stance_for_orientation=None, params=None):
+    """qlamd_pose_geometric_batch, host buffers -> pose [B,7]."""
+    prm = params if params is not None else default_pose_params()
+    B = int(problems["stance"].shape[0])
+    pb, keep = _pose_batch(problems, MEM_HOST)
+    sfo = None if stance_for_orientation is None else np.ascontiguousarray(stance_for_orientation, dtype=np.float64)
+    pose = np.zeros((B, 7))
+    rc = lib().qlamd_pose_geometric_batch(ctx._h, C.byref(prm), C.byref(pb), _ptr(sfo), B, _ptr(pose), MEM_HOST, None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_pose_geometric_batch")
+    return pose
+
+
+def base_auto_optimize_pose(ctx, problems, stance_for_orientation=None, min_len=None, leg_tol=0.0, params=None,
+                            memory=MEM_HOST, out=None, stream=None):
+    """qlamd_base_auto_optimize_pose_batch -> (pose [B,7], stage [B], iterations [B], status [B]).  Host buffers by
+    default; for device memory pass torch CUDA tensors in `problems` and preallocated outputs in `out`."""
+    prm = params if params is not None else default_pose_params()
+    B = int(problems["stance"].shape[0])
+    pb, keep = _pose_batch(problems, memory)
+    if memory == MEM_HOST:
+        sfo = None if stance_for_orientation is None else np.ascontiguousarray(stance_for_orientation, dtype=np.float64)
+        mn = None if min_len is None else np.ascontiguousarray(min_len, dtype=np.float64)
+        pose = np.zeros((B, 7)); stage = np.zeros(B, np.int32); it = np.zeros(B, np.int32); st = np.full(B, -1, np.int32)
+    else:
+        sfo, mn = stance_for_orientation, min_len
+        pose, stage, it, st = out
+    rc = lib().qlamd_base_auto_optimize_pose_batch(ctx._h, C.byref(prm), C.byref(pb), _ptr(sfo), _ptr(mn), float(leg_tol), B,
+                                                   _ptr(pose), _ptr(stage), _ptr(it), _ptr(st), memory,
+                                                   C.c_void_p(stream) if stream else None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_base_auto_optimize_pose_batch")
+    return pose, stage, it, st
 
 
 def qp_solve(ctx, G, g0, CE, ce0, CI, ci0):

@@ -274,7 +274,7 @@ __device__ __forceinline__ void load_pose_problem(const PoseParamsDev &P, const 
   for (int a = 0; a < 3; a++) pb.r_com[a] = s.rcom ? s.rcom[3 * i + a] : 0.0;
   pb.n_vertices = s.nverts ? s.nverts[i] : 4;
 #pragma unroll
-  for (int a = 0; a < 7; a++) pose[a] = s.pose[7 * i + a];
+  for (int a = 0; a < 7; a++) pose[a] = s.pose ? s.pose[7 * i + a] : (a == 3 ? 1.0 : 0.0);
 }
 
 __global__ __launch_bounds__(64) void pose_sqp_kernel(const PoseParamsDev P, const PosePtrs s, int64_t B,
@@ -324,6 +324,54 @@ __global__ __launch_bounds__(64) void pose_check_kernel(const PoseParamsDev P, c
 #pragma unroll
   for (int k = 0; k < 4; k++) mn[k] = min_len ? min_len[4 * i + P.leg_order[k]] : 0.0;
   ok[i] = pose_check(pb, pose, mn, leg_tol) ? 1 : 0;
+}
+
+__device__ __forceinline__ void load_sfo(const PosePtrs &s, const double *__restrict__ sfo_in, int64_t i, double sfo[4][3]) {
+  const double *src = sfo_in ? sfo_in : s.stance; // default: the stance itself (all four limbs needed, :76-77)
+#pragma unroll
+  for (int l = 0; l < 4; l++)
+#pragma unroll
+    for (int a = 0; a < 3; a++) sfo[l][a] = src[12 * i + 3 * l + a];
+}
+
+__global__ __launch_bounds__(64) void pose_geometric_kernel(const PoseParamsDev P, const PosePtrs s,
+                                                            const double *__restrict__ sfo_in, int64_t B,
+                                                            double *__restrict__ pose_out) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= B) return;
+  PoseProblem pb;
+  double pose[7], sfo[4][3];
+  load_pose_problem(P, s, i, pb, pose);
+  load_sfo(s, sfo_in, i, sfo);
+  pose_geometric(pb, sfo, pose);
+#pragma unroll
+  for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
+}
+
+// BaseAuto::optimizePose: geometric -> QP -> check -> SQP for the problems the check rejects
+__global__ __launch_bounds__(64) void base_auto_pose_kernel(const PoseParamsDev P, const PosePtrs s,
+                                                            const double *__restrict__ sfo_in,
+                                                            const double *__restrict__ min_len, double leg_tol, int64_t B,
+                                                            double *__restrict__ pose_out, int32_t *__restrict__ stage,
+                                                            int32_t *__restrict__ iters, int32_t *__restrict__ status) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * kPosePerWave + lane;
+  if (lane >= kPosePerWave || i >= B) return;
+  PoseProblem pb;
+  double pose[7], sfo[4][3], mn[4];
+  load_pose_problem(P, s, i, pb, pose);
+  load_sfo(s, sfo_in, i, sfo);
+#pragma unroll
+  for (int k = 0; k < 4; k++) mn[k] = min_len ? min_len[4 * i + P.leg_order[k]] : 0.0;
+  LdsScratch scr{lds + lane, kPosePerWave};
+  int stg = 0, it = 0;
+  const int st = base_auto_optimize_pose(P, pb, sfo, mn, leg_tol, scr, pose, &stg, &it);
+#pragma unroll
+  for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
+  if (stage) stage[i] = stg;
+  if (iters) iters[i] = it;
+  status[i] = st;
 }
 
 // ---- dense QP batch: one problem per lane, 8 problems per wavefront, arrays in LDS ------------
@@ -491,15 +539,31 @@ void qlamd_pose_default_params(qlamd_pose_params *p) {
   p->leg_order[0] = 2; p->leg_order[1] = 3; p->leg_order[2] = 1; p->leg_order[3] = 0;
 }
 
-// mode 0: SQP, 1: QP (position only), 2: constraints check (ok flags through `ok`)
-static int pose_impl(int mode, qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
-                     int64_t batch, double *pose_out, int32_t *iterations, int32_t *status, const double *min_len,
-                     double leg_tol, uint8_t *ok, int memory, void *stream) {
+// One driver for the pose entries; what differs per entry is the kernel and which optional arrays exist.
+enum PoseMode { kPoseSqp = 0, kPoseQp = 1, kPoseCheck = 2, kPoseGeometric = 3, kPoseBaseAuto = 4 };
+struct PoseCall {
+  PoseMode mode;
+  double *pose_out = nullptr;        // [B][7]   (all but check)
+  int32_t *iterations = nullptr;     // [B]      (sqp, base_auto; optional)
+  int32_t *status = nullptr;         // [B]      (sqp, qp, base_auto)
+  int32_t *stage = nullptr;          // [B]      (base_auto; optional)
+  uint8_t *ok = nullptr;             // [B]      (check)
+  const double *min_len = nullptr;   // [B][4]   (check, base_auto; optional)
+  const double *sfo = nullptr;       // [B][12]  (geometric, base_auto; optional -> stance)
+  double leg_tol = 0.0;
+};
+
+static int pose_impl(const PoseCall &call, qlamd_context *ctx, const qlamd_pose_params *params,
+                     const qlamd_pose_batch *in, int64_t batch, int memory, void *stream) {
+  const PoseMode mode = call.mode;
   if (!ctx || !in || batch < 0) return QLAMD_ERR_INVALID_ARGUMENT;
-  if (mode == 2 ? !ok : (!pose_out || !status)) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (mode == kPoseCheck ? !call.ok : !call.pose_out) return QLAMD_ERR_INVALID_ARGUMENT;
+  const bool has_status = mode == kPoseSqp || mode == kPoseQp || mode == kPoseBaseAuto;
+  if (has_status && !call.status) return QLAMD_ERR_INVALID_ARGUMENT;
   if (!params) return QLAMD_ERR_NOT_LOADED;
-  if (!in->stance || !in->nominal_stance || !in->support_polygon || !in->max_limb_length || !in->pose)
-    return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!in->stance || !in->nominal_stance || !in->support_polygon || !in->max_limb_length) return QLAMD_ERR_INVALID_ARGUMENT;
+  const bool needs_pose = mode != kPoseGeometric && mode != kPoseBaseAuto; // those two start from scratch
+  if (needs_pose && !in->pose) return QLAMD_ERR_INVALID_ARGUMENT;
   if (params->max_iterations < 0) return QLAMD_ERR_INVALID_ARGUMENT;
   for (int k = 0; k < 4; k++)
     if (params->leg_order[k] < 0 || params->leg_order[k] > 3) return QLAMD_ERR_INVALID_ARGUMENT;
@@ -516,59 +580,75 @@ static int pose_impl(int mode, qlamd_context *ctx, const qlamd_pose_params *para
 
   PosePtrs s{in->stance, in->nominal_stance, in->support_polygon, in->center_of_mass, in->max_limb_length,
              in->pose, in->stance_mask, in->n_vertices};
-  double *d_out = pose_out;
-  int32_t *d_it = iterations, *d_st = status;
-  const double *d_min = min_len;
-  uint8_t *d_ok = ok;
+  double *d_out = call.pose_out;
+  int32_t *d_it = call.iterations, *d_st = call.status, *d_stage = call.stage;
+  const double *d_min = call.min_len, *d_sfo = call.sfo;
+  uint8_t *d_ok = call.ok;
   if (memory == QLAMD_MEM_HOST) {
-    const size_t sz[9] = {B * 96, B * 96, B * 64, in->center_of_mass ? B * 24 : 0, B * 32, B * 56,
-                          in->stance_mask ? B * 4 : 0, in->n_vertices ? B * 4 : 0, min_len ? B * 32 : 0};
-    const void *src[9] = {in->stance, in->nominal_stance, in->support_polygon, in->center_of_mass,
-                          in->max_limb_length, in->pose, in->stance_mask, in->n_vertices, min_len};
-    size_t off[13], total = 0;
-    for (int k = 0; k < 9; k++) { off[k] = total; total += align256(sz[k]); }
-    off[9] = total; total += align256(B * 56);
-    off[10] = total; total += align256(B * 4);
-    off[11] = total; total += align256(B * 4);
-    off[12] = total; total += align256(B);
+    enum { kIn = 10 };
+    const size_t sz[kIn] = {B * 96, B * 96, B * 64, in->center_of_mass ? B * 24 : 0, B * 32, in->pose ? B * 56 : 0,
+                            in->stance_mask ? B * 4 : 0, in->n_vertices ? B * 4 : 0, call.min_len ? B * 32 : 0,
+                            call.sfo ? B * 96 : 0};
+    const void *src[kIn] = {in->stance, in->nominal_stance, in->support_polygon, in->center_of_mass,
+                            in->max_limb_length, in->pose, in->stance_mask, in->n_vertices, call.min_len, call.sfo};
+    size_t off[kIn + 5], total = 0;
+    for (int k = 0; k < kIn; k++) { off[k] = total; total += align256(sz[k]); }
+    const size_t osz[5] = {B * 56, B * 4, B * 4, B * 4, B};
+    for (int k = 0; k < 5; k++) { off[kIn + k] = total; total += align256(osz[k]); }
     int rc = ensure_ws(ctx, total);
     if (rc != QLAMD_OK) return rc;
     char *w = (char *)ctx->ws;
-    for (int k = 0; k < 9; k++)
+    for (int k = 0; k < kIn; k++)
       if (sz[k] && hipMemcpyAsync(w + off[k], src[k], sz[k], hipMemcpyHostToDevice, st) != hipSuccess)
         return QLAMD_ERR_HIP;
     s = PosePtrs{(const double *)(w + off[0]), (const double *)(w + off[1]), (const double *)(w + off[2]),
                  in->center_of_mass ? (const double *)(w + off[3]) : nullptr, (const double *)(w + off[4]),
-                 (const double *)(w + off[5]), in->stance_mask ? (const uint8_t *)(w + off[6]) : nullptr,
+                 in->pose ? (const double *)(w + off[5]) : nullptr,
+                 in->stance_mask ? (const uint8_t *)(w + off[6]) : nullptr,
                  in->n_vertices ? (const int32_t *)(w + off[7]) : nullptr};
-    d_out = (double *)(w + off[9]);
-    d_it = (int32_t *)(w + off[10]);
-    d_st = (int32_t *)(w + off[11]);
-    d_min = min_len ? (const double *)(w + off[8]) : nullptr;
-    d_ok = (uint8_t *)(w + off[12]);
+    d_min = call.min_len ? (const double *)(w + off[8]) : nullptr;
+    d_sfo = call.sfo ? (const double *)(w + off[9]) : nullptr;
+    d_out = (double *)(w + off[kIn]);
+    d_it = (int32_t *)(w + off[kIn + 1]);
+    d_st = (int32_t *)(w + off[kIn + 2]);
+    d_stage = (int32_t *)(w + off[kIn + 3]);
+    d_ok = (uint8_t *)(w + off[kIn + 4]);
   }
   const unsigned grid = (unsigned)((batch + kPosePerWave - 1) / kPosePerWave);
-  if (mode == 0) {
-    const size_t lds = (size_t)kPosePerWave * Gi6Layout::kTotal * sizeof(double);
-    hipLaunchKernelGGL(pose_sqp_kernel, dim3(grid), dim3(64), lds, st, P, s, batch, d_out, d_it, d_st);
-  } else if (mode == 1) {
-    const size_t lds = (size_t)kPosePerWave * PoseQpGi::kTotal * sizeof(double);
-    hipLaunchKernelGGL(pose_qp_kernel, dim3(grid), dim3(64), lds, st, P, s, batch, d_out, d_st);
-  } else {
-    hipLaunchKernelGGL(pose_check_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, P, s, d_min, leg_tol,
-                       batch, d_ok);
+  const size_t lds6 = (size_t)kPosePerWave * Gi6Layout::kTotal * sizeof(double);
+  const size_t lds3 = (size_t)kPosePerWave * PoseQpGi::kTotal * sizeof(double);
+  switch (mode) {
+    case kPoseSqp:
+      hipLaunchKernelGGL(pose_sqp_kernel, dim3(grid), dim3(64), lds6, st, P, s, batch, d_out, d_it, d_st);
+      break;
+    case kPoseQp:
+      hipLaunchKernelGGL(pose_qp_kernel, dim3(grid), dim3(64), lds3, st, P, s, batch, d_out, d_st);
+      break;
+    case kPoseCheck:
+      hipLaunchKernelGGL(pose_check_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, P, s, d_min,
+                         call.leg_tol, batch, d_ok);
+      break;
+    case kPoseGeometric:
+      hipLaunchKernelGGL(pose_geometric_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, P, s, d_sfo, batch,
+                         d_out);
+      break;
+    case kPoseBaseAuto:
+      hipLaunchKernelGGL(base_auto_pose_kernel, dim3(grid), dim3(64), lds6 > lds3 ? lds6 : lds3, st, P, s, d_sfo, d_min,
+                         call.leg_tol, batch, d_out, d_stage, d_it, d_st);
+      break;
   }
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   if (memory == QLAMD_MEM_HOST) {
-    if (mode != 2) {
-      if (hipMemcpyAsync(pose_out, d_out, B * 56, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
-      if (iterations && mode == 0 && hipMemcpyAsync(iterations, d_it, B * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
-        return QLAMD_ERR_HIP;
-      if (hipMemcpyAsync(status, d_st, B * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
-    } else if (hipMemcpyAsync(ok, d_ok, B, hipMemcpyDeviceToHost, st) != hipSuccess) {
-      return QLAMD_ERR_HIP;
-    }
-    if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
+    const auto back = [&](void *dst, const void *srcp, size_t n) {
+      return !dst || hipMemcpyAsync(dst, srcp, n, hipMemcpyDeviceToHost, st) == hipSuccess;
+    };
+    bool fine = true;
+    if (mode != kPoseCheck) fine = fine && back(call.pose_out, d_out, B * 56);
+    if (mode == kPoseSqp || mode == kPoseBaseAuto) fine = fine && back(call.iterations, d_it, B * 4);
+    if (has_status) fine = fine && back(call.status, d_st, B * 4);
+    if (mode == kPoseBaseAuto) fine = fine && back(call.stage, d_stage, B * 4);
+    if (mode == kPoseCheck) fine = fine && back(call.ok, d_ok, B);
+    if (!fine || hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
   }
   return QLAMD_OK;
 }
@@ -576,19 +656,42 @@ static int pose_impl(int mode, qlamd_context *ctx, const qlamd_pose_params *para
 int qlamd_pose_sqp_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
                          int64_t batch, double *pose_out, int32_t *iterations, int32_t *status, int memory,
                          void *stream) {
-  return pose_impl(0, ctx, params, in, batch, pose_out, iterations, status, nullptr, 0.0, nullptr, memory, stream);
+  PoseCall c{kPoseSqp};
+  c.pose_out = pose_out; c.iterations = iterations; c.status = status;
+  return pose_impl(c, ctx, params, in, batch, memory, stream);
 }
 
 int qlamd_pose_qp_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in, int64_t batch,
                         double *pose_out, int32_t *status, int memory, void *stream) {
-  return pose_impl(1, ctx, params, in, batch, pose_out, nullptr, status, nullptr, 0.0, nullptr, memory, stream);
+  PoseCall c{kPoseQp};
+  c.pose_out = pose_out; c.status = status;
+  return pose_impl(c, ctx, params, in, batch, memory, stream);
 }
 
 int qlamd_pose_check_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
                            const double *min_limb_length, double leg_length_tolerance, int64_t batch, uint8_t *ok,
                            int memory, void *stream) {
-  return pose_impl(2, ctx, params, in, batch, nullptr, nullptr, nullptr, min_limb_length, leg_length_tolerance, ok,
-                   memory, stream);
+  PoseCall c{kPoseCheck};
+  c.ok = ok; c.min_len = min_limb_length; c.leg_tol = leg_length_tolerance;
+  return pose_impl(c, ctx, params, in, batch, memory, stream);
+}
+
+int qlamd_pose_geometric_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
+                               const double *stance_for_orientation, int64_t batch, double *pose_out, int memory,
+                               void *stream) {
+  PoseCall c{kPoseGeometric};
+  c.pose_out = pose_out; c.sfo = stance_for_orientation;
+  return pose_impl(c, ctx, params, in, batch, memory, stream);
+}
+
+int qlamd_base_auto_optimize_pose_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
+                                        const double *stance_for_orientation, const double *min_limb_length,
+                                        double leg_length_tolerance, int64_t batch, double *pose_out, int32_t *stage,
+                                        int32_t *iterations, int32_t *status, int memory, void *stream) {
+  PoseCall c{kPoseBaseAuto};
+  c.pose_out = pose_out; c.stage = stage; c.iterations = iterations; c.status = status;
+  c.sfo = stance_for_orientation; c.min_len = min_limb_length; c.leg_tol = leg_length_tolerance;
+  return pose_impl(c, ctx, params, in, batch, memory, stream);
 }
 
 int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *G, const double *g0,

@@ -306,6 +306,141 @@ QL_HD bool pose_check(const PoseProblem &pb, const double pose[7], const double 
   return ok;
 }
 
+// ---- PoseOptimizationGeometric::optimize (PoseOptimizationGeometric.cpp:34-105) -----------------------
+// Cyclic Jacobi on a symmetric 4x4 (the reference calls Eigen::EigenSolver, :69); fully unrolled so that
+// A and V stay in registers.
+QL_HD void sym4_eigen(const double C[16], double w[4], double V[16]) {
+  double A[16];
+  QL_UNROLL for (int i = 0; i < 4; i++)
+    QL_UNROLL for (int j = 0; j < 4; j++) {
+      A[4 * i + j] = 0.5 * (C[4 * i + j] + C[4 * j + i]);
+      V[4 * i + j] = i == j ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 12; sweep++) {
+    QL_UNROLL for (int p = 0; p < 3; p++)
+      QL_UNROLL for (int q = p + 1; q < 4; q++) {
+        const double apq = A[4 * p + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[4 * q + q] - A[4 * p + p]) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        QL_UNROLL for (int k = 0; k < 4; k++) {
+          const double akp = A[4 * k + p], akq = A[4 * k + q];
+          A[4 * k + p] = c * akp - sn * akq;
+          A[4 * k + q] = sn * akp + c * akq;
+          const double vkp = V[4 * k + p], vkq = V[4 * k + q];
+          V[4 * k + p] = c * vkp - sn * vkq;
+          V[4 * k + q] = sn * vkp + c * vkq;
+        }
+        QL_UNROLL for (int k = 0; k < 4; k++) {
+          const double apk = A[4 * p + k], aqk = A[4 * q + k];
+          A[4 * p + k] = c * apk - sn * aqk;
+          A[4 * q + k] = sn * apk + c * aqk;
+        }
+      }
+  }
+  QL_UNROLL for (int i = 0; i < 4; i++) w[i] = A[5 * i];
+}
+
+QL_HD void quat_mul(const double a[4], const double b[4], double o[4]) {
+  o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+
+QL_HD void quat_log(const double d[4], double out[3]) { // rotation vector of d (boxMinus identity)
+  const double s2 = 1.0 - d[0] * d[0];
+  double k = 2.0;
+  if (s2 >= 1e-12) k = 2.0 * acos(d[0]) / sqrt(s2);
+  out[0] = k * d[1]; out[1] = k * d[2]; out[2] = k * d[3];
+}
+
+// sfo: stance for orientation by limb id (LF, RF, RH, LH).  pb holds the legs in iteration order.
+QL_HD void pose_geometric(const PoseProblem &pb, const double sfo[4][3], double pose[7]) {
+  double cen[2];
+  polygon_centroid(pb.n_vertices, pb.polygon, cen);
+  double z = 0.0, Cm[16], Am[16];
+  QL_UNROLL for (int i = 0; i < 16; i++) { Cm[i] = 0.0; Am[i] = 0.0; }
+  int nl = 0;
+  QL_UNROLL for (int k = 0; k < 4; k++) {
+    if (!((pb.present >> k) & 1u)) continue;
+    nl++;
+    z += pb.stance[k][2] - pb.nominal[k][2];
+    const double *a = pb.stance[k], *b = pb.nominal[k];
+    // Ak = Q(0,a) - Qc(0,b): left minus right quaternion-product matrix (:63-65)
+    const double Ak[16] = {0.0,         -a[0] + b[0], -a[1] + b[1], -a[2] + b[2],
+                           a[0] - b[0], 0.0,          -a[2] - b[2], a[1] + b[1],
+                           a[1] - b[1], a[2] + b[2],  0.0,          -a[0] - b[0],
+                           a[2] - b[2], -a[1] - b[1], a[0] + b[0],  0.0};
+    QL_UNROLL for (int i = 0; i < 4; i++)
+      QL_UNROLL for (int j = 0; j < 4; j++) {
+        double acc = 0.0;
+        QL_UNROLL for (int m = 0; m < 4; m++) acc += Ak[4 * i + m] * Ak[4 * m + j];
+        Cm[4 * i + j] += acc;
+        Am[4 * i + j] += Ak[4 * i + j];
+      }
+  }
+  const double n = (double)nl;
+  z /= n;
+  QL_UNROLL for (int i = 0; i < 16; i++) Am[i] = Am[i] / n;
+  QL_UNROLL for (int i = 0; i < 4; i++)
+    QL_UNROLL for (int j = 0; j < 4; j++) {
+      double acc = 0.0;
+      QL_UNROLL for (int m = 0; m < 4; m++) acc += Am[4 * i + m] * Am[4 * m + j];
+      Cm[4 * i + j] -= n * acc;
+    }
+  double w[4], V[16];
+  sym4_eigen(Cm, w, V);
+  double wb = w[0], q[4] = {V[0], V[4], V[8], V[12]};
+  QL_UNROLL for (int i = 1; i < 4; i++)
+    if (w[i] > wb) { wb = w[i]; q[0] = V[i]; q[1] = V[4 + i]; q[2] = V[8 + i]; q[3] = V[12 + i]; }
+  const double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  QL_UNROLL for (int i = 0; i < 4; i++) q[i] /= nq;
+  { // setUnique: first non-zero component positive
+    bool neg = false, decided = false;
+    QL_UNROLL for (int i = 0; i < 4; i++)
+      if (!decided && q[i] != 0.0) { decided = true; neg = q[i] < 0.0; }
+    if (neg) {
+      QL_UNROLL for (int i = 0; i < 4; i++) q[i] = -q[i];
+    }
+  }
+  // heading (:76-81), Eigen setFromTwoVectors(UnitX, dir)
+  double dir[3];
+  QL_UNROLL for (int i = 0; i < 3; i++) dir[i] = 0.5 * (sfo[0][i] + sfo[1][i]) - 0.5 * (sfo[3][i] + sfo[2][i]);
+  dir[2] = 0.0;
+  double heading[4];
+  {
+    const double nb = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    const double v1[3] = {dir[0] / nb, dir[1] / nb, dir[2] / nb};
+    double c = v1[0]; // v0 = (1, 0, 0) after normalisation
+    if (c < -1.0 + 1e-12) {
+      c = c > -1.0 ? c : -1.0;
+      const double w2 = (1.0 + c) * 0.5;
+      heading[0] = sqrt(w2); heading[1] = 0.0; heading[2] = 0.0; heading[3] = sqrt(1.0 - w2);
+    } else {
+      const double sc = sqrt((1.0 + c) * 2.0), invs = 1.0 / sc;
+      heading[0] = sc * 0.5;
+      heading[1] = (0.0 * v1[2] - 0.0 * v1[1]) * invs;
+      heading[2] = (0.0 * v1[0] - 1.0 * v1[2]) * invs;
+      heading[3] = (1.0 * v1[1] - 0.0 * v1[0]) * invs;
+    }
+  }
+  // 70 % of roll/pitch (:84-87)
+  const double ident[4] = {1.0, 0.0, 0.0, 0.0};
+  double rv[3], yaw[4], rel[4], rp[4];
+  quat_log(q, rv);
+  const double rvz[3] = {0.0, 0.0, rv[2]};
+  quat_box_plus(ident, rvz, yaw);
+  const double yaw_inv[4] = {yaw[0], -yaw[1], -yaw[2], -yaw[3]};
+  quat_mul(yaw_inv, q, rel);
+  quat_log(rel, rv);
+  QL_UNROLL for (int i = 0; i < 3; i++) rv[i] *= 0.7;
+  quat_box_plus(ident, rv, rp);
+  pose[0] = cen[0]; pose[1] = cen[1]; pose[2] = z;
+  quat_mul(heading, rp, pose + 3);
+}
+
 // Register-resident variant (gi6_core.hpp): the one the kernel runs.
 template <class Scr>
 QL_HD int pose_sqp6(const PoseParamsDev &P, const PoseProblem &pb, Scr &s, double pose[7], int *iters_out) {
@@ -330,6 +465,23 @@ QL_HD int pose_sqp6(const PoseParamsDev &P, const PoseProblem &pb, Scr &s, doubl
   }
   if (iters_out) *iters_out = k;
   return status;
+}
+
+// ---- BaseAuto::optimizePose (BaseAuto.cpp:394-400): geometric -> QP -> check -> SQP -----------------
+// stage: 2 = the QP result passed the checker, 3 = the SQP ran.  The scratch must hold
+// max(PoseQpGi::kTotal, Gi6Layout::kTotal) doubles.
+template <class Scr>
+QL_HD int base_auto_optimize_pose(const PoseParamsDev &P, const PoseProblem &pb, const double sfo[4][3],
+                                  const double min_len[4], double leg_tol, Scr &s, double pose[7], int *stage,
+                                  int *iters_out) {
+  pose_geometric(pb, sfo, pose);
+  *stage = 2;
+  if (iters_out) *iters_out = 0;
+  int st = pose_qp(P, pb, s, pose);
+  if (st != kStatusOk) return st;
+  if (pose_check(pb, pose, min_len, leg_tol)) return kStatusOk;
+  *stage = 3;
+  return pose_sqp6(P, pb, s, pose, iters_out);
 }
 
 } // namespace qlamd

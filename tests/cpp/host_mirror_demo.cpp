@@ -12,6 +12,7 @@
 
 #include "balance_controller/RosBalanceController.hpp"
 #include "free_gait_core/PoseConstraintsChecker.hpp"
+#include "free_gait_core/PoseOptimizationGeometric.hpp"
 #include "free_gait_core/PoseOptimizationQP.hpp"
 #include "free_gait_core/PoseOptimizationSQP.hpp"
 #include "qp_solver/quadraticproblemsolver.hpp"
@@ -89,6 +90,15 @@ int main() {
   qlamd::Pose far(qlamd::Position(0.5, 0.0, 0.3), qlamd::RotationQuaternion());  // CoM outside the footprint
   const bool ok_out = checker.check(far);
   std::printf("pose_check %d %d\n", ok_in ? 1 : 0, ok_out ? 1 : 0);
+
+  free_gait::PoseOptimizationGeometric geometric(ctx);
+  geometric.setNominalStance(nominal); geometric.setStance(stance); geometric.setSupportStance(stance);
+  geometric.setSupportRegion({{0.3, 0.2}, {-0.3, 0.2}, {-0.3, -0.2}, {0.3, -0.2}});
+  geometric.setStanceForOrientation(stance);
+  qlamd::Pose geo;
+  if (!geometric.optimize(geo)) return 11;
+  std::printf("pose_geometric %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", geo.position(0), geo.position(1), geo.position(2),
+              geo.rotation.q[0], geo.rotation.q[1], geo.rotation.q[2], geo.rotation.q[3]);
 
   // ---- 3. the QuadProg++ demo problem -----------------------------------------------------------
   qp_solver::QuadraticObjectiveFunction cost;

@@ -120,12 +120,14 @@ extern "C" void mirror_pose_sqp_batch(const PoseParamsDev *P, int64_t B, const d
   }
 }
 
-// PoseOptimizationQP / PoseConstraintsChecker (row f3): mode 1 = QP (pose_out, status), 2 = check (ok)
+// PoseOptimizationQP / PoseConstraintsChecker / PoseOptimizationGeometric / BaseAuto::optimizePose (row f3):
+// mode 1 = QP (pose_out, status), 2 = check (ok), 3 = geometric (pose_out), 4 = the whole sequence
 extern "C" void mirror_pose_aux_batch(int mode, const PoseParamsDev *P, int64_t B, const double *stance,
                                       const uint8_t *mask, const double *nominal, const double *polygon,
                                       const int32_t *nverts, const double *rcom, const double *maxlen,
                                       const double *pose_in, const double *min_len, double leg_tol, double *pose_out,
-                                      int32_t *status, uint8_t *ok) {
+                                      int32_t *status, uint8_t *ok, const double *sfo_in, int32_t *stage,
+                                      int32_t *iters) {
   for (int64_t i = 0; i < B; i++) {
     PoseProblem pb;
     unsigned limb_mask = 0;
@@ -136,17 +138,26 @@ extern "C" void mirror_pose_aux_batch(int mode, const PoseParamsDev *P, int64_t 
     for (int l = 0; l < 4; l++) { pb.polygon[l][0] = polygon[8 * i + 2 * l]; pb.polygon[l][1] = polygon[8 * i + 2 * l + 1]; }
     for (int a = 0; a < 3; a++) pb.r_com[a] = rcom ? rcom[3 * i + a] : 0.0;
     pb.n_vertices = nverts ? nverts[i] : 4;
-    double pose[7];
-    for (int a = 0; a < 7; a++) pose[a] = pose_in[7 * i + a];
+    double pose[7], mn[4], sfo[4][3];
+    for (int a = 0; a < 7; a++) pose[a] = pose_in ? pose_in[7 * i + a] : (a == 3 ? 1.0 : 0.0);
+    for (int k = 0; k < 4; k++) mn[k] = min_len ? min_len[4 * i + P->leg_order[k]] : 0.0;
+    for (int l = 0; l < 4; l++)
+      for (int a = 0; a < 3; a++) sfo[l][a] = (sfo_in ? sfo_in : stance)[12 * i + 3 * l + a];
     if (mode == 1) {
       HostScr<PoseQpGi::kTotal> s;
       status[i] = pose_qp(*P, pb, s, pose);
-      for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
-    } else {
-      double mn[4];
-      for (int k = 0; k < 4; k++) mn[k] = min_len ? min_len[4 * i + P->leg_order[k]] : 0.0;
+    } else if (mode == 2) {
       ok[i] = pose_check(pb, pose, mn, leg_tol) ? 1 : 0;
+    } else if (mode == 3) {
+      pose_geometric(pb, sfo, pose);
+    } else {
+      HostScr<(PoseQpGi::kTotal > Gi6Layout::kTotal ? PoseQpGi::kTotal : Gi6Layout::kTotal)> s;
+      int stg = 0, it = 0;
+      status[i] = base_auto_optimize_pose(*P, pb, sfo, mn, leg_tol, s, pose, &stg, &it);
+      stage[i] = stg; iters[i] = it;
     }
+    if (mode != 2)
+      for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
   }
 }
 

@@ -72,6 +72,7 @@ def test_mirror_matches_oracle(oracle):
     # PoseOptimizationQpTest.cpp:20-52 and the checker on an inside / outside pose
     assert np.allclose(out["pose_qp"], [0, 0, 0.3], atol=1e-3)
     assert list(out["pose_check"]) == [1, 0]
+    assert np.allclose(out["pose_geometric"], [0, 0, 0.3, 1, 0, 0, 0], atol=1e-9)
     # 3. qp_solver/src/main.cc:46-101, true optimum and the dummy-equality answer the demo prints
     assert np.allclose(out["qp"], [2 / 3, 4 / 3, -8.222222222222221], atol=1e-9)
     assert np.allclose(out["qp_dummy_eq"], [5 / 3, -1 / 3, 0.7222222222222222], atol=1e-9)

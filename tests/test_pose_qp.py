@@ -73,7 +73,7 @@ def test_oracle_constrained_inside_region(oracle):
     assert np.abs(free[:2] - r["pose"][:2]).max() > 1e-3
 
 
-def mirror_aux(mirror, mode, pb, min_len=None, leg_tol=0.0):
+def mirror_aux(mirror, mode, pb, min_len=None, leg_tol=0.0, sfo=None, full=False):
     B = pb["pose"].shape[0]
     P = _PoseParamsDev()
     for l in range(4):
@@ -83,13 +83,18 @@ def mirror_aux(mirror, mode, pb, min_len=None, leg_tol=0.0):
     P.com_weight, P.tol, P.max_iter, P.dummy_equality = 2.0, 0.05, 30, 1
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
     out = np.zeros((B, 7)); st = np.zeros(B, np.int32); ok = np.zeros(B, np.uint8)
+    stage = np.zeros(B, np.int32); it = np.zeros(B, np.int32)
     mn = None if min_len is None else np.ascontiguousarray(min_len, dtype=np.float64)
+    sf = None if sfo is None else np.ascontiguousarray(sfo, dtype=np.float64)
     mirror.L.mirror_pose_aux_batch(
         C.c_int(mode), C.byref(P), C.c_int64(B), pb["stance"].ctypes.data_as(dp),
         pb["stance_mask"].ctypes.data_as(C.POINTER(C.c_uint8)), pb["nominal"].ctypes.data_as(dp), pb["polygon"].ctypes.data_as(dp),
         pb["n_vertices"].ctypes.data_as(ip), pb["r_com"].ctypes.data_as(dp), pb["max_len"].ctypes.data_as(dp),
         pb["pose"].ctypes.data_as(dp), mn.ctypes.data_as(dp) if mn is not None else None, C.c_double(leg_tol),
-        out.ctypes.data_as(dp), st.ctypes.data_as(ip), ok.ctypes.data_as(C.POINTER(C.c_uint8)))
+        out.ctypes.data_as(dp), st.ctypes.data_as(ip), ok.ctypes.data_as(C.POINTER(C.c_uint8)),
+        sf.ctypes.data_as(dp) if sf is not None else None, stage.ctypes.data_as(ip), it.ctypes.data_as(ip))
+    if full:
+        return out, st, stage, it
     return out, st, ok
 
 
