@@ -281,6 +281,79 @@ int qlamd_base_auto_optimize_pose_batch(qlamd_context *ctx, const qlamd_pose_par
                                         double leg_length_tolerance, int64_t batch, double *pose_out, int32_t *stage,
                                         int32_t *iterations, int32_t *status, int memory, void *stream);
 
+/* ---- leg state machine of the controller plugin -------------------------------
+ * One call = one control tick for every robot: the command side of baseCommandCallback
+ * (ros_balance_controller.cpp:966-1078), footContactsCallback (:1084-1135) and the switch at the top of update()
+ * (:234-380).  State ids as StateSwitcher::States (state_switcher/StateSwitcher.hpp:62-72).  All arrays [B][k] by
+ * limb id (LF, RF, RH, LH); the 1-byte-per-leg arrays must be 4-byte aligned per robot (they are, at [B][4]). */
+#define QLAMD_LEG_INIT 0
+#define QLAMD_LEG_STANCE_NORMAL 1
+#define QLAMD_LEG_STANCE_SLIPPING 2
+#define QLAMD_LEG_STANCE_LOST_CONTACT 3
+#define QLAMD_LEG_SWING_NORMAL 4
+#define QLAMD_LEG_SWING_LATE_LIFT_OFF 5
+#define QLAMD_LEG_SWING_EARLY_TOUCH_DOWN 6
+#define QLAMD_LEG_SWING_BUMPED_INTO_OBSTACLE 7
+#define QLAMD_LEG_SWING_LATELY_TOUCH_DOWN 8
+
+typedef struct qlamd_leg_state_batch {
+  /* in: desired_robot_state.{lf,rf,rh,lh}_leg_mode and the contact sensors */
+  const uint8_t *support_leg;    /* [B][4]  leg_mode.support_leg                                   */
+  const double *phase;           /* [B][4]  leg_mode.phase (stance phase if support_leg, else swing) */
+  const uint8_t *is_footstep;    /* [B][4]  leg_mode.name == "footstep" (:951-964)                 */
+  const uint8_t *contact;        /* [B][4]  foot_contacts[i].is_contact                            */
+  const double *joint_position;  /* [B][12] measured joint positions                               */
+  /* in/out: what the plugin keeps between ticks */
+  int8_t *limb_state;            /* [B][4]  limbs_state                                            */
+  uint8_t *store_flag;           /* [B][4]  store_current_joint_state_flag_                        */
+  double *stored_joint_position; /* [B][12] stored_limb_joint_position_                            */
+  double *joint_command;         /* [B][12] commands (held at the stored position after a lost contact) */
+  double *foot_target;           /* [B][12] foot_positions (nudged back/up when bumped, down when late)  */
+  uint8_t *support;              /* [B][4]  robot_state->isSupportLeg: feeds qlamd_state_batch.stance   */
+  /* out */
+  int8_t *leg_state_code;        /* [B][4]  the leg_state message (:222-224): 0, 2, 1, 3 or -1     */
+} qlamd_leg_state_batch;
+
+/* index_quirk != 0 reproduces footContactsCallback's `continue` that skips `i++` (:1100,1122): the next contact is
+ * then applied to the same limb, as in the reference.  0 gives every limb its own contact. */
+int qlamd_leg_state_machine_batch(qlamd_context *ctx, const qlamd_leg_state_batch *io, int index_quirk, int64_t batch,
+                                  int memory, void *stream);
+
+/* ---- free_gait_msgs/RobotState wire format -> structure-of-arrays -------------
+ * What RosBalanceController::baseCommandCallback reads from a /desired_robot_state message
+ * (ros_balance_controller.cpp:761-1083), for a batch of serialised messages (ROS 1 wire format, e.g. the record
+ * payloads of a bag): messages = the concatenated bytes, message b = [offsets[b], offsets[b+1]).
+ * The outputs line up with the des_* fields of qlamd_state_batch, with support_leg / phase / joint_command /
+ * foot_target (= foot_position) / is_footstep (= leg_mode == 4) of qlamd_leg_state_batch and with the foot targets
+ * of qlamd_swing_batch.  Any output pointer may be NULL. */
+#define QLAMD_LEG_MODE_OTHER 0
+#define QLAMD_LEG_MODE_JOINT 1
+#define QLAMD_LEG_MODE_LEG_MODE 2
+#define QLAMD_LEG_MODE_CARTESIAN 3
+#define QLAMD_LEG_MODE_FOOTSTEP 4
+#define QLAMD_WIRE_OK 0
+#define QLAMD_WIRE_TRUNCATED 1      /* the message ends before its own length fields say it should            */
+#define QLAMD_WIRE_MISSING_FIELD 2  /* joints.position has < 3 entries or a target_{position,velocity,acceleration}
+                                       array is empty: the reference indexes them unchecked (:802-861)          */
+
+typedef struct qlamd_robot_state_fields {
+  double *des_pos;           /* [B][3]  base_pose.pose.pose.position                                 */
+  double *des_quat;          /* [B][4]  base_pose.pose.pose.orientation as (w, x, y, z)              */
+  double *des_linvel;        /* [B][3]  base_pose.twist.twist.linear                                 */
+  double *des_angvel;        /* [B][3]  base_pose.twist.twist.angular                                */
+  double *joint_command;     /* [B][12] {lf,rf,rh,lh}_leg_joints.position[0..2]                      */
+  double *foot_position;     /* [B][12] *_target.target_position[0].point                            */
+  double *foot_velocity;     /* [B][12] *_target.target_velocity[0].vector                           */
+  double *foot_acceleration; /* [B][12] *_target.target_acceleration[0].vector                       */
+  double *surface_normal;    /* [B][12] *_leg_mode.surface_normal.vector                             */
+  double *phase;             /* [B][4]  *_leg_mode.phase                                             */
+  uint8_t *support_leg;      /* [B][4]  *_leg_mode.support_leg                                       */
+  uint8_t *leg_mode;         /* [B][4]  *_leg_mode.name as QLAMD_LEG_MODE_*                          */
+} qlamd_robot_state_fields;
+
+int qlamd_robot_state_unpack_batch(qlamd_context *ctx, const uint8_t *messages, const int64_t *offsets, int64_t batch,
+                                   const qlamd_robot_state_fields *out, int32_t *status, int memory, void *stream);
+
 const char *qlamd_strerror(int code);
 int qlamd_version(void);
 

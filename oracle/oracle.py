@@ -366,3 +366,32 @@ def sym4_eigen(Cm):
 def pose_check(pb, i, pose, hips, leg_order, min_len=(0.2, 0.2, 0.2, 0.2), leg_tol=0.0):
     p = pose_problem(pb, i, hips, leg_order)
     return int(lib().oracle_pose_check(C.byref(p), (C.c_double * 7)(*pose), (C.c_double * 4)(*min_len), C.c_double(leg_tol)))
+
+
+def leg_state_machine(io, i, index_quirk=1):
+    """oracle_leg_state_machine on robot i of the arrays in `io` (fields of qlamd_leg_state_batch); in/out arrays are
+    updated in place."""
+    u8, i8 = C.POINTER(C.c_uint8), C.POINTER(C.c_int8)
+    row = lambda name, ty: io[name][i:i + 1].ctypes.data_as(ty)  # noqa: E731
+    lib().oracle_leg_state_machine(row("support_leg", u8), row("phase", _dp), row("is_footstep", u8), row("contact", u8),
+                                   row("joint_position", _dp), int(index_quirk), row("limb_state", i8), row("store_flag", u8),
+                                   row("stored_joint_position", _dp), row("joint_command", _dp), row("foot_target", _dp),
+                                   row("support", u8), row("leg_state_code", i8))
+
+
+class RobotStateFields(C.Structure):
+    _fields_ = [("des_pos", C.c_double * 3), ("des_quat", C.c_double * 4), ("des_linvel", C.c_double * 3),
+                ("des_angvel", C.c_double * 3), ("joint_command", C.c_double * 12), ("foot_position", C.c_double * 12),
+                ("foot_velocity", C.c_double * 12), ("foot_acceleration", C.c_double * 12), ("surface_normal", C.c_double * 12),
+                ("phase", C.c_double * 4), ("support_leg", C.c_uint8 * 4), ("leg_mode", C.c_uint8 * 4)]
+
+    def as_dict(self):
+        return {n: np.array(getattr(self, n)[:]) for n, _ in self._fields_}
+
+
+def robot_state_unpack(msg):
+    """oracle_robot_state_unpack on one serialised free_gait_msgs/RobotState.  Returns (dict, status)."""
+    f = RobotStateFields()
+    buf = (C.c_uint8 * max(len(msg), 1)).from_buffer_copy(bytes(msg) if len(msg) else b"\0")
+    st = lib().oracle_robot_state_unpack(buf, C.c_size_t(len(msg)), C.byref(f))
+    return f.as_dict(), st

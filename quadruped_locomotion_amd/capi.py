@@ -23,7 +23,7 @@ EXPORTS = (
     "qlamd_qp_solve_batch", "qlamd_pose_default_params", "qlamd_pose_sqp_batch",
     "qlamd_force_distribution_batch", "qlamd_swing_default_params", "qlamd_swing_leg_torque_batch",
     "qlamd_pose_qp_batch", "qlamd_pose_check_batch", "qlamd_pose_geometric_batch",
-    "qlamd_base_auto_optimize_pose_batch",
+    "qlamd_base_auto_optimize_pose_batch", "qlamd_leg_state_machine_batch", "qlamd_robot_state_unpack_batch",
 )
 
 
@@ -45,6 +45,27 @@ class RobotModel(C.Structure):
         ("link_mass", (C.c_double * 4) * 4), ("link_com", ((C.c_double * 3) * 4) * 4),
         ("link_inertia", ((C.c_double * 6) * 4) * 4),
     ]
+
+
+class LegStateBatch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("support_leg", "phase", "is_footstep", "contact", "joint_position", "limb_state",
+                                          "store_flag", "stored_joint_position", "joint_command", "foot_target", "support",
+                                          "leg_state_code")]
+
+
+LEG_STATE_DTYPES = dict(support_leg=np.uint8, phase=np.float64, is_footstep=np.uint8, contact=np.uint8,
+                        joint_position=np.float64, limb_state=np.int8, store_flag=np.uint8,
+                        stored_joint_position=np.float64, joint_command=np.float64, foot_target=np.float64,
+                        support=np.uint8, leg_state_code=np.int8)
+
+
+ROBOT_STATE_FIELDS = (("des_pos", 3), ("des_quat", 4), ("des_linvel", 3), ("des_angvel", 3), ("joint_command", 12),
+                      ("foot_position", 12), ("foot_velocity", 12), ("foot_acceleration", 12), ("surface_normal", 12),
+                      ("phase", 4))
+
+
+class RobotStateFields(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n, _ in ROBOT_STATE_FIELDS] + [("support_leg", C.c_void_p), ("leg_mode", C.c_void_p)]
 
 
 class SwingParams(C.Structure):
@@ -134,6 +155,9 @@ def lib():
         L.qlamd_base_auto_optimize_pose_batch.argtypes = [C.c_void_p, C.POINTER(PoseParams), C.POINTER(PoseBatch), C.c_void_p,
                                                           C.c_void_p, C.c_double, C.c_int64, C.c_void_p, C.c_void_p,
                                                           C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.qlamd_leg_state_machine_batch.argtypes = [C.c_void_p, C.POINTER(LegStateBatch), C.c_int, C.c_int64, C.c_int, C.c_void_p]
+        L.qlamd_robot_state_unpack_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(RobotStateFields),
+                                                     C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_swing_leg_torque_batch.argtypes = [C.c_void_p, C.POINTER(SwingParams), C.POINTER(SwingBatch), C.c_int64,
                                                    C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_pose_sqp_batch.argtypes = [C.c_void_p, C.POINTER(PoseParams), C.POINTER(PoseBatch), C.c_int64,
@@ -390,6 +414,48 @@ def base_auto_optimize_pose(ctx, problems, stance_for_orientation=None, min_len=
     if rc != OK:
         raise QlamdError(rc, "qlamd_base_auto_optimize_pose_batch")
     return pose, stage, it, st
+
+
+def leg_state_machine(ctx, io, index_quirk=1, memory=MEM_HOST, stream=None):
+    """qlamd_leg_state_machine_batch.  `io`: dict with the fields of qlamd_leg_state_batch (numpy arrays of the
+    dtypes in LEG_STATE_DTYPES for host memory, torch CUDA tensors for device memory); the in/out and out arrays
+    are updated in place."""
+    b = LegStateBatch()
+    for name, dt in LEG_STATE_DTYPES.items():
+        a = io[name]
+        if memory == MEM_HOST:
+            assert a.dtype == dt and a.flags["C_CONTIGUOUS"], name
+        setattr(b, name, _ptr(a))
+    B = int(io["phase"].shape[0])
+    rc = lib().qlamd_leg_state_machine_batch(ctx._h, C.byref(b), int(index_quirk), B, memory,
+                                             C.c_void_p(stream) if stream else None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_leg_state_machine_batch")
+    return io
+
+
+def robot_state_unpack(ctx, messages, offsets, want=None):
+    """qlamd_robot_state_unpack_batch on host buffers.  messages: bytes / uint8 array, offsets: int64 [B+1].
+    Returns (dict of arrays, status [B]); `want` limits the outputs (default: all)."""
+    buf = np.frombuffer(messages, dtype=np.uint8) if isinstance(messages, (bytes, bytearray)) else np.ascontiguousarray(messages, np.uint8)
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    B = off.shape[0] - 1
+    f, out = RobotStateFields(), {}
+    for name, w in ROBOT_STATE_FIELDS:
+        if want is None or name in want:
+            out[name] = np.zeros((B, w))
+            setattr(f, name, _ptr(out[name]))
+    for name in ("support_leg", "leg_mode"):
+        if want is None or name in want:
+            out[name] = np.zeros((B, 4), np.uint8)
+            setattr(f, name, _ptr(out[name]))
+    st = np.full(B, -1, np.int32)
+    if buf.size == 0:
+        buf = np.zeros(1, np.uint8)
+    rc = lib().qlamd_robot_state_unpack_batch(ctx._h, _ptr(buf), _ptr(off), B, C.byref(f), _ptr(st), MEM_HOST, None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_robot_state_unpack_batch")
+    return out, st
 
 
 def qp_solve(ctx, G, g0, CE, ce0, CI, ci0):

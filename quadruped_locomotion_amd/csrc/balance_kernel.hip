@@ -11,6 +11,8 @@
 #include "params_build.hpp"
 #include "pose_core.hpp"
 #include "swing_core.hpp"
+#include "leg_state_core.hpp"
+#include "wire_core.hpp"
 #include "qlamd.h"
 
 using namespace qlamd;
@@ -374,6 +376,98 @@ __global__ __launch_bounds__(64) void base_auto_pose_kernel(const PoseParamsDev 
   status[i] = st;
 }
 
+// ---- leg state machine (row f2): one robot per lane, flags and a few doubles in, flags out ----------
+struct LegStatePtrs {
+  const uint8_t *support_leg, *is_footstep, *contact;
+  const double *phase, *joint_position;
+  int8_t *limb_state;
+  uint8_t *store_flag;
+  double *stored_joint_position, *joint_command, *foot_target;
+  uint8_t *support;
+  int8_t *code;
+};
+
+__global__ __launch_bounds__(256) void leg_state_kernel(const LegStatePtrs s, int index_quirk, int64_t B) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B) return;
+  LegStateRobot r;
+  // four flags per robot travel as one 32-bit word
+  const uint32_t sup = *reinterpret_cast<const uint32_t *>(s.support_leg + 4 * i);
+  const uint32_t fst = *reinterpret_cast<const uint32_t *>(s.is_footstep + 4 * i);
+  const uint32_t con = *reinterpret_cast<const uint32_t *>(s.contact + 4 * i);
+  const uint32_t lst = *reinterpret_cast<const uint32_t *>(s.limb_state + 4 * i);
+  const uint32_t sto = *reinterpret_cast<const uint32_t *>(s.store_flag + 4 * i);
+  const double2 p01 = *reinterpret_cast<const double2 *>(s.phase + 4 * i);
+  const double2 p23 = *reinterpret_cast<const double2 *>(s.phase + 4 * i + 2);
+  const double ph[4] = {p01.x, p01.y, p23.x, p23.y};
+#pragma unroll
+  for (int l = 0; l < 4; l++) {
+    r.support_leg[l] = ((sup >> (8 * l)) & 0xFFu) != 0;
+    r.is_footstep[l] = ((fst >> (8 * l)) & 0xFFu) != 0;
+    r.contact[l] = ((con >> (8 * l)) & 0xFFu) != 0;
+    r.limb_state[l] = (int)(int8_t)((lst >> (8 * l)) & 0xFFu);
+    r.store_flag[l] = ((sto >> (8 * l)) & 0xFFu) != 0;
+    r.phase[l] = ph[l];
+  }
+  leg_state_machine(r, index_quirk != 0);
+  uint32_t lst_o = 0, sto_o = 0, code_o = 0;
+  uint32_t sup_o = *reinterpret_cast<const uint32_t *>(s.support + 4 * i);
+#pragma unroll
+  for (int l = 0; l < 4; l++) {
+    lst_o |= (uint32_t)(uint8_t)(int8_t)r.limb_state[l] << (8 * l);
+    sto_o |= (r.store_flag[l] ? 1u : 0u) << (8 * l);
+    code_o |= (uint32_t)(uint8_t)(int8_t)r.code[l] << (8 * l);
+    if (r.support_written[l]) sup_o = (sup_o & ~(0xFFu << (8 * l))) | ((r.support[l] ? 1u : 0u) << (8 * l));
+    if (r.nudge_bumped[l]) { s.foot_target[12 * i + 3 * l] -= 0.005; s.foot_target[12 * i + 3 * l + 2] += 0.02; }
+    if (r.nudge_late[l]) s.foot_target[12 * i + 3 * l + 2] -= 0.01;
+    if (r.capture[l]) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) s.stored_joint_position[12 * i + 3 * l + k] = s.joint_position[12 * i + 3 * l + k];
+    }
+    if (r.hold[l]) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) s.joint_command[12 * i + 3 * l + k] = s.stored_joint_position[12 * i + 3 * l + k];
+    }
+  }
+  *reinterpret_cast<uint32_t *>(s.limb_state + 4 * i) = lst_o;
+  *reinterpret_cast<uint32_t *>(s.store_flag + 4 * i) = sto_o;
+  *reinterpret_cast<uint32_t *>(s.support + 4 * i) = sup_o;
+  *reinterpret_cast<uint32_t *>(s.code + 4 * i) = code_o;
+}
+
+// ---- free_gait_msgs/RobotState wire format -> SoA (row f2): one message per lane ---------------------
+struct RobotStateOutPtrs {
+  double *des_pos, *des_quat, *des_linvel, *des_angvel, *joint_command, *foot_position, *foot_velocity,
+      *foot_acceleration, *surface_normal, *phase;
+  uint8_t *support_leg, *leg_mode;
+};
+
+__global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *__restrict__ messages,
+                                                                const int64_t *__restrict__ offsets, int64_t B,
+                                                                const RobotStateOutPtrs o, int32_t *__restrict__ status) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= B) return;
+  RobotStateFields f;
+  memset(&f, 0, sizeof(f));
+  const int64_t a = offsets[i], b = offsets[i + 1];
+  const int st = robot_state_unpack(messages + a, b - a, f);
+  const auto put = [&](double *dst, const double *src, int n) {
+    if (!dst) return;
+    for (int k = 0; k < n; k++) dst[(int64_t)n * i + k] = src[k];
+  };
+  put(o.des_pos, f.des_pos, 3); put(o.des_quat, f.des_quat, 4);
+  put(o.des_linvel, f.des_linvel, 3); put(o.des_angvel, f.des_angvel, 3);
+  put(o.joint_command, f.joint_command, 12);
+  put(o.foot_position, f.foot_position, 12); put(o.foot_velocity, f.foot_velocity, 12);
+  put(o.foot_acceleration, f.foot_acceleration, 12);
+  put(o.surface_normal, f.surface_normal, 12); put(o.phase, f.phase, 4);
+  for (int l = 0; l < 4; l++) {
+    if (o.support_leg) o.support_leg[4 * i + l] = f.support_leg[l];
+    if (o.leg_mode) o.leg_mode[4 * i + l] = f.leg_mode[l];
+  }
+  status[i] = st;
+}
+
 // ---- dense QP batch: one problem per lane, 8 problems per wavefront, arrays in LDS ------------
 typedef GiLayout<12, 2, 24> QpGi;
 constexpr int kQpPerWave = 8;
@@ -692,6 +786,116 @@ int qlamd_base_auto_optimize_pose_batch(qlamd_context *ctx, const qlamd_pose_par
   c.pose_out = pose_out; c.stage = stage; c.iterations = iterations; c.status = status;
   c.sfo = stance_for_orientation; c.min_len = min_limb_length; c.leg_tol = leg_length_tolerance;
   return pose_impl(c, ctx, params, in, batch, memory, stream);
+}
+
+int qlamd_leg_state_machine_batch(qlamd_context *ctx, const qlamd_leg_state_batch *io, int index_quirk, int64_t batch,
+                                  int memory, void *stream) {
+  if (!ctx || !io || batch < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!io->support_leg || !io->phase || !io->is_footstep || !io->contact || !io->joint_position || !io->limb_state ||
+      !io->store_flag || !io->stored_joint_position || !io->joint_command || !io->foot_target || !io->support ||
+      !io->leg_state_code)
+    return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+  LegStatePtrs s{io->support_leg, io->is_footstep, io->contact, io->phase, io->joint_position, io->limb_state,
+                 io->store_flag, io->stored_joint_position, io->joint_command, io->foot_target, io->support,
+                 io->leg_state_code};
+  // host staging: every array goes up, the in/out and out arrays come back
+  enum { kN = 12 };
+  const size_t sz[kN] = {B * 4, B * 4, B * 4, B * 32, B * 96, B * 4, B * 4, B * 96, B * 96, B * 96, B * 4, B * 4};
+  void *host[kN] = {(void *)io->support_leg, (void *)io->is_footstep, (void *)io->contact, (void *)io->phase,
+                    (void *)io->joint_position, io->limb_state, io->store_flag, io->stored_joint_position,
+                    io->joint_command, io->foot_target, io->support, io->leg_state_code};
+  size_t off[kN];
+  if (memory == QLAMD_MEM_HOST) {
+    size_t total = 0;
+    for (int k = 0; k < kN; k++) { off[k] = total; total += align256(sz[k]); }
+    int rc = ensure_ws(ctx, total);
+    if (rc != QLAMD_OK) return rc;
+    char *w = (char *)ctx->ws;
+    for (int k = 0; k < kN - 1; k++) // leg_state_code is output only
+      if (hipMemcpyAsync(w + off[k], host[k], sz[k], hipMemcpyHostToDevice, st) != hipSuccess) return QLAMD_ERR_HIP;
+    s = LegStatePtrs{(const uint8_t *)(w + off[0]), (const uint8_t *)(w + off[1]), (const uint8_t *)(w + off[2]),
+                     (const double *)(w + off[3]), (const double *)(w + off[4]), (int8_t *)(w + off[5]),
+                     (uint8_t *)(w + off[6]), (double *)(w + off[7]), (double *)(w + off[8]), (double *)(w + off[9]),
+                     (uint8_t *)(w + off[10]), (int8_t *)(w + off[11])};
+  }
+  hipLaunchKernelGGL(leg_state_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, s, index_quirk, batch);
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  if (memory == QLAMD_MEM_HOST) {
+    char *w = (char *)ctx->ws;
+    for (int k = 5; k < kN; k++)
+      if (hipMemcpyAsync(host[k], w + off[k], sz[k], hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
+  }
+  return QLAMD_OK;
+}
+
+int qlamd_robot_state_unpack_batch(qlamd_context *ctx, const uint8_t *messages, const int64_t *offsets, int64_t batch,
+                                   const qlamd_robot_state_fields *out, int32_t *status, int memory, void *stream) {
+  if (!ctx || !messages || !offsets || !out || !status || batch < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+  enum { kD = 10 };
+  const int width[kD] = {3, 4, 3, 3, 12, 12, 12, 12, 12, 4};
+  double *hostd[kD] = {out->des_pos, out->des_quat, out->des_linvel, out->des_angvel, out->joint_command,
+                       out->foot_position, out->foot_velocity, out->foot_acceleration, out->surface_normal, out->phase};
+  RobotStateOutPtrs o{out->des_pos, out->des_quat, out->des_linvel, out->des_angvel, out->joint_command,
+                      out->foot_position, out->foot_velocity, out->foot_acceleration, out->surface_normal, out->phase,
+                      out->support_leg, out->leg_mode};
+  const uint8_t *d_msg = messages;
+  const int64_t *d_off = offsets;
+  int32_t *d_st = status;
+  size_t off[kD + 5];
+  if (memory == QLAMD_MEM_HOST) {
+    for (size_t k = 0; k < B; k++)
+      if (offsets[k + 1] < offsets[k] || offsets[0] < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+    const size_t nbytes = (size_t)(offsets[B] - offsets[0]);
+    size_t total = 0;
+    for (int k = 0; k < kD; k++) { off[k] = total; total += align256(hostd[k] ? B * 8 * (size_t)width[k] : 0); }
+    off[kD] = total; total += align256(out->support_leg ? B * 4 : 0);
+    off[kD + 1] = total; total += align256(out->leg_mode ? B * 4 : 0);
+    off[kD + 2] = total; total += align256(B * 4);             // status
+    off[kD + 3] = total; total += align256((B + 1) * 8);       // offsets
+    off[kD + 4] = total; total += align256(nbytes ? nbytes : 1);
+    int rc = ensure_ws(ctx, total);
+    if (rc != QLAMD_OK) return rc;
+    char *w = (char *)ctx->ws;
+    if (hipMemcpyAsync(w + off[kD + 3], offsets, (B + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess) return QLAMD_ERR_HIP;
+    if (nbytes && hipMemcpyAsync(w + off[kD + 4], messages + offsets[0], nbytes, hipMemcpyHostToDevice, st) != hipSuccess)
+      return QLAMD_ERR_HIP;
+    double *dd[kD];
+    for (int k = 0; k < kD; k++) dd[k] = hostd[k] ? (double *)(w + off[k]) : nullptr;
+    o = RobotStateOutPtrs{dd[0], dd[1], dd[2], dd[3], dd[4], dd[5], dd[6], dd[7], dd[8], dd[9],
+                          out->support_leg ? (uint8_t *)(w + off[kD]) : nullptr,
+                          out->leg_mode ? (uint8_t *)(w + off[kD + 1]) : nullptr};
+    d_st = (int32_t *)(w + off[kD + 2]);
+    d_off = (const int64_t *)(w + off[kD + 3]);
+    d_msg = (const uint8_t *)(w + off[kD + 4]) - offsets[0]; // the kernel indexes with the caller's offsets
+  }
+  hipLaunchKernelGGL(robot_state_unpack_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, d_msg, d_off, batch,
+                     o, d_st);
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  if (memory == QLAMD_MEM_HOST) {
+    char *w = (char *)ctx->ws;
+    bool fine = true;
+    for (int k = 0; k < kD; k++)
+      if (hostd[k])
+        fine = fine && hipMemcpyAsync(hostd[k], w + off[k], B * 8 * (size_t)width[k], hipMemcpyDeviceToHost, st) == hipSuccess;
+    if (out->support_leg)
+      fine = fine && hipMemcpyAsync(out->support_leg, w + off[kD], B * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+    if (out->leg_mode)
+      fine = fine && hipMemcpyAsync(out->leg_mode, w + off[kD + 1], B * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+    fine = fine && hipMemcpyAsync(status, d_st, B * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+    if (!fine || hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
+  }
+  return QLAMD_OK;
 }
 
 int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *G, const double *g0,

@@ -46,6 +46,8 @@ class Mirror:
                 os.path.join(ROOT, "quadruped_locomotion_amd", "csrc", "params_build.hpp"),
                 os.path.join(ROOT, "quadruped_locomotion_amd", "csrc", "gi_core.hpp"),
                 os.path.join(ROOT, "quadruped_locomotion_amd", "csrc", "pose_core.hpp"),
+                os.path.join(ROOT, "quadruped_locomotion_amd", "csrc", "leg_state_core.hpp"),
+                os.path.join(ROOT, "quadruped_locomotion_amd", "csrc", "wire_core.hpp"),
                 os.path.join(ROOT, "quadruped_locomotion_amd", "csrc", "gi6_core.hpp"),
                 os.path.join(ROOT, "quadruped_locomotion_amd", "csrc", "swing_core.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):

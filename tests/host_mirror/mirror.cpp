@@ -161,6 +161,41 @@ extern "C" void mirror_pose_aux_batch(int mode, const PoseParamsDev *P, int64_t 
   }
 }
 
+// ---- leg state machine (row f2): same unpack / apply as leg_state_kernel ----
+#include "leg_state_core.hpp"
+extern "C" void mirror_leg_state_batch(int64_t B, const uint8_t *support_leg, const double *phase, const uint8_t *is_footstep,
+                                       const uint8_t *contact, const double *joint_position, int index_quirk,
+                                       int8_t *limb_state, uint8_t *store_flag, double *stored, double *cmd, double *foot,
+                                       uint8_t *support, int8_t *code) {
+  for (int64_t i = 0; i < B; i++) {
+    LegStateRobot r;
+    for (int l = 0; l < 4; l++) {
+      r.support_leg[l] = support_leg[4 * i + l] != 0; r.is_footstep[l] = is_footstep[4 * i + l] != 0;
+      r.contact[l] = contact[4 * i + l] != 0; r.phase[l] = phase[4 * i + l];
+      r.limb_state[l] = limb_state[4 * i + l]; r.store_flag[l] = store_flag[4 * i + l] != 0;
+    }
+    leg_state_machine(r, index_quirk != 0);
+    for (int l = 0; l < 4; l++) {
+      limb_state[4 * i + l] = (int8_t)r.limb_state[l]; store_flag[4 * i + l] = r.store_flag[l];
+      code[4 * i + l] = (int8_t)r.code[l];
+      if (r.support_written[l]) support[4 * i + l] = r.support[l];
+      if (r.nudge_bumped[l]) { foot[12 * i + 3 * l] -= 0.005; foot[12 * i + 3 * l + 2] += 0.02; }
+      if (r.nudge_late[l]) foot[12 * i + 3 * l + 2] -= 0.01;
+      for (int k = 0; k < 3; k++) {
+        if (r.capture[l]) stored[12 * i + 3 * l + k] = joint_position[12 * i + 3 * l + k];
+        if (r.hold[l]) cmd[12 * i + 3 * l + k] = stored[12 * i + 3 * l + k];
+      }
+    }
+  }
+}
+
+// ---- RobotState wire format (row f2) ----
+#include "wire_core.hpp"
+extern "C" int mirror_robot_state_unpack(const uint8_t *msg, int64_t len, RobotStateFields *out) {
+  memset(out, 0, sizeof(*out));
+  return robot_state_unpack(msg, len, *out);
+}
+
 // ---- swing-leg torque (row a18) ----
 #include "swing_core.hpp"
 extern "C" void mirror_swing_leg(int leg, const SwingParamsDev *SP, const double *q_id, const double *q, const double *qd,

@@ -1,0 +1,143 @@
+"""free_gait_msgs/RobotState wire format -> SoA.  Three independent pieces written from the
+message definitions: the serialiser in tests/ros1_wire.py, the C oracle parser, the kernel's parser (host build
+here, device under -m gpu).  Doubles travel as bit patterns: everything is compared exactly."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ros1_wire as W
+
+LEGS = ("lf", "rf", "rh", "lh")
+MODES = ["joint", "leg_mode", "cartesian", "footstep", "LF_LEG", "", "footsteps", "Joint"]
+MODE_CODE = {"joint": 1, "leg_mode": 2, "cartesian": 3, "footstep": 4}
+
+
+def random_message(rng, ragged=True):
+    """A RobotState with random content; `ragged` varies string lengths and array counts so that every message has
+    its own field offsets.  Returns (bytes, expected fields)."""
+    exp = dict(des_pos=rng.normal(size=3), des_quat=rng.normal(size=4), des_linvel=rng.normal(size=3),
+               des_angvel=rng.normal(size=3), joint_command=rng.normal(size=12), foot_position=rng.normal(size=12),
+               foot_velocity=rng.normal(size=12), foot_acceleration=rng.normal(size=12), surface_normal=rng.normal(size=12),
+               phase=rng.random(4), support_leg=rng.integers(0, 2, 4).astype(np.uint8), leg_mode=np.zeros(4, np.uint8))
+    word = lambda: "".join(rng.choice(list("abcdefgh_/0123"), rng.integers(0, 12 if ragged else 1)))  # noqa: E731
+    hdr = lambda: dict(seq=int(rng.integers(0, 2 ** 32)), stamp=(int(rng.integers(0, 2 ** 31)), int(rng.integers(0, 10 ** 9))),  # noqa: E731
+                       frame_id=word())
+    msg = {}
+    for l, leg in enumerate(LEGS):
+        extra = int(rng.integers(0, 3)) if ragged else 0
+        msg[f"{leg}_leg_joints"] = dict(
+            header=hdr(), name=[word() for _ in range(3 + extra)],
+            position=list(exp["joint_command"][3 * l:3 * l + 3]) + list(rng.normal(size=extra)),
+            velocity=list(rng.normal(size=int(rng.integers(0, 4)) if ragged else 3)),
+            effort=list(rng.normal(size=int(rng.integers(0, 4)) if ragged else 0)))
+        mode = MODES[int(rng.integers(0, len(MODES)))]
+        exp["leg_mode"][l] = MODE_CODE.get(mode, 0)
+        msg[f"{leg}_leg_mode"] = dict(
+            name=mode, support_leg=int(exp["support_leg"][l]), duration=(int(rng.integers(-5, 5)), int(rng.integers(0, 10 ** 9))),
+            phase=float(exp["phase"][l]),
+            surface_normal={"header": hdr(), "vector": W.xyz(exp["surface_normal"][3 * l:3 * l + 3])},
+            ignore_for_pose_adaptation=int(rng.integers(0, 2)))
+        more = lambda kind: [{"header": hdr(), kind: W.xyz(rng.normal(size=3))} for _ in range(int(rng.integers(0, 3)) if ragged else 0)]  # noqa: E731
+        msg[f"{leg}_target"] = dict(
+            name=word(),
+            target_position=[{"header": hdr(), "point": W.xyz(exp["foot_position"][3 * l:3 * l + 3])}] + more("point"),
+            target_velocity=[{"header": hdr(), "vector": W.xyz(exp["foot_velocity"][3 * l:3 * l + 3])}] + more("vector"),
+            target_acceleration=[{"header": hdr(), "vector": W.xyz(exp["foot_acceleration"][3 * l:3 * l + 3])}] + more("vector"),
+            target_force=more("vector"), average_velocity=float(rng.normal()),
+            surface_normal={"header": hdr(), "vector": W.xyz(rng.normal(size=3))},
+            ignore_contact=int(rng.integers(0, 2)), ignore_for_pose_adaptation=int(rng.integers(0, 2)))
+    q = exp["des_quat"]
+    msg["base_pose"] = dict(
+        header=hdr(), child_frame_id=word(),
+        pose=dict(pose=dict(position=W.xyz(exp["des_pos"]), orientation=dict(x=q[1], y=q[2], z=q[3], w=q[0])),
+                  covariance=list(rng.normal(size=36))),
+        twist=dict(twist=dict(linear=W.xyz(exp["des_linvel"]), angular=W.xyz(exp["des_angvel"])), covariance=list(rng.normal(size=36))))
+    return W.serialize("free_gait_msgs/RobotState", msg), exp
+
+
+def same(got, exp):
+    for k, v in exp.items():
+        assert np.array_equal(np.asarray(got[k]).ravel(), np.asarray(v).ravel()), k
+
+
+def test_serialiser_layout_of_a_minimal_message():
+    """Size of an all-default message follows from the definitions: 4 JointState (16+4+4+4+4), Odometry
+    (16 + 4 + 56 + 288 + 48 + 288), 4 LegMode (4+1+8+8+16+24+1), 4 EndEffectorTarget (4 + 4*4 + 8 + 16+24 + 2)."""
+    raw = W.serialize("free_gait_msgs/RobotState", {})
+    assert len(raw) == 4 * 32 + 700 + 4 * 62 + 4 * 70
+
+
+def test_oracle_parses_what_the_serialiser_writes(oracle):
+    rng = np.random.default_rng(5)
+    for k in range(200):
+        raw, exp = random_message(rng, ragged=k % 4 != 0)
+        got, st = oracle.robot_state_unpack(raw)
+        assert st == 0
+        same(got, exp)
+
+
+def test_oracle_flags_truncated_and_short_messages(oracle):
+    rng = np.random.default_rng(6)
+    raw, _ = random_message(rng)
+    for cut in (0, 1, 17, len(raw) // 2, len(raw) - 1):
+        assert oracle.robot_state_unpack(raw[:cut])[1] == 1
+    assert oracle.robot_state_unpack(raw + b"\0" * 5)[1] == 0        # trailing bytes are not read
+    msg = {"lf_leg_joints": dict(position=[0.1, 0.2])}               # position[2] missing
+    for leg in LEGS:
+        msg[f"{leg}_target"] = dict(target_position=[W.stamped("point", [1, 2, 3])], target_velocity=[W.stamped("vector", [0, 0, 0])],
+                                    target_acceleration=[W.stamped("vector", [0, 0, 0])])
+        if leg != "lf":
+            msg[f"{leg}_leg_joints"] = dict(position=[0.0, 0.0, 0.0])
+    assert oracle.robot_state_unpack(W.serialize("free_gait_msgs/RobotState", msg))[1] == 2
+    msg["lf_leg_joints"] = dict(position=[0.1, 0.2, 0.3])
+    assert oracle.robot_state_unpack(W.serialize("free_gait_msgs/RobotState", msg))[1] == 0
+    msg["rh_target"]["target_velocity"] = []
+    assert oracle.robot_state_unpack(W.serialize("free_gait_msgs/RobotState", msg))[1] == 2
+    huge = bytearray(raw); huge[12:16] = b"\xff\xff\xff\xff"          # frame_id length 4 GiB
+    assert oracle.robot_state_unpack(bytes(huge))[1] == 1
+
+
+def test_kernel_parser_on_host_matches_oracle(oracle, mirror):
+    rng = np.random.default_rng(7)
+    f = oracle.RobotStateFields()
+    for k in range(300):
+        raw, exp = random_message(rng, ragged=k % 3 != 0)
+        if k % 10 == 9:
+            raw = raw[:int(rng.integers(0, len(raw)))]
+        buf = (C.c_uint8 * max(len(raw), 1)).from_buffer_copy(raw if raw else b"\0")
+        st = mirror.L.mirror_robot_state_unpack(buf, C.c_int64(len(raw)), C.byref(f))
+        want, wst = oracle.robot_state_unpack(raw)
+        assert st == wst
+        if st == 0:
+            same(f.as_dict(), exp)
+            same(f.as_dict(), want)
+
+
+def batch_of_messages(B, seed):
+    rng = np.random.default_rng(seed)
+    raws, exps = zip(*[random_message(rng, ragged=k % 5 != 0) for k in range(B)])
+    raws = list(raws)
+    raws[3] = raws[3][:40]                                           # one truncated message in the batch
+    off = np.zeros(B + 1, np.int64)
+    off[1:] = np.cumsum([len(r) for r in raws])
+    return b"".join(raws), off, exps
+
+
+@pytest.mark.gpu
+def test_device_unpack_matches_oracle(oracle):
+    from quadruped_locomotion_amd import capi
+    ctx = capi.Context()
+    B = 300
+    blob, off, exps = batch_of_messages(B, 8)
+    out, st = capi.robot_state_unpack(ctx, blob, off)
+    for i in range(B):
+        want, wst = oracle.robot_state_unpack(blob[off[i]:off[i + 1]])
+        assert st[i] == wst
+        if wst == 0:
+            same({k: v[i] for k, v in out.items()}, exps[i])
+    assert st[3] == 1 and (np.delete(st, 3) == 0).all()
+    # a subset of outputs, non-zero first offset
+    out2, st2 = capi.robot_state_unpack(ctx, b"\xAA" * 7 + blob, off + 7, want=("des_quat", "support_leg"))
+    assert set(out2) == {"des_quat", "support_leg"} and np.array_equal(st2, st)
+    assert np.array_equal(out2["des_quat"], out["des_quat"]) and np.array_equal(out2["support_leg"], out["support_leg"])
