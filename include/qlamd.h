@@ -354,6 +354,29 @@ typedef struct qlamd_robot_state_fields {
 int qlamd_robot_state_unpack_batch(qlamd_context *ctx, const uint8_t *messages, const int64_t *offsets, int64_t batch,
                                    const qlamd_robot_state_fields *out, int32_t *status, int memory, void *stream);
 
+/* ---- analytic leg inverse kinematics ------------------------------------------
+ * QuadrupedKinematics::InverseKinematicsSolve (quadruped_model/src/quadrupedkinematics.cpp:377-483) for the four
+ * feet of every robot, as QuadrupedState::getLimbJointPositionsFromPositionBaseToFootInBaseFrame calls it
+ * (quadruped_state.cpp:283-300): on failure (a NaN angle) the leg keeps joint_position_last and ok = 0. */
+#define QLAMD_IK_OUT_LEFT 0   /* the row of `results` the reference returns for each LimbType string (:466-473) */
+#define QLAMD_IK_IN_RIGHT 1
+#define QLAMD_IK_IN_LEFT 2
+#define QLAMD_IK_OUT_RIGHT 3
+
+typedef struct qlamd_ik_params {
+  double d, l1, l2;         /* hip offset and link lengths; the reference hard-codes 0.1, 0.25, 0.25 (:383-385), which
+                               is not the geometry of its own URDF (0.23 / 0.22053, 0.308, 0.308)               */
+  uint8_t limb_config[4];   /* QLAMD_IK_* per limb; default "><" (quadruped_state.cpp:61,385-390)               */
+} qlamd_ik_params;
+
+void qlamd_ik_default_params(qlamd_ik_params *p);
+
+/* foot_position [B][12] in the base frame, joint_position_last [B][12] or NULL, joint_position [B][12] out,
+ * ok [B][4] out or NULL. */
+int qlamd_leg_inverse_kinematics_batch(qlamd_context *ctx, const qlamd_ik_params *params, const double *foot_position,
+                                       const double *joint_position_last, int64_t batch, double *joint_position,
+                                       uint8_t *ok, int memory, void *stream);
+
 const char *qlamd_strerror(int code);
 int qlamd_version(void);
 

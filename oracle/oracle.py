@@ -395,3 +395,14 @@ def robot_state_unpack(msg):
     buf = (C.c_uint8 * max(len(msg), 1)).from_buffer_copy(bytes(msg) if len(msg) else b"\0")
     st = lib().oracle_robot_state_unpack(buf, C.c_size_t(len(msg)), C.byref(f))
     return f.as_dict(), st
+
+
+IK_REFERENCE_GEOMETRY = (0.1, 0.25, 0.25)   # d, l1, l2 hard-coded at quadrupedkinematics.cpp:383-385
+IK_DEFAULT_CONFIG = (2, 0, 2, 0)            # "><": LF IN_LEFT, RF OUT_LEFT, RH IN_LEFT, LH OUT_LEFT (quadruped_state.cpp:61,385-390)
+
+
+def leg_ik(leg, p_base, config, geom=IK_REFERENCE_GEOMETRY):
+    p, pp = _d(p_base)
+    q = np.zeros(3)
+    ok = lib().oracle_leg_ik(int(leg), pp, int(config), (C.c_double * 3)(*geom), q.ctypes.data_as(_dp))
+    return q, ok

@@ -2,6 +2,9 @@
 #include "oracle_model.h"
 
 #include <math.h>
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
 #include <string.h>
 
 #include "qlamd_robot_constants.h"
@@ -134,4 +137,50 @@ double oracle_leg_potential(int leg, const double q[3], const double g[3]) {
   for (int k = 0; k < 4; k++)
     U -= QLAMD_LINK_MASS[leg][k] * (g[0] * c[k][0] + g[1] * c[k][1] + g[2] * c[k][2]);
   return U;
+}
+
+/* QuadrupedKinematics::MapToPI (quadrupedkinematics.cpp:554-563): note 2 pi - q, not q - 2 pi, above pi */
+static double map_to_pi(double q) {
+  double out = q;
+  if (q > M_PI) out = 2 * M_PI - q;
+  if (q < -M_PI) out = 2 * M_PI + q;
+  return out;
+}
+
+/* QuadrupedKinematics::InverseKinematicsSolve (quadrupedkinematics.cpp:377-483).
+ * hip frame = first segment's frame at q = 0 (setHipPoseInBase, :109-122; KDL Segment::getFrameToTip() =
+ * joint.pose(0) * f_tip = the URDF joint origin, xyz + rpy).  config = row of `results` the reference picks:
+ * 0 "OUT_LEFT", 1 "IN_RIGHT", 2 "IN_LEFT", 3 "OUT_RIGHT" (:466-473).  geom = {d, l1, l2}; the reference
+ * hard-codes {0.1, 0.25, 0.25} (:383-385).  A left-arm row with a == 0 is never written by the reference
+ * (:420-429); it is NaN here.  Returns 1 when all three angles are finite (:478-483). */
+int oracle_leg_ik(int leg, const double p_base[3], int config, const double geom[3], double q_out[3]) {
+  const double d = geom[0], l1 = geom[1], l2 = geom[2];
+  double R0[9], rel[3], ph[3];
+  rpy_to_mat(QLAMD_JOINT_RPY[leg][0], R0);
+  for (int i = 0; i < 3; i++) rel[i] = p_base[i] - QLAMD_JOINT_XYZ[leg][0][i];
+  for (int i = 0; i < 3; i++) ph[i] = R0[i] * rel[0] + R0[3 + i] * rel[1] + R0[6 + i] * rel[2]; /* R0^T rel */
+  const double px = ph[0], py = ph[1], pz = ph[2];
+  double cos_theta3 = (l2 * l2 + l1 * l1 - ((px * px + py * py + pz * pz) - d * d)) / 2 / l1 / l2;
+  if (cos_theta3 < -1) cos_theta3 = -1;
+  if (cos_theta3 > 1) cos_theta3 = 1;
+  const double theta3 = (config < 2) ? M_PI - acos(cos_theta3) : -M_PI + acos(cos_theta3);
+  const double alpha = atan2(py, px);
+  const double rxy = sqrt(fabs(px * px + py * py - d * d));
+  const double beta1 = atan2(d, rxy), beta2 = atan2(-d, -rxy);
+  const double q3 = map_to_pi(theta3);
+  const double b = atan2(l2 * sin(q3), l1 + l2 * cos(q3));
+  double q1, q2;
+  if ((config & 1) == 0) { /* left arm, rows 0 and 2 */
+    q1 = map_to_pi(alpha - beta1);
+    const double a = atan2(pz, -rxy);
+    if (a > 0) q2 = map_to_pi(a - b - M_PI);
+    else if (a < 0) q2 = map_to_pi(a - b + M_PI);
+    else q2 = (double)NAN;
+  } else {                 /* right arm, rows 1 and 3 */
+    q1 = map_to_pi(alpha + beta2);
+    const double a = atan2(pz, rxy);
+    q2 = map_to_pi(a - b + M_PI);
+  }
+  q_out[0] = q1; q_out[1] = q2; q_out[2] = q3;
+  return !isnan(q1) && !isnan(q2) && !isnan(q3);
 }

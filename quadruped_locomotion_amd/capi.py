@@ -24,6 +24,7 @@ EXPORTS = (
     "qlamd_force_distribution_batch", "qlamd_swing_default_params", "qlamd_swing_leg_torque_batch",
     "qlamd_pose_qp_batch", "qlamd_pose_check_batch", "qlamd_pose_geometric_batch",
     "qlamd_base_auto_optimize_pose_batch", "qlamd_leg_state_machine_batch", "qlamd_robot_state_unpack_batch",
+    "qlamd_ik_default_params", "qlamd_leg_inverse_kinematics_batch",
 )
 
 
@@ -66,6 +67,10 @@ ROBOT_STATE_FIELDS = (("des_pos", 3), ("des_quat", 4), ("des_linvel", 3), ("des_
 
 class RobotStateFields(C.Structure):
     _fields_ = [(n, C.c_void_p) for n, _ in ROBOT_STATE_FIELDS] + [("support_leg", C.c_void_p), ("leg_mode", C.c_void_p)]
+
+
+class IkParams(C.Structure):
+    _fields_ = [("d", C.c_double), ("l1", C.c_double), ("l2", C.c_double), ("limb_config", C.c_uint8 * 4)]
 
 
 class SwingParams(C.Structure):
@@ -158,6 +163,10 @@ def lib():
         L.qlamd_leg_state_machine_batch.argtypes = [C.c_void_p, C.POINTER(LegStateBatch), C.c_int, C.c_int64, C.c_int, C.c_void_p]
         L.qlamd_robot_state_unpack_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(RobotStateFields),
                                                      C.c_void_p, C.c_int, C.c_void_p]
+        L.qlamd_ik_default_params.argtypes = [C.POINTER(IkParams)]
+        L.qlamd_ik_default_params.restype = None
+        L.qlamd_leg_inverse_kinematics_batch.argtypes = [C.c_void_p, C.POINTER(IkParams), C.c_void_p, C.c_void_p, C.c_int64,
+                                                         C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_swing_leg_torque_batch.argtypes = [C.c_void_p, C.POINTER(SwingParams), C.POINTER(SwingBatch), C.c_int64,
                                                    C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_pose_sqp_batch.argtypes = [C.c_void_p, C.POINTER(PoseParams), C.POINTER(PoseBatch), C.c_int64,
@@ -456,6 +465,25 @@ def robot_state_unpack(ctx, messages, offsets, want=None):
     if rc != OK:
         raise QlamdError(rc, "qlamd_robot_state_unpack_batch")
     return out, st
+
+
+def default_ik_params():
+    p = IkParams()
+    lib().qlamd_ik_default_params(C.byref(p))
+    return p
+
+
+def leg_inverse_kinematics(ctx, foot_position, joint_position_last=None, params=None):
+    """qlamd_leg_inverse_kinematics_batch on host buffers -> (q [B,12], ok [B,4])."""
+    prm = params if params is not None else default_ik_params()
+    foot = np.ascontiguousarray(foot_position, dtype=np.float64)
+    last = None if joint_position_last is None else np.ascontiguousarray(joint_position_last, dtype=np.float64)
+    B = foot.shape[0]
+    q = np.zeros((B, 12)); ok = np.zeros((B, 4), np.uint8)
+    rc = lib().qlamd_leg_inverse_kinematics_batch(ctx._h, C.byref(prm), _ptr(foot), _ptr(last), B, _ptr(q), _ptr(ok), MEM_HOST, None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_leg_inverse_kinematics_batch")
+    return q, ok
 
 
 def qp_solve(ctx, G, g0, CE, ce0, CI, ci0):

@@ -177,6 +177,50 @@ QL_HD void virtual_wrench(const DeviceParams &P, const RobotIn &in, const double
   QL_UNROLL for (int i = 0; i < 3; i++) b[3 + i] = P.kp_r[i] * e_o[i] + Rd[i] + Rf[i] - Tg[i];
 }
 
+// ---------------------------------------------------- analytic leg IK ----
+// QuadrupedKinematics::InverseKinematicsSolve (quadrupedkinematics.cpp:377-483): foot position in the base frame
+// -> (q1, q2, q3) of one leg.  The hip frame is the first joint's origin (setHipPoseInBase, :109-122) = R0[0],
+// xyz[0] of the leg table.  config = the row of `results` the reference returns: 0 OUT_LEFT, 1 IN_RIGHT,
+// 2 IN_LEFT, 3 OUT_RIGHT (:466-473).  geom = {d, l1, l2}.  Returns false when an angle is NaN (:478-483).
+QL_HD double map_to_pi(double q) { // :554-563, as written there (2 pi - q above pi)
+  const double pi = 3.14159265358979323846;
+  double out = q;
+  if (q > pi) out = 2 * pi - q;
+  if (q < -pi) out = 2 * pi + q;
+  return out;
+}
+
+template <class Tab>
+QL_HD bool leg_inverse_kinematics(const Tab &tab, const double p_base[3], int config, const double geom[3], double q[3]) {
+  const double pi = 3.14159265358979323846;
+  const double d = geom[0], l1 = geom[1], l2 = geom[2];
+  double rel[3], ph[3];
+  QL_UNROLL for (int i = 0; i < 3; i++) rel[i] = p_base[i] - tab[kTabXyz + i];
+  QL_UNROLL for (int i = 0; i < 3; i++)
+    ph[i] = tab[kTabR0 + i] * rel[0] + tab[kTabR0 + 3 + i] * rel[1] + tab[kTabR0 + 6 + i] * rel[2];
+  const double px = ph[0], py = ph[1], pz = ph[2];
+  double cos_theta3 = (l2 * l2 + l1 * l1 - ((px * px + py * py + pz * pz) - d * d)) / 2 / l1 / l2;
+  if (cos_theta3 < -1) cos_theta3 = -1;
+  if (cos_theta3 > 1) cos_theta3 = 1;
+  const double theta3 = (config < 2) ? pi - acos(cos_theta3) : -pi + acos(cos_theta3);
+  const double alpha = atan2(py, px);
+  const double rxy = sqrt(fabs(px * px + py * py - d * d));
+  const double q3 = map_to_pi(theta3);
+  const double b = atan2(l2 * sin(q3), l1 + l2 * cos(q3));
+  double q1, q2;
+  if ((config & 1) == 0) { // left arm (:416-429); the reference writes nothing when a == 0
+    q1 = map_to_pi(alpha - atan2(d, rxy));
+    const double a = atan2(pz, -rxy);
+    q2 = a > 0 ? map_to_pi(a - b - pi) : a < 0 ? map_to_pi(a - b + pi) : (double)NAN;
+  } else {                 // right arm (:431-435)
+    q1 = map_to_pi(alpha + atan2(-d, -rxy));
+    const double a = atan2(pz, rxy);
+    q2 = map_to_pi(a - b + pi);
+  }
+  q[0] = q1; q[1] = q2; q[2] = q3;
+  return !(q1 != q1) && !(q2 != q2) && !(q3 != q3);
+}
+
 // ------------------------------------------------------- leg kinematics ----
 
 // Scratch element space (doubles per robot), [element][robot] in LDS:

@@ -224,6 +224,25 @@ __global__ __launch_bounds__(64) void leg_kinematics_kernel(const DeviceParams *
   if (grav) { grav[3 * t] = Gq[0]; grav[3 * t + 1] = Gq[1]; grav[3 * t + 2] = Gq[2]; }
 }
 
+// ---- analytic leg IK (row f4), one lane per (robot, leg) -------------------------------------------------
+struct IkGeom { double g[3]; uint8_t config[4]; };
+
+__global__ __launch_bounds__(64) void leg_ik_kernel(const DeviceParams *__restrict__ Pp, const IkGeom G,
+                                                    const double *__restrict__ foot, const double *__restrict__ q_last,
+                                                    int64_t B, double *__restrict__ q_out, uint8_t *__restrict__ ok) {
+  const DeviceParams &P = *Pp;
+  const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (t >= 4 * B) return;
+  const int leg = (int)(t & 3);
+  const double p[3] = {foot[3 * t], foot[3 * t + 1], foot[3 * t + 2]};
+  double q[3];
+  const bool good = leg_inverse_kinematics(GlobalTab{P.legtab + kTabPerLeg * leg}, p, G.config[leg], G.g, q);
+  // on failure the caller's previous joint positions are kept (quadruped_state.cpp:289-294)
+#pragma unroll
+  for (int k = 0; k < 3; k++) q_out[3 * t + k] = good ? q[k] : (q_last ? q_last[3 * t + k] : q[k]);
+  if (ok) ok[t] = good ? 1 : 0;
+}
+
 // ---- row a18: swing-leg torque, one lane per (robot, leg) -------------------------------------
 struct SwingPtrs {
   const double *q, *qd, *qd_old, *tpos, *tvel, *q_id;
@@ -555,6 +574,39 @@ int ensure_ws(qlamd_context *ctx, size_t bytes) {
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Host-buffer calls: the listed arrays are laid out in the context workspace, inputs copied up front,
+// outputs copied back (and the stream synchronised) by finish().
+struct Staged {
+  struct Item { void *host; size_t bytes; bool in, out; size_t off; };
+  Item items[16];
+  int n = 0;
+  char *base = nullptr;
+  int add(const void *host, size_t bytes, bool in, bool out) {
+    items[n] = Item{const_cast<void *>(host), host ? bytes : 0, in, out, 0};
+    return n++;
+  }
+  int upload(qlamd_context *ctx, hipStream_t st) {
+    size_t total = 0;
+    for (int k = 0; k < n; k++) { items[k].off = total; total += align256(items[k].bytes); }
+    const int rc = ensure_ws(ctx, total ? total : 256);
+    if (rc != QLAMD_OK) return rc;
+    base = (char *)ctx->ws;
+    for (int k = 0; k < n; k++)
+      if (items[k].in && items[k].bytes &&
+          hipMemcpyAsync(base + items[k].off, items[k].host, items[k].bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+        return QLAMD_ERR_HIP;
+    return QLAMD_OK;
+  }
+  template <class T> T *dev(int k) const { return items[k].host ? (T *)(base + items[k].off) : nullptr; }
+  int finish(hipStream_t st) {
+    for (int k = 0; k < n; k++)
+      if (items[k].out && items[k].bytes &&
+          hipMemcpyAsync(items[k].host, base + items[k].off, items[k].bytes, hipMemcpyDeviceToHost, st) != hipSuccess)
+        return QLAMD_ERR_HIP;
+    return hipStreamSynchronize(st) == hipSuccess ? QLAMD_OK : QLAMD_ERR_HIP;
+  }
+};
 
 } // namespace
 
@@ -896,6 +948,47 @@ int qlamd_robot_state_unpack_batch(qlamd_context *ctx, const uint8_t *messages, 
     if (!fine || hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
   }
   return QLAMD_OK;
+}
+
+void qlamd_ik_default_params(qlamd_ik_params *p) {
+  if (!p) return;
+  p->d = 0.1; p->l1 = 0.25; p->l2 = 0.25;       // quadrupedkinematics.cpp:383-385
+  // setLimbConfigure("><"), quadruped_state.cpp:61,385-390: LF IN_LEFT, RF OUT_LEFT, RH IN_LEFT, LH OUT_LEFT
+  p->limb_config[0] = QLAMD_IK_IN_LEFT; p->limb_config[1] = QLAMD_IK_OUT_LEFT;
+  p->limb_config[2] = QLAMD_IK_IN_LEFT; p->limb_config[3] = QLAMD_IK_OUT_LEFT;
+}
+
+int qlamd_leg_inverse_kinematics_batch(qlamd_context *ctx, const qlamd_ik_params *params, const double *foot_position,
+                                       const double *joint_position_last, int64_t batch, double *joint_position,
+                                       uint8_t *ok, int memory, void *stream) {
+  if (!ctx || !foot_position || !joint_position || batch < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!params) return QLAMD_ERR_NOT_LOADED;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  IkGeom G;
+  G.g[0] = params->d; G.g[1] = params->l1; G.g[2] = params->l2;
+  for (int l = 0; l < 4; l++) {
+    if (params->limb_config[l] > 3) return QLAMD_ERR_INVALID_ARGUMENT;
+    G.config[l] = params->limb_config[l];
+  }
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+  const double *d_foot = foot_position, *d_last = joint_position_last;
+  double *d_q = joint_position;
+  uint8_t *d_ok = ok;
+  Staged sg;
+  if (memory == QLAMD_MEM_HOST) {
+    const int a = sg.add(foot_position, B * 96, true, false), b2 = sg.add(joint_position_last, B * 96, true, false);
+    const int c = sg.add(joint_position, B * 96, false, true), d = sg.add(ok, B * 4, false, true);
+    const int rc = sg.upload(ctx, st);
+    if (rc != QLAMD_OK) return rc;
+    d_foot = sg.dev<const double>(a); d_last = sg.dev<const double>(b2); d_q = sg.dev<double>(c); d_ok = sg.dev<uint8_t>(d);
+  }
+  hipLaunchKernelGGL(leg_ik_kernel, dim3((unsigned)((4 * batch + 63) / 64)), dim3(64), 0, st, ctx->d_params, G, d_foot,
+                     d_last, batch, d_q, d_ok);
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  return memory == QLAMD_MEM_HOST ? sg.finish(st) : QLAMD_OK;
 }
 
 int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *G, const double *g0,

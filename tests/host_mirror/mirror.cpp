@@ -196,6 +196,17 @@ extern "C" int mirror_robot_state_unpack(const uint8_t *msg, int64_t len, RobotS
   return robot_state_unpack(msg, len, *out);
 }
 
+// ---- analytic leg IK (row f4) ----
+extern "C" int mirror_leg_ik(int leg, const double *p_base, int config, const double *geom, double *q) {
+  qlamd_balance_params prm;
+  default_balance_params(&prm);
+  qlamd_robot_model model;
+  default_robot_model(&model);
+  DeviceParams P;
+  build_device_params(prm, model, &P);
+  return leg_inverse_kinematics(P.legtab + kTabPerLeg * leg, p_base, config, geom, q) ? 1 : 0;
+}
+
 // ---- swing-leg torque (row a18) ----
 #include "swing_core.hpp"
 extern "C" void mirror_swing_leg(int leg, const SwingParamsDev *SP, const double *q_id, const double *q, const double *qd,
