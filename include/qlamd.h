@@ -377,6 +377,36 @@ int qlamd_leg_inverse_kinematics_batch(qlamd_context *ctx, const qlamd_ik_params
                                        const double *joint_position_last, int64_t batch, double *joint_position,
                                        uint8_t *ok, int memory, void *stream);
 
+/* ---- swing branch of RosBalanceController::update -----------------------------
+ * ros_balance_controller.cpp:467-603: for every NON-support leg the joint effort command is
+ *   the swing-leg torque (qlamd_swing_leg_torque_batch)       when the leg mode is "cartesian" or "footstep",
+ *   joint PID on the position command + gravity compensation   when it is "joint" (or was never set),
+ *   gravity compensation alone                                 when it is "leg_mode";
+ * computeTorqueFromPositionCommand (:720-756): command clamped to the joint limits, control_toolbox PID on
+ * (command - position) with the gains of balance_controller/config/control.yaml:18-29.  Support legs are left
+ * untouched in joint_effort, so that running qlamd_balance_solve_batch first and this entry second on the same
+ * array yields all 12 commands of a tick. */
+typedef struct qlamd_joint_pid_params {
+  double p[12], i[12], d[12], i_max[12], i_min[12];
+  double lower[12], upper[12];   /* joint limits (enforceJointLimits, :1152-1166) */
+  int antiwindup;
+} qlamd_joint_pid_params;
+
+typedef struct qlamd_swing_branch_extra {
+  const double *base_orientation;   /* [B][4]  measured base orientation (w,x,y,z): gravity_in_base (:471)      */
+  const double *joint_command;      /* [B][12] position commands (RobotState.*_leg_joints.position)             */
+  const uint8_t *leg_mode;          /* [B][4]  QLAMD_LEG_MODE_* in force, or NULL (= never set)                */
+  double *pid_error_last;           /* [B][12] in/out: Pid::p_error_last_                                      */
+  double *pid_error_integral;       /* [B][12] in/out: Pid::i_error_                                           */
+} qlamd_swing_branch_extra;
+
+void qlamd_joint_pid_default_params(qlamd_joint_pid_params *p);
+
+/* joint_effort [B][12] in/out.  period: the control period handed to update(). */
+int qlamd_swing_branch_batch(qlamd_context *ctx, const qlamd_swing_params *params, const qlamd_joint_pid_params *pid,
+                             const qlamd_swing_batch *in, const qlamd_swing_branch_extra *extra, double period,
+                             int64_t batch, double *joint_effort, int memory, void *stream);
+
 const char *qlamd_strerror(int code);
 int qlamd_version(void);
 

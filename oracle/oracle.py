@@ -406,3 +406,26 @@ def leg_ik(leg, p_base, config, geom=IK_REFERENCE_GEOMETRY):
     q = np.zeros(3)
     ok = lib().oracle_leg_ik(int(leg), pp, int(config), (C.c_double * 3)(*geom), q.ctypes.data_as(_dp))
     return q, ok
+
+
+class PidParams(C.Structure):
+    _fields_ = [(n, C.c_double * 12) for n in ("p", "i", "d", "i_max", "i_min")] + [("antiwindup", C.c_int)] + \
+               [(n, C.c_double * 12) for n in ("lower", "upper")]
+
+
+def default_pid_params():
+    p = PidParams()
+    lib().oracle_pid_default_params(C.byref(p))
+    return p
+
+
+def swing_branch_leg(leg, leg_mode, base_quat, q_id, q, qd, qd_oldest, target_pos, target_vel, joint_command, period,
+                     e_last, e_int, params=None, pid=None):
+    """oracle_swing_branch_leg; e_last / e_int (3-vectors, float64) are updated in place.  Returns effort[3]."""
+    prm = params or default_swing_params()
+    pp = pid or default_pid_params()
+    a = [_d(v) for v in (base_quat, q_id, q, qd, qd_oldest, target_pos, target_vel, joint_command)]
+    eff = np.zeros(3)
+    lib().oracle_swing_branch_leg(C.byref(prm), C.byref(pp), int(leg), int(leg_mode), *[x[1] for x in a], C.c_double(period),
+                                  e_last.ctypes.data_as(_dp), e_int.ctypes.data_as(_dp), eff.ctypes.data_as(_dp))
+    return eff

@@ -129,3 +129,56 @@ void oracle_swing_leg_torque(const oracle_swing_params *P, int leg, const double
   }
   for (int j = 0; j < 3; j++) tau[j] = (J[j] * f[0] + J[3 + j] * f[1] + J[6 + j] * f[2]) + tid[j];
 }
+
+void oracle_pid_default_params(oracle_pid_params *p) {
+  for (int j = 0; j < 12; j++) { /* balance_controller/config/control.yaml:18-29 */
+    p->p[j] = 300.0; p->i[j] = 0.01; p->d[j] = 3.0;
+    p->i_max[j] = 0.0; p->i_min[j] = 0.0;      /* no i_clamp parameter: control_toolbox defaults */
+    p->lower[j] = -3.0; p->upper[j] = 3.0;      /* quadruped_model.urdf:53-57 and siblings */
+  }
+  p->antiwindup = 0;
+}
+
+static double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static double pid_command(const oracle_pid_params *g, int j, double error, double dt, double *e_last, double *e_int) {
+  if (dt == 0.0 || isnan(error) || isinf(error)) return 0.0;
+  double error_dot = 0.0;
+  if (dt > 0.0) {
+    error_dot = (error - *e_last) / dt;
+    *e_last = error;
+  }
+  if (isnan(error_dot) || isinf(error_dot)) return 0.0;
+  const double p_term = g->p[j] * error;
+  *e_int += dt * error;
+  if (g->antiwindup && g->i[j] != 0.0) {
+    const double a = g->i_min[j] / g->i[j], b = g->i_max[j] / g->i[j];
+    *e_int = clampd(*e_int, a < b ? a : b, a < b ? b : a);
+  }
+  double i_term = g->i[j] * *e_int;
+  if (!g->antiwindup) i_term = clampd(i_term, g->i_min[j], g->i_max[j]);
+  const double d_term = g->d[j] * error_dot;
+  return p_term + i_term + d_term;
+}
+
+void oracle_swing_branch_leg(const oracle_swing_params *sp, const oracle_pid_params *pid, int leg, int leg_mode,
+                             const double base_quat[4], const double q_id[3], const double q[3], const double qd[3],
+                             const double qd_oldest[3], const double target_pos[3], const double target_vel[3],
+                             const double joint_command[3], double period, double pid_error_last[3],
+                             double pid_error_integral[3], double effort[3]) {
+  /* base_orientation.rotate((0,0,-9.8)): third column of R times -9.8 */
+  const double w = base_quat[0], x = base_quat[1], y = base_quat[2], z = base_quat[3];
+  const double g[3] = {-9.8 * (2.0 * (x * z + w * y)), -9.8 * (2.0 * (y * z - w * x)), -9.8 * (1.0 - 2.0 * (x * x + y * y))};
+  double G[3], tsw[3];
+  oracle_leg_gravity(leg, q, g, G);
+  oracle_swing_leg_torque(sp, leg, q_id, q, qd, qd_oldest, target_pos, target_vel, tsw);
+  for (int k = 0; k < 3; k++) {
+    const int j = 3 * leg + k;
+    const double cmd = clampd(joint_command[k], pid->lower[j], pid->upper[j]);
+    double e = pid_command(pid, j, cmd - q[k], period, &pid_error_last[k], &pid_error_integral[k]);
+    if (leg_mode == 3 || leg_mode == 4) e = tsw[k];
+    else if (leg_mode != 2) e += G[k];
+    else e = G[k];
+    effort[k] = e;
+  }
+}

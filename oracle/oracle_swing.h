@@ -42,6 +42,38 @@ void oracle_swing_leg_torque(const oracle_swing_params *p, int leg, const double
                              const double qd[3], const double qd_oldest[3], const double target_pos[3],
                              const double target_vel[3], double tau[3]);
 
+/* ---- the swing branch of RosBalanceController::update (ros_balance_controller.cpp:467-603,720-756) -----------
+ * For one NON-support leg:
+ *   gravity_in_base = base_orientation.rotate((0,0,-9.8))                            :471   (rotate, as written)
+ *   G   = getGravityCompensationForLimb(limb, q_leg, gravity_in_base)                :476-478
+ *   pid = computeTorqueFromPositionCommand(command, joint, period)                   :484, 720-756
+ *         command clamped to the URDF limits (enforceJointLimits :1152-1166), error from
+ *         angles::shortest_angular_distance_with_limits (= command - position while both lie inside limits
+ *         narrower than 2 pi), control_toolbox::Pid::computeCommand(error, dt)
+ *   effort = swing-leg torque (a18) if the leg mode is "cartesian" or "footstep"     :485-486
+ *          = pid + G               if not "leg_mode" (i.e. "joint" or never set)      :487-488
+ *          = G                     if "leg_mode"                                      :489-490
+ * control_toolbox and angles are third-party, un-vendored: PARITY UNPINNED.  Pid::computeCommand restated from
+ * control_toolbox 1.1x: error_dot = (e - e_last)/dt; i_error += dt*e (clamped to i_min/i..i_max/i with
+ * antiwindup); i_term = i*i_error (clamped to [i_min,i_max] without antiwindup); cmd = p*e + i_term + d*error_dot;
+ * 0 when dt == 0 or the error is not finite.  With the shipped gains {p,i,d} and no i_clamp, i_max = i_min = 0 and
+ * the integral term is clamped to zero. */
+typedef struct {
+  double p[12], i[12], d[12], i_max[12], i_min[12];
+  int antiwindup;
+  double lower[12], upper[12];   /* joint limits, quadruped_model.urdf (+-3.0) */
+} oracle_pid_params;
+
+void oracle_pid_default_params(oracle_pid_params *p);
+
+/* leg_mode: 0 other / never set, 1 "joint", 2 "leg_mode", 3 "cartesian", 4 "footstep".
+ * pid_error_last[3], pid_error_integral[3]: controller state of the leg's joints, updated. */
+void oracle_swing_branch_leg(const oracle_swing_params *sp, const oracle_pid_params *pid, int leg, int leg_mode,
+                             const double base_quat[4], const double q_id[3], const double q[3], const double qd[3],
+                             const double qd_oldest[3], const double target_pos[3], const double target_vel[3],
+                             const double joint_command[3], double period, double pid_error_last[3],
+                             double pid_error_integral[3], double effort[3]);
+
 #ifdef __cplusplus
 }
 #endif

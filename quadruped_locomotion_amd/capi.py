@@ -25,6 +25,7 @@ EXPORTS = (
     "qlamd_pose_qp_batch", "qlamd_pose_check_batch", "qlamd_pose_geometric_batch",
     "qlamd_base_auto_optimize_pose_batch", "qlamd_leg_state_machine_batch", "qlamd_robot_state_unpack_batch",
     "qlamd_ik_default_params", "qlamd_leg_inverse_kinematics_batch",
+    "qlamd_joint_pid_default_params", "qlamd_swing_branch_batch",
 )
 
 
@@ -67,6 +68,14 @@ ROBOT_STATE_FIELDS = (("des_pos", 3), ("des_quat", 4), ("des_linvel", 3), ("des_
 
 class RobotStateFields(C.Structure):
     _fields_ = [(n, C.c_void_p) for n, _ in ROBOT_STATE_FIELDS] + [("support_leg", C.c_void_p), ("leg_mode", C.c_void_p)]
+
+
+class JointPidParams(C.Structure):
+    _fields_ = [(n, C.c_double * 12) for n in ("p", "i", "d", "i_max", "i_min", "lower", "upper")] + [("antiwindup", C.c_int)]
+
+
+class SwingBranchExtra(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("base_orientation", "joint_command", "leg_mode", "pid_error_last", "pid_error_integral")]
 
 
 class IkParams(C.Structure):
@@ -167,6 +176,10 @@ def lib():
         L.qlamd_ik_default_params.restype = None
         L.qlamd_leg_inverse_kinematics_batch.argtypes = [C.c_void_p, C.POINTER(IkParams), C.c_void_p, C.c_void_p, C.c_int64,
                                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.qlamd_joint_pid_default_params.argtypes = [C.POINTER(JointPidParams)]
+        L.qlamd_joint_pid_default_params.restype = None
+        L.qlamd_swing_branch_batch.argtypes = [C.c_void_p, C.POINTER(SwingParams), C.POINTER(JointPidParams), C.POINTER(SwingBatch),
+                                               C.POINTER(SwingBranchExtra), C.c_double, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_swing_leg_torque_batch.argtypes = [C.c_void_p, C.POINTER(SwingParams), C.POINTER(SwingBatch), C.c_int64,
                                                    C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_pose_sqp_batch.argtypes = [C.c_void_p, C.POINTER(PoseParams), C.POINTER(PoseBatch), C.c_int64,
@@ -327,6 +340,36 @@ def swing_leg_torque(ctx, q, qd, qd_oldest, target_pos, target_vel, support, q_i
     if rc != OK:
         raise QlamdError(rc, "qlamd_swing_leg_torque_batch")
     return tau
+
+
+def default_joint_pid_params():
+    p = JointPidParams()
+    lib().qlamd_joint_pid_default_params(C.byref(p))
+    return p
+
+
+def swing_branch(ctx, joint_effort, q, qd, qd_oldest, target_pos, target_vel, support, base_orientation, joint_command,
+                 leg_mode, pid_error_last, pid_error_integral, period, q_id=None, params=None, pid=None, memory=MEM_HOST,
+                 stream=None):
+    """qlamd_swing_branch_batch.  joint_effort, pid_error_last, pid_error_integral are updated in place (host:
+    C-contiguous float64 numpy arrays; device: torch CUDA tensors)."""
+    prm = params if params is not None else default_swing_params()
+    pidp = pid if pid is not None else default_joint_pid_params()
+    arrs = [q, qd, qd_oldest, target_pos, target_vel, support, q_id]
+    ext = [base_orientation, joint_command, leg_mode, pid_error_last, pid_error_integral]
+    if memory == MEM_HOST:
+        arrs = [None if a is None else np.ascontiguousarray(a) for a in arrs]
+        ext[:3] = [None if a is None else np.ascontiguousarray(a) for a in ext[:3]]
+        for a in (joint_effort, pid_error_last, pid_error_integral):
+            assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    sb = SwingBatch(*[_ptr(a) for a in arrs])
+    ex = SwingBranchExtra(*[_ptr(a) for a in ext])
+    B = int(arrs[0].shape[0])
+    rc = lib().qlamd_swing_branch_batch(ctx._h, C.byref(prm), C.byref(pidp), C.byref(sb), C.byref(ex), float(period), B,
+                                        _ptr(joint_effort), memory, C.c_void_p(stream) if stream else None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_swing_branch_batch")
+    return joint_effort
 
 
 def pose_sqp(ctx, problems, params=None, memory=MEM_HOST, out=None, stream=None):

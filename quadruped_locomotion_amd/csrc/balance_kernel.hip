@@ -269,6 +269,41 @@ __global__ __launch_bounds__(64) void swing_leg_kernel(const DeviceParams *__res
   tau[3 * t] = out[0]; tau[3 * t + 1] = out[1]; tau[3 * t + 2] = out[2];
 }
 
+// ---- swing branch of update(): PID / gravity compensation / swing torque per leg mode ---------------------
+struct SwingBranchPtrs {
+  const double *quat, *cmd;
+  const uint8_t *mode;
+  double *e_last, *e_int;
+};
+
+__global__ __launch_bounds__(64) void swing_branch_kernel(const DeviceParams *__restrict__ Pp, const SwingParamsDev SP,
+                                                          const PidParamsDev pid, const SwingPtrs s,
+                                                          const SwingBranchPtrs b, double period, int64_t B,
+                                                          double *__restrict__ effort) {
+  const DeviceParams &P = *Pp;
+  const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (t >= 4 * B) return;
+  if (s.support[t]) return; // support legs keep the clamped QP torque already in `effort` (:497-502)
+  const int64_t i = t >> 2;
+  const int leg = (int)(t & 3);
+  const double q[3] = {s.q[3 * t], s.q[3 * t + 1], s.q[3 * t + 2]};
+  const double qd[3] = {s.qd[3 * t], s.qd[3 * t + 1], s.qd[3 * t + 2]};
+  const double qo[3] = {s.qd_old[3 * t], s.qd_old[3 * t + 1], s.qd_old[3 * t + 2]};
+  const double tp[3] = {s.tpos[3 * t], s.tpos[3 * t + 1], s.tpos[3 * t + 2]};
+  const double tv[3] = {s.tvel[3 * t], s.tvel[3 * t + 1], s.tvel[3 * t + 2]};
+  const double cmd[3] = {b.cmd[3 * t], b.cmd[3 * t + 1], b.cmd[3 * t + 2]};
+  const double quat[4] = {b.quat[4 * i], b.quat[4 * i + 1], b.quat[4 * i + 2], b.quat[4 * i + 3]};
+  double qi[3] = {q[0], q[1], q[2]};
+  if (s.q_id) { qi[0] = s.q_id[3 * t]; qi[1] = s.q_id[3 * t + 1]; qi[2] = s.q_id[3 * t + 2]; }
+  double el[3] = {b.e_last[3 * t], b.e_last[3 * t + 1], b.e_last[3 * t + 2]};
+  double ei[3] = {b.e_int[3 * t], b.e_int[3 * t + 1], b.e_int[3 * t + 2]};
+  double out[3];
+  swing_branch_leg(GlobalTab{P.legtab + kTabPerLeg * leg}, SP, pid, leg, b.mode ? b.mode[t] : 0, quat, qi, q, qd, qo, tp,
+                   tv, cmd, period, el, ei, out);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { effort[3 * t + k] = out[k]; b.e_last[3 * t + k] = el[k]; b.e_int[3 * t + k] = ei[k]; }
+}
+
 // ---- config 5: one pose-optimisation problem per lane, 16 problems per wavefront --------------
 struct PosePtrs {
   const double *stance, *nominal, *polygon, *rcom, *maxlen, *pose;
@@ -671,6 +706,70 @@ int qlamd_swing_leg_torque_batch(qlamd_context *ctx, const qlamd_swing_params *p
     if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
   }
   return QLAMD_OK;
+}
+
+void qlamd_joint_pid_default_params(qlamd_joint_pid_params *p) {
+  if (!p) return;
+  for (int j = 0; j < 12; j++) { // balance_controller/config/control.yaml:18-29; limits quadruped_model.urdf:53-57
+    p->p[j] = 300.0; p->i[j] = 0.01; p->d[j] = 3.0;
+    p->i_max[j] = 0.0; p->i_min[j] = 0.0;
+    p->lower[j] = -3.0; p->upper[j] = 3.0;
+  }
+  p->antiwindup = 0;
+}
+
+int qlamd_swing_branch_batch(qlamd_context *ctx, const qlamd_swing_params *params, const qlamd_joint_pid_params *pid,
+                             const qlamd_swing_batch *in, const qlamd_swing_branch_extra *extra, double period,
+                             int64_t batch, double *joint_effort, int memory, void *stream) {
+  if (!ctx || !in || !extra || batch < 0 || !joint_effort) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!params || !pid) return QLAMD_ERR_NOT_LOADED;
+  if (!in->joint_position || !in->joint_velocity || !in->joint_velocity_oldest || !in->target_foot_position ||
+      !in->target_foot_velocity || !in->support_leg || !extra->base_orientation || !extra->joint_command ||
+      !extra->pid_error_last || !extra->pid_error_integral)
+    return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!(params->period > 0.0) || !(params->accel_window > 0.0)) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+  SwingParamsDev SP;
+  for (int i = 0; i < 3; i++) { SP.kp[i] = params->kp[i]; SP.kd[i] = params->kd[i]; }
+  SP.period = params->period; SP.accel_window = params->accel_window; SP.accel_scale = params->accel_scale;
+  SP.gravity = params->gravity;
+  PidParamsDev PD;
+  memcpy(PD.p, pid->p, sizeof(PD.p)); memcpy(PD.i, pid->i, sizeof(PD.i)); memcpy(PD.d, pid->d, sizeof(PD.d));
+  memcpy(PD.i_max, pid->i_max, sizeof(PD.i_max)); memcpy(PD.i_min, pid->i_min, sizeof(PD.i_min));
+  memcpy(PD.lower, pid->lower, sizeof(PD.lower)); memcpy(PD.upper, pid->upper, sizeof(PD.upper));
+  PD.antiwindup = pid->antiwindup;
+  SwingPtrs s{in->joint_position, in->joint_velocity, in->joint_velocity_oldest, in->target_foot_position,
+              in->target_foot_velocity, in->id_joint_position, in->support_leg};
+  SwingBranchPtrs sb{extra->base_orientation, extra->joint_command, extra->leg_mode, extra->pid_error_last,
+                     extra->pid_error_integral};
+  double *d_eff = joint_effort;
+  Staged sg;
+  if (memory == QLAMD_MEM_HOST) {
+    const int a0 = sg.add(in->joint_position, B * 96, true, false), a1 = sg.add(in->joint_velocity, B * 96, true, false);
+    const int a2 = sg.add(in->joint_velocity_oldest, B * 96, true, false);
+    const int a3 = sg.add(in->target_foot_position, B * 96, true, false);
+    const int a4 = sg.add(in->target_foot_velocity, B * 96, true, false);
+    const int a5 = sg.add(in->id_joint_position, B * 96, true, false), a6 = sg.add(in->support_leg, B * 4, true, false);
+    const int b0 = sg.add(extra->base_orientation, B * 32, true, false), b1 = sg.add(extra->joint_command, B * 96, true, false);
+    const int b2 = sg.add(extra->leg_mode, B * 4, true, false);
+    const int b3 = sg.add(extra->pid_error_last, B * 96, true, true), b4 = sg.add(extra->pid_error_integral, B * 96, true, true);
+    const int e0 = sg.add(joint_effort, B * 96, true, true);
+    const int rc = sg.upload(ctx, st);
+    if (rc != QLAMD_OK) return rc;
+    s = SwingPtrs{sg.dev<const double>(a0), sg.dev<const double>(a1), sg.dev<const double>(a2), sg.dev<const double>(a3),
+                  sg.dev<const double>(a4), sg.dev<const double>(a5), sg.dev<const uint8_t>(a6)};
+    sb = SwingBranchPtrs{sg.dev<const double>(b0), sg.dev<const double>(b1), sg.dev<const uint8_t>(b2), sg.dev<double>(b3),
+                         sg.dev<double>(b4)};
+    d_eff = sg.dev<double>(e0);
+  }
+  hipLaunchKernelGGL(swing_branch_kernel, dim3((unsigned)((4 * batch + 63) / 64)), dim3(64), 0, st, ctx->d_params, SP, PD,
+                     s, sb, period, batch, d_eff);
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  return memory == QLAMD_MEM_HOST ? sg.finish(st) : QLAMD_OK;
 }
 
 void qlamd_pose_default_params(qlamd_pose_params *p) {

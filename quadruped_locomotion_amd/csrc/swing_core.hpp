@@ -119,4 +119,58 @@ QL_HD void swing_leg_torque(const Tab &tab, const SwingParamsDev &P, const doubl
   QL_UNROLL for (int j = 0; j < 3; j++) tau[j] = (J[j] * f[0] + J[3 + j] * f[1] + J[6 + j] * f[2]) + tid[j];
 }
 
+// ---- the swing branch of RosBalanceController::update (ros_balance_controller.cpp:467-603,720-756) -------
+struct PidParamsDev {
+  double p[12], i[12], d[12], i_max[12], i_min[12], lower[12], upper[12];
+  int antiwindup;
+};
+
+QL_HD double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+QL_HD bool finite_d(double v) { return v == v && v - v == 0.0; }
+
+// control_toolbox::Pid::computeCommand(error, dt) (third-party, restated; see oracle_swing.h)
+QL_HD double pid_command(const PidParamsDev &g, int j, double error, double dt, double &e_last, double &e_int) {
+  if (dt == 0.0 || !finite_d(error)) return 0.0;
+  double error_dot = 0.0;
+  if (dt > 0.0) {
+    error_dot = (error - e_last) / dt;
+    e_last = error;
+  }
+  if (!finite_d(error_dot)) return 0.0;
+  const double p_term = g.p[j] * error;
+  e_int += dt * error;
+  if (g.antiwindup && g.i[j] != 0.0) {
+    const double a = g.i_min[j] / g.i[j], b = g.i_max[j] / g.i[j];
+    e_int = clampd(e_int, a < b ? a : b, a < b ? b : a);
+  }
+  double i_term = g.i[j] * e_int;
+  if (!g.antiwindup) i_term = clampd(i_term, g.i_min[j], g.i_max[j]);
+  return p_term + i_term + g.d[j] * error_dot;
+}
+
+// One non-support leg: joint PID on the position command, gravity compensation, or the swing-leg torque,
+// selected by the leg mode (1 "joint", 2 "leg_mode", 3 "cartesian", 4 "footstep", 0 never set = as "joint").
+template <class Tab>
+QL_HD void swing_branch_leg(const Tab &tab, const SwingParamsDev &SP, const PidParamsDev &pid, int leg, int leg_mode,
+                            const double base_quat[4], const double q_id[3], const double q[3], const double qd[3],
+                            const double qd_oldest[3], const double target_pos[3], const double target_vel[3],
+                            const double joint_command[3], double period, double e_last[3], double e_int[3],
+                            double effort[3]) {
+  double Rm[9], g[3], foot[3], J[9], G[3], tsw[3];
+  quat_to_matrix(base_quat, Rm);
+  const double gW[3] = {0.0, 0.0, -9.8};
+  rot(Rm, gW, g); // base_orientation.rotate(...), :471 -- as the reference writes it
+  leg_kinematics(tab, q, g, foot, J, G);
+  swing_leg_torque(tab, SP, q_id, q, qd, qd_oldest, target_pos, target_vel, tsw);
+  QL_UNROLL for (int k = 0; k < 3; k++) {
+    const int j = 3 * leg + k;
+    const double cmd = clampd(joint_command[k], pid.lower[j], pid.upper[j]); // enforceJointLimits
+    double e = pid_command(pid, j, cmd - q[k], period, e_last[k], e_int[k]);
+    if (leg_mode == 3 || leg_mode == 4) e = tsw[k];
+    else if (leg_mode != 2) e += G[k];
+    else e = G[k];
+    effort[k] = e;
+  }
+}
+
 } // namespace qlamd

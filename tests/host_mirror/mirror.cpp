@@ -220,6 +220,20 @@ extern "C" void mirror_swing_leg(int leg, const SwingParamsDev *SP, const double
   swing_leg_torque(P.legtab + kTabPerLeg * leg, *SP, q_id, q, qd, qd_old, tp, tv, tau);
 }
 
+extern "C" void mirror_swing_branch_leg(int leg, int leg_mode, const SwingParamsDev *SP, const PidParamsDev *pid,
+                                        const double *quat, const double *q_id, const double *q, const double *qd,
+                                        const double *qd_old, const double *tp, const double *tv, const double *cmd,
+                                        double period, double *e_last, double *e_int, double *effort) {
+  qlamd_balance_params prm;
+  default_balance_params(&prm);
+  qlamd_robot_model model;
+  default_robot_model(&model);
+  DeviceParams P;
+  build_device_params(prm, model, &P);
+  swing_branch_leg(P.legtab + kTabPerLeg * leg, *SP, *pid, leg, leg_mode, quat, q_id, q, qd, qd_old, tp, tv, cmd, period,
+                   e_last, e_int, effort);
+}
+
 extern "C" int mirror_qp6_solve(int p, int m, const double *G, const double *g0, const double *CE, double ce0,
                                 const double *CI, const double *ci0, double *x, double *f) {
   HostScr<Gi6Layout::kTotal> s;
