@@ -54,6 +54,13 @@ void oracle_sym4_eigen(const double C[16], double w[4], double V[16]) {
       V[4 * i + j] = i == j ? 1.0 : 0.0;
     }
   for (int sweep = 0; sweep < 12; sweep++) {
+    /* converged when the off-diagonal mass is below 1e-20 of the diagonal's (quadratic convergence: 4-6 sweeps) */
+    double off = 0.0, dia = 0.0;
+    for (int p = 0; p < 4; p++) {
+      dia += fabs(A[5 * p]);
+      for (int q = p + 1; q < 4; q++) off += fabs(A[4 * p + q]);
+    }
+    if (off <= 1e-20 * dia) break;
     for (int p = 0; p < 3; p++)
       for (int q = p + 1; q < 4; q++) {
         const double apq = A[4 * p + q];

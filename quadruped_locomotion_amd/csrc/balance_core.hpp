@@ -41,9 +41,13 @@
 #if defined(__HIPCC__)
 #define QL_HD __host__ __device__ __forceinline__
 #define QL_UNROLL _Pragma("unroll")
+#define QL_NOUNROLL _Pragma("nounroll")
+#define QL_HD_CALL __host__ __device__ __attribute__((noinline)) // real calls: keeps cold straight-line code small
 #else
 #define QL_HD inline
 #define QL_UNROLL
+#define QL_NOUNROLL
+#define QL_HD_CALL inline
 #endif
 
 namespace qlamd {

@@ -463,24 +463,38 @@ __global__ __launch_bounds__(256) void leg_state_kernel(const LegStatePtrs s, in
     r.store_flag[l] = ((sto >> (8 * l)) & 0xFFu) != 0;
     r.phase[l] = ph[l];
   }
+  // every array the tick may touch is fetched up front (independent 16-byte loads, one round trip); what
+  // the state machine decides only selects which values are written back
+  double jp[12], sj[12], ft[12];
+  {
+    const double2 *pj = reinterpret_cast<const double2 *>(s.joint_position + 12 * i);
+    const double2 *ps = reinterpret_cast<const double2 *>(s.stored_joint_position + 12 * i);
+    const double2 *pf = reinterpret_cast<const double2 *>(s.foot_target + 12 * i);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const double2 a = pj[k], b = ps[k], c = pf[k];
+      jp[2 * k] = a.x; jp[2 * k + 1] = a.y; sj[2 * k] = b.x; sj[2 * k + 1] = b.y; ft[2 * k] = c.x; ft[2 * k + 1] = c.y;
+    }
+  }
+  const uint32_t sup_i = *reinterpret_cast<const uint32_t *>(s.support + 4 * i);
   leg_state_machine(r, index_quirk != 0);
   uint32_t lst_o = 0, sto_o = 0, code_o = 0;
-  uint32_t sup_o = *reinterpret_cast<const uint32_t *>(s.support + 4 * i);
+  uint32_t sup_o = sup_i;
 #pragma unroll
   for (int l = 0; l < 4; l++) {
     lst_o |= (uint32_t)(uint8_t)(int8_t)r.limb_state[l] << (8 * l);
     sto_o |= (r.store_flag[l] ? 1u : 0u) << (8 * l);
     code_o |= (uint32_t)(uint8_t)(int8_t)r.code[l] << (8 * l);
     if (r.support_written[l]) sup_o = (sup_o & ~(0xFFu << (8 * l))) | ((r.support[l] ? 1u : 0u) << (8 * l));
-    if (r.nudge_bumped[l]) { s.foot_target[12 * i + 3 * l] -= 0.005; s.foot_target[12 * i + 3 * l + 2] += 0.02; }
-    if (r.nudge_late[l]) s.foot_target[12 * i + 3 * l + 2] -= 0.01;
+    if (r.nudge_bumped[l]) { s.foot_target[12 * i + 3 * l] = ft[3 * l] - 0.005; s.foot_target[12 * i + 3 * l + 2] = ft[3 * l + 2] + 0.02; }
+    if (r.nudge_late[l]) s.foot_target[12 * i + 3 * l + 2] = ft[3 * l + 2] - 0.01;
     if (r.capture[l]) {
 #pragma unroll
-      for (int k = 0; k < 3; k++) s.stored_joint_position[12 * i + 3 * l + k] = s.joint_position[12 * i + 3 * l + k];
+      for (int k = 0; k < 3; k++) s.stored_joint_position[12 * i + 3 * l + k] = jp[3 * l + k];
     }
     if (r.hold[l]) {
 #pragma unroll
-      for (int k = 0; k < 3; k++) s.joint_command[12 * i + 3 * l + k] = s.stored_joint_position[12 * i + 3 * l + k];
+      for (int k = 0; k < 3; k++) s.joint_command[12 * i + 3 * l + k] = sj[3 * l + k];
     }
   }
   *reinterpret_cast<uint32_t *>(s.limb_state + 4 * i) = lst_o;
@@ -496,30 +510,229 @@ struct RobotStateOutPtrs {
   uint8_t *support_leg, *leg_mode;
 };
 
+// Byte source in LDS: aligned 32-bit reads joined with v_alignbyte (fields sit at arbitrary byte offsets).
+struct LdsBytes {
+  static constexpr bool kOverread = true; // the staging window extends 16 bytes past the last message
+  const uint32_t *w; // LDS, word-aligned base
+  uint32_t shift;    // byte position of message offset 0 relative to w
+  __device__ __forceinline__ uint32_t u32(uint32_t at) const {
+    const uint32_t b = at + shift;
+    const uint32_t lo = w[b >> 2], hi = w[(b >> 2) + 1];
+    return __builtin_amdgcn_alignbyte(hi, lo, b & 3u);
+  }
+  __device__ __forceinline__ uint8_t u8(uint32_t at) const {
+    const uint32_t b = at + shift;
+    return (uint8_t)(w[b >> 2] >> (8 * (b & 3u)));
+  }
+  __device__ __forceinline__ double f64(uint32_t at) const {
+    const uint32_t b = at + shift;
+    const uint32_t w0 = w[b >> 2], w1 = w[(b >> 2) + 1], w2 = w[(b >> 2) + 2];
+    const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, b & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, b & 3u);
+    return __hiloint2double((int)hi, (int)lo);
+  }
+};
+
+// Two-pass walk over a message staged in LDS.  Pass 1 follows only the length fields (the one true dependency
+// chain: every string / array length decides where the next field starts) and notes where the wanted payload
+// sits; pass 2 reads the payload at those anchors with independent loads.  Same results as robot_state_unpack
+// (wire_core.hpp), which stays the reference implementation for the host build and the global-memory fallback.
+struct WireSkeleton {
+  const LdsBytes &p;
+  uint32_t pos, cap; // cap = len + 1; pos saturates there ("bad")
+  __device__ __forceinline__ void skip(uint32_t n) { pos = min(pos + min(n, cap), cap); }
+  __device__ __forceinline__ uint32_t len_field() { // read a uint32 at pos, step over it
+    const uint32_t v = p.u32(min(pos, cap - 1));
+    skip(4);
+    return v;
+  }
+  __device__ __forceinline__ void header() { skip(12); skip(len_field()); }
+};
+
+enum WireAnchor : int { // uint32 slots per message
+  kAnJointPos = 0,      // [4] start of *_leg_joints.position data
+  kAnOdomPose = 4,      // start of base_pose.pose.pose.position
+  kAnModeName = 5,      // [4] start of *_leg_mode.name bytes
+  kAnModeLen = 9,       // [4] its length
+  kAnModeFlag = 13,     // [4] support_leg byte
+  kAnModeNormal = 17,   // [4] surface_normal.vector
+  kAnTarget = 21,       // [4][3] target_{position,velocity,acceleration}[0] payload
+  kAnJointCnt = 33,     // [4] number of entries in *_leg_joints.position
+  kAnCount = 37
+};
+
+__device__ __forceinline__ int wire_lds_unpack(const LdsBytes &src, int64_t len64, RobotStateFields &f, uint32_t *an) {
+  if (len64 < 0 || len64 > 0x7FFFFFF0ll) return kWireTruncated;
+  const uint32_t len = (uint32_t)len64;
+  WireSkeleton c{src, 0u, len + 1u};
+  bool missing = false;
+  // ---- pass 1: skeleton
+#pragma nounroll
+  for (int l = 0; l < 4; l++) { // sensor_msgs/JointState
+    c.header();
+    uint32_t nn = c.len_field();
+#pragma nounroll
+    for (; nn > 0 && c.pos < c.cap; nn--) c.skip(c.len_field());
+    const uint32_t np = c.len_field();
+    missing = missing || np < 3;
+    an[kAnJointPos + l] = c.pos;
+    an[kAnJointCnt + l] = np;
+    c.skip(np > 0x0FFFFFFFu ? 0xFFFFFFFFu : 8u * np);
+    const uint32_t nv = c.len_field(); c.skip(nv > 0x0FFFFFFFu ? 0xFFFFFFFFu : 8u * nv);
+    const uint32_t ne = c.len_field(); c.skip(ne > 0x0FFFFFFFu ? 0xFFFFFFFFu : 8u * ne);
+  }
+  c.header();                       // nav_msgs/Odometry
+  c.skip(c.len_field());            // child_frame_id
+  an[kAnOdomPose] = c.pos;
+  c.skip(56 + 288 + 48 + 288);
+#pragma nounroll
+  for (int l = 0; l < 4; l++) {     // free_gait_msgs/LegMode
+    const uint32_t n = c.len_field();
+    an[kAnModeName + l] = c.pos;
+    an[kAnModeLen + l] = n;
+    c.skip(n);
+    an[kAnModeFlag + l] = c.pos;
+    c.skip(1 + 8 + 8);              // support_leg, duration, phase
+    c.header();
+    an[kAnModeNormal + l] = c.pos;
+    c.skip(24 + 1);
+  }
+#pragma nounroll
+  for (int l = 0; l < 4; l++) {     // free_gait_msgs/EndEffectorTarget
+    c.skip(c.len_field());          // name
+#pragma nounroll
+    for (int arr = 0; arr < 4; arr++) {
+      uint32_t n = c.len_field();
+      if (arr < 3) missing = missing || n == 0;
+#pragma nounroll
+      for (uint32_t k = 0; k < n && c.pos < c.cap; k++) {
+        c.header();
+        if (k == 0 && arr < 3) an[kAnTarget + 3 * l + arr] = c.pos;
+        c.skip(24);
+      }
+    }
+    c.skip(8);                      // average_velocity
+    c.header();
+    c.skip(24 + 2);                 // surface_normal.vector, ignore_contact, ignore_for_pose_adaptation
+  }
+  if (c.pos >= c.cap) return kWireTruncated; // some field ran past the end: the record stays cleared
+  // ---- pass 2: payload (independent reads)
+#pragma unroll
+  for (int l = 0; l < 4; l++) {
+    const uint32_t at = an[kAnJointPos + l];
+    const uint32_t np = an[kAnJointCnt + l]; // fewer than 3 entries: flagged missing, keep what exists
+    if (np > 0) f.joint_command[3 * l] = src.f64(at);
+    if (np > 1) f.joint_command[3 * l + 1] = src.f64(at + 8);
+    if (np > 2) f.joint_command[3 * l + 2] = src.f64(at + 16);
+  }
+  {
+    const uint32_t at = an[kAnOdomPose];
+    f.des_pos[0] = src.f64(at); f.des_pos[1] = src.f64(at + 8); f.des_pos[2] = src.f64(at + 16);
+    f.des_quat[1] = src.f64(at + 24); f.des_quat[2] = src.f64(at + 32); f.des_quat[3] = src.f64(at + 40); f.des_quat[0] = src.f64(at + 48);
+    const uint32_t tw = at + 56 + 288;
+    f.des_linvel[0] = src.f64(tw); f.des_linvel[1] = src.f64(tw + 8); f.des_linvel[2] = src.f64(tw + 16);
+    f.des_angvel[0] = src.f64(tw + 24); f.des_angvel[1] = src.f64(tw + 32); f.des_angvel[2] = src.f64(tw + 40);
+  }
+#pragma unroll
+  for (int l = 0; l < 4; l++) {
+    const uint32_t nm = an[kAnModeName + l], nl = an[kAnModeLen + l];
+    // "joint" 5, "leg_mode" 8, "cartesian" 9, "footstep" 8: compare 12 bytes read as three words against the literals
+    const uint32_t w0 = src.u32(nm), w1 = src.u32(nm + 4), w2 = src.u32(nm + 8);
+    int mode = kModeOther;
+    if (nl == 5 && w0 == 0x6E696F6Au && (w1 & 0xFFu) == 0x74u) mode = kModeJoint;                    // "join" "t"
+    else if (nl == 8 && w0 == 0x5F67656Cu && w1 == 0x65646F6Du) mode = kModeLegMode;                // "leg_" "mode"
+    else if (nl == 9 && w0 == 0x74726163u && w1 == 0x61697365u && (w2 & 0xFFu) == 0x6Eu) mode = kModeCartesian; // "cart" "esia" "n"
+    else if (nl == 8 && w0 == 0x746F6F66u && w1 == 0x70657473u) mode = kModeFootstep;               // "foot" "step"
+    f.leg_mode[l] = (uint8_t)mode;
+    const uint32_t fl = an[kAnModeFlag + l];
+    f.support_leg[l] = src.u8(fl) != 0;
+    f.phase[l] = src.f64(fl + 9);
+    const uint32_t nv = an[kAnModeNormal + l];
+    f.surface_normal[3 * l] = src.f64(nv); f.surface_normal[3 * l + 1] = src.f64(nv + 8); f.surface_normal[3 * l + 2] = src.f64(nv + 16);
+  }
+#pragma unroll
+  for (int l = 0; l < 4; l++) {
+#pragma unroll
+    for (int arr = 0; arr < 3; arr++) {
+      const uint32_t at = an[kAnTarget + 3 * l + arr];
+      if (at == 0u) continue; // empty array (flagged missing): nothing to copy
+      double *dst = arr == 0 ? f.foot_position : arr == 1 ? f.foot_velocity : f.foot_acceleration;
+      dst[3 * l] = src.f64(at); dst[3 * l + 1] = src.f64(at + 8); dst[3 * l + 2] = src.f64(at + 16);
+    }
+  }
+  return missing ? kWireMissingField : kWireOk;
+}
+
+constexpr int kWireMsgsPerBlock = 4;          // messages parsed per 64-lane block (one lane each)
+constexpr int kWireLdsBytes = 32 * 1024;      // staging window; longer runs are parsed straight from global memory
+
+// One block = kWireMsgsPerBlock consecutive messages: the block copies their contiguous byte range into LDS with
+// coalesced 16-byte loads, one lane per message walks the length-prefixed fields out of LDS (the walk is a chain
+// of dependent reads: ~100 cycles each from LDS instead of a DRAM round trip each from global memory) into a
+// per-message record in LDS, and the whole block writes the records out.
 __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *__restrict__ messages,
                                                                 const int64_t *__restrict__ offsets, int64_t B,
                                                                 const RobotStateOutPtrs o, int32_t *__restrict__ status) {
-  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= B) return;
-  RobotStateFields f;
-  memset(&f, 0, sizeof(f));
-  const int64_t a = offsets[i], b = offsets[i + 1];
-  const int st = robot_state_unpack(messages + a, b - a, f);
-  const auto put = [&](double *dst, const double *src, int n) {
-    if (!dst) return;
-    for (int k = 0; k < n; k++) dst[(int64_t)n * i + k] = src[k];
-  };
-  put(o.des_pos, f.des_pos, 3); put(o.des_quat, f.des_quat, 4);
-  put(o.des_linvel, f.des_linvel, 3); put(o.des_angvel, f.des_angvel, 3);
-  put(o.joint_command, f.joint_command, 12);
-  put(o.foot_position, f.foot_position, 12); put(o.foot_velocity, f.foot_velocity, 12);
-  put(o.foot_acceleration, f.foot_acceleration, 12);
-  put(o.surface_normal, f.surface_normal, 12); put(o.phase, f.phase, 4);
-  for (int l = 0; l < 4; l++) {
-    if (o.support_leg) o.support_leg[4 * i + l] = f.support_leg[l];
-    if (o.leg_mode) o.leg_mode[4 * i + l] = f.leg_mode[l];
+  extern __shared__ uint32_t wire_lds[];
+  __shared__ RobotStateFields rec[kWireMsgsPerBlock];
+  __shared__ uint32_t anchors[kWireMsgsPerBlock][kAnCount];
+  const int tid = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.x * kWireMsgsPerBlock;
+  const int n = (int)((B - i0) < kWireMsgsPerBlock ? (B - i0) : kWireMsgsPerBlock);
+  const int64_t a = offsets[i0], b = offsets[i0 + n];
+  const uintptr_t src = (uintptr_t)(messages + a);
+  const uintptr_t src_al = src & ~(uintptr_t)15;
+  const int64_t lead = (int64_t)(src - src_al), nbytes = lead + (b - a);
+  const bool staged = nbytes + 16 <= kWireLdsBytes; // +16: u32 / f64 reads may touch the next two words
+  if (staged) {
+    const int64_t full = nbytes >> 4;
+    const uint4 *g = (const uint4 *)src_al;
+    uint4 *l4 = (uint4 *)wire_lds;
+    // eight 16-byte loads in flight per lane before the first LDS store (a load-store-load-store chain would
+    // pay one DRAM latency per kilobyte)
+    int64_t k = tid;
+    for (; k + 64 * 7 < full; k += 64 * 8) {
+      const uint4 v0 = g[k], v1 = g[k + 64], v2 = g[k + 128], v3 = g[k + 192], v4 = g[k + 256], v5 = g[k + 320],
+                  v6 = g[k + 384], v7 = g[k + 448];
+      l4[k] = v0; l4[k + 64] = v1; l4[k + 128] = v2; l4[k + 192] = v3; l4[k + 256] = v4; l4[k + 320] = v5;
+      l4[k + 384] = v6; l4[k + 448] = v7;
+    }
+    for (; k < full; k += 64) l4[k] = g[k];
+    const int64_t tail0 = full << 4;                 // last partial chunk byte by byte: never read past the blob
+    if (tid < nbytes - tail0) ((uint8_t *)wire_lds)[tail0 + tid] = ((const uint8_t *)src_al)[tail0 + tid];
   }
-  status[i] = st;
+  // clear the records (fields a malformed message never reaches read as zero)
+  for (int w = tid; w < (int)(sizeof(rec) / 4); w += 64) ((uint32_t *)rec)[w] = 0u;
+  for (int w = tid; w < kWireMsgsPerBlock * kAnCount; w += 64) (&anchors[0][0])[w] = 0u;
+  __syncthreads();
+  if (tid < n) {
+    const int64_t ma = offsets[i0 + tid], mb = offsets[i0 + tid + 1];
+    int st;
+    if (ma < a || mb > b || mb < ma) st = kWireTruncated; // offsets not ascending: nothing to parse
+    else if (staged) st = wire_lds_unpack(LdsBytes{wire_lds, (uint32_t)(lead + (ma - a))}, mb - ma, rec[tid], anchors[tid]);
+    else st = robot_state_unpack(PlainBytes{messages + ma}, mb - ma, rec[tid]);
+    status[i0 + tid] = st;
+  }
+  __syncthreads();
+  // write-out: message m's k doubles of each field are contiguous in the output arrays
+  const auto put = [&](double *dst, int width, size_t field_off) {
+    if (!dst) return;
+    for (int e = tid; e < n * width; e += 64) {
+      const int m = e / width, k2 = e - m * width;
+      dst[(int64_t)width * i0 + e] = ((const double *)((const char *)&rec[m] + field_off))[k2];
+    }
+  };
+  put(o.des_pos, 3, offsetof(RobotStateFields, des_pos)); put(o.des_quat, 4, offsetof(RobotStateFields, des_quat));
+  put(o.des_linvel, 3, offsetof(RobotStateFields, des_linvel)); put(o.des_angvel, 3, offsetof(RobotStateFields, des_angvel));
+  put(o.joint_command, 12, offsetof(RobotStateFields, joint_command));
+  put(o.foot_position, 12, offsetof(RobotStateFields, foot_position));
+  put(o.foot_velocity, 12, offsetof(RobotStateFields, foot_velocity));
+  put(o.foot_acceleration, 12, offsetof(RobotStateFields, foot_acceleration));
+  put(o.surface_normal, 12, offsetof(RobotStateFields, surface_normal)); put(o.phase, 4, offsetof(RobotStateFields, phase));
+  if (tid < 4 * n) {
+    const int m = tid >> 2, l = tid & 3;
+    if (o.support_leg) o.support_leg[4 * i0 + tid] = rec[m].support_leg[l];
+    if (o.leg_mode) o.leg_mode[4 * i0 + tid] = rec[m].leg_mode[l];
+  }
 }
 
 // ---- dense QP batch: one problem per lane, 8 problems per wavefront, arrays in LDS ------------
@@ -1030,8 +1243,8 @@ int qlamd_robot_state_unpack_batch(qlamd_context *ctx, const uint8_t *messages, 
     d_off = (const int64_t *)(w + off[kD + 3]);
     d_msg = (const uint8_t *)(w + off[kD + 4]) - offsets[0]; // the kernel indexes with the caller's offsets
   }
-  hipLaunchKernelGGL(robot_state_unpack_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, d_msg, d_off, batch,
-                     o, d_st);
+  hipLaunchKernelGGL(robot_state_unpack_kernel, dim3((unsigned)((batch + kWireMsgsPerBlock - 1) / kWireMsgsPerBlock)),
+                     dim3(64), kWireLdsBytes, st, d_msg, d_off, batch, o, d_st);
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   if (memory == QLAMD_MEM_HOST) {
     char *w = (char *)ctx->ws;

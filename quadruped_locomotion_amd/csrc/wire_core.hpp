@@ -17,43 +17,56 @@ namespace qlamd {
 enum WireStatus : int { kWireOk = 0, kWireTruncated = 1, kWireMissingField = 2 };
 enum LegModeName : int { kModeOther = 0, kModeJoint = 1, kModeLegMode = 2, kModeCartesian = 3, kModeFootstep = 4 };
 
-struct WireCursor {
+// Byte source: plain memory (host build, or a device pointer into global memory).  kOverread = false: the cursor
+// never reads a byte at or beyond the message end.
+struct PlainBytes {
+  static constexpr bool kOverread = false;
   const uint8_t *p;
-  int64_t pos, len;
-  bool bad;
+  QL_HD uint8_t u8(uint32_t at) const { return p[at]; }
+  QL_HD uint32_t u32(uint32_t at) const { uint32_t v; memcpy(&v, p + at, 4); return v; }
+  QL_HD double f64(uint32_t at) const { double v; memcpy(&v, p + at, 8); return v; }
+};
 
-  QL_HD bool need(int64_t n) {
-    if (bad || n < 0 || pos + n > len) { bad = true; return false; }
-    return true;
-  }
+// Positions are 32-bit and saturate at len + 1: once a length field points past the end the cursor stays "bad"
+// and every later read returns 0 (or, for an over-readable source, harmless bytes of the staging window).
+template <class Bytes>
+struct WireCursor {
+  Bytes p;
+  uint32_t pos, len;
+
+  QL_HD bool bad() const { return pos > len; }
+  QL_HD void skip(uint32_t n) { pos = (n >= len + 1 - pos) ? len + 1 : pos + n; } // sticky: room is 0 once bad
+  QL_HD void skip64(uint64_t n) { skip(n > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n); }
   QL_HD uint32_t u32() {
-    if (!need(4)) return 0;
     uint32_t v;
-    memcpy(&v, p + pos, 4);
-    pos += 4;
-    return v;
+    if (Bytes::kOverread) v = p.u32(pos > len ? len : pos);
+    else v = (pos <= len && len - pos >= 4) ? p.u32(pos) : 0u;
+    skip(4);
+    return bad() ? 0u : v;
   }
   QL_HD uint8_t u8() {
-    if (!need(1)) return 0;
-    return p[pos++];
+    uint8_t v;
+    if (Bytes::kOverread) v = p.u8(pos > len ? len : pos);
+    else v = (pos < len) ? p.u8(pos) : (uint8_t)0;
+    skip(1);
+    return bad() ? (uint8_t)0 : v;
   }
   QL_HD double f64() {
-    if (!need(8)) return 0.0;
     double v;
-    memcpy(&v, p + pos, 8);
-    pos += 8;
-    return v;
+    if (Bytes::kOverread) v = p.f64(pos > len ? len : pos);
+    else v = (pos <= len && len - pos >= 8) ? p.f64(pos) : 0.0;
+    skip(8);
+    return bad() ? 0.0 : v;
   }
-  QL_HD void skip(int64_t n) { if (need(n)) pos += n; }
   QL_HD void skip_string() { const uint32_t n = u32(); skip(n); }
   QL_HD void skip_header() { skip(12); skip_string(); } // seq, stamp, frame_id
-  QL_HD void vec3(double v[3]) { v[0] = f64(); v[1] = f64(); v[2] = f64(); }
-  // does the string at the cursor equal `lit` (length n)?  Consumes the string.
-  QL_HD bool string_is(const char *lit, uint32_t n, uint32_t slen, int64_t start) const {
+  // does the string of length slen that starts at `start` equal `lit` (length n)?  Only called when the string
+  // lies inside the message.
+  QL_HD bool string_is(const char *lit, uint32_t n, uint32_t slen, uint32_t start) const {
     if (slen != n) return false;
-    for (uint32_t k = 0; k < n; k++)
-      if (p[start + k] != (uint8_t)lit[k]) return false;
-    return true;
+    bool same = true;
+    QL_NOUNROLL for (uint32_t k = 0; k < n; k++) same = same && (p.u8(start + k) == (uint8_t)lit[k]);
+    return same;
   }
 };
 
@@ -66,55 +79,59 @@ struct RobotStateFields {
 };
 
 // sensor_msgs/JointState: keep position[0..2] (:802-812)
-QL_HD void wire_joint_state(WireCursor &c, double q[3], bool &missing) {
+template <class Cur>
+QL_HD void wire_joint_state(Cur &c, double *q, bool &missing) {
   c.skip_header();
   const uint32_t nn = c.u32();
-  for (uint32_t k = 0; k < nn && !c.bad; k++) c.skip_string();
+  QL_NOUNROLL for (uint32_t k = 0; k < nn && !c.bad(); k++) c.skip_string();
   const uint32_t np = c.u32();
   if (np < 3) missing = true;
-  for (uint32_t k = 0; k < np && !c.bad; k++) {
-    const double v = c.f64();
-    if (k < 3) q[k] = v;
-  }
-  const uint32_t nv = c.u32(); c.skip(8 * (int64_t)nv);
-  const uint32_t ne = c.u32(); c.skip(8 * (int64_t)ne);
+  const uint32_t keep = np < 3 ? np : 3;
+  QL_NOUNROLL for (uint32_t k = 0; k < keep; k++) q[k] = c.f64();
+  c.skip64(8 * ((uint64_t)np - keep));
+  const uint32_t nv = c.u32(); c.skip64(8 * (uint64_t)nv);
+  const uint32_t ne = c.u32(); c.skip64(8 * (uint64_t)ne);
 }
 
-// geometry_msgs/{Point,Vector3}Stamped[]: keep element 0 (:820-861), skip the rest
-QL_HD void wire_stamped_array(WireCursor &c, double v0[3], bool required, bool &missing) {
+// geometry_msgs/{Point,Vector3}Stamped[]: keep element 0 (:820-861) when `v0` is given, walk over the rest
+template <class Cur>
+QL_HD void wire_stamped_array(Cur &c, double *v0, bool &missing) {
   const uint32_t n = c.u32();
-  if (n == 0 && required) missing = true;
-  for (uint32_t k = 0; k < n && !c.bad; k++) {
+  if (n == 0 && v0) missing = true;
+  QL_NOUNROLL for (uint32_t k = 0; k < n && !c.bad(); k++) {
     c.skip_header();
-    double v[3];
-    c.vec3(v);
-    if (k == 0) { v0[0] = v[0]; v0[1] = v[1]; v0[2] = v[2]; }
+    if (k == 0 && v0) { v0[0] = c.f64(); v0[1] = c.f64(); v0[2] = c.f64(); }
+    else c.skip(24);
   }
 }
 
-QL_HD int robot_state_unpack(const uint8_t *msg, int64_t len, RobotStateFields &f) {
-  WireCursor c{msg, 0, len, false};
+// `f` is indexed with run-time limb numbers on purpose (compact code: the walk is latency-bound, not issue-bound);
+// on the device the caller keeps it in LDS, where run-time indexing is free.
+template <class Bytes>
+QL_HD int robot_state_unpack(const Bytes &msg, int64_t len, RobotStateFields &f) {
+  if (len < 0 || len > 0x7FFFFFF0ll) return kWireTruncated;
+  WireCursor<Bytes> c{msg, 0u, (uint32_t)len};
   bool missing = false;
-  for (int l = 0; l < 4; l++) wire_joint_state(c, f.joint_command + 3 * l, missing); // lf, rf, rh, lh
+  QL_NOUNROLL for (int l = 0; l < 4; l++) wire_joint_state(c, f.joint_command + 3 * l, missing); // lf, rf, rh, lh
   // nav_msgs/Odometry base_pose (:763-777)
   c.skip_header();
   c.skip_string();               // child_frame_id
-  c.vec3(f.des_pos);
+  for (int k = 0; k < 3; k++) f.des_pos[k] = c.f64();
   {
     const double x = c.f64(), y = c.f64(), z = c.f64(), w = c.f64(); // geometry_msgs/Quaternion is x, y, z, w
     f.des_quat[0] = w; f.des_quat[1] = x; f.des_quat[2] = y; f.des_quat[3] = z;
   }
   c.skip(36 * 8);
-  c.vec3(f.des_linvel);
-  c.vec3(f.des_angvel);
+  for (int k = 0; k < 3; k++) f.des_linvel[k] = c.f64();
+  for (int k = 0; k < 3; k++) f.des_angvel[k] = c.f64();
   c.skip(36 * 8);
   // free_gait_msgs/LegMode x4 (:876-1078)
-  for (int l = 0; l < 4; l++) {
+  QL_NOUNROLL for (int l = 0; l < 4; l++) {
     const uint32_t n = c.u32();
-    const int64_t start = c.pos;
+    const uint32_t start = c.pos;
     c.skip(n);
     int mode = kModeOther;
-    if (!c.bad) {
+    if (!c.bad()) {
       if (c.string_is("joint", 5, n, start)) mode = kModeJoint;
       else if (c.string_is("leg_mode", 8, n, start)) mode = kModeLegMode;
       else if (c.string_is("cartesian", 9, n, start)) mode = kModeCartesian;
@@ -125,23 +142,22 @@ QL_HD int robot_state_unpack(const uint8_t *msg, int64_t len, RobotStateFields &
     c.skip(8);                   // duration
     f.phase[l] = c.f64();
     c.skip_header();
-    c.vec3(f.surface_normal + 3 * l);
+    for (int k = 0; k < 3; k++) f.surface_normal[3 * l + k] = c.f64();
     c.skip(1);                   // ignore_for_pose_adaptation
   }
   // free_gait_msgs/EndEffectorTarget x4 (:816-861)
-  for (int l = 0; l < 4; l++) {
+  QL_NOUNROLL for (int l = 0; l < 4; l++) {
     c.skip_string();
-    double force[3];
-    wire_stamped_array(c, f.foot_position + 3 * l, true, missing);
-    wire_stamped_array(c, f.foot_velocity + 3 * l, true, missing);
-    wire_stamped_array(c, f.foot_acceleration + 3 * l, true, missing);
-    wire_stamped_array(c, force, false, missing);
+    wire_stamped_array(c, f.foot_position + 3 * l, missing);
+    wire_stamped_array(c, f.foot_velocity + 3 * l, missing);
+    wire_stamped_array(c, f.foot_acceleration + 3 * l, missing);
+    wire_stamped_array(c, (double *)nullptr, missing); // target_force
     c.skip(8);                   // average_velocity
     c.skip_header();
     c.skip(24);                  // surface_normal
     c.skip(2);                   // ignore_contact, ignore_for_pose_adaptation
   }
-  if (c.bad) return kWireTruncated;
+  if (c.bad()) return kWireTruncated;
   return missing ? kWireMissingField : kWireOk;
 }
 

@@ -193,7 +193,7 @@ extern "C" void mirror_leg_state_batch(int64_t B, const uint8_t *support_leg, co
 #include "wire_core.hpp"
 extern "C" int mirror_robot_state_unpack(const uint8_t *msg, int64_t len, RobotStateFields *out) {
   memset(out, 0, sizeof(*out));
-  return robot_state_unpack(msg, len, *out);
+  return robot_state_unpack(PlainBytes{msg}, len, *out);
 }
 
 // ---- analytic leg IK (row f4) ----

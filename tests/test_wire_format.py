@@ -119,6 +119,14 @@ def batch_of_messages(B, seed):
     raws, exps = zip(*[random_message(rng, ragged=k % 5 != 0) for k in range(B)])
     raws = list(raws)
     raws[3] = raws[3][:40]                                           # one truncated message in the batch
+    short = {"lf_leg_joints": dict(position=[0.5, 0.25])}            # position[2] missing, rh velocity target empty
+    for leg in LEGS:
+        short[f"{leg}_target"] = dict(target_position=[W.stamped("point", [1, 2, 3])], target_velocity=[W.stamped("vector", [4, 5, 6])],
+                                      target_acceleration=[W.stamped("vector", [7, 8, 9])])
+        if leg != "lf":
+            short[f"{leg}_leg_joints"] = dict(position=[0.1, 0.2, 0.3, 0.4])
+    short["rh_target"]["target_velocity"] = []
+    raws[5] = W.serialize("free_gait_msgs/RobotState", short)
     off = np.zeros(B + 1, np.int64)
     off[1:] = np.cumsum([len(r) for r in raws])
     return b"".join(raws), off, exps
@@ -136,7 +144,9 @@ def test_device_unpack_matches_oracle(oracle):
         assert st[i] == wst
         if wst == 0:
             same({k: v[i] for k, v in out.items()}, exps[i])
-    assert st[3] == 1 and (np.delete(st, 3) == 0).all()
+        elif wst == 2:                                              # a missing field: everything else is still delivered
+            same({k: v[i] for k, v in out.items()}, want)
+    assert st[3] == 1 and st[5] == 2 and (np.delete(st, [3, 5]) == 0).all()
     # a subset of outputs, non-zero first offset
     out2, st2 = capi.robot_state_unpack(ctx, b"\xAA" * 7 + blob, off + 7, want=("des_quat", "support_leg"))
     assert set(out2) == {"des_quat", "support_leg"} and np.array_equal(st2, st)

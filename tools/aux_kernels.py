@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""GPU probe: run every auxiliary entry (rows a2, a10-a18, f1-f4) a few times at batch 4096 so that
+`rocprofv3 --kernel-trace --stats` reports their kernel durations (profiles/r1/aux_kernels_*)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+
+from quadruped_locomotion_amd import capi, synth
+
+B, REPS = 4096, 5
+ctx = capi.Context()
+rng = np.random.default_rng(0)
+
+pb = synth.make_pose_problems(B)
+prm = capi.default_pose_params()
+for it in (1, 5):
+    prm.tolerance, prm.max_iterations = 0.0, it
+    for _ in range(REPS):
+        capi.pose_sqp(ctx, pb, prm)
+for _ in range(REPS):
+    capi.pose_qp(ctx, pb)
+    capi.pose_check(ctx, pb, np.full((B, 4), 0.1), 0.0)
+    capi.pose_geometric(ctx, pb)
+    capi.base_auto_optimize_pose(ctx, pb, None, np.full((B, 4), 0.1), 0.0)
+
+sw = synth.make_swing_inputs(B)
+st = synth.make_states(B, "trot")
+tpos = rng.uniform(-0.3, 0.3, (B, 12))
+eff = np.zeros((B, 12)); el = np.zeros((B, 12)); ei = np.zeros((B, 12))
+mode = rng.integers(0, 5, (B, 4)).astype(np.uint8)
+for _ in range(REPS):
+    capi.swing_leg_torque(ctx, sw["q"], sw["qd"], sw["qd_old"], tpos, sw["tvel"], sw["support"])
+    capi.swing_branch(ctx, eff, sw["q"], sw["qd"], sw["qd_old"], tpos, sw["tvel"], sw["support"], st["base_quat"], sw["q"], mode,
+                      el, ei, 0.0025)
+    capi.leg_inverse_kinematics(ctx, tpos, sw["q"])
+
+from test_leg_state import make_io
+io = make_io(B)
+for _ in range(REPS):
+    capi.leg_state_machine(ctx, io)
+
+from test_wire_format import batch_of_messages
+blob, off, _ = batch_of_messages(B, 1)
+print("wire bytes per message: %.0f" % (len(blob) / B))
+for _ in range(REPS):
+    capi.robot_state_unpack(ctx, blob, off)
+
+for _ in range(REPS):
+    ctx.balance_solve_host(st)
+    ctx.balance_solve_host(synth.make_states(B, "static"))
+print("done")
