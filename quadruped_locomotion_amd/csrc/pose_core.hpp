@@ -61,16 +61,21 @@ QL_HD void mm3(const double A[9], const double B[9], double C[9]) {
       C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
 }
 
+// The polygon helpers index the vertex array with compile-time constants only (loops unrolled to the maximum of
+// four vertices and predicated on nv): a run-time index would send the whole problem struct to scratch memory.
 // grid_map::Polygon::getCentroid (grid_map_core, restated; vertices counter-clockwise)
 QL_HD void polygon_centroid(int nv, const double poly[4][2], double c[2]) {
   double area = 0.0;
   c[0] = c[1] = 0.0;
-  for (int i = 0; i < nv; i++) {
-    const int k = (i + 1 == nv) ? 0 : i + 1;
-    const double cr = poly[i][0] * poly[k][1] - poly[k][0] * poly[i][1];
+  QL_UNROLL for (int i = 0; i < 4; i++) {
+    if (i >= nv) continue;
+    double nx[2]; // vertex (i + 1) mod nv
+    if (i + 1 < 4 && i + 1 != nv) { nx[0] = poly[i + 1 < 4 ? i + 1 : 0][0]; nx[1] = poly[i + 1 < 4 ? i + 1 : 0][1]; }
+    else { nx[0] = poly[0][0]; nx[1] = poly[0][1]; }
+    const double cr = poly[i][0] * nx[1] - nx[0] * poly[i][1];
     area += cr;
-    c[0] += cr * (poly[i][0] + poly[k][0]);
-    c[1] += cr * (poly[i][1] + poly[k][1]);
+    c[0] += cr * (poly[i][0] + nx[0]);
+    c[1] += cr * (poly[i][1] + nx[1]);
   }
   area *= 0.5;
   c[0] /= (6.0 * area);
@@ -80,18 +85,23 @@ QL_HD void polygon_centroid(int nv, const double poly[4][2], double c[2]) {
 // grid_map::Polygon::convertToInequalityConstraints: A x <= b, one row per non-degenerate edge
 QL_HD int polygon_halfspaces(int nv, const double poly[4][2], double A[4][2], double b[4]) {
   double c[2] = {0, 0};
-  for (int i = 0; i < nv; i++) { c[0] += poly[i][0]; c[1] += poly[i][1]; }
+  QL_UNROLL for (int i = 0; i < 4; i++)
+    if (i < nv) { c[0] += poly[i][0]; c[1] += poly[i][1]; }
   c[0] /= nv; c[1] /= nv;
   int rows = 0;
-  for (int i = 0; i < nv; i++) {
-    const int k = (i + 1 == nv) ? 0 : i + 1;
+  QL_UNROLL for (int i = 0; i < 4; i++) {
+    if (i >= nv) continue;
+    double nx[2];
+    if (i + 1 < 4 && i + 1 != nv) { nx[0] = poly[i + 1 < 4 ? i + 1 : 0][0]; nx[1] = poly[i + 1 < 4 ? i + 1 : 0][1]; }
+    else { nx[0] = poly[0][0]; nx[1] = poly[0][1]; }
     const double x1 = poly[i][0] - c[0], y1 = poly[i][1] - c[1];
-    const double x2 = poly[k][0] - c[0], y2 = poly[k][1] - c[1];
+    const double x2 = nx[0] - c[0], y2 = nx[1] - c[1];
     const double det = x1 * y2 - x2 * y1;
     if (fabs(det) <= 1e-12 * (fabs(x1 * y2) + fabs(x2 * y1) + 1e-300)) continue;
     const double a0 = (y2 - y1) / det, a1 = (x1 - x2) / det;
-    A[rows][0] = a0; A[rows][1] = a1;
-    b[rows] = 1.0 + (a0 * c[0] + a1 * c[1]);
+    const double bb = 1.0 + (a0 * c[0] + a1 * c[1]);
+    QL_UNROLL for (int r = 0; r < 4; r++)
+      if (r == rows) { A[r][0] = a0; A[r][1] = a1; b[r] = bb; }
     rows++;
   }
   return rows;
@@ -171,11 +181,12 @@ QL_HD int pose_linearise_to(const PoseParamsDev &P, const PoseProblem &pb, const
 
   const int m = nsp + nl;
   const double cw[2] = {p[0] + Pr3[0], p[1] + Pr3[1]};
-  for (int i = 0; i < nsp; i++) {
+  QL_UNROLL for (int i = 0; i < 4; i++) {
+    if (i >= nsp) continue;
     const double val = GA[i][0] * cw[0] + GA[i][1] * cw[1];
     s.at(Ly::CI0 + i) = gb[i] - val;
     const double G3[3] = {GA[i][0], GA[i][1], 0.0};
-    for (int j = 0; j < 3; j++) {
+    QL_UNROLL for (int j = 0; j < 3; j++) {
       s.at(Ly::CI + j * m + i) = -G3[j];
       s.at(Ly::CI + (3 + j) * m + i) = (G3[0] * Rr3[j] + G3[1] * Rr3[3 + j] + G3[2] * Rr3[6 + j]);
     }
@@ -265,7 +276,8 @@ QL_HD int pose_qp(const PoseParamsDev &P, const PoseProblem &pb, Scr &s, double 
   double GA[4][2], gb[4], Rr[3];
   const int m = polygon_halfspaces(pb.n_vertices, pb.polygon, GA, gb);
   rot(R, pb.r_com, Rr);
-  for (int i = 0; i < m; i++) {
+  QL_UNROLL for (int i = 0; i < 4; i++) {
+    if (i >= m) continue;
     s.at(Ly::CI0 + i) = gb[i] - (GA[i][0] * Rr[0] + GA[i][1] * Rr[1]);
     s.at(Ly::CI + 0 * m + i) = -GA[i][0];
     s.at(Ly::CI + 1 * m + i) = -GA[i][1];
@@ -280,10 +292,16 @@ QL_HD int pose_qp(const PoseParamsDev &P, const PoseProblem &pb, Scr &s, double 
 
 // ---- PoseConstraintsChecker::check (PoseConstraintsChecker.cpp:29-64) --------------------------------
 QL_HD bool polygon_is_inside(int nv, const double poly[4][2], const double pt[2]) { // grid_map crossing number
+  // edges (v_j, v_i) with j = i - 1, and (v_{nv-1}, v_0) for i = 0; the latter is picked up at the unrolled
+  // step idx == nv - 1 so that every vertex index is a constant (crossings are only counted: order is free)
   int cross = 0;
-  for (int i = 0, j = nv - 1; i < nv; j = i++) {
-    const double xi = poly[i][0], yi = poly[i][1], xj = poly[j][0], yj = poly[j][1];
+  const auto edge = [&](double xj, double yj, double xi, double yi) {
     if (((yi > pt[1]) != (yj > pt[1])) && (pt[0] < (xj - xi) * (pt[1] - yi) / (yj - yi) + xi)) cross++;
+  };
+  QL_UNROLL for (int i = 0; i < 4; i++) {
+    if (i >= nv) continue;
+    if (i > 0) edge(poly[i > 0 ? i - 1 : 0][0], poly[i > 0 ? i - 1 : 0][1], poly[i][0], poly[i][1]);
+    if (i == nv - 1) edge(poly[i][0], poly[i][1], poly[0][0], poly[0][1]);
   }
   return (cross & 1) != 0;
 }
