@@ -30,6 +30,11 @@ FP64_VALU_PEAK_TFLOPS = 78.6
 # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), see
 # profiles/r1/hbm_traffic_and_sq_pmc_bench_static_b4096_coop.json; None for configurations not profiled.
 MEASURED_TRAFFIC_BYTES = {(4096, "static"): int((1116.58 + 416.0) * 1024)}
+# VALU wave-instructions per launch from the same file (SQ_INSTS_VALU, its own pass).  A wave64 VALU instruction
+# occupies its SIMD16 for 4 cycles, so insts * 4 / (SIMDs * kernel cycles) is the fraction of the chip's VALU
+# issue slots the launch used -- the resource this FP64 path is actually bound by.
+MEASURED_VALU_INSTS = {(4096, "static"): 1811464}
+N_SIMD, SHADER_CLOCK_HZ = 1024, 2.4e9
 
 
 def parse():
@@ -45,6 +50,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph of K steps")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the multi-GPU code path (process group + all-gather) even with one rank (self-test)")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="several ranks without the per-step all-gather of the torques (scaling with / without it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -155,7 +162,8 @@ def main():
     d = capi.to_device(state, dev)
     tau = [torch.zeros(B, 12, dtype=torch.float64, device=dev) for _ in range(2)]
     status = torch.full((B,), -1, dtype=torch.int32, device=dev)
-    gathered = [torch.zeros(world * B, 12, dtype=torch.float64, device=dev) for _ in range(2)] if collective else None
+    gather = collective and not args.no_gather
+    gathered = [torch.zeros(world * B, 12, dtype=torch.float64, device=dev) for _ in range(2)] if gather else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(k, events=None):
@@ -165,7 +173,7 @@ def main():
         ctx.balance_solve_device(d, tau[buf], None, status, stream=stream)
         if events is not None:
             events[1].record()
-        if collective:
+        if gather:
             # result collection only; overlaps with the next step's solve (double-buffered)
             return dist.all_gather_into_tensor(gathered[buf], tau[buf], async_op=True)
         return None
@@ -201,7 +209,7 @@ def main():
                     cap = torch.cuda.current_stream().cuda_stream
                     for k in range(args.steps):
                         ctx.balance_solve_device(d, tau[k & 1], None, status, stream=cap)
-                        if collective:  # RCCL collectives are capturable; they replay from the graph
+                        if gather:  # RCCL collectives are capturable; they replay from the graph
                             dist.all_gather_into_tensor(gathered[k & 1], tau[k & 1])
             torch.cuda.current_stream().wait_stream(side)
         except Exception as e:  # pragma: no cover - fall back to eager launches
@@ -241,7 +249,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        if rank == 0 and args.steps > 0:  # the gathered buffer holds every rank's torques in rank order
+        if rank == 0 and args.steps > 0 and gather:  # the gathered buffer holds every rank's torques in rank order
             last = (args.steps - 1) & 1
             assert torch.equal(gathered[last][:B], tau[last]), "all-gather layout"
 
@@ -270,7 +278,8 @@ def main():
                                    % (B, "static 4-contact stance" if args.gait == "static"
                                       else "trot gait (2<->4 contacts)"),
                        "robots_per_gpu": B, "gait": args.gait, "seed": synth.SEED,
-                       "result_collection": "rccl all_gather of torques" if collective else "none (single GPU)",
+                       "result_collection": "rccl all_gather of torques" if gather else
+                       ("none (--no-gather)" if collective else "none (single GPU)"),
                        "launch": "hipGraph of K steps" if graph is not None else "eager",
                        "all_status_ok": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -278,6 +287,10 @@ def main():
                          "kernel": "balance_coop_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
+        insts = MEASURED_VALU_INSTS.get((B, args.gait))
+        if insts is not None:
+            line["valu_issue"] = {"insts_per_launch": insts, "frac": insts * 4.0 / (N_SIMD * kernel_ms * 1e-3 * SHADER_CLOCK_HZ),
+                                  "note": "SQ_INSTS_VALU (rocprofv3 --pmc) x 4 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz)"}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(state, args.cpu_seconds)
         print(json.dumps(line), flush=True)
