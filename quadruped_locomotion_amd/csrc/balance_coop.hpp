@@ -365,13 +365,14 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     // Row update H[j] -= f * H_k[j] is one v_fmac_f64_dpp (pivot row read through the DPP operand);
     // on the pivot lane f = 1 - 1/d turns the same formula into H_k[j] / d.
     bool bad = false;
+    double my_pivot = 1.0; // pivot of my own row, for c2 below
     static_for<12>([&](auto K) {
       constexpr int k = K;
       const double d = bcv<k>(H[k]);
       bad = bad || !(d > 0.0);
       const double p = rcp_nr(d);
-      if ((stance >> (k / 3)) & 1u) c2 += rsqrt_nr(d); // only feeds the termination tolerance
       const bool piv = comp && (myidx == k);
+      my_pivot = piv ? d : my_pivot;
       const double f = piv ? (1.0 - p) : H[k] * p;
       const double nf = -f;
       static_for<12>([&](auto J) {
@@ -380,6 +381,9 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       });
       H[k] = piv ? p : nf;
     });
+    // c2 = trace(J) = sum over the stance rows of 1/sqrt(pivot): one rsqrt per lane instead of one per pivot
+    // (it only feeds the termination tolerance psi_tol)
+    c2 = row_sum(row_on ? rsqrt_nr(my_pivot) : 0.0);
     if (bad && nS > 0) {
       if (lr == 0 && robot_live) status_out[i] = kStatusNotPd;
       if (comp && robot_live) { tau_out[12 * i + myidx] = 0.0; if (grf_out) grf_out[12 * i + myidx] = 0.0; }
