@@ -156,8 +156,15 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 }
 
 // element c (0..2) of a replicated 3-vector; 0 for the spare lane
+// (a chain of single-level selects: nested ?: on a lane-varying index is lowered to exec-mask control flow,
+// a dozen scalar instructions and two branches per use, instead of two v_cndmask)
+__device__ __forceinline__ double sel(bool p, double a, double b) { return p ? a : b; }
 __device__ __forceinline__ double pick3(const double v[3], int c) {
-  return c == 0 ? v[0] : c == 1 ? v[1] : c == 2 ? v[2] : 0.0;
+  double r = 0.0;
+  r = sel(c == 2, v[2], r);
+  r = sel(c == 1, v[1], r);
+  r = sel(c == 0, v[0], r);
+  return r;
 }
 
 struct CoopTab { // one leg's model block in LDS
@@ -178,7 +185,7 @@ constexpr int kCoopLdsDoubles = 12 * 12 + 12;
 
 template <bool kPerLeg>
 __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs &s, int64_t irobot, bool robot_live,
-                                           const double *lds_tab, double *lds_row, double *__restrict__ tau_out,
+                                           double *lds_tab, double *lds_row, double *__restrict__ tau_out,
                                            double *__restrict__ grf_out, int32_t *__restrict__ status_out) {
   const int lr = threadIdx.x & 15;   // lane in row
   const int leg = lr >> 2, c = lr & 3;
@@ -189,6 +196,15 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
 
   QL_STAMP(0);
   // ---------------------------------------------------------------- load
+  // The model table (4 x 88 doubles) goes to LDS for the leg-indexed reads below.  Its six loads per lane are
+  // issued first and unconditionally (clamped index), the robot's own state right behind them, and only then
+  // are the table values stored and the barrier taken: one memory round trip instead of seven in a row.
+  double tabv[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    const int idx = (int)threadIdx.x + 64 * j;
+    tabv[j] = P.legtab[idx < 4 * kTabPerLeg ? idx : 4 * kTabPerLeg - 1];
+  }
   const int64_t i = irobot;
   double quat[4], dquat[4], pos[3], linvel[3], angvel[3], dpos[3], dlinvel[3], dangvel[3];
   {
@@ -205,12 +221,24 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     }
   }
   const uint32_t sm = *reinterpret_cast<const uint32_t *>(s.stance + 4 * i);
+  const double qj = s.q[12 * i + (comp ? myidx : 0)];
+  double wr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; // externally supplied (F_B, T_B), if any: issued with the rest
+  if (s.wrench) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) wr[k] = s.wrench[6 * i + k];
+  }
+  // (all loads above are in flight before the first of them is consumed)
   const unsigned stance = robot_live ? (((sm & 0xFFu) ? 1u : 0u) | ((sm & 0xFF00u) ? 2u : 0u) |
                                         ((sm & 0xFF0000u) ? 4u : 0u) | ((sm & 0xFF000000u) ? 8u : 0u))
                                      : 0u;
   const int nS = __popc(stance);
   const bool on = ((stance >> leg) & 1u) != 0; // my leg supports
-  const double qj = comp ? s.q[12 * i + myidx] : 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    const int idx = (int)threadIdx.x + 64 * j;
+    if (idx < 4 * kTabPerLeg) lds_tab[idx] = tabv[j];
+  }
+  __syncthreads();
 
   QL_STAMP(1);
   // ---------------------------------------------------------------- wrench (replicated)
@@ -229,7 +257,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     for (int k = 0; k < 4; k++) { in.quat[k] = quat[k]; in.dquat[k] = dquat[k]; }
     if (s.wrench) {
 #pragma unroll
-      for (int k = 0; k < 6; k++) b[k] = s.wrench[6 * i + k];
+      for (int k = 0; k < 6; k++) b[k] = wr[k];
     } else {
       in.has_wrench = false;
       virtual_wrench(P, in, Rm, gB, b);
@@ -292,10 +320,11 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       Hs += Hk[k];
       M += tab[kTabMass + k];
       const double d = pc - pj[k];
-      Jrow[k] = comp ? qcross(zax[k], d) : 0.0;
+      const double jc = qcross(zax[k], d); // unconditionally: a DPP op under a lane condition becomes a branch
+      Jrow[k] = sel(comp, jc, 0.0);
       const double h = Hs - M * pj[k];
       const double zh = qcross(zax[k], h);
-      Gq[k] = -quad_sum(comp ? my_g * zh : 0.0);
+      Gq[k] = -quad_sum(sel(comp, my_g * zh, 0.0));
     }
   }
 
@@ -329,8 +358,8 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     static_for<12>([&](auto J) { constexpr int j = J; r[j / 3][j % 3] = bcv<j>(foot); });
     const double rl[3] = {quad_bc<0>(foot), quad_bc<1>(foot), quad_bc<2>(foot)};
     // a = r_leg x e_c  (column c of skew(r_leg))
-    const double a[3] = {c == 1 ? -rl[2] : c == 2 ? rl[1] : 0.0, c == 0 ? rl[2] : c == 2 ? -rl[0] : 0.0,
-                         c == 0 ? -rl[1] : c == 1 ? rl[0] : 0.0};
+    const double a[3] = {sel(c == 1, -rl[2], sel(c == 2, rl[1], 0.0)), sel(c == 0, rl[2], sel(c == 2, -rl[0], 0.0)),
+                         sel(c == 0, -rl[1], sel(c == 1, rl[0], 0.0))};
     const double sa[3] = {P.S[3] * a[0], P.S[4] * a[1], P.S[5] * a[2]};
     const double Sfc = pick3(P.S, c);
     const bool row_on = comp && on;
@@ -351,7 +380,8 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       if (comp && j == myidx) Gm[j] += P.w_reg;
     const double Fc = pick3(b, c);
     const double ST[3] = {P.S[3] * b[3], P.S[4] * b[4], P.S[5] * b[5]};
-    g0 = row_on ? -(Sfc * Fc + (a[0] * ST[0] + a[1] * ST[1] + a[2] * ST[2])) : 0.0;
+    const double g0v = -(Sfc * Fc + (a[0] * ST[0] + a[1] * ST[1] + a[2] * ST[2]));
+    g0 = sel(row_on, g0v, 0.0);
 #pragma unroll
     for (int j = 0; j < 12; j++) H[j] = Gm[j];
     // trace(G) over the stance block
@@ -359,7 +389,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       double diag = 0.0;
 #pragma unroll
       for (int j = 0; j < 12; j++) diag = (j == myidx) ? Gm[j] : diag;
-      c1 = row_sum(row_on ? diag : 0.0);
+      c1 = row_sum(sel(row_on, diag, 0.0));
     }
     // in-place Gauss-Jordan inversion, row per lane; pivot k = L_kk^2 of the Cholesky factor.
     // Row update H[j] -= f * H_k[j] is one v_fmac_f64_dpp (pivot row read through the DPP operand);
@@ -383,7 +413,8 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     });
     // c2 = trace(J) = sum over the stance rows of 1/sqrt(pivot): one rsqrt per lane instead of one per pivot
     // (it only feeds the termination tolerance psi_tol)
-    c2 = row_sum(row_on ? rsqrt_nr(my_pivot) : 0.0);
+    const double rp = rsqrt_nr(my_pivot);
+    c2 = row_sum(sel(row_on, rp, 0.0));
     if (bad && nS > 0) {
       if (lr == 0 && robot_live) status_out[i] = kStatusNotPd;
       if (comp && robot_live) { tau_out[12 * i + myidx] = 0.0; if (grf_out) grf_out[12 * i + myidx] = 0.0; }
@@ -442,34 +473,30 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       if (fresh) { iters++; excl = 0; }
       double s_min, s_fric;
       slacks(x, s_min, s_fric);
-      const double psi = row_sum(on ? (fmin(0.0, s_fric) + (c == 0 ? fmin(0.0, s_min) : 0.0)) : 0.0);
+      const double viol = fmin(0.0, s_fric) + sel(c == 0, fmin(0.0, s_min), 0.0);
+      const double psi = row_sum(sel(on, viol, 0.0));
       const unsigned blocked = act_mask | excl;
       // candidates of this lane: friction row 5*leg + c + 1 and (lane c == 0) the minimum-force row
       // 5*leg.  Exact ties go to the lowest lane (the reference takes the lowest row index; either
       // way the minimiser is the same, only the path differs).
-      double v = inf;
-      bool cand_min = false;
-      if (on) {
-        const int idf = 5 * leg + c + 1, idm = 5 * leg;
-        if (!((blocked >> idf) & 1u) && s_fric < 0.0) v = s_fric;
-        if (c == 0 && !((blocked >> idm) & 1u) && s_min < 0.0 && s_min <= v) { v = s_min; cand_min = true; }
-      }
+      const int idf = 5 * leg + c + 1, idm = 5 * leg;
+      double v = sel(on && !((blocked >> idf) & 1u) && s_fric < 0.0, s_fric, inf);
+      const bool cand_min = on && c == 0 && !((blocked >> idm) & 1u) && s_min < 0.0 && s_min <= v;
+      v = sel(cand_min, s_min, v);
       const double vbest = row_min(v);
       const int wl = row_first(v == vbest && v < 0.0);
       const bool wmin = ((unsigned)(__ballot(cand_min) >> ((threadIdx.x & 48) + (wl & 15))) & 1u) != 0;
       v = vbest;
       const int key = 5 * (wl >> 2) + (wmin ? 0 : (wl & 3) + 1);
       const bool feasible = fresh && (fabs(psi) <= psi_tol); // QuadProg++.cc:246-250
-      if (feasible || !(v < 0.0) || iters > kMaxOuter) {      // :271-274
-        if (iters > kMaxOuter) status = kStatusMaxIter;
-        done = true;
-      } else {
-        ip = key;
-        pleg = id_leg(ip); pt = ip - 5 * pleg;
-        sp = v;
-        ucand = 0.0;
-        need_select = false;
-      }
+      const bool stop = feasible || !(v < 0.0) || iters > kMaxOuter; // :271-274
+      status = (stop && iters > kMaxOuter) ? kStatusMaxIter : status;
+      done = stop;
+      ip = stop ? ip : key;
+      pleg = id_leg(ip); pt = ip - 5 * pleg;
+      sp = sel(stop, sp, v);
+      ucand = sel(stop, ucand, 0.0);
+      need_select = stop;
     }
     if (!done) {
       // ---- directions: z = H n_p (lane i), r = N* n_p (slot lane k)
@@ -486,15 +513,12 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       const double zn = row_sum(z * npj);
       const double zz = row_sum(z * z);
       // ---- step lengths, QuadProg++.cc:304-331
-      double ratio = inf;
-      if (slot && r > 0.0) ratio = u * rcp_nr(r);
+      const double ur = u * rcp_nr(r);
+      const double ratio = sel(slot && r > 0.0, ur, inf);
       const double t1 = row_min(ratio);
       const int lpos = row_first(ratio == t1 && ratio < inf);
-      double t2 = inf;
-      if (fabs(zz) > eps) {
-        t2 = -sp * rcp_nr(zn);
-        if (t2 < 0.0) t2 = inf;
-      }
+      const double t2v = -sp * rcp_nr(zn);
+      const double t2 = sel(fabs(zz) > eps && !(t2v < 0.0), t2v, inf);
       const double t = fmin(t1, t2);
       // what happens this tick (all row-uniform)
       const bool infeasible = !(t < inf);                          // :339-344
@@ -509,7 +533,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       const double tp = (infeasible || dual_only || degenerate) ? 0.0 : t;
       const double td = (infeasible || degenerate) ? 0.0 : t;
       x += tp * z;
-      u -= slot ? td * r : 0.0;
+      u -= sel(slot, td * r, 0.0);
       ucand += td;
       sp += tp * zn; // slack of ip after a partial step (:436-440, linear in t)
       // ---- rank-one update of H and N*:  H[j] += hc * v_j,  N*[j] += nc * v_j
@@ -519,7 +543,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       const bool newslot = is_add && (lr == newlane);
       double vec = is_add ? z * rcp_nr(zn) : 0.0;
       double hc = is_add ? -z : 0.0;
-      double nc = newslot ? 1.0 : ((is_add && slot) ? -r : 0.0);
+      double nc = sel(newslot, 1.0, sel(is_add && slot, -r, 0.0));
       u = newslot ? ucand : u;
       idk = newslot ? ip : idk;
       used |= is_add ? (1u << newlane) : 0u;
@@ -594,7 +618,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       double s_min, s_fric;
       slacks(x, s_min, s_fric);
       const double vm = __shfl(s_min, src, 16), vf = __shfl(s_fric, src, 16);
-      const double rho = myslot ? -(tt == 0 ? vm : vf) : 0.0;
+      const double rho = sel(myslot, -sel(tt == 0, vm, vf), 0.0);
       double dx = 0.0;
       static_for<12>([&](auto K) { constexpr int k = K; fmac_bc<k, k == 0>(dx, rho, NsT[k]); });
       x += dx;
@@ -606,10 +630,10 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   {
     const bool live = on && status == kStatusOk;
     const double fx = live ? -x : 0.0;
-    const double t0 = quad_sum(comp ? Jrow[0] * fx : 0.0) + Gq[0];
-    const double t1 = quad_sum(comp ? Jrow[1] * fx : 0.0) + Gq[1];
-    const double t2 = quad_sum(comp ? Jrow[2] * fx : 0.0) + Gq[2];
-    double t = c == 0 ? t0 : c == 1 ? t1 : t2;
+    const double t0 = quad_sum(sel(comp, Jrow[0] * fx, 0.0)) + Gq[0];
+    const double t1 = quad_sum(sel(comp, Jrow[1] * fx, 0.0)) + Gq[1];
+    const double t2 = quad_sum(sel(comp, Jrow[2] * fx, 0.0)) + Gq[2];
+    double t = sel(c == 0, t0, sel(c == 1, t1, t2));
     t = t > P.tau_max ? P.tau_max : t;
     t = t < -P.tau_max ? -P.tau_max : t;
     if (comp && robot_live) {

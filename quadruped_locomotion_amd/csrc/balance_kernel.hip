@@ -160,9 +160,6 @@ __global__ __launch_bounds__(64) void balance_coop_kernel(const DeviceParams *__
   __shared__ double tab[4 * kTabPerLeg];
   __shared__ double rows[4 * coop::kCoopLdsDoubles];
   const DeviceParams &P = *Pp;
-#pragma unroll
-  for (int i = threadIdx.x; i < 4 * kTabPerLeg; i += 64) tab[i] = P.legtab[i];
-  __syncthreads();
   const int row = threadIdx.x >> 4;
   int64_t i = (int64_t)blockIdx.x * 4 + row;
   const bool live = i < B;
