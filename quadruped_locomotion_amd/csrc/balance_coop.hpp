@@ -82,6 +82,15 @@ __device__ __forceinline__ double row_sum(double x) {
   x += dpp<0x121>(x);
   return x;
 }
+// Row sum in single precision for quantities that only feed a threshold test (|z|^2 > eps, |psi| <= tol):
+// v_add_f32 takes a DPP operand, so a level is one instruction instead of two moves and an add.
+__device__ __forceinline__ float row_sum_f32(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x124, 0xF, 0xF, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x122, 0xF, 0xF, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x121, 0xF, 0xF, true));
+  return x;
+}
 __device__ __forceinline__ double quad_sum(double x) {
   x += dpp<0xB1>(x); // quad_perm [1,0,3,2]
   x += dpp<0x4E>(x); // quad_perm [2,3,0,1]
@@ -103,11 +112,18 @@ __device__ __forceinline__ void fmac_bc(double &acc, double src, double mul) {
                  : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
 }
 
+// v_min_f64 as is: fmin() adds two canonicalising v_max per call (NaN quieting the hardware min already does)
+__device__ __forceinline__ double vmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ double row_min(double x) {
-  x = fmin(x, dpp<0x128>(x));
-  x = fmin(x, dpp<0x124>(x));
-  x = fmin(x, dpp<0x122>(x));
-  x = fmin(x, dpp<0x121>(x));
+  x = vmin(x, dpp<0x128>(x));
+  x = vmin(x, dpp<0x124>(x));
+  x = vmin(x, dpp<0x122>(x));
+  x = vmin(x, dpp<0x121>(x));
   return x;
 }
 // lowest lane of my row for which `pred` holds (16 if none)
@@ -473,8 +489,8 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       if (fresh) { iters++; excl = 0; }
       double s_min, s_fric;
       slacks(x, s_min, s_fric);
-      const double viol = fmin(0.0, s_fric) + sel(c == 0, fmin(0.0, s_min), 0.0);
-      const double psi = row_sum(sel(on, viol, 0.0));
+      const double viol = vmin(0.0, s_fric) + sel(c == 0, vmin(0.0, s_min), 0.0);
+      const double psi = (double)row_sum_f32((float)sel(on, viol, 0.0)); // only compared with psi_tol below
       const unsigned blocked = act_mask | excl;
       // candidates of this lane: friction row 5*leg + c + 1 and (lane c == 0) the minimum-force row
       // 5*leg.  Exact ties go to the lowest lane (the reference takes the lowest row index; either
@@ -511,7 +527,8 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       const double z = (za[0] + za[1]) + za[2], r = (ra[0] + ra[1]) + ra[2];
       const bool slot = (used >> lr) & 1u;
       const double zn = row_sum(z * npj);
-      const double zz = row_sum(z * z);
+      const float zf = (float)z;
+      const double zz = (double)row_sum_f32(zf * zf); // only compared with eps below
       // ---- step lengths, QuadProg++.cc:304-331
       const double ur = u * rcp_nr(r);
       const double ratio = sel(slot && r > 0.0, ur, inf);
@@ -519,7 +536,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       const int lpos = row_first(ratio == t1 && ratio < inf);
       const double t2v = -sp * rcp_nr(zn);
       const double t2 = sel(fabs(zz) > eps && !(t2v < 0.0), t2v, inf);
-      const double t = fmin(t1, t2);
+      const double t = vmin(t1, t2);
       // what happens this tick (all row-uniform)
       const bool infeasible = !(t < inf);                          // :339-344
       const bool dual_only = (t2 >= inf);
