@@ -309,25 +309,46 @@ struct PosePtrs {
 };
 constexpr int kPosePerWave = 16;
 
+// Every load of a problem is issued unconditionally and before the first use: an absent optional array is read
+// through `stance` (always present and at least as long) and its value replaced afterwards, so that no load sits
+// behind a branch and the whole problem costs one memory round trip.
 __device__ __forceinline__ void load_pose_problem(const PoseParamsDev &P, const PosePtrs &s, int64_t i, PoseProblem &pb,
                                                   double pose[7]) {
-  unsigned limb_mask = 0;
+  const uint8_t *maskp = s.mask ? s.mask : reinterpret_cast<const uint8_t *>(s.stance);
+  const double *rcomp = s.rcom ? s.rcom : s.stance;
+  const int32_t *nvp = s.nverts ? s.nverts : reinterpret_cast<const int32_t *>(s.stance);
+  const double *posep = s.pose ? s.pose : s.stance;
+  const uint32_t m4 = *reinterpret_cast<const uint32_t *>(maskp + 4 * i);
+  const int32_t nv = nvp[i];
+  double rc[3], ps[7], poly[8];
 #pragma unroll
-  for (int l = 0; l < 4; l++)
-    if (!s.mask || s.mask[4 * i + l]) limb_mask |= 1u << l;
+  for (int a = 0; a < 3; a++) rc[a] = rcomp[3 * i + a];
+#pragma unroll
+  for (int a = 0; a < 7; a++) ps[a] = posep[7 * i + a];
+  {
+    const double2 *p2 = reinterpret_cast<const double2 *>(s.polygon + 8 * i);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const double2 v = p2[k]; poly[2 * k] = v.x; poly[2 * k + 1] = v.y; }
+  }
   pose_problem_load_legs(
       P, pb, [&](int l, int a) { return s.stance[12 * i + 3 * l + a]; },
-      [&](int l, int a) { return s.nominal[12 * i + 3 * l + a]; }, [&](int l) { return s.maxlen[4 * i + l]; }, limb_mask);
+      [&](int l, int a) { return s.nominal[12 * i + 3 * l + a]; }, [&](int l) { return s.maxlen[4 * i + l]; },
+      [&]() {
+        unsigned limb_mask = 0xFu;
+        if (s.mask) {
+          limb_mask = 0;
 #pragma unroll
-  for (int l = 0; l < 4; l++) {
-    pb.polygon[l][0] = s.polygon[8 * i + 2 * l];
-    pb.polygon[l][1] = s.polygon[8 * i + 2 * l + 1];
-  }
+          for (int l = 0; l < 4; l++) limb_mask |= ((m4 >> (8 * l)) & 0xFFu) ? (1u << l) : 0u;
+        }
+        return limb_mask;
+      });
 #pragma unroll
-  for (int a = 0; a < 3; a++) pb.r_com[a] = s.rcom ? s.rcom[3 * i + a] : 0.0;
-  pb.n_vertices = s.nverts ? s.nverts[i] : 4;
+  for (int l = 0; l < 4; l++) { pb.polygon[l][0] = poly[2 * l]; pb.polygon[l][1] = poly[2 * l + 1]; }
 #pragma unroll
-  for (int a = 0; a < 7; a++) pose[a] = s.pose ? s.pose[7 * i + a] : (a == 3 ? 1.0 : 0.0);
+  for (int a = 0; a < 3; a++) pb.r_com[a] = s.rcom ? rc[a] : 0.0;
+  pb.n_vertices = s.nverts ? nv : 4;
+#pragma unroll
+  for (int a = 0; a < 7; a++) pose[a] = s.pose ? ps[a] : (a == 3 ? 1.0 : 0.0);
 }
 
 __global__ __launch_bounds__(64) void pose_sqp_kernel(const PoseParamsDev P, const PosePtrs s, int64_t B,
@@ -336,8 +357,12 @@ __global__ __launch_bounds__(64) void pose_sqp_kernel(const PoseParamsDev P, con
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
   const int64_t i = (int64_t)blockIdx.x * kPosePerWave + lane;
+  // the problem data lives in LDS (one record per lane): it is read a few values at a time over the whole SQP
+  // loop, and holding its 60 doubles in registers next to the QP's made the compiler spill each freshly loaded
+  // value to scratch, one memory round trip after the other
+  __shared__ PoseProblem pbs[kPosePerWave];
   if (lane >= kPosePerWave || i >= B) return;
-  PoseProblem pb;
+  PoseProblem &pb = pbs[lane];
   double pose[7];
   load_pose_problem(P, s, i, pb, pose);
   LdsScratch scr{lds + lane, kPosePerWave};
@@ -410,8 +435,9 @@ __global__ __launch_bounds__(64) void base_auto_pose_kernel(const PoseParamsDev 
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
   const int64_t i = (int64_t)blockIdx.x * kPosePerWave + lane;
+  __shared__ PoseProblem pbs[kPosePerWave]; // see pose_sqp_kernel
   if (lane >= kPosePerWave || i >= B) return;
-  PoseProblem pb;
+  PoseProblem &pb = pbs[lane];
   double pose[7], sfo[4][3], mn[4];
   load_pose_problem(P, s, i, pb, pose);
   load_sfo(s, sfo_in, i, sfo);

@@ -33,19 +33,29 @@ struct PoseProblem {
 };
 
 // Fill slot k from limb-indexed batch arrays (get(l, a) style accessors keep this usable on host and device).
-template <class FS, class FN, class F1>
-QL_HD void pose_problem_load_legs(const PoseParamsDev &P, PoseProblem &pb, FS stance, FN nominal, F1 maxlen, unsigned limb_mask) {
-  pb.present = 0;
+template <class FS, class FN, class F1, class FM>
+QL_HD void pose_problem_load_legs(const PoseParamsDev &P, PoseProblem &pb, FS stance, FN nominal, F1 maxlen, FM limb_mask_of) {
+  // gather first, store second: when pb lives in LDS (device) the loads of all four legs are then in flight
+  // together instead of load - wait - store, leg after leg
+  double st[4][3], nm[4][3], ml[4];
   QL_UNROLL for (int k = 0; k < 4; k++) {
     const int l = P.leg_order[k];
-    if ((limb_mask >> l) & 1u) pb.present |= 1u << k;
+    QL_UNROLL for (int a = 0; a < 3; a++) { st[k][a] = stance(l, a); nm[k][a] = nominal(l, a); }
+    ml[k] = maxlen(l);
+  }
+  const unsigned limb_mask = limb_mask_of(); // evaluated after the gather: may depend on a load of its own
+  unsigned present = 0;
+  QL_UNROLL for (int k = 0; k < 4; k++) {
+    const int l = P.leg_order[k];
+    if ((limb_mask >> l) & 1u) present |= 1u << k;
     QL_UNROLL for (int a = 0; a < 3; a++) {
-      pb.stance[k][a] = stance(l, a);
-      pb.nominal[k][a] = nominal(l, a);
+      pb.stance[k][a] = st[k][a];
+      pb.nominal[k][a] = nm[k][a];
       pb.hips[k][a] = P.hips[l][a];
     }
-    pb.max_len[k] = maxlen(l);
+    pb.max_len[k] = ml[k];
   }
+  pb.present = present;
 }
 
 typedef GiLayout<6, 1, 8> PoseGi;

@@ -106,7 +106,7 @@ extern "C" void mirror_pose_sqp_batch(const PoseParamsDev *P, int64_t B, const d
     for (int l = 0; l < 4; l++) if (!mask || mask[4 * i + l]) limb_mask |= 1u << l;
     pose_problem_load_legs(
         *P, pb, [&](int l, int a) { return stance[12 * i + 3 * l + a]; },
-        [&](int l, int a) { return nominal[12 * i + 3 * l + a]; }, [&](int l) { return maxlen[4 * i + l]; }, limb_mask);
+        [&](int l, int a) { return nominal[12 * i + 3 * l + a]; }, [&](int l) { return maxlen[4 * i + l]; }, [&]() { return limb_mask; });
     for (int l = 0; l < 4; l++) { pb.polygon[l][0] = polygon[8 * i + 2 * l]; pb.polygon[l][1] = polygon[8 * i + 2 * l + 1]; }
     for (int a = 0; a < 3; a++) pb.r_com[a] = rcom ? rcom[3 * i + a] : 0.0;
     pb.n_vertices = nverts ? nverts[i] : 4;
@@ -134,7 +134,7 @@ extern "C" void mirror_pose_aux_batch(int mode, const PoseParamsDev *P, int64_t 
     for (int l = 0; l < 4; l++) if (!mask || mask[4 * i + l]) limb_mask |= 1u << l;
     pose_problem_load_legs(
         *P, pb, [&](int l, int a) { return stance[12 * i + 3 * l + a]; },
-        [&](int l, int a) { return nominal[12 * i + 3 * l + a]; }, [&](int l) { return maxlen[4 * i + l]; }, limb_mask);
+        [&](int l, int a) { return nominal[12 * i + 3 * l + a]; }, [&](int l) { return maxlen[4 * i + l]; }, [&]() { return limb_mask; });
     for (int l = 0; l < 4; l++) { pb.polygon[l][0] = polygon[8 * i + 2 * l]; pb.polygon[l][1] = polygon[8 * i + 2 * l + 1]; }
     for (int a = 0; a < 3; a++) pb.r_com[a] = rcom ? rcom[3 * i + a] : 0.0;
     pb.n_vertices = nverts ? nverts[i] : 4;
