@@ -189,10 +189,31 @@ __global__ __launch_bounds__(64) void virtual_wrench_kernel(const DeviceParams *
   for (int k = 0; k < 6; k++) wrench[6 * i + k] = b[k];
 }
 
-struct GlobalTab {
-  const double *p;
-  __device__ __forceinline__ double operator[](int i) const { return p[i]; }
+// The per-leg kernels below read ~60 model constants per lane.  Straight from global memory the compiler
+// interleaves those reads with the arithmetic, a memory round trip every few dozen instructions; instead the
+// 4 x 88-double table is staged in LDS once per block: its six loads per lane are issued first, the lane's own
+// inputs right behind them, then the table is stored and the block synchronises -- one round trip in all.
+struct TabStage {
+  double v[6];
+  __device__ __forceinline__ void issue(const DeviceParams &P) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const int idx = (int)threadIdx.x + 64 * j;
+      v[j] = P.legtab[idx < 4 * kTabPerLeg ? idx : 4 * kTabPerLeg - 1];
+    }
+  }
+  __device__ __forceinline__ void commit(double *lds_tab) const {
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const int idx = (int)threadIdx.x + 64 * j;
+      if (idx < 4 * kTabPerLeg) lds_tab[idx] = v[j];
+    }
+    __syncthreads();
+  }
 };
+__device__ __forceinline__ void load3(const double *p, int64_t t, double o[3]) {
+  o[0] = p[3 * t]; o[1] = p[3 * t + 1]; o[2] = p[3 * t + 2];
+}
 
 __global__ __launch_bounds__(64) void leg_kinematics_kernel(const DeviceParams *__restrict__ Pp,
                                                             const double *__restrict__ q,
@@ -200,19 +221,26 @@ __global__ __launch_bounds__(64) void leg_kinematics_kernel(const DeviceParams *
                                                             double *__restrict__ foot, double *__restrict__ jac,
                                                             double *__restrict__ grav) {
   // one lane per (robot, leg)
+  __shared__ double tab[4 * kTabPerLeg];
   const DeviceParams &P = *Pp;
-  const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (t >= 4 * B) return;
+  TabStage ts;
+  ts.issue(P);
+  const int64_t t0 = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool live = t0 < 4 * B;
+  const int64_t t = live ? t0 : 4 * B - 1;
   const int64_t i = t >> 2;
   const int leg = (int)(t & 3);
-  const double ql[3] = {q[12 * i + 3 * leg], q[12 * i + 3 * leg + 1], q[12 * i + 3 * leg + 2]};
+  double ql[3];
+  load3(q, t, ql);
   const double qq[4] = {quat[4 * i], quat[4 * i + 1], quat[4 * i + 2], quat[4 * i + 3]};
+  ts.commit(tab);
   double Rm[9], gB[3];
   quat_to_matrix(qq, Rm);
   const double gW[3] = {0.0, 0.0, -P.grav};
   irot(Rm, gW, gB);
   double F[3], J[9], Gq[3];
-  leg_kinematics(GlobalTab{P.legtab + kTabPerLeg * leg}, ql, gB, F, J, Gq);
+  leg_kinematics(LdsTab{tab + kTabPerLeg * leg}, ql, gB, F, J, Gq);
+  if (!live) return;
   if (foot) { foot[3 * t] = F[0]; foot[3 * t + 1] = F[1]; foot[3 * t + 2] = F[2]; }
   if (jac) {
 #pragma unroll
@@ -231,12 +259,25 @@ __global__ __launch_bounds__(64) void leg_ik_kernel(const DeviceParams *__restri
   const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (t >= 4 * B) return;
   const int leg = (int)(t & 3);
-  const double p[3] = {foot[3 * t], foot[3 * t + 1], foot[3 * t + 2]};
+  // the hip frame (12 constants) and the inputs, all loads issued before the first use
+  const double *tb = P.legtab + kTabPerLeg * leg;
+  double hip[12];
+#pragma unroll
+  for (int k = 0; k < 9; k++) hip[k] = tb[kTabR0 + k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) hip[9 + k] = tb[kTabXyz + k];
+  double p[3], last[3] = {0.0, 0.0, 0.0};
+  load3(foot, t, p);
+  if (q_last) load3(q_last, t, last);
+  struct HipTab { // kTabR0 + k -> hip[k], kTabXyz + k -> hip[9 + k]: the only entries the IK reads
+    const double *h;
+    __device__ __forceinline__ double operator[](int i) const { return i < kTabXyz ? h[i - kTabR0] : h[9 + i - kTabXyz]; }
+  };
   double q[3];
-  const bool good = leg_inverse_kinematics(GlobalTab{P.legtab + kTabPerLeg * leg}, p, G.config[leg], G.g, q);
+  const bool good = leg_inverse_kinematics(HipTab{hip}, p, G.config[leg], G.g, q);
   // on failure the caller's previous joint positions are kept (quadruped_state.cpp:289-294)
 #pragma unroll
-  for (int k = 0; k < 3; k++) q_out[3 * t + k] = good ? q[k] : (q_last ? q_last[3 * t + k] : q[k]);
+  for (int k = 0; k < 3; k++) q_out[3 * t + k] = good ? q[k] : (q_last ? last[k] : q[k]);
   if (ok) ok[t] = good ? 1 : 0;
 }
 
@@ -248,21 +289,22 @@ struct SwingPtrs {
 
 __global__ __launch_bounds__(64) void swing_leg_kernel(const DeviceParams *__restrict__ Pp, const SwingParamsDev SP,
                                                        const SwingPtrs s, int64_t B, double *__restrict__ tau) {
+  __shared__ double tab[4 * kTabPerLeg];
   const DeviceParams &P = *Pp;
-  const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (t >= 4 * B) return;
+  TabStage ts;
+  ts.issue(P);
+  const int64_t t0 = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool live = t0 < 4 * B;
+  const int64_t t = live ? t0 : 4 * B - 1;
   const int leg = (int)(t & 3);
+  double q[3], qd[3], qo[3], tp[3], tv[3], qi[3];
+  load3(s.q, t, q); load3(s.qd, t, qd); load3(s.qd_old, t, qo); load3(s.tpos, t, tp); load3(s.tvel, t, tv);
+  load3(s.q_id ? s.q_id : s.q, t, qi);
+  const bool support = s.support[t] != 0;
+  ts.commit(tab);
   double out[3] = {0.0, 0.0, 0.0};
-  if (!s.support[t]) {
-    const double q[3] = {s.q[3 * t], s.q[3 * t + 1], s.q[3 * t + 2]};
-    const double qd[3] = {s.qd[3 * t], s.qd[3 * t + 1], s.qd[3 * t + 2]};
-    const double qo[3] = {s.qd_old[3 * t], s.qd_old[3 * t + 1], s.qd_old[3 * t + 2]};
-    const double tp[3] = {s.tpos[3 * t], s.tpos[3 * t + 1], s.tpos[3 * t + 2]};
-    const double tv[3] = {s.tvel[3 * t], s.tvel[3 * t + 1], s.tvel[3 * t + 2]};
-    double qi[3] = {q[0], q[1], q[2]};
-    if (s.q_id) { qi[0] = s.q_id[3 * t]; qi[1] = s.q_id[3 * t + 1]; qi[2] = s.q_id[3 * t + 2]; }
-    swing_leg_torque(GlobalTab{P.legtab + kTabPerLeg * leg}, SP, qi, q, qd, qo, tp, tv, out);
-  }
+  if (!support) swing_leg_torque(LdsTab{tab + kTabPerLeg * leg}, SP, qi, q, qd, qo, tp, tv, out);
+  if (!live) return;
   tau[3 * t] = out[0]; tau[3 * t + 1] = out[1]; tau[3 * t + 2] = out[2];
 }
 
@@ -277,26 +319,28 @@ __global__ __launch_bounds__(64) void swing_branch_kernel(const DeviceParams *__
                                                           const PidParamsDev pid, const SwingPtrs s,
                                                           const SwingBranchPtrs b, double period, int64_t B,
                                                           double *__restrict__ effort) {
+  __shared__ double tab[4 * kTabPerLeg];
   const DeviceParams &P = *Pp;
-  const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (t >= 4 * B) return;
-  if (s.support[t]) return; // support legs keep the clamped QP torque already in `effort` (:497-502)
+  TabStage ts;
+  ts.issue(P);
+  const int64_t t0 = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool live = t0 < 4 * B;
+  const int64_t t = live ? t0 : 4 * B - 1;
   const int64_t i = t >> 2;
   const int leg = (int)(t & 3);
-  const double q[3] = {s.q[3 * t], s.q[3 * t + 1], s.q[3 * t + 2]};
-  const double qd[3] = {s.qd[3 * t], s.qd[3 * t + 1], s.qd[3 * t + 2]};
-  const double qo[3] = {s.qd_old[3 * t], s.qd_old[3 * t + 1], s.qd_old[3 * t + 2]};
-  const double tp[3] = {s.tpos[3 * t], s.tpos[3 * t + 1], s.tpos[3 * t + 2]};
-  const double tv[3] = {s.tvel[3 * t], s.tvel[3 * t + 1], s.tvel[3 * t + 2]};
-  const double cmd[3] = {b.cmd[3 * t], b.cmd[3 * t + 1], b.cmd[3 * t + 2]};
+  double q[3], qd[3], qo[3], tp[3], tv[3], cmd[3], qi[3], el[3], ei[3];
+  load3(s.q, t, q); load3(s.qd, t, qd); load3(s.qd_old, t, qo); load3(s.tpos, t, tp); load3(s.tvel, t, tv);
+  load3(b.cmd, t, cmd); load3(s.q_id ? s.q_id : s.q, t, qi); load3(b.e_last, t, el); load3(b.e_int, t, ei);
   const double quat[4] = {b.quat[4 * i], b.quat[4 * i + 1], b.quat[4 * i + 2], b.quat[4 * i + 3]};
-  double qi[3] = {q[0], q[1], q[2]};
-  if (s.q_id) { qi[0] = s.q_id[3 * t]; qi[1] = s.q_id[3 * t + 1]; qi[2] = s.q_id[3 * t + 2]; }
-  double el[3] = {b.e_last[3 * t], b.e_last[3 * t + 1], b.e_last[3 * t + 2]};
-  double ei[3] = {b.e_int[3 * t], b.e_int[3 * t + 1], b.e_int[3 * t + 2]};
+  const int mode = (b.mode ? b.mode : s.support)[t];
+  const bool support = s.support[t] != 0;
+  PidLeg pl; // this leg's gains out of the kernel arguments, fetched with everything else
+  pid_leg_of(pid, leg, pl);
+  ts.commit(tab);
+  if (support || !live) return; // support legs keep the clamped QP torque already in `effort` (:497-502)
   double out[3];
-  swing_branch_leg(GlobalTab{P.legtab + kTabPerLeg * leg}, SP, pid, leg, b.mode ? b.mode[t] : 0, quat, qi, q, qd, qo, tp,
-                   tv, cmd, period, el, ei, out);
+  swing_branch_leg(LdsTab{tab + kTabPerLeg * leg}, SP, pl, b.mode ? mode : 0, quat, qi, q, qd, qo, tp, tv, cmd, period, el,
+                   ei, out);
 #pragma unroll
   for (int k = 0; k < 3; k++) { effort[3 * t + k] = out[k]; b.e_last[3 * t + k] = el[k]; b.e_int[3 * t + k] = ei[k]; }
 }

@@ -128,8 +128,22 @@ struct PidParamsDev {
 QL_HD double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 QL_HD bool finite_d(double v) { return v == v && v - v == 0.0; }
 
+// gains and limits of one leg's three joints (a slice of PidParamsDev; fetched once, up front, by the kernel)
+struct PidLeg {
+  double p[3], i[3], d[3], i_max[3], i_min[3], lower[3], upper[3];
+  int antiwindup;
+};
+QL_HD void pid_leg_of(const PidParamsDev &g, int leg, PidLeg &o) {
+  QL_UNROLL for (int k = 0; k < 3; k++) {
+    const int j = 3 * leg + k;
+    o.p[k] = g.p[j]; o.i[k] = g.i[j]; o.d[k] = g.d[j]; o.i_max[k] = g.i_max[j]; o.i_min[k] = g.i_min[j];
+    o.lower[k] = g.lower[j]; o.upper[k] = g.upper[j];
+  }
+  o.antiwindup = g.antiwindup;
+}
+
 // control_toolbox::Pid::computeCommand(error, dt) (third-party, restated; see oracle_swing.h)
-QL_HD double pid_command(const PidParamsDev &g, int j, double error, double dt, double &e_last, double &e_int) {
+QL_HD double pid_command(const PidLeg &g, int k, double error, double dt, double &e_last, double &e_int) {
   if (dt == 0.0 || !finite_d(error)) return 0.0;
   double error_dot = 0.0;
   if (dt > 0.0) {
@@ -137,21 +151,21 @@ QL_HD double pid_command(const PidParamsDev &g, int j, double error, double dt, 
     e_last = error;
   }
   if (!finite_d(error_dot)) return 0.0;
-  const double p_term = g.p[j] * error;
+  const double p_term = g.p[k] * error;
   e_int += dt * error;
-  if (g.antiwindup && g.i[j] != 0.0) {
-    const double a = g.i_min[j] / g.i[j], b = g.i_max[j] / g.i[j];
+  if (g.antiwindup && g.i[k] != 0.0) {
+    const double a = g.i_min[k] / g.i[k], b = g.i_max[k] / g.i[k];
     e_int = clampd(e_int, a < b ? a : b, a < b ? b : a);
   }
-  double i_term = g.i[j] * e_int;
-  if (!g.antiwindup) i_term = clampd(i_term, g.i_min[j], g.i_max[j]);
-  return p_term + i_term + g.d[j] * error_dot;
+  double i_term = g.i[k] * e_int;
+  if (!g.antiwindup) i_term = clampd(i_term, g.i_min[k], g.i_max[k]);
+  return p_term + i_term + g.d[k] * error_dot;
 }
 
 // One non-support leg: joint PID on the position command, gravity compensation, or the swing-leg torque,
 // selected by the leg mode (1 "joint", 2 "leg_mode", 3 "cartesian", 4 "footstep", 0 never set = as "joint").
 template <class Tab>
-QL_HD void swing_branch_leg(const Tab &tab, const SwingParamsDev &SP, const PidParamsDev &pid, int leg, int leg_mode,
+QL_HD void swing_branch_leg(const Tab &tab, const SwingParamsDev &SP, const PidLeg &pid, int leg_mode,
                             const double base_quat[4], const double q_id[3], const double q[3], const double qd[3],
                             const double qd_oldest[3], const double target_pos[3], const double target_vel[3],
                             const double joint_command[3], double period, double e_last[3], double e_int[3],
@@ -163,14 +177,25 @@ QL_HD void swing_branch_leg(const Tab &tab, const SwingParamsDev &SP, const PidP
   leg_kinematics(tab, q, g, foot, J, G);
   swing_leg_torque(tab, SP, q_id, q, qd, qd_oldest, target_pos, target_vel, tsw);
   QL_UNROLL for (int k = 0; k < 3; k++) {
-    const int j = 3 * leg + k;
-    const double cmd = clampd(joint_command[k], pid.lower[j], pid.upper[j]); // enforceJointLimits
-    double e = pid_command(pid, j, cmd - q[k], period, e_last[k], e_int[k]);
+    const double cmd = clampd(joint_command[k], pid.lower[k], pid.upper[k]); // enforceJointLimits
+    double e = pid_command(pid, k, cmd - q[k], period, e_last[k], e_int[k]);
     if (leg_mode == 3 || leg_mode == 4) e = tsw[k];
     else if (leg_mode != 2) e += G[k];
     else e = G[k];
     effort[k] = e;
   }
+}
+
+template <class Tab>
+QL_HD void swing_branch_leg(const Tab &tab, const SwingParamsDev &SP, const PidParamsDev &pid, int leg, int leg_mode,
+                            const double base_quat[4], const double q_id[3], const double q[3], const double qd[3],
+                            const double qd_oldest[3], const double target_pos[3], const double target_vel[3],
+                            const double joint_command[3], double period, double e_last[3], double e_int[3],
+                            double effort[3]) {
+  PidLeg pl;
+  pid_leg_of(pid, leg, pl);
+  swing_branch_leg(tab, SP, pl, leg_mode, base_quat, q_id, q, qd, qd_oldest, target_pos, target_vel, joint_command, period,
+                   e_last, e_int, effort);
 }
 
 } // namespace qlamd
