@@ -243,6 +243,8 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
 #pragma unroll
     for (int k = 0; k < 6; k++) wr[k] = s.wrench[6 * i + k];
   }
+  double nWl[3] = {0.0, 0.0, 1.0}; // caller-supplied surface normal of my leg (world frame), if any
+  if (kPerLeg) { nWl[0] = s.normals[12 * i + 3 * leg]; nWl[1] = s.normals[12 * i + 3 * leg + 1]; nWl[2] = s.normals[12 * i + 3 * leg + 2]; }
   // (all loads above are in flight before the first of them is consumed)
   const unsigned stance = robot_live ? (((sm & 0xFFu) ? 1u : 0u) | ((sm & 0xFF00u) ? 2u : 0u) |
                                         ((sm & 0xFF0000u) ? 4u : 0u) | ((sm & 0xFF000000u) ? 8u : 0u))
@@ -351,7 +353,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     const double ey[3] = {0.0, 1.0, 0.0}, ez[3] = {0.0, 0.0, 1.0};
     double yB[3], nW[3], nb[3], t1[3], t2[3];
     irot(Rm, ey, yB);
-    if (kPerLeg) { nW[0] = s.normals[12 * i + 3 * leg]; nW[1] = s.normals[12 * i + 3 * leg + 1]; nW[2] = s.normals[12 * i + 3 * leg + 2]; }
+    if (kPerLeg) { nW[0] = nWl[0]; nW[1] = nWl[1]; nW[2] = nWl[2]; }
     else rot(Rm, ez, nW);
     irot(Rm, nW, nb);
     cross3(nb, yB, t1);
