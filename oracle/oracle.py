@@ -429,3 +429,19 @@ def swing_branch_leg(leg, leg_mode, base_quat, q_id, q, qd, qd_oldest, target_po
     lib().oracle_swing_branch_leg(C.byref(prm), C.byref(pp), int(leg), int(leg_mode), *[x[1] for x in a], C.c_double(period),
                                   e_last.ctypes.data_as(_dp), e_int.ctypes.data_as(_dp), eff.ctypes.data_as(_dp))
     return eff
+
+
+def pose_sqp_batch(pb, hips, leg_order, tol=0.05, max_iter=30, dummy_equality=1, nthreads=1, problems=None):
+    """oracle_pose_sqp_batch over a whole batch dict.  Returns (pose [B,7], iters [B], status [B], problems) --
+    pass `problems` back in to skip the marshalling on repeated calls (timing loops)."""
+    B = pb["pose"].shape[0]
+    if problems is None:
+        problems = (PoseProblem * B)()
+        for i in range(B):
+            problems[i] = pose_problem(pb, i, hips, leg_order)
+    pose_in = np.ascontiguousarray(pb["pose"], dtype=np.float64)
+    out = np.zeros((B, 7)); it = np.zeros(B, np.int32); st = np.zeros(B, np.int32)
+    lib().oracle_pose_sqp_batch(problems, pose_in.ctypes.data_as(_dp), C.c_longlong(B), C.c_double(tol), int(max_iter),
+                                int(dummy_equality), out.ctypes.data_as(_dp), it.ctypes.data_as(C.POINTER(C.c_int)),
+                                st.ctypes.data_as(C.POINTER(C.c_int)), int(nthreads))
+    return out, it, st, problems

@@ -312,3 +312,19 @@ int oracle_pose_check(const oracle_pose_problem *pb, const double pose[7], const
   }
   return 1;
 }
+
+void oracle_pose_sqp_batch(const oracle_pose_problem *pbs, const double *pose_in, long long B, double tol, int max_iter,
+                           int dummy_equality, double *pose_out, int *iters, int *status, int nthreads) {
+#ifdef _OPENMP
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+  for (long long i = 0; i < B; i++) {
+    int it = 0;
+    double cost = 0.0;
+    const int st = oracle_pose_sqp(&pbs[i], pose_in + 7 * i, tol, max_iter, dummy_equality, pose_out + 7 * i, &it, &cost, NULL);
+    if (iters) iters[i] = it;
+    if (status) status[i] = st;
+  }
+  (void)nthreads;
+}

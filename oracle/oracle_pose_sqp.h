@@ -35,6 +35,10 @@ int oracle_pose_constraints(const oracle_pose_problem *pb, const double pose[7],
 int oracle_pose_sqp(const oracle_pose_problem *pb, const double pose_in[7], double tol, int max_iter,
                     int dummy_equality, double pose_out[7], int *iters_out, double *cost_out, double *dp_hist);
 
+/* A batch of problems (array of structs), OpenMP over problems: the CPU baseline of bench.py --workload pose_sqp. */
+void oracle_pose_sqp_batch(const oracle_pose_problem *pbs, const double *pose_in, long long B, double tol, int max_iter,
+                           int dummy_equality, double *pose_out, int *iters, int *status, int nthreads);
+
 /* PoseOptimizationQP::optimize (free_gait_core/src/pose_optimization/PoseOptimizationQP.cpp:42-140): position only,
  * orientation kept; min sum |x + R d_i - f_i|^2  s.t.  G (x + R r_com)_xy <= h, plus the dummy equality. */
 int oracle_pose_qp(const oracle_pose_problem *pb, const double pose_in[7], int dummy_equality, double pose_out[7]);
