@@ -183,7 +183,8 @@ int qlamd_swing_leg_torque_batch(qlamd_context *ctx, const qlamd_swing_params *p
 
 /* Virtual wrench only: (F_B, T_B) [B][6].  Replaces
  * VirtualModelController::computeError/GravityCompensation/VirtualForce/VirtualTorque
- * (VirtualModelController.cpp:104-268). */
+ * (VirtualModelController.cpp:104-268).  Reads the base and desired-base fields of `in` only
+ * (joint_position / support_leg may be NULL). */
 int qlamd_virtual_wrench_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch,
                                double *wrench, int memory, void *stream);
 

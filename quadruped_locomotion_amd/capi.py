@@ -298,6 +298,35 @@ class Context:
             raise QlamdError(rc, "qlamd_leg_kinematics_batch")
 
 
+def virtual_wrench(ctx, state):
+    """qlamd_virtual_wrench_batch on host buffers (state dict as synth.make_states) -> wrench [B,6]."""
+    B = int(np.asarray(state["base_pos"]).shape[0])
+    sb, keep = StateBatch(), []
+    for key, field, k in FIELD_OF_KEY:
+        if key == "q":
+            continue
+        a = np.ascontiguousarray(np.asarray(state[key], dtype=np.float64).reshape(B, k))
+        keep.append(a)
+        setattr(sb, field, a.ctypes.data)
+    w = np.zeros((B, 6))
+    rc = lib().qlamd_virtual_wrench_batch(ctx._h, C.byref(sb), B, w.ctypes.data, MEM_HOST, None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_virtual_wrench_batch")
+    return w
+
+
+def leg_kinematics(ctx, q, quat):
+    """qlamd_leg_kinematics_batch on host buffers -> (foot [B,4,3], jacobian [B,4,9], gravity torque [B,4,3])."""
+    q = np.ascontiguousarray(q, dtype=np.float64); quat = np.ascontiguousarray(quat, dtype=np.float64)
+    B = q.shape[0]
+    foot, jac, grav = np.zeros((B, 4, 3)), np.zeros((B, 4, 9)), np.zeros((B, 4, 3))
+    rc = lib().qlamd_leg_kinematics_batch(ctx._h, q.ctypes.data, quat.ctypes.data, B, foot.ctypes.data, jac.ctypes.data,
+                                          grav.ctypes.data, MEM_HOST, None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_leg_kinematics_batch")
+    return foot, jac, grav
+
+
 def _ptr(a):
     """data pointer of a numpy array or a torch tensor (None -> NULL)."""
     if a is None:

@@ -178,8 +178,21 @@ __global__ __launch_bounds__(64) void virtual_wrench_kernel(const DeviceParams *
   const DeviceParams &P = *Pp;
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= B) return;
-  RobotIn in;
-  load_robot(s, i, in);
+  RobotIn in; // only the base state enters the wrench (joint positions and stance flags are not read)
+  {
+    const double2 *a2 = reinterpret_cast<const double2 *>(s.quat + 4 * i);
+    const double2 *b2 = reinterpret_cast<const double2 *>(s.dquat + 4 * i);
+    double2 v = a2[0]; in.quat[0] = v.x; in.quat[1] = v.y;
+    v = a2[1]; in.quat[2] = v.x; in.quat[3] = v.y;
+    v = b2[0]; in.dquat[0] = v.x; in.dquat[1] = v.y;
+    v = b2[1]; in.dquat[2] = v.x; in.dquat[3] = v.y;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      in.pos[k] = s.pos[3 * i + k]; in.linvel[k] = s.linvel[3 * i + k]; in.angvel[k] = s.angvel[3 * i + k];
+      in.dpos[k] = s.dpos[3 * i + k]; in.dlinvel[k] = s.dlinvel[3 * i + k]; in.dangvel[k] = s.dangvel[3 * i + k];
+    }
+    in.stance = 0; in.has_wrench = false;
+  }
   double Rm[9], gB[3], b[6];
   quat_to_matrix(in.quat, Rm);
   const double gW[3] = {0.0, 0.0, -P.grav};
@@ -1598,29 +1611,63 @@ int qlamd_force_distribution_batch(qlamd_context *ctx, const double *joint_posit
 int qlamd_virtual_wrench_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch, double *wrench,
                                int memory, void *stream) {
   if (!ctx || !in || batch < 0 || !wrench) return QLAMD_ERR_INVALID_ARGUMENT;
-  if (memory != QLAMD_MEM_DEVICE) return QLAMD_ERR_INVALID_ARGUMENT; // device buffers only
+  if (!in->base_position || !in->base_orientation || !in->base_linear_velocity || !in->base_angular_velocity ||
+      !in->desired_position || !in->desired_orientation || !in->desired_linear_velocity || !in->desired_angular_velocity)
+    return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
   if (batch == 0) return QLAMD_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
   StatePtrs s{in->joint_position, in->base_position, in->base_orientation, in->base_linear_velocity,
               in->base_angular_velocity, in->desired_position, in->desired_orientation,
               in->desired_linear_velocity, in->desired_angular_velocity, in->support_leg, nullptr, nullptr};
+  double *d_w = wrench;
+  Staged sg;
+  if (memory == QLAMD_MEM_HOST) {
+    const int a1 = sg.add(in->base_position, B * 24, true, false), a2 = sg.add(in->base_orientation, B * 32, true, false);
+    const int a3 = sg.add(in->base_linear_velocity, B * 24, true, false), a4 = sg.add(in->base_angular_velocity, B * 24, true, false);
+    const int a5 = sg.add(in->desired_position, B * 24, true, false), a6 = sg.add(in->desired_orientation, B * 32, true, false);
+    const int a7 = sg.add(in->desired_linear_velocity, B * 24, true, false);
+    const int a8 = sg.add(in->desired_angular_velocity, B * 24, true, false), o = sg.add(wrench, B * 48, false, true);
+    const int rc = sg.upload(ctx, st);
+    if (rc != QLAMD_OK) return rc;
+    s = StatePtrs{nullptr, sg.dev<const double>(a1), sg.dev<const double>(a2), sg.dev<const double>(a3),
+                  sg.dev<const double>(a4), sg.dev<const double>(a5), sg.dev<const double>(a6), sg.dev<const double>(a7),
+                  sg.dev<const double>(a8), nullptr, nullptr, nullptr};
+    d_w = sg.dev<double>(o);
+  }
   const unsigned grid = (unsigned)((batch + 63) / 64);
-  hipLaunchKernelGGL(virtual_wrench_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, ctx->d_params, s, batch,
-                     wrench);
-  return hipGetLastError() == hipSuccess ? QLAMD_OK : QLAMD_ERR_HIP;
+  hipLaunchKernelGGL(virtual_wrench_kernel, dim3(grid), dim3(64), 0, st, ctx->d_params, s, batch, d_w);
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  return memory == QLAMD_MEM_HOST ? sg.finish(st) : QLAMD_OK;
 }
 
 int qlamd_leg_kinematics_batch(qlamd_context *ctx, const double *joint_position, const double *base_orientation,
                                int64_t batch, double *foot_position, double *jacobian, double *gravity_torque,
                                int memory, void *stream) {
   if (!ctx || !joint_position || !base_orientation || batch < 0) return QLAMD_ERR_INVALID_ARGUMENT;
-  if (memory != QLAMD_MEM_DEVICE) return QLAMD_ERR_INVALID_ARGUMENT; // device buffers only
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
   if (batch == 0) return QLAMD_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+  const double *d_q = joint_position, *d_quat = base_orientation;
+  double *d_f = foot_position, *d_j = jacobian, *d_g = gravity_torque;
+  Staged sg;
+  if (memory == QLAMD_MEM_HOST) {
+    const int a1 = sg.add(joint_position, B * 96, true, false), a2 = sg.add(base_orientation, B * 32, true, false);
+    const int o1 = sg.add(foot_position, B * 96, false, true), o2 = sg.add(jacobian, B * 288, false, true);
+    const int o3 = sg.add(gravity_torque, B * 96, false, true);
+    const int rc = sg.upload(ctx, st);
+    if (rc != QLAMD_OK) return rc;
+    d_q = sg.dev<const double>(a1); d_quat = sg.dev<const double>(a2);
+    d_f = sg.dev<double>(o1); d_j = sg.dev<double>(o2); d_g = sg.dev<double>(o3);
+  }
   const unsigned grid = (unsigned)((4 * batch + 63) / 64);
-  hipLaunchKernelGGL(leg_kinematics_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, ctx->d_params,
-                     joint_position, base_orientation, batch, foot_position, jacobian, gravity_torque);
-  return hipGetLastError() == hipSuccess ? QLAMD_OK : QLAMD_ERR_HIP;
+  hipLaunchKernelGGL(leg_kinematics_kernel, dim3(grid), dim3(64), 0, st, ctx->d_params, d_q, d_quat, batch, d_f, d_j, d_g);
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  return memory == QLAMD_MEM_HOST ? sg.finish(st) : QLAMD_OK;
 }
 
 } // extern "C"

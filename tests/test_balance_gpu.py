@@ -165,3 +165,7 @@ def test_wrench_and_kinematics_kernels(gpu, oracle):
             assert np.allclose(foot[i, l], oracle.leg_fk(l, q)[0], atol=1e-13)
             assert np.allclose(jac[i, l].reshape(3, 3), oracle.leg_jacobian(l, q), atol=1e-13)
             assert np.allclose(grav[i, l], oracle.leg_gravity(l, q, gB), atol=1e-12)
+    # host-buffer mode of the same two entries
+    wh = capi.virtual_wrench(ctx, s)
+    fh, jh, gh = capi.leg_kinematics(ctx, s["q"], s["base_quat"])
+    assert np.array_equal(wh, w) and np.array_equal(fh, foot) and np.array_equal(jh, jac) and np.array_equal(gh, grav)
