@@ -14,6 +14,7 @@ struct RobotStateHandleData { // robot_state_interface.hpp:28-65
   const double *angular_velocity = nullptr;   // [3]
   const double *linear_velocity = nullptr;    // [3]
   const double *joint_position_read = nullptr;// [12]
+  const double *joint_velocity_read = nullptr;// [12] (only the full tick, updateFullTick, reads it)
   double *joint_effort_write = nullptr;       // [12]
   const bool *foot_contact = nullptr;         // [4]
 };
@@ -66,6 +67,62 @@ class RosBalanceController {
     return true;
   }
 
+  // ---- the whole tick (SURVEY.md section 8 rows f1/f2 on top of a1) ----------------------------------------
+  // baseCommandCallback on a serialised free_gait_msgs/RobotState (ros_balance_controller.cpp:761-1083)
+  bool baseCommandCallback(const uint8_t *msg, size_t len) {
+    const int64_t off[2] = {0, static_cast<int64_t>(len)};
+    double pos[3], quat[4], lin[3], ang[3];
+    uint8_t mode[4];
+    qlamd_robot_state_fields f{};
+    f.des_pos = pos; f.des_quat = quat; f.des_linvel = lin; f.des_angvel = ang;
+    f.joint_command = joint_command_.data(); f.foot_position = foot_target_.data(); f.foot_velocity = foot_velocity_.data();
+    f.phase = phase_; f.support_leg = support_leg_; f.leg_mode = mode;
+    int32_t status = -1;
+    if (qlamd_robot_state_unpack_batch(ctx_->get(), msg, off, 1, &f, &status, QLAMD_MEM_HOST, nullptr) != QLAMD_OK ||
+        status != QLAMD_WIRE_OK)
+      return false; // the reference would index past the end of the message's arrays here
+    cmd_.position = qlamd::Position(pos[0], pos[1], pos[2]);
+    cmd_.orientation = qlamd::RotationQuaternion(quat[0], quat[1], quat[2], quat[3]);
+    cmd_.linear_velocity = qlamd::LinearVelocity(lin[0], lin[1], lin[2]);
+    cmd_.angular_velocity = qlamd::LocalAngularVelocity(ang[0], ang[1], ang[2]);
+    for (int l = 0; l < 4; ++l)
+      if (mode[l] != QLAMD_LEG_MODE_OTHER) leg_mode_[l] = mode[l]; // an unknown name leaves the flags as they are (:876-964)
+    return true;
+  }
+  // footContactsCallback (:1084-1135) only records the sensors; the transitions run inside updateFullTick
+  void footContactsCallback(const bool contact[4]) {
+    for (int l = 0; l < 4; ++l) contact_[l] = contact[l] ? 1 : 0;
+  }
+  // update() with its leg state machine (:234-380), the balance solve (:419-454) and the swing branch (:467-603):
+  // all 12 effort commands (what joints[i].setCommand receives) go to joint_effort_write.
+  bool updateFullTick(double period) {
+    uint8_t is_footstep[4];
+    for (int l = 0; l < 4; ++l) is_footstep[l] = leg_mode_[l] == QLAMD_LEG_MODE_FOOTSTEP;
+    qlamd_leg_state_batch ls{support_leg_, phase_, is_footstep, contact_, hw_.joint_position_read, limb_state_, store_flag_,
+                             stored_joint_position_.data(), joint_command_.data(), foot_target_.data(), support_, leg_state_code_};
+    if (qlamd_leg_state_machine_batch(ctx_->get(), &ls, 1, 1, QLAMD_MEM_HOST, nullptr) != QLAMD_OK) return false;
+    for (int l = 0; l < 4; ++l) cmd_.support[l] = support_[l] != 0;
+    const bool solved = update();                      // stance legs: QP torques, clamped; others 0
+    // joint velocity queue of MyRobotSolver (11 deep, model_test_header.cpp:417-431)
+    for (int i = 0; i < 12; ++i) {
+      for (int k = 10; k > 0; --k) qd_queue_[k][i] = qd_queue_[k - 1][i];
+      qd_queue_[0][i] = hw_.joint_velocity_read ? hw_.joint_velocity_read[i] : 0.0;
+    }
+    qlamd_swing_params sp; qlamd_swing_default_params(&sp);
+    sp.period = period;
+    qlamd_joint_pid_params pid; qlamd_joint_pid_default_params(&pid);
+    const qlamd_swing_batch sw{hw_.joint_position_read, qd_queue_[0].data(), qd_queue_[10].data(), foot_target_.data(),
+                               foot_velocity_.data(), support_, nullptr};
+    const qlamd_swing_branch_extra ex{hw_.orientation, joint_command_.data(), leg_mode_, pid_error_last_.data(),
+                                      pid_error_integral_.data()};
+    if (qlamd_swing_branch_batch(ctx_->get(), &sp, &pid, &sw, &ex, period, 1, hw_.joint_effort_write, QLAMD_MEM_HOST, nullptr) !=
+        QLAMD_OK)
+      return false;
+    return solved;
+  }
+  const int8_t *legStateCodes() const { return leg_state_code_; }
+  const int8_t *limbStates() const { return limb_state_; }
+
   const VirtualModelController &vmc() const { return *virtual_model_controller_; }
 
  private:
@@ -75,6 +132,14 @@ class RosBalanceController {
   std::shared_ptr<free_gait::State> robot_state_;
   std::shared_ptr<ContactForceDistribution> contact_distribution_;
   std::shared_ptr<VirtualModelController> virtual_model_controller_;
+  // what the plugin keeps between ticks for the leg state machine and the swing branch
+  std::array<double, 12> joint_command_{}, foot_target_{}, foot_velocity_{}, stored_joint_position_{}, pid_error_last_{},
+      pid_error_integral_{};
+  std::array<std::array<double, 12>, 11> qd_queue_{};
+  double phase_[4] = {0, 0, 0, 0};
+  uint8_t support_leg_[4] = {1, 1, 1, 1}, contact_[4] = {1, 1, 1, 1}, store_flag_[4] = {0, 0, 0, 0}, support_[4] = {1, 1, 1, 1};
+  uint8_t leg_mode_[4] = {0, 0, 0, 0};
+  int8_t limb_state_[4] = {0, 0, 0, 0}, leg_state_code_[4] = {0, 0, 0, 0};
 };
 
 } // namespace balance_controller

@@ -9,6 +9,7 @@
 // Exit code 3 when no GPU is present (init() returns false: there is no CPU fallback).
 #include <cmath>
 #include <cstdio>
+#include <vector>
 
 #include "balance_controller/RosBalanceController.hpp"
 #include "free_gait_core/PoseConstraintsChecker.hpp"
@@ -17,7 +18,7 @@
 #include "free_gait_core/PoseOptimizationSQP.hpp"
 #include "qp_solver/quadraticproblemsolver.hpp"
 
-int main() {
+int main(int argc, char **argv) {
   qlamd_balance_params params;
   qlamd_balance_default_params(&params);
 
@@ -56,6 +57,30 @@ int main() {
   std::printf("cfd_effort"); for (double v : state->getAllJointEfforts()) std::printf(" %.17g", v); std::printf("\n");
   qlamd::Force f_lf; cfd.getForceForLeg(qlamd::LimbEnum::LF_LEG, f_lf);
   std::printf("cfd_force_lf %.17g %.17g %.17g\n", f_lf(0), f_lf(1), f_lf(2));
+
+  // ---- 1b. the whole tick from a serialised /desired_robot_state message (argv[1], written by the test) -----
+  if (argc > 1) {
+    std::vector<uint8_t> msg;
+    if (FILE *fp = std::fopen(argv[1], "rb")) {
+      uint8_t buf[4096];
+      size_t n;
+      while ((n = std::fread(buf, 1, sizeof(buf), fp)) > 0) msg.insert(msg.end(), buf, buf + n);
+      std::fclose(fp);
+    }
+    double qd[12];
+    for (int i = 0; i < 12; ++i) qd[i] = 0.1 * std::sin(1.0 + i);
+    hw.joint_velocity_read = qd;
+    balance_controller::RosBalanceController tick;
+    if (!tick.init(hw, params, 0)) return 12;
+    if (tick.baseCommandCallback(msg.data(), 17)) return 13;              // a truncated message is refused
+    if (!tick.baseCommandCallback(msg.data(), msg.size())) return 14;
+    const bool touching[4] = {false, true, true, true};
+    tick.footContactsCallback(touching);
+    if (!tick.updateFullTick(0.0025)) return 15;
+    std::printf("tick_effort"); for (int i = 0; i < 12; ++i) std::printf(" %.17g", effort[i]); std::printf("\n");
+    std::printf("tick_leg_state"); for (int l = 0; l < 4; ++l) std::printf(" %d", tick.legStateCodes()[l]); std::printf("\n");
+    std::printf("tick_qd"); for (int i = 0; i < 12; ++i) std::printf(" %.17g", qd[i]); std::printf("\n");
+  }
 
   // ---- 2. pose optimisation ---------------------------------------------------------------------
   free_gait::PoseOptimizationSQP optimization(ctx);
