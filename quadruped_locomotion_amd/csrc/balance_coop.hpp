@@ -57,17 +57,9 @@ __device__ __forceinline__ double dpp(double x) {
   hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
-template <int CTRL>
-__device__ __forceinline__ int dppi(int x) {
-  return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, true);
-}
 // broadcast from lane J of the 16-lane row (one v_mov_b64_dpp row_newbcast)
 template <int J>
 __device__ __forceinline__ double bc(double x) {
-  return __builtin_amdgcn_mov_dpp(x, 0x150 + J, 0xF, 0xF, true);
-}
-template <int J>
-__device__ __forceinline__ int bci(int x) {
   return __builtin_amdgcn_mov_dpp(x, 0x150 + J, 0xF, 0xF, true);
 }
 // lane that carries variable index j (0..11)
@@ -131,20 +123,6 @@ __device__ __forceinline__ int row_first(bool pred) {
   const unsigned long long m = __ballot(pred);
   const unsigned bits = (unsigned)(m >> (threadIdx.x & 48)) & 0xFFFFu;
   return bits ? (__ffs(bits) - 1) : 16;
-}
-
-// (value, key) minimum over the row; ties -> smaller key.  Invalid lanes pass +inf.
-__device__ __forceinline__ void row_argmin(double &v, int &key) {
-#define QL_ARGMIN_STEP(CTRL)                                        \
-  {                                                                 \
-    const double ov = dpp<CTRL>(v);                                 \
-    const int ok = dppi<CTRL>(key);                                 \
-    const bool take = (ov < v) || (ov == v && ok < key);            \
-    v = take ? ov : v;                                              \
-    key = take ? ok : key;                                          \
-  }
-  QL_ARGMIN_STEP(0x128) QL_ARGMIN_STEP(0x124) QL_ARGMIN_STEP(0x122) QL_ARGMIN_STEP(0x121)
-#undef QL_ARGMIN_STEP
 }
 
 template <int I, int N, class F>
