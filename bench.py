@@ -146,7 +146,7 @@ def bench_pose_sqp(args):
         "config": {"workload": "batch=%d pose optimisations, 5 SQP iterations x inner Goldfarb-Idnani QP "
                                "(n=6, m=8, dummy equality)" % B, "all_status_ok": bool((out[2] == 0).all().item())},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "pose_sqp_kernel", "kernel_ms": kernel_ms,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "pose_sqp_coop_kernel", "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": algo},
         **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
 

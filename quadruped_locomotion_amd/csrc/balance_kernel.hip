@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "balance_coop.hpp"
+#include "pose_coop.hpp"
 #include "balance_core.hpp"
 #include "params_build.hpp"
 #include "pose_core.hpp"
@@ -429,6 +430,37 @@ __global__ __launch_bounds__(64) void pose_sqp_kernel(const PoseParamsDev P, con
   for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
   if (iters) iters[i] = it;
   status[i] = st;
+}
+
+// Lane-cooperative form (csrc/pose_coop.hpp): 16 lanes per problem, 4 problems per wavefront -- the default.
+__global__ __launch_bounds__(64) void pose_sqp_coop_kernel(const PoseParamsDev P, const PosePtrs s, int64_t B,
+                                                           double *__restrict__ pose_out, int32_t *__restrict__ iters,
+                                                           int32_t *__restrict__ status) {
+  __shared__ PoseProblem pbs[coop::kPoseCoopRows];
+  __shared__ double pose0[coop::kPoseCoopRows][8];
+  __shared__ double rows[coop::kPoseCoopRows * coop::kPoseCoopLdsDoubles];
+  const int row = threadIdx.x >> 4, lr = threadIdx.x & 15;
+  int64_t i = (int64_t)blockIdx.x * coop::kPoseCoopRows + row;
+  const bool live = i < B;
+  if (!live) i = B - 1;
+  if (lr == 0) { // one lane per problem fetches the record; the row reads it back from LDS
+    double ps[7];
+    load_pose_problem(P, s, i, pbs[row], ps);
+#pragma unroll
+    for (int a = 0; a < 7; a++) pose0[row][a] = ps[a];
+  }
+  __syncthreads();
+  double pose[7];
+#pragma unroll
+  for (int a = 0; a < 7; a++) pose[a] = pose0[row][a];
+  int it = 0;
+  const int st = coop::pose_sqp_coop(P, pbs[row], live, rows + row * coop::kPoseCoopLdsDoubles, pose, it);
+  if (lr == 0 && live) {
+#pragma unroll
+    for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
+    if (iters) iters[i] = it;
+    status[i] = st;
+  }
 }
 
 // PoseOptimizationQP (position only) and PoseConstraintsChecker, same problem layout
@@ -1157,7 +1189,12 @@ static int pose_impl(const PoseCall &call, qlamd_context *ctx, const qlamd_pose_
   const size_t lds3 = (size_t)kPosePerWave * PoseQpGi::kTotal * sizeof(double);
   switch (mode) {
     case kPoseSqp:
-      hipLaunchKernelGGL(pose_sqp_kernel, dim3(grid), dim3(64), lds6, st, P, s, batch, d_out, d_it, d_st);
+      if (getenv("QLAMD_POSE_ONE_LANE")) // the one-lane-per-problem form, kept as a second implementation
+        hipLaunchKernelGGL(pose_sqp_kernel, dim3(grid), dim3(64), lds6, st, P, s, batch, d_out, d_it, d_st);
+      else
+        hipLaunchKernelGGL(pose_sqp_coop_kernel,
+                           dim3((unsigned)((batch + coop::kPoseCoopRows - 1) / coop::kPoseCoopRows)), dim3(64), 0, st, P, s,
+                           batch, d_out, d_it, d_st);
       break;
     case kPoseQp:
       hipLaunchKernelGGL(pose_qp_kernel, dim3(grid), dim3(64), lds3, st, P, s, batch, d_out, d_st);

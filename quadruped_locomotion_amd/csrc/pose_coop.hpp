@@ -1,0 +1,387 @@
+// Lane-cooperative pose optimisation (BASELINE config 5): 16 lanes per problem, 4 problems per wavefront.
+// Device-only; included by balance_kernel.hip after balance_coop.hpp (whose DPP helpers it uses).
+//
+// Same algorithm as pose_sqp / pose_sqp6 in pose_core.hpp (PoseOptimizationSQP.cpp:58-111,
+// sequencequadraticproblemsolver.cpp:18-102, the objective / constraint classes cited there), restated so that one
+// problem's work is spread over a DPP row instead of running as one lane's serial instruction stream:
+//   lanes 0..5   variable lanes: component i of x, g0, z; row i of the 6x6 Hessian G and of the operator H;
+//                also slot lanes: row k of N*, multiplier u_k, constraint id of active-set slot k
+//   lanes 8..15  constraint lanes: constraint j = lane - 8 (0..3 support-region half-spaces, 4..7 limb-length
+//                bounds of the stance legs in iteration order): its normal a_j[0..5], its bound, its slack
+//   everything that is per problem (pose, rotation, sums over legs) is replicated on the 16 lanes.
+//
+// Linearisation.  The reference builds the rotational Hessian block from four 3x3 products of skew matrices per
+// leg; with skew(a) skew(b) = b a' - (a.b) I they collapse to
+//   1/2 (T1 + T2 - T3 - T4) = 1/2 (Pd e' + e Pd') - (e.Pd) I,   e = p - f_k,  Pd = R d_k,
+// (and the same with Pr, p - c for the centre-of-mass term), which is what is evaluated here.
+//
+// Inner QP.  Goldfarb-Idnani with explicit operators as in balance_coop.hpp.  The reference always passes one
+// all-zero equality column.  In QuadProg++ that column consumes the first column of J = L^-T without
+// moving x, which is exactly an equality constraint with normal G e_1 (the first column of G) that holds at the
+// unconstrained minimiser x0: the projector starts as H0 = G^-1 - e_1 e_1' / G_11 instead of G^-1 (checked against
+// the reference solver on random QPs to 5e-13, tests/test_oracle_quadprog.py).  Its multiplier is never needed,
+// so no slot is spent on it.
+#pragma once
+
+#include "balance_coop.hpp"
+#include "pose_core.hpp"
+
+namespace qlamd {
+namespace coop {
+
+constexpr int kPoseCoopRows = 4;                 // problems per wavefront
+constexpr int kPoseCoopLdsDoubles = 8 * 6 + 6 + 6 * 6; // per problem: normals by constraint, one N* row, N* (refinement)
+
+// ---- the 6-variable QP ------------------------------------------------------------------------------------
+// Gm: row lr of G on variable lanes (0 elsewhere); g0: component lr; a, bci0, cvalid: this constraint lane's
+// normal (CI column), ci0 and presence; m: number of inequality constraints present.  Returns the status;
+// x_out = component lr of the minimiser on variable lanes.
+__device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const double (&a)[6], double bci0, bool cvalid,
+                                        int m, bool dummy_eq, bool skip, double *lds_row, double &x_out) {
+  const int lr = threadIdx.x & 15;
+  const bool var = lr < 6;
+  const int cj = lr - 8; // constraint id on constraint lanes
+  const double eps = 2.220446049250313e-16;
+  const double inf = INFINITY;
+  double *ct = lds_row, *nrow = lds_row + 48, *nst = lds_row + 54;
+
+  // normals by constraint into LDS: variable lane i later reads a_p[i] = ct[6 p + i]
+  if (lr >= 8) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) ct[6 * cj + i] = a[i];
+  }
+  // c1 = trace(G)
+  double diag = 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; j++) diag = sel(lr == j, Gm[j], diag);
+  const double c1 = row_sum(sel(var, diag, 0.0));
+  // H = G^-1 by Gauss-Jordan, row per lane (non-variable lanes carry zero rows)
+  double H[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) H[j] = Gm[j];
+  bool bad = false;
+  double my_pivot = 1.0;
+  static_for<6>([&](auto K) {
+    constexpr int k = K;
+    const double d = bc<k>(H[k]);
+    bad = bad || !(d > 0.0);
+    const double p = rcp_nr(d);
+    const bool piv = lr == k;
+    my_pivot = piv ? d : my_pivot;
+    const double f = piv ? (1.0 - p) : H[k] * p;
+    const double nf = -f;
+    static_for<6>([&](auto J) {
+      constexpr int j = J;
+      if constexpr (j != k) fmac_bc<k, (j == (k == 0 ? 1 : 0))>(H[j], H[j], nf);
+    });
+    H[k] = piv ? p : nf;
+  });
+  const double rp = rsqrt_nr(my_pivot);
+  const double c2 = row_sum(sel(var, rp, 0.0));
+  // x0 = -G^-1 g0 (the equality below holds there by construction)
+  double x = 0.0;
+  {
+    const double ng0 = -g0;
+    double xa[2] = {0.0, 0.0};
+    static_for<6>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(xa[j & 1], ng0, H[j]); });
+    x = xa[0] + xa[1];
+  }
+  if (dummy_eq) { // H0 = G^-1 - e1 e1'/G11: only element (0,0) changes
+    const double g11 = bc<0>(Gm[0]);
+    H[0] = sel(lr == 0, H[0] - rcp_nr(g11), H[0]);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F); // the normals are in LDS
+
+  double Ns[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) Ns[j] = 0.0;
+  double u = 0.0;
+  int idk = 0;
+  unsigned used = 0, act_mask = 0, excl = 0;
+  int q = 0, iters = 0, status = kStatusOk;
+  const double psi_tol = (double)m * eps * c1 * c2 * 100.0;
+  double rnorm2 = 1.0;
+  bool done = skip, need_select = true, fresh = true;
+  int ip = 0;
+  double sp = 0.0, ucand = 0.0;
+  if (bad && !skip) { status = kStatusNotPd; done = true; }
+
+  for (int tick = 0; tick < 40 * kMaxOuter; tick++) {
+    if (__all(done)) break;
+    if (!done && need_select) {
+      if (fresh) { iters++; excl = 0; }
+      // slacks on the constraint lanes: s_j = a_j'x + ci0_j
+      double s = bci0;
+      static_for<6>([&](auto I) { constexpr int i = I; fmac_bc<i, i == 0>(s, x, a[i]); });
+      const bool mine = cvalid && lr >= 8;
+      const float viol = mine ? (float)vmin(0.0, s) : 0.0f;
+      const double psi = (double)row_sum_f32(viol);
+      const unsigned blocked = act_mask | excl;
+      double v = sel(mine && !((blocked >> (cj & 7)) & 1u) && s < 0.0, s, inf);
+      const double vbest = row_min(v);
+      const int wl = row_first(v == vbest && v < 0.0);
+      const bool feasible = fresh && (fabs(psi) <= psi_tol);     // QuadProg++.cc:246-250
+      const bool stop = feasible || !(vbest < 0.0) || iters > kMaxOuter; // :271-274
+      status = (stop && iters > kMaxOuter) ? kStatusMaxIter : status;
+      done = stop;
+      ip = stop ? ip : (wl - 8);
+      sp = sel(stop, sp, vbest);
+      ucand = sel(stop, ucand, 0.0);
+      need_select = stop;
+    }
+    if (!done) {
+      const double npj = var ? ct[6 * ip + lr] : 0.0;
+      double za[2] = {0.0, 0.0}, ra[2] = {0.0, 0.0};
+      static_for<6>([&](auto J) {
+        constexpr int j = J;
+        fmac_bc<j, j == 0>(za[j & 1], npj, H[j]);
+        fmac_bc<j>(ra[j & 1], npj, Ns[j]);
+      });
+      const double z = za[0] + za[1], r = ra[0] + ra[1];
+      const bool slot = (used >> lr) & 1u;
+      const double zn = row_sum(z * npj);
+      const float zf = (float)z;
+      const double zz = (double)row_sum_f32(zf * zf);
+      // step lengths, QuadProg++.cc:304-331
+      const double ur = u * rcp_nr(r);
+      const double ratio = sel(slot && r > 0.0, ur, inf);
+      const double t1 = row_min(ratio);
+      const int lpos = row_first(ratio == t1 && ratio < inf);
+      const double t2v = -sp * rcp_nr(zn);
+      const double t2 = sel(fabs(zz) > eps && !(t2v < 0.0), t2v, inf);
+      const double t = vmin(t1, t2);
+      const bool infeasible = !(t < inf);                          // :339-344
+      const bool dual_only = (t2 >= inf);
+      const bool full = !infeasible && !dual_only && (t2 <= t1);   // :384
+      const bool degenerate = full && !(zn > eps * eps * rnorm2);  // add_constraint failure (:392)
+      const bool is_add = full && !degenerate;
+      const bool is_drop = !infeasible && !full;
+      if (infeasible) { status = kStatusInfeasible; done = true; }
+      const double tp = (infeasible || dual_only || degenerate) ? 0.0 : t;
+      const double td = (infeasible || degenerate) ? 0.0 : t;
+      x += tp * z;
+      u -= sel(slot, td * r, 0.0);
+      ucand += td;
+      sp += tp * zn;
+      const int newlane = __ffs(~used & 0x3Fu) - 1;
+      const bool newslot = is_add && (lr == newlane);
+      double vec = is_add ? z * rcp_nr(zn) : 0.0;
+      double hc = is_add ? -z : 0.0;
+      double nc = sel(newslot, 1.0, sel(is_add && slot, -r, 0.0));
+      u = newslot ? ucand : u;
+      idk = newslot ? ip : idk;
+      used |= is_add ? (1u << newlane) : 0u;
+      act_mask |= is_add ? (1u << ip) : 0u;
+      rnorm2 = is_add ? fmax(rnorm2, zn) : rnorm2;
+      q += is_add ? 1 : 0;
+      excl |= degenerate ? (1u << ip) : 0u;
+      need_select = need_select || full;
+      fresh = is_add ? true : (degenerate ? false : fresh);
+      if (is_drop) {
+        if (lr == lpos) {
+#pragma unroll
+          for (int j = 0; j < 6; j++) nrow[j] = Ns[j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        const double nt_me = var ? nrow[lr] : 0.0;
+        double Gn = 0.0;
+        static_for<6>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(Gn, nt_me, Gm[j]); });
+        const double einv = rcp_nr(row_sum(nt_me * Gn));
+        double coef = 0.0;
+        static_for<6>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(coef, Gn, Ns[j]); });
+        vec = nt_me;
+        hc = nt_me * einv;
+        nc = -coef * einv;
+        const int drop_id = __shfl(idk, lpos, 16);
+        act_mask &= ~(1u << drop_id);
+        used &= ~(1u << lpos);
+        if (lr == lpos) u = 0.0;
+        q--;
+      }
+      static_for<6>([&](auto J) {
+        constexpr int j = J;
+        fmac_bc<j, j == 0>(H[j], vec, hc);
+        fmac_bc<j>(Ns[j], vec, nc);
+      });
+      if (is_drop && lr == lpos) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) Ns[j] = 0.0;
+      }
+    }
+  }
+  if (!done) status = kStatusMaxIter;
+  // one refinement pass on the final working set (see balance_coop.hpp)
+  if (status == kStatusOk && q > 0 && !skip) {
+    if (lr < 6) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) nst[6 * lr + j] = Ns[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    double NsT[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) NsT[k] = var ? nst[6 * k + lr] : 0.0;
+    const bool myslot = (used >> lr) & 1u;
+    double grad = g0;
+    static_for<6>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(grad, x, Gm[j]); });
+    double corr = 0.0;
+    static_for<6>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(corr, grad, H[j]); });
+    x -= corr;
+    double s = bci0;
+    static_for<6>([&](auto I) { constexpr int i = I; fmac_bc<i, i == 0>(s, x, a[i]); });
+    const double sv = __shfl(s, myslot ? 8 + idk : 0, 16);
+    const double rho = sel(myslot, -sv, 0.0);
+    double dx = 0.0;
+    static_for<6>([&](auto K) { constexpr int k = K; fmac_bc<k, k == 0>(dx, rho, NsT[k]); });
+    x += dx;
+  }
+  x_out = x;
+  return status;
+}
+
+// ---- linearisation + SQP loop -----------------------------------------------------------------------------
+// pb: this problem's record (LDS, iteration order); pose: replicated, updated in place.
+__device__ __forceinline__ int pose_sqp_coop(const PoseParamsDev &P, const PoseProblem &pb, bool live, double *lds_row,
+                                             double pose[7], int &iters_out) {
+  const int lr = threadIdx.x & 15;
+  const int cj = lr - 8;
+  double centroid[2], GA[4][2], gb[4];
+  polygon_centroid(pb.n_vertices, pb.polygon, centroid);
+  const int nsp = polygon_halfspaces(pb.n_vertices, pb.polygon, GA, gb);
+  // my constraint's fixed data: half-space row (cj < 4) or leg slot (cj >= 4)
+  double ga0 = 0.0, ga1 = 0.0, gbj = 0.0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) { ga0 = sel(cj == j, GA[j][0], ga0); ga1 = sel(cj == j, GA[j][1], ga1); gbj = sel(cj == j, gb[j], gbj); }
+  const int kleg = cj - 4;
+  double lf[3] = {0, 0, 0}, lh[3] = {0, 0, 0}, lmax = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) { lf[c] = sel(kleg == k, pb.stance[k][c], lf[c]); lh[c] = sel(kleg == k, pb.hips[k][c], lh[c]); }
+    lmax = sel(kleg == k, pb.max_len[k], lmax);
+  }
+  const unsigned present = pb.present;
+  const int nl = __popc(present & 0xFu);
+  const bool cvalid = lr >= 8 && (cj < 4 ? cj < nsp : ((present >> (kleg & 3)) & 1u) != 0);
+  const int m = nsp + nl;
+
+  int k = 0, status = kStatusOk;
+  bool sqp_done = !live;
+  for (int outer = 0; outer < P.max_iter; outer++) {
+    if (__all(sqp_done)) break;
+    const double *p = pose;
+    double R[9];
+    quat_to_matrix(pose + 3, R);
+    // ---- objective: sums over the stance legs (replicated)
+    double sPd[3] = {0, 0, 0}, sg[3] = {0, 0, 0}, sx[3] = {0, 0, 0}, sB[6] = {0, 0, 0, 0, 0, 0}, sdot = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      if (!((present >> kk) & 1u)) continue;
+      double Pd[3];
+      rot(R, pb.nominal[kk], Pd);
+      const double e[3] = {p[0] - pb.stance[kk][0], p[1] - pb.stance[kk][1], p[2] - pb.stance[kk][2]};
+      double cr[3];
+      cross3(Pd, e, cr); // D (p - f) = Pd x e
+#pragma unroll
+      for (int c = 0; c < 3; c++) { sPd[c] += Pd[c]; sg[c] += e[c] + Pd[c]; sx[c] += cr[c]; }
+      sdot += dot3(e, Pd);
+      sB[0] += Pd[0] * e[0]; sB[1] += 0.5 * (Pd[0] * e[1] + e[0] * Pd[1]); sB[2] += 0.5 * (Pd[0] * e[2] + e[0] * Pd[2]);
+      sB[3] += Pd[1] * e[1]; sB[4] += 0.5 * (Pd[1] * e[2] + e[1] * Pd[2]); sB[5] += Pd[2] * e[2];
+    }
+    // centre-of-mass term (weight w, planar): Pr = (R r_com)_xy, e = (p - centroid) with z = p_z
+    double Pr3[3];
+    rot(R, pb.r_com, Pr3);
+    const double w = P.com_weight;
+    const double Pr[3] = {Pr3[0], Pr3[1], 0.0};
+    const double pc[3] = {p[0] - centroid[0], p[1] - centroid[1], 0.0}; // pbar - rc
+    const double ec[3] = {p[0] - centroid[0], p[1] - centroid[1], p[2]}; // p - rc (p enters skew(p) with its z)
+    double cc[3];
+    cross3(Pr, pc, cc);
+    const double cdot = dot3(ec, Pr);
+    // gradient (6) and Hessian rows: G = 2 [[nl I + w diag(1,1,0), -skew(sPd + w Pr)], [skew(sPd + w Pr), B]]
+    const double g[6] = {sg[0] + w * (pc[0] + Pr[0]), sg[1] + w * (pc[1] + Pr[1]), sg[2], sx[0] + w * cc[0],
+                         sx[1] + w * cc[1], sx[2] + w * cc[2]};
+    const double q3[3] = {sPd[0] + w * Pr[0], sPd[1] + w * Pr[1], sPd[2]}; // skew(q3) = sum D_k + w skew(Pr)
+    double Bm[6]; // symmetric 3x3, packed 00 01 02 11 12 22
+    Bm[0] = sB[0] - sdot + w * (Pr[0] * ec[0] - cdot);
+    Bm[1] = sB[1] + w * 0.5 * (Pr[0] * ec[1] + ec[0] * Pr[1]);
+    Bm[2] = sB[2] + w * 0.5 * (Pr[0] * ec[2] + ec[0] * Pr[2]);
+    Bm[3] = sB[3] - sdot + w * (Pr[1] * ec[1] - cdot);
+    Bm[4] = sB[4] + w * 0.5 * (Pr[1] * ec[2] + ec[1] * Pr[2]);
+    Bm[5] = sB[5] - sdot + w * (Pr[2] * ec[2] - cdot);
+    // full 6x6 (replicated), then my row
+    const double n0 = (double)nl + w, n2 = (double)nl;
+    const double Gfull[6][6] = {
+        {n0, 0, 0, 0, q3[2], -q3[1]},   {0, n0, 0, -q3[2], 0, q3[0]},  {0, 0, n2, q3[1], -q3[0], 0},
+        {0, -q3[2], q3[1], Bm[0], Bm[1], Bm[2]}, {q3[2], 0, -q3[0], Bm[1], Bm[3], Bm[4]}, {-q3[1], q3[0], 0, Bm[2], Bm[4], Bm[5]}};
+    double Gm[6] = {0, 0, 0, 0, 0, 0}, g0 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      g0 = sel(lr == i, 2.0 * g[i], g0);
+#pragma unroll
+      for (int j = 0; j < 6; j++) Gm[j] = sel(lr == i, 2.0 * Gfull[i][j], Gm[j]);
+    }
+    // ---- constraints: my row of CI = -A', ci0 = max - value (PoseOptimizationFunctionConstraints.cpp:95-194)
+    double a[6] = {0, 0, 0, 0, 0, 0}, bci0 = 0.0;
+    {
+      // support half-space j: A = [GA_j, 0 | GA_j skew(Pr3)], value GA_j (p + Pr3)_xy
+      const double cw0 = p[0] + Pr3[0], cw1 = p[1] + Pr3[1];
+      const double hs_b = gbj - (ga0 * cw0 + ga1 * cw1);
+      // (G3 skew(Pr3))_c with G3 = (ga0, ga1, 0): column c of skew(Pr3) dotted with G3
+      const double hs3 = ga1 * Pr3[2], hs4 = -ga0 * Pr3[2], hs5 = ga0 * Pr3[1] - ga1 * Pr3[0];
+      const double hs_a[6] = {-ga0, -ga1, -0.0, hs3 * 1.0, hs4 * 1.0, hs5 * 1.0};
+      // limb-length bound of my leg slot: value |R'(f - p) - hip|, gradient through ln = (p + R hip - f)/|.|
+      const double df[3] = {lf[0] - p[0], lf[1] - p[1], lf[2] - p[2]};
+      double bf[3], Ph[3];
+      irot(R, df, bf);
+      const double ev[3] = {bf[0] - lh[0], bf[1] - lh[1], bf[2] - lh[2]};
+      const double len2 = dot3(ev, ev);
+      const double rl = rsqrt_nr(len2);
+      const double len = len2 * rl;
+      rot(R, lh, Ph);
+      double ln[3] = {p[0] + Ph[0] - lf[0], p[1] + Ph[1] - lf[1], p[2] + Ph[2] - lf[2]};
+      const double rn = rsqrt_nr(dot3(ln, ln));
+      ln[0] *= rn; ln[1] *= rn; ln[2] *= rn;
+      double lx[3];
+      cross3(ln, Ph, lx); // ln' skew(Ph) = (Ph x ln)' ... see below
+      // CI rows 3..5 of the reference: ln[0] Hs[j] + ln[1] Hs[3+j] + ln[2] Hs[6+j] with Hs = skew(Ph)
+      //   = (skew(Ph)' ln)_j = -(Ph x ln)_j = (ln x Ph)_j
+      const double ll_a[6] = {-ln[0], -ln[1], -ln[2], lx[0], lx[1], lx[2]};
+      const bool hs = cj < 4;
+#pragma unroll
+      for (int i = 0; i < 6; i++) a[i] = sel(hs, hs_a[i], ll_a[i]);
+      bci0 = sel(hs, hs_b, lmax - len);
+      if (!cvalid) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) a[i] = 0.0;
+        bci0 = 0.0;
+      }
+    }
+    // ---- QP and the update
+    double x;
+    const int st = qp6_coop(Gm, g0, a, bci0, cvalid, m, P.dummy_equality != 0, sqp_done, lds_row, x);
+    double dp[6];
+    static_for<6>([&](auto I) { constexpr int i = I; dp[i] = bc<i>(x); });
+    if (!sqp_done) {
+      k++;
+      status = st;
+      if (st != kStatusOk) {
+        sqp_done = true;
+      } else {
+        pose[0] += dp[0]; pose[1] += dp[1]; pose[2] += dp[2];
+        double qn[4];
+        quat_box_plus(pose + 3, dp + 3, qn);
+        pose[3] = qn[0]; pose[4] = qn[1]; pose[5] = qn[2]; pose[6] = qn[3];
+        const double nrm = sqrt(dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2] + dp[3] * dp[3] + dp[4] * dp[4] + dp[5] * dp[5]);
+        if (nrm < P.tol) sqp_done = true; // sequencequadraticproblemsolver.cpp:72-76
+      }
+    }
+  }
+  iters_out = k;
+  return status;
+}
+
+} // namespace coop
+} // namespace qlamd

@@ -69,3 +69,27 @@ def test_against_live_reference(oracle):
         assert a["status"] == b["status"]
         if a["status"] == 0:
             assert np.array_equal(a["x"], b["x"]) and a["f"] == b["f"]
+
+
+def test_dummy_zero_equality_is_an_equality_along_the_first_column_of_G(oracle):
+    """SURVEY.md Q1 explained: the all-zero equality column the reference always passes consumes the first column of
+    J = L^-T without moving x, i.e. it acts as the equality  (G e_1)'(x - x0) = 0  held at the unconstrained minimiser
+    x0.  The lane-cooperative pose QP (csrc/pose_coop.hpp) relies on this: its projector starts as
+    G^-1 - e_1 e_1'/G_11.  Checked here against the pinned restatement of the reference solver."""
+    rng = np.random.default_rng(12)
+    n_cmp, differs = 0, 0
+    for _ in range(300):
+        n, m = int(rng.integers(2, 9)), int(rng.integers(1, 10))
+        A = rng.normal(size=(n, n)); G = A @ A.T + 0.5 * np.eye(n); g0 = rng.normal(size=n)
+        CI = rng.normal(size=(n, m)); ci0 = rng.uniform(-0.5, 1.0, size=m)
+        dummy = oracle.solve_quadprog(G.copy(), g0, np.zeros((n, 1)), np.zeros(1), CI, ci0)
+        x0 = -np.linalg.solve(G, g0)
+        g1 = G[:, 0].copy()
+        equal = oracle.solve_quadprog(G.copy(), g0, g1[:, None], np.array([-g1 @ x0]), CI, ci0)
+        plain = oracle.solve_quadprog(G.copy(), g0, None, None, CI, ci0)
+        assert dummy["status"] == equal["status"]
+        if dummy["status"] == 0:
+            n_cmp += 1
+            assert np.abs(dummy["x"] - equal["x"]).max() < 1e-9
+            differs += plain["status"] == 0 and np.abs(dummy["x"] - plain["x"]).max() > 1e-3
+    assert n_cmp > 100 and differs > 50          # and it is not the plain inequality-only optimum
