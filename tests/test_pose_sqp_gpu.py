@@ -44,6 +44,20 @@ def test_pose_sqp_4096_matches_oracle(gpu, oracle, tol, max_iter):
         assert oracle.pose_cost(pb, i, pose[i], HIPS, ORDER) <= oracle.pose_cost(pb, i, pb["pose"][i], HIPS, ORDER) + 1e-12
 
 
+def test_one_lane_kernel_still_matches_oracle(gpu, oracle, monkeypatch):
+    """The first, one-lane-per-problem kernel stays available as a second implementation (QLAMD_POSE_ONE_LANE)."""
+    capi, ctx, torch = gpu
+    monkeypatch.setenv("QLAMD_POSE_ONE_LANE", "1")
+    pb = synth.make_pose_problems(512)
+    pose, it, st = capi.pose_sqp(ctx, pb)
+    monkeypatch.delenv("QLAMD_POSE_ONE_LANE")
+    pose2, it2, st2 = capi.pose_sqp(ctx, pb)                      # the cooperative kernel on the same problems
+    assert (st == 0).all() and np.array_equal(it, it2) and np.abs(pose - pose2).max() < POSE_TOL
+    for i in range(0, 512, 9):
+        r = oracle.pose_sqp(pb, i, HIPS, ORDER)
+        assert r["iters"] == it[i] and np.abs(r["pose"] - pose[i]).max() < POSE_TOL
+
+
 def test_pose_sqp_host_memory_edge_cases(gpu, oracle):
     capi, ctx, torch = gpu
     # the reference's SquareUp case, a single problem through host buffers
