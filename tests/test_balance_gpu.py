@@ -169,3 +169,22 @@ def test_wrench_and_kinematics_kernels(gpu, oracle):
     wh = capi.virtual_wrench(ctx, s)
     fh, jh, gh = capi.leg_kinematics(ctx, s["q"], s["base_quat"])
     assert np.array_equal(wh, w) and np.array_equal(fh, foot) and np.array_equal(jh, jac) and np.array_equal(gh, grav)
+
+
+def test_non_finite_inputs_do_not_hang_or_leak(gpu, oracle):
+    """A robot with NaN / inf in its state must not stall the wavefront it shares with three healthy robots, and must
+    not change their results (every loop of the kernel is bounded; comparisons with NaN fall through)."""
+    capi, ctx, torch = gpu
+    s = synth.make_states(64, "trot")
+    clean_tau, _, clean_st = ctx.balance_solve_host(s)
+    bad = {k: v.copy() for k, v in s.items()}
+    bad["q"][1, 4] = np.nan
+    bad["base_quat"][5] = np.nan
+    bad["base_pos"][9, 2] = np.inf
+    bad["des_linvel"][14, 0] = -np.inf
+    bad["base_quat"][18] = 0.0                                     # not a rotation at all
+    tau, _, st = ctx.balance_solve_host(bad)
+    touched = np.array([1, 5, 9, 14, 18])
+    keep = np.setdiff1d(np.arange(64), touched)
+    assert np.array_equal(tau[keep], clean_tau[keep]) and np.array_equal(st[keep], clean_st[keep])
+    assert np.isfinite(tau[keep]).all()

@@ -127,3 +127,18 @@ def test_qp_batch_random_and_error_paths(gpu, oracle):
     assert st[0] == capi.STATUS_NOT_PD
     x, f, st = capi.qp_solve(ctx, np.ones((1, 1, 1)), np.zeros((1, 1)), None, None, np.array([[[1.0, -1.0]]]), np.array([[-1.0, -1.0]]))
     assert st[0] == capi.STATUS_INFEASIBLE and np.isinf(f[0])
+
+
+def test_pose_non_finite_inputs_do_not_hang_or_leak(gpu):
+    capi, ctx, torch = gpu
+    pb = synth.make_pose_problems(64)
+    clean, it0, st0 = capi.pose_sqp(ctx, pb)
+    bad = {k: v.copy() for k, v in pb.items()}
+    bad["stance"][2, 1, 0] = np.nan
+    bad["pose"][7, 3:] = 0.0
+    bad["polygon"][11] = 0.0                                        # degenerate support region
+    bad["max_len"][13] = -1.0                                       # infeasible limb-length bounds
+    pose, it, st = capi.pose_sqp(ctx, bad)
+    keep = np.setdiff1d(np.arange(64), [2, 7, 11, 13])
+    assert np.array_equal(pose[keep], clean[keep]) and np.array_equal(st[keep], st0[keep]) and np.array_equal(it[keep], it0[keep])
+    assert st[13] != 0
