@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB = os.path.join(_PKG, "libqlamd.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("balance_kernel.hip",)]
-HEADERS = [os.path.join(_PKG, "csrc", f) for f in ("balance_core.hpp", "balance_coop.hpp", "pose_coop.hpp", "params_build.hpp", "gi_core.hpp",
+HEADERS = [os.path.join(_PKG, "csrc", f) for f in ("balance_core.hpp", "balance_coop.hpp", "pose_coop.hpp", "qp_coop.hpp", "params_build.hpp", "gi_core.hpp",
                                                      "gi6_core.hpp", "pose_core.hpp", "swing_core.hpp", "leg_state_core.hpp", "wire_core.hpp")] + [
     os.path.join(_ROOT, "include", f) for f in ("qlamd.h", "qlamd_robot_constants.h")]
 

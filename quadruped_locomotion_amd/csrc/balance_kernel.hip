@@ -8,6 +8,7 @@
 
 #include "balance_coop.hpp"
 #include "pose_coop.hpp"
+#include "qp_coop.hpp"
 #include "balance_core.hpp"
 #include "params_build.hpp"
 #include "pose_core.hpp"
@@ -875,6 +876,60 @@ __global__ __launch_bounds__(64) void qp_solve_kernel(int n, int p, int m, const
   status[i] = st;
 }
 
+// Lane-cooperative dense QP batch (csrc/qp_coop.hpp): 16 lanes per problem, 4 problems per wavefront.
+// N = 6 for n <= 6, N = 12 otherwise; at most one equality column (two go to qp_solve_kernel).
+template <int N>
+__global__ __launch_bounds__(64) void qp_coop_kernel(int n, int p, int m, const double *__restrict__ G,
+                                                     const double *__restrict__ g0, const double *__restrict__ CE,
+                                                     const double *__restrict__ ce0, const double *__restrict__ CI,
+                                                     const double *__restrict__ ci0, int64_t B, double *__restrict__ x,
+                                                     double *__restrict__ obj, int32_t *__restrict__ status) {
+  __shared__ double rows[coop::kQpCoopRows * coop::QpCoopLds<N>::kTotal];
+  const int row = threadIdx.x >> 4, lr = threadIdx.x & 15;
+  int64_t i = (int64_t)blockIdx.x * coop::kQpCoopRows + row;
+  const bool live = i < B;
+  if (!live) i = B - 1;
+  // every load is issued unconditionally with a clamped index; values outside the problem are replaced afterwards
+  const int rv = lr < n ? lr : 0;               // my variable (row of G)
+  const int c0 = lr < m ? lr : 0;               // my first inequality
+  const int c1 = lr + 16 < m ? lr + 16 : 0;     // my second inequality
+  double Gm[N], a0[N], a1[N];
+  const double *Gp = G + (size_t)i * n * n + (size_t)rv * n;
+  const double *Cp = CI ? CI + (size_t)i * n * m : G;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const int kk = k < n ? k : 0;
+    Gm[k] = Gp[kk];
+    a0[k] = Cp[(size_t)kk * (m > 0 ? m : 1) + c0];
+    a1[k] = Cp[(size_t)kk * (m > 0 ? m : 1) + c1];
+  }
+  double gl = g0[(size_t)i * n + rv];
+  double b0 = m > 0 ? ci0[(size_t)i * m + c0] : 0.0, b1 = m > 0 ? ci0[(size_t)i * m + c1] : 0.0;
+  double ne = p > 0 ? CE[((size_t)i * n + rv) * p] : 0.0, e0 = p > 0 ? ce0[(size_t)i * p] : 0.0;
+  const bool var = lr < n, v0 = lr < m, v1 = lr + 16 < m;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const bool in = var && k < n;
+    Gm[k] = in ? Gm[k] : ((lr == k && lr < N) ? 1.0 : 0.0); // identity padding for rows n..N-1
+    a0[k] = (v0 && k < n) ? a0[k] : 0.0;
+    a1[k] = (v1 && k < n) ? a1[k] : 0.0;
+  }
+  gl = var ? gl : 0.0;
+  ne = var ? ne : 0.0;
+  b0 = v0 ? b0 : 0.0;
+  b1 = v1 ? b1 : 0.0;
+  double xo, fo;
+  const int st = coop::qp_coop<N>(Gm, gl, n, m, p > 0, ne, e0, a0, b0, v0, a1, b1, v1, !live,
+                                  rows + row * coop::QpCoopLds<N>::kTotal, xo, fo);
+  if (live) {
+    if (var) x[(size_t)i * n + lr] = xo;
+    if (lr == 0) {
+      if (obj) obj[i] = fo;
+      status[i] = st;
+    }
+  }
+}
+
 } // namespace
 
 // ------------------------------------------------------------------ C-ABI ---
@@ -1453,13 +1508,25 @@ int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *
     dce0 = (const double *)(w + off[3]); dCI = (const double *)(w + off[4]); dci0 = (const double *)(w + off[5]);
     dx = (double *)(w + off[6]); dobj = objective ? (double *)(w + off[7]) : nullptr; dst = (int32_t *)(w + off[8]);
   }
-  const size_t lds = (size_t)kQpPerWave * QpGi::kTotal * sizeof(double);
-  if (lds > 48 * 1024 &&
-      hipFuncSetAttribute((const void *)qp_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return QLAMD_ERR_HIP;
-  const unsigned grid = (unsigned)((batch + kQpPerWave - 1) / kQpPerWave);
-  hipLaunchKernelGGL(qp_solve_kernel, dim3(grid), dim3(64), lds, st, n, p, m, dG, dg0, dCE, dce0, dCI, dci0, batch,
-                     dx, dobj, dst);
+  if (p <= 1 && !getenv("QLAMD_QP_ONE_LANE")) {
+    // lane-cooperative kernel (at most one equality column: what every caller in the reference passes)
+    const unsigned cgrid = (unsigned)((batch + coop::kQpCoopRows - 1) / coop::kQpCoopRows);
+    if (n <= 6)
+      hipLaunchKernelGGL(qp_coop_kernel<6>, dim3(cgrid), dim3(64), 0, st, n, p, m, dG, dg0, dCE, dce0, dCI, dci0, batch, dx,
+                         dobj, dst);
+    else
+      hipLaunchKernelGGL(qp_coop_kernel<12>, dim3(cgrid), dim3(64), 0, st, n, p, m, dG, dg0, dCE, dce0, dCI, dci0, batch, dx,
+                         dobj, dst);
+  } else {
+    // one lane per problem, following solve_quadprog step by step (two equality columns, or on request)
+    const size_t lds = (size_t)kQpPerWave * QpGi::kTotal * sizeof(double);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute((const void *)qp_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return QLAMD_ERR_HIP;
+    const unsigned grid = (unsigned)((batch + kQpPerWave - 1) / kQpPerWave);
+    hipLaunchKernelGGL(qp_solve_kernel, dim3(grid), dim3(64), lds, st, n, p, m, dG, dg0, dCE, dce0, dCI, dci0, batch, dx,
+                       dobj, dst);
+  }
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   if (memory == QLAMD_MEM_HOST) {
     if (hipMemcpyAsync(x, dx, B * n * 8, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;

@@ -52,6 +52,12 @@ print("wire bytes per message: %.0f" % (len(blob) / B))
 for _ in range(REPS):
     capi.robot_state_unpack(ctx, blob, off)
 
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "qp_goldens.npz"))
+for tag in ("n12", "n6"):                      # the golden force QPs (n = 12, m = 20 and n = 6, m = 10), tiled to 4096
+    Gq, g0q, CIq, ci0q = (np.tile(g[f"{tag}_{k}"], (B // 128,) + (1,) * (g[f"{tag}_{k}"].ndim - 1)) for k in ("G", "g0", "CI", "ci0"))
+    for _ in range(REPS):
+        capi.qp_solve(ctx, Gq, g0q, None, None, CIq, ci0q)
+
 for _ in range(REPS):
     ctx.balance_solve_host(st)
     ctx.balance_solve_host(synth.make_states(B, "static"))
