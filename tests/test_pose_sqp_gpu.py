@@ -109,7 +109,7 @@ def test_qp_batch_against_reference_goldens(gpu, goldens):
 def test_qp_batch_random_and_error_paths(gpu, oracle):
     capi, ctx, torch = gpu
     rng = np.random.default_rng(11)
-    for n, p, m in ((2, 0, 3), (6, 1, 8), (12, 2, 24), (7, 0, 0)):
+    for n, p, m in ((2, 0, 3), (6, 1, 8), (12, 2, 24), (7, 0, 0), (12, 1, 24), (9, 1, 17), (12, 0, 24), (3, 1, 4), (1, 0, 2)):
         B = 33
         M = rng.normal(size=(B, n, n))
         G = M @ M.transpose(0, 2, 1) + 1e-3 * np.eye(n)
@@ -122,6 +122,21 @@ def test_qp_batch_random_and_error_paths(gpu, oracle):
             assert r["status"] == st[i]
             if st[i] == 0:
                 assert np.abs(r["x"] - x[i]).max() < 1e-8 * max(1.0, np.abs(r["x"]).max())
+    # the one-lane kernel (second implementation) agrees with the cooperative one
+    import os
+    n, m, B = 12, 20, 64
+    M = rng.normal(size=(B, n, n)); G = M @ M.transpose(0, 2, 1) + 1e-2 * np.eye(n); g0 = 10 * rng.normal(size=(B, n))
+    CI, ci0 = rng.normal(size=(B, n, m)), rng.normal(size=(B, m)) + 1.0
+    zero_eq = (np.zeros((B, n, 1)), np.zeros((B, 1)))              # the reference's dummy column
+    xa, fa, sa = capi.qp_solve(ctx, G, g0, *zero_eq, CI, ci0)
+    os.environ["QLAMD_QP_ONE_LANE"] = "1"
+    try:
+        xb, fb, sb = capi.qp_solve(ctx, G, g0, *zero_eq, CI, ci0)
+    finally:
+        del os.environ["QLAMD_QP_ONE_LANE"]
+    assert np.array_equal(sa, sb)
+    ok = sa == 0
+    assert ok.sum() > 10 and np.abs(xa[ok] - xb[ok]).max() < 1e-8 * max(1.0, np.abs(xb[ok]).max()) and np.allclose(fa[ok], fb[ok], rtol=1e-9)
     # not positive definite / infeasible
     x, f, st = capi.qp_solve(ctx, np.array([[[1.0, 2.0], [2.0, 1.0]]]), np.zeros((1, 2)), None, None, None, None)
     assert st[0] == capi.STATUS_NOT_PD
