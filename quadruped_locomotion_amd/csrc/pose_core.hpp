@@ -356,9 +356,10 @@ QL_HD void sym4_eigen(const double C[16], double w[4], double V[16]) {
       QL_UNROLL for (int q = p + 1; q < 4; q++) {
         const double apq = A[4 * p + q];
         if (apq == 0.0) continue;
-        const double theta = (A[4 * q + q] - A[4 * p + p]) / (2.0 * apq);
-        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        const double theta = (A[4 * q + q] - A[4 * p + p]) * (0.5 * ql_rcp(apq));
+        const double th1 = theta * theta + 1.0;
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) * ql_rcp(fabs(theta) + th1 * ql_rsqrt(th1));
+        const double c = ql_rsqrt(t * t + 1.0), sn = t * c;
         QL_UNROLL for (int k = 0; k < 4; k++) {
           const double akp = A[4 * k + p], akq = A[4 * k + q];
           A[4 * k + p] = c * akp - sn * akq;
@@ -416,9 +417,9 @@ QL_HD void pose_geometric(const PoseProblem &pb, const double sfo[4][3], double 
         Am[4 * i + j] += Ak[4 * i + j];
       }
   }
-  const double n = (double)nl;
-  z /= n;
-  QL_UNROLL for (int i = 0; i < 16; i++) Am[i] = Am[i] / n;
+  const double n = (double)nl, rn = ql_rcp(n);
+  z *= rn;
+  QL_UNROLL for (int i = 0; i < 16; i++) Am[i] = Am[i] * rn;
   QL_UNROLL for (int i = 0; i < 4; i++)
     QL_UNROLL for (int j = 0; j < 4; j++) {
       double acc = 0.0;
@@ -430,8 +431,8 @@ QL_HD void pose_geometric(const PoseProblem &pb, const double sfo[4][3], double 
   double wb = w[0], q[4] = {V[0], V[4], V[8], V[12]};
   QL_UNROLL for (int i = 1; i < 4; i++)
     if (w[i] > wb) { wb = w[i]; q[0] = V[i]; q[1] = V[4 + i]; q[2] = V[8 + i]; q[3] = V[12 + i]; }
-  const double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  QL_UNROLL for (int i = 0; i < 4; i++) q[i] /= nq;
+  const double inq = ql_rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  QL_UNROLL for (int i = 0; i < 4; i++) q[i] *= inq;
   { // setUnique: first non-zero component positive
     bool neg = false, decided = false;
     QL_UNROLL for (int i = 0; i < 4; i++)
@@ -446,15 +447,15 @@ QL_HD void pose_geometric(const PoseProblem &pb, const double sfo[4][3], double 
   dir[2] = 0.0;
   double heading[4];
   {
-    const double nb = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
-    const double v1[3] = {dir[0] / nb, dir[1] / nb, dir[2] / nb};
+    const double inb = ql_rsqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    const double v1[3] = {dir[0] * inb, dir[1] * inb, dir[2] * inb};
     double c = v1[0]; // v0 = (1, 0, 0) after normalisation
     if (c < -1.0 + 1e-12) {
       c = c > -1.0 ? c : -1.0;
       const double w2 = (1.0 + c) * 0.5;
       heading[0] = sqrt(w2); heading[1] = 0.0; heading[2] = 0.0; heading[3] = sqrt(1.0 - w2);
     } else {
-      const double sc = sqrt((1.0 + c) * 2.0), invs = 1.0 / sc;
+      const double invs = ql_rsqrt((1.0 + c) * 2.0), sc = (1.0 + c) * 2.0 * invs;
       heading[0] = sc * 0.5;
       heading[1] = (0.0 * v1[2] - 0.0 * v1[1]) * invs;
       heading[2] = (0.0 * v1[0] - 1.0 * v1[2]) * invs;
