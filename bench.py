@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph of K steps")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the multi-GPU code path (process group + all-gather) even with one rank (self-test)")
+    ap.add_argument("--overlap-gather", action="store_true",
+                    help="capture the gathers on a second stream even with one rank (self-test of the multi-rank graph)")
     ap.add_argument("--no-gather", action="store_true",
                     help="several ranks without the per-step all-gather of the torques (scaling with / without it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -217,7 +219,8 @@ def main():
 
     # ---- timed region: exactly K steps -----------------------------------------
     # The K steps (solve, plus the all-gather of the torques when there are several ranks) are
-    # captured once into a hipGraph and replayed: a step is a few tens of microseconds, comparable
+    # captured once into a hipGraph (solves on one stream, gathers on a second one) and replayed: a step is a few
+    # tens of microseconds, comparable
     # to one eager launch from Python.  The graph is built outside the timed region; the timed
     # region is one replay = K control steps.  If capture fails the steps are launched eagerly,
     # the all-gather of step k then overlapping the solve of step k+1.
@@ -231,10 +234,30 @@ def main():
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=side):
                     cap = torch.cuda.current_stream().cuda_stream
+                    # The gathers go to a second captured stream: gather k (reads tau[k & 1]) overlaps solve k+1
+                    # (writes the other buffer); solve k+2 waits for gather k before it reuses the buffer.
+                    # (with a single rank the "gather" is a local copy and the extra graph edges cost more than they
+                    # hide -- measured 27.8 vs 22.6 us per step -- so the self-test keeps everything on one stream)
+                    overlap = gather and (world > 1 or args.overlap_gather)
+                    comm = torch.cuda.Stream() if overlap else None
+                    gathered_ev = [None, None]
                     for k in range(args.steps):
-                        ctx.balance_solve_device(d, tau[k & 1], None, status, stream=cap)
-                        if gather:  # RCCL collectives are capturable; they replay from the graph
-                            dist.all_gather_into_tensor(gathered[k & 1], tau[k & 1])
+                        buf = k & 1
+                        if overlap and gathered_ev[buf] is not None:
+                            side.wait_event(gathered_ev[buf])
+                        ctx.balance_solve_device(d, tau[buf], None, status, stream=cap)
+                        if overlap:  # RCCL collectives are capturable; they replay from the graph
+                            solved = torch.cuda.Event()
+                            solved.record(side)
+                            comm.wait_event(solved)
+                            with torch.cuda.stream(comm):
+                                dist.all_gather_into_tensor(gathered[buf], tau[buf])
+                                gathered_ev[buf] = torch.cuda.Event()
+                                gathered_ev[buf].record(comm)
+                        elif gather:
+                            dist.all_gather_into_tensor(gathered[buf], tau[buf])
+                    if overlap:
+                        side.wait_stream(comm)  # join before the capture ends
             torch.cuda.current_stream().wait_stream(side)
         except Exception as e:  # pragma: no cover - fall back to eager launches
             sys.stderr.write("hipGraph capture failed (%s); eager launches\n" % e)
