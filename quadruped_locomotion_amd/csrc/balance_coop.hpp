@@ -515,7 +515,8 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       const double t1 = row_min(ratio);
       const int lpos = row_first(ratio == t1 && ratio < inf);
       const double t2v = -sp * rcp_nr(zn);
-      const double t2 = sel(fabs(zz) > eps && !(t2v < 0.0), t2v, inf);
+      const bool exhausted = q >= 3 * nS; // empty null space: z is exactly 0 in the reference
+      const double t2 = sel(!exhausted && fabs(zz) > eps && !(t2v < 0.0), t2v, inf);
       const double t = vmin(t1, t2);
       // what happens this tick (all row-uniform)
       const bool infeasible = !(t < inf);                          // :339-344

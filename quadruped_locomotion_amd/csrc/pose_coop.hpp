@@ -149,7 +149,8 @@ __device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const 
       const double t1 = row_min(ratio);
       const int lpos = row_first(ratio == t1 && ratio < inf);
       const double t2v = -sp * rcp_nr(zn);
-      const double t2 = sel(fabs(zz) > eps && !(t2v < 0.0), t2v, inf);
+      const bool exhausted = q + (dummy_eq ? 1 : 0) >= 6; // empty null space: z is exactly 0 in the reference
+      const double t2 = sel(!exhausted && fabs(zz) > eps && !(t2v < 0.0), t2v, inf);
       const double t = vmin(t1, t2);
       const bool infeasible = !(t < inf);                          // :339-344
       const bool dual_only = (t2 >= inf);

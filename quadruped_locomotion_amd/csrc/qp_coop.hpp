@@ -161,7 +161,10 @@ __device__ __forceinline__ int qp_coop(const double (&Gm)[N], double g0, int n, 
       const double t1 = row_min(ratio);
       const int lpos = row_first(ratio == t1 && ratio < inf);
       const double t2v = -sp * rcp_nr(zn);
-      const double t2 = sel(fabs(zz) > eps && !(t2v < 0.0), t2v, inf);
+      // with n - (equality) constraints active the null space is empty and z is exactly 0 in the reference (J2 has
+      // no columns); the explicit projector only leaves ~1e-7 of drift there, which must not pass for a direction
+      const bool exhausted = q + (has_eq ? 1 : 0) >= n;
+      const double t2 = sel(!exhausted && fabs(zz) > eps && !(t2v < 0.0), t2v, inf);
       const double t = vmin(t1, t2);
       const bool infeasible = !(t < inf);                          // :339-344
       const bool dual_only = (t2 >= inf);

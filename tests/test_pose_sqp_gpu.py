@@ -157,3 +157,26 @@ def test_pose_non_finite_inputs_do_not_hang_or_leak(gpu):
     keep = np.setdiff1d(np.arange(64), [2, 7, 11, 13])
     assert np.array_equal(pose[keep], clean[keep]) and np.array_equal(st[keep], st0[keep]) and np.array_equal(it[keep], it0[keep])
     assert st[13] != 0
+
+
+def test_qp_batch_stress_against_oracle(gpu, oracle):
+    """2048 random ill-scaled QPs (n = 12, m = 24, the reference's dummy equality column) and 2048 with n = 5, m = 9
+    without it: statuses equal the oracle's, minimisers within 1e-7 relative."""
+    capi, ctx, torch = gpu
+    rng = np.random.default_rng(2026)
+    for n, m, dummy in ((12, 24, True), (5, 9, False)):
+        B = 2048
+        M = rng.normal(size=(B, n, n)) * rng.uniform(0.1, 3.0, size=(B, 1, n))
+        G = M @ M.transpose(0, 2, 1) + 1e-3 * np.eye(n)
+        g0 = 5 * rng.normal(size=(B, n))
+        CI, ci0 = rng.normal(size=(B, n, m)), rng.normal(size=(B, m)) + 0.5
+        CE, ce0 = (np.zeros((B, n, 1)), np.zeros((B, 1))) if dummy else (None, None)
+        x, f, st = capi.qp_solve(ctx, G, g0, CE, ce0, CI, ci0)
+        n_ok = 0
+        for i in range(B):
+            r = oracle.solve_quadprog(G[i], g0[i], None if CE is None else CE[i], None if ce0 is None else ce0[i], CI[i], ci0[i])
+            assert r["status"] == st[i], (n, i)
+            if st[i] == 0:
+                n_ok += 1
+                assert np.abs(r["x"] - x[i]).max() < 1e-7 * max(1.0, np.abs(r["x"]).max()), (n, i)
+        assert n_ok > B // 2
