@@ -180,3 +180,31 @@ def test_qp_batch_stress_against_oracle(gpu, oracle):
                 n_ok += 1
                 assert np.abs(r["x"] - x[i]).max() < 1e-7 * max(1.0, np.abs(r["x"]).max()), (n, i)
         assert n_ok > B // 2
+
+
+def test_pose_sqp_stress_against_oracle(gpu, oracle):
+    """4096 harder problems (random limb-length bounds down to infeasible, a quarter three-legged with a triangular
+    region, centre of mass off the base origin): every status and iteration count equals the oracle's, every pose is
+    within tolerance."""
+    capi, ctx, torch = gpu
+    B = 4096
+    pb = synth.make_pose_problems(B)
+    rng = np.random.default_rng(77)
+    pb["max_len"][:] = rng.uniform(0.15, 0.60, (B, 4))
+    pb["r_com"][:] = rng.uniform(-0.03, 0.03, (B, 3))
+    tri = np.arange(B) % 4 == 0
+    pb["stance_mask"][tri, 1] = 0
+    pb["polygon"][tri, :3] = pb["stance"][tri][:, [0, 3, 2], :2]
+    pb["n_vertices"][tri] = 3
+    pose, it, st = capi.pose_sqp(ctx, pb)
+    n_bad = 0
+    for i in range(B):
+        r = oracle.pose_sqp(pb, i, HIPS, ORDER)
+        assert r["status"] == st[i], i
+        if st[i] == 0:
+            assert r["iters"] == it[i], i
+            assert np.abs(r["pose"] - pose[i]).max() < 1e-8, i
+        else:
+            n_bad += 1
+    assert n_bad < B // 2
+    print("non-OK statuses:", n_bad)
