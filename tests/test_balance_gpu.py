@@ -188,3 +188,24 @@ def test_non_finite_inputs_do_not_hang_or_leak(gpu, oracle):
     keep = np.setdiff1d(np.arange(64), touched)
     assert np.array_equal(tau[keep], clean_tau[keep]) and np.array_equal(st[keep], clean_st[keep])
     assert np.isfinite(tau[keep]).all()
+
+
+def test_balance_stress_against_oracle(gpu, oracle):
+    """8192 hard robots: random stance subsets, tracking errors three times the trot level (friction pyramids saturated
+    on most legs), random per-leg surface normals up to ~20 degrees off vertical: every status equals the oracle's and
+    every torque is within the parity bar."""
+    B = 8192
+    s = synth.make_states(B, "trot")
+    rng = np.random.default_rng(99)
+    s["stance"][:] = rng.integers(0, 2, (B, 4)).astype(np.uint8)
+    s["des_linvel"] = s["base_linvel"] + 3.0 * (s["des_linvel"] - s["base_linvel"])
+    s["des_pos"] = s["base_pos"] + rng.normal(scale=0.03, size=(B, 3))
+    nw = np.tile(np.array([0, 0, 1.0]), (B, 4, 1)) + 0.2 * rng.normal(size=(B, 4, 3))
+    nw /= np.linalg.norm(nw, axis=2, keepdims=True)
+    tau, grf, status = solve_device(gpu, s, normals=nw.reshape(B, 12))
+    t0, g0, s0 = oracle.balance_batch(s, normals_world=nw.reshape(B, 12), nthreads=8)
+    assert np.array_equal(status, s0)
+    ok = status == 0
+    assert ok.sum() > B // 2
+    assert np.abs(tau[ok] - t0[ok]).max() < TAU_TOL
+    print("non-OK:", int((~ok).sum()), "max |dtau|:", np.abs(tau[ok] - t0[ok]).max())
