@@ -242,6 +242,26 @@ __device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const 
   return status;
 }
 
+// q (+) d = exp(d) * q as quat_box_plus (pose_core.hpp), with the Cody-Waite / minimax sincos of balance_core.hpp
+// (one call for both, < 1 ulp) and a Newton reciprocal instead of two libm calls and a division
+__device__ __forceinline__ void quat_box_plus_fast(const double q[4], const double d[3], double out[4]) {
+  const double v2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  double e[4];
+  if (v2 < 1e-24) {
+    e[0] = 1.0; e[1] = 0.5 * d[0]; e[2] = 0.5 * d[1]; e[3] = 0.5 * d[2];
+  } else {
+    const double rv = rsqrt_nr(v2), v = v2 * rv;
+    double sn, cs;
+    sincos_reduced(0.5 * v, sn, cs);
+    const double k = sn * rv;
+    e[0] = cs; e[1] = k * d[0]; e[2] = k * d[1]; e[3] = k * d[2];
+  }
+  out[0] = e[0] * q[0] - e[1] * q[1] - e[2] * q[2] - e[3] * q[3];
+  out[1] = e[0] * q[1] + e[1] * q[0] + e[2] * q[3] - e[3] * q[2];
+  out[2] = e[0] * q[2] - e[1] * q[3] + e[2] * q[0] + e[3] * q[1];
+  out[3] = e[0] * q[3] + e[1] * q[2] - e[2] * q[1] + e[3] * q[0];
+}
+
 // ---- linearisation + SQP loop -----------------------------------------------------------------------------
 // pb: this problem's record (LDS, iteration order); pose: replicated, updated in place.
 __device__ __forceinline__ int pose_sqp_coop(const PoseParamsDev &P, const PoseProblem &pb, bool live, double *lds_row,
@@ -373,10 +393,10 @@ __device__ __forceinline__ int pose_sqp_coop(const PoseParamsDev &P, const PoseP
       } else {
         pose[0] += dp[0]; pose[1] += dp[1]; pose[2] += dp[2];
         double qn[4];
-        quat_box_plus(pose + 3, dp + 3, qn);
+        quat_box_plus_fast(pose + 3, dp + 3, qn);
         pose[3] = qn[0]; pose[4] = qn[1]; pose[5] = qn[2]; pose[6] = qn[3];
-        const double nrm = sqrt(dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2] + dp[3] * dp[3] + dp[4] * dp[4] + dp[5] * dp[5]);
-        if (nrm < P.tol) sqp_done = true; // sequencequadraticproblemsolver.cpp:72-76
+        const double nrm2 = dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2] + dp[3] * dp[3] + dp[4] * dp[4] + dp[5] * dp[5];
+        if (nrm2 < P.tol * P.tol && P.tol > 0.0) sqp_done = true; // |dp| < tol, sequencequadraticproblemsolver.cpp:72-76
       }
     }
   }
