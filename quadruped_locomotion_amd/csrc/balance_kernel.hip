@@ -943,6 +943,8 @@ struct qlamd_context {
   // HOST-memory mode staging (grown on demand)
   void *ws;
   size_t ws_bytes;
+  void *pinned;        // page-locked mirror of the head of ws, for small host-buffer calls (one copy each way)
+  size_t pinned_bytes;
 };
 
 namespace {
@@ -989,6 +991,17 @@ int ensure_ws(qlamd_context *ctx, size_t bytes) {
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int ensure_pinned(qlamd_context *ctx, size_t bytes) {
+  if (ctx->pinned_bytes >= bytes) return QLAMD_OK;
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  ctx->pinned = nullptr;
+  ctx->pinned_bytes = 0;
+  if (hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;
+  ctx->pinned_bytes = bytes;
+  return QLAMD_OK;
+}
+constexpr size_t kSmallHostCall = 256 * 1024; // below this a host-buffer call goes through one pinned slab
 
 // Host-buffer calls: the listed arrays are laid out in the context workspace, inputs copied up front,
 // outputs copied back (and the stream synchronised) by finish().
@@ -1574,6 +1587,8 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
   ctx->num_cu = prop.multiProcessorCount;
   ctx->ws = nullptr;
   ctx->ws_bytes = 0;
+  ctx->pinned = nullptr;
+  ctx->pinned_bytes = 0;
   qlamd_robot_model m;
   if (model) m = *model; else default_robot_model(&m);
   build_device_params(*params, m, &ctx->params);
@@ -1592,6 +1607,7 @@ void qlamd_context_destroy(qlamd_context *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->d_params) (void)hipFree(ctx->d_params);
   delete ctx;
 }
@@ -1628,6 +1644,8 @@ static int balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, co
   StatePtrs s;
   double *d_tau = joint_effort, *d_grf = contact_force;
   int32_t *d_status = status;
+  bool small_host = false;
+  size_t out_off = 0, out_bytes = 0;
   if (memory == QLAMD_MEM_HOST) {
     // one staging slab: inputs then outputs, 256-byte aligned pieces
     // (with an external wrench the pose / twist fields alias the head of joint_position)
@@ -1646,9 +1664,20 @@ static int balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, co
     int rc = ensure_ws(ctx, total);
     if (rc != QLAMD_OK) return rc;
     char *w = (char *)ctx->ws;
-    for (int k = 0; k < 12; k++)
-      if (sz[k] && hipMemcpyAsync(w + off[k], src[k], sz[k], hipMemcpyHostToDevice, st) != hipSuccess)
-        return QLAMD_ERR_HIP;
+    small_host = total <= kSmallHostCall && ensure_pinned(ctx, kSmallHostCall) == QLAMD_OK;
+    out_off = off[12];
+    out_bytes = total - off[12];
+    if (small_host) {
+      // a single robot or a few: a dozen separate pageable copies cost ~10 us each; pack, copy once
+      char *h = (char *)ctx->pinned;
+      for (int k = 0; k < 12; k++)
+        if (sz[k]) memcpy(h + off[k], src[k], sz[k]);
+      if (hipMemcpyAsync(w, h, off[12], hipMemcpyHostToDevice, st) != hipSuccess) return QLAMD_ERR_HIP;
+    } else {
+      for (int k = 0; k < 12; k++)
+        if (sz[k] && hipMemcpyAsync(w + off[k], src[k], sz[k], hipMemcpyHostToDevice, st) != hipSuccess)
+          return QLAMD_ERR_HIP;
+    }
     s = StatePtrs{(const double *)(w + off[0]), (const double *)(w + off[1]), (const double *)(w + off[2]),
                   (const double *)(w + off[3]), (const double *)(w + off[4]), (const double *)(w + off[5]),
                   (const double *)(w + off[6]), (const double *)(w + off[7]), (const double *)(w + off[8]),
@@ -1682,7 +1711,14 @@ static int balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, co
   }
   if (e != hipSuccess) return QLAMD_ERR_HIP;
 
-  if (memory == QLAMD_MEM_HOST) {
+  if (memory == QLAMD_MEM_HOST && small_host) {
+    char *h = (char *)ctx->pinned, *w = (char *)ctx->ws;
+    if (hipMemcpyAsync(h + out_off, w + out_off, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
+    memcpy(joint_effort, h + ((char *)d_tau - w), B * 96);
+    if (contact_force) memcpy(contact_force, h + ((char *)d_grf - w), B * 96);
+    memcpy(status, h + ((char *)d_status - w), B * 4);
+  } else if (memory == QLAMD_MEM_HOST) {
     if (hipMemcpyAsync(joint_effort, d_tau, B * 96, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
     if (contact_force &&
         hipMemcpyAsync(contact_force, d_grf, B * 96, hipMemcpyDeviceToHost, st) != hipSuccess)
