@@ -1004,22 +1004,45 @@ int ensure_pinned(qlamd_context *ctx, size_t bytes) {
 constexpr size_t kSmallHostCall = 256 * 1024; // below this a host-buffer call goes through one pinned slab
 
 // Host-buffer calls: the listed arrays are laid out in the context workspace, inputs copied up front,
-// outputs copied back (and the stream synchronised) by finish().
+// outputs copied back (and the stream synchronised) by finish().  Calls whose arrays total at most
+// kSmallHostCall bytes go through the context's pinned slab: one copy up (the span of the inputs) and
+// one copy down (the span of the outputs) instead of one pageable copy per array.
 struct Staged {
   struct Item { void *host; size_t bytes; bool in, out; size_t off; };
-  Item items[16];
+  Item items[20];
   int n = 0;
   char *base = nullptr;
+  char *slab = nullptr; // pinned mirror of the workspace for small calls
   int add(const void *host, size_t bytes, bool in, bool out) {
     items[n] = Item{const_cast<void *>(host), host ? bytes : 0, in, out, 0};
     return n++;
   }
+  void span(bool want_out, size_t *lo, size_t *hi) const {
+    *lo = ~(size_t)0; *hi = 0;
+    for (int k = 0; k < n; k++) {
+      if (!items[k].bytes || !(want_out ? items[k].out : items[k].in)) continue;
+      if (items[k].off < *lo) *lo = items[k].off;
+      if (items[k].off + items[k].bytes > *hi) *hi = items[k].off + items[k].bytes;
+    }
+  }
   int upload(qlamd_context *ctx, hipStream_t st) {
     size_t total = 0;
     for (int k = 0; k < n; k++) { items[k].off = total; total += align256(items[k].bytes); }
-    const int rc = ensure_ws(ctx, total ? total : 256);
+    int rc = ensure_ws(ctx, total ? total : 256);
     if (rc != QLAMD_OK) return rc;
     base = (char *)ctx->ws;
+    if (total && total <= kSmallHostCall) {
+      rc = ensure_pinned(ctx, kSmallHostCall);
+      if (rc != QLAMD_OK) return rc;
+      slab = (char *)ctx->pinned;
+      for (int k = 0; k < n; k++)
+        if (items[k].in && items[k].bytes) memcpy(slab + items[k].off, items[k].host, items[k].bytes);
+      size_t lo, hi;
+      span(false, &lo, &hi);
+      if (hi > lo && hipMemcpyAsync(base + lo, slab + lo, hi - lo, hipMemcpyHostToDevice, st) != hipSuccess)
+        return QLAMD_ERR_HIP;
+      return QLAMD_OK;
+    }
     for (int k = 0; k < n; k++)
       if (items[k].in && items[k].bytes &&
           hipMemcpyAsync(base + items[k].off, items[k].host, items[k].bytes, hipMemcpyHostToDevice, st) != hipSuccess)
@@ -1028,6 +1051,16 @@ struct Staged {
   }
   template <class T> T *dev(int k) const { return items[k].host ? (T *)(base + items[k].off) : nullptr; }
   int finish(hipStream_t st) {
+    if (slab) {
+      size_t lo, hi;
+      span(true, &lo, &hi);
+      if (hi > lo && hipMemcpyAsync(slab + lo, base + lo, hi - lo, hipMemcpyDeviceToHost, st) != hipSuccess)
+        return QLAMD_ERR_HIP;
+      if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
+      for (int k = 0; k < n; k++)
+        if (items[k].out && items[k].bytes) memcpy(items[k].host, slab + items[k].off, items[k].bytes);
+      return QLAMD_OK;
+    }
     for (int k = 0; k < n; k++)
       if (items[k].out && items[k].bytes &&
           hipMemcpyAsync(items[k].host, base + items[k].off, items[k].bytes, hipMemcpyDeviceToHost, st) != hipSuccess)
@@ -1073,31 +1106,26 @@ int qlamd_swing_leg_torque_batch(qlamd_context *ctx, const qlamd_swing_params *p
   SwingPtrs s{in->joint_position, in->joint_velocity, in->joint_velocity_oldest, in->target_foot_position,
               in->target_foot_velocity, in->id_joint_position, in->support_leg};
   double *d_tau = joint_effort;
+  Staged sg;
   if (memory == QLAMD_MEM_HOST) {
-    const size_t sz[7] = {B * 96, B * 96, B * 96, B * 96, B * 96, in->id_joint_position ? B * 96 : 0, B * 4};
-    const void *src[7] = {in->joint_position, in->joint_velocity, in->joint_velocity_oldest,
-                          in->target_foot_position, in->target_foot_velocity, in->id_joint_position, in->support_leg};
-    size_t off[8], total = 0;
-    for (int k = 0; k < 7; k++) { off[k] = total; total += align256(sz[k]); }
-    off[7] = total; total += align256(B * 96);
-    int rc = ensure_ws(ctx, total);
+    sg.add(in->joint_position, B * 96, true, false);
+    sg.add(in->joint_velocity, B * 96, true, false);
+    sg.add(in->joint_velocity_oldest, B * 96, true, false);
+    sg.add(in->target_foot_position, B * 96, true, false);
+    sg.add(in->target_foot_velocity, B * 96, true, false);
+    sg.add(in->id_joint_position, B * 96, true, false);
+    sg.add(in->support_leg, B * 4, true, false);
+    sg.add(joint_effort, B * 96, false, true);
+    const int rc = sg.upload(ctx, st);
     if (rc != QLAMD_OK) return rc;
-    char *w = (char *)ctx->ws;
-    for (int k = 0; k < 7; k++)
-      if (sz[k] && hipMemcpyAsync(w + off[k], src[k], sz[k], hipMemcpyHostToDevice, st) != hipSuccess)
-        return QLAMD_ERR_HIP;
-    s = SwingPtrs{(const double *)(w + off[0]), (const double *)(w + off[1]), (const double *)(w + off[2]),
-                  (const double *)(w + off[3]), (const double *)(w + off[4]),
-                  in->id_joint_position ? (const double *)(w + off[5]) : nullptr, (const uint8_t *)(w + off[6])};
-    d_tau = (double *)(w + off[7]);
+    s = SwingPtrs{sg.dev<const double>(0), sg.dev<const double>(1), sg.dev<const double>(2), sg.dev<const double>(3),
+                  sg.dev<const double>(4), sg.dev<const double>(5), sg.dev<const uint8_t>(6)};
+    d_tau = sg.dev<double>(7);
   }
   const unsigned grid = (unsigned)((4 * batch + 63) / 64);
   hipLaunchKernelGGL(swing_leg_kernel, dim3(grid), dim3(64), 0, st, ctx->d_params, SP, s, batch, d_tau);
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
-  if (memory == QLAMD_MEM_HOST) {
-    if (hipMemcpyAsync(joint_effort, d_tau, B * 96, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
-    if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
-  }
+  if (memory == QLAMD_MEM_HOST) return sg.finish(st);
   return QLAMD_OK;
 }
 
@@ -1352,34 +1380,30 @@ int qlamd_leg_state_machine_batch(qlamd_context *ctx, const qlamd_leg_state_batc
   LegStatePtrs s{io->support_leg, io->is_footstep, io->contact, io->phase, io->joint_position, io->limb_state,
                  io->store_flag, io->stored_joint_position, io->joint_command, io->foot_target, io->support,
                  io->leg_state_code};
-  // host staging: every array goes up, the in/out and out arrays come back
-  enum { kN = 12 };
-  const size_t sz[kN] = {B * 4, B * 4, B * 4, B * 32, B * 96, B * 4, B * 4, B * 96, B * 96, B * 96, B * 4, B * 4};
-  void *host[kN] = {(void *)io->support_leg, (void *)io->is_footstep, (void *)io->contact, (void *)io->phase,
-                    (void *)io->joint_position, io->limb_state, io->store_flag, io->stored_joint_position,
-                    io->joint_command, io->foot_target, io->support, io->leg_state_code};
-  size_t off[kN];
+  // host staging: every array goes up except leg_state_code; the in/out and out arrays come back
+  Staged sg;
   if (memory == QLAMD_MEM_HOST) {
-    size_t total = 0;
-    for (int k = 0; k < kN; k++) { off[k] = total; total += align256(sz[k]); }
-    int rc = ensure_ws(ctx, total);
+    sg.add(io->support_leg, B * 4, true, false);
+    sg.add(io->is_footstep, B * 4, true, false);
+    sg.add(io->contact, B * 4, true, false);
+    sg.add(io->phase, B * 32, true, false);
+    sg.add(io->joint_position, B * 96, true, false);
+    sg.add(io->limb_state, B * 4, true, true);
+    sg.add(io->store_flag, B * 4, true, true);
+    sg.add(io->stored_joint_position, B * 96, true, true);
+    sg.add(io->joint_command, B * 96, true, true);
+    sg.add(io->foot_target, B * 96, true, true);
+    sg.add(io->support, B * 4, true, true);
+    sg.add(io->leg_state_code, B * 4, false, true);
+    const int rc = sg.upload(ctx, st);
     if (rc != QLAMD_OK) return rc;
-    char *w = (char *)ctx->ws;
-    for (int k = 0; k < kN - 1; k++) // leg_state_code is output only
-      if (hipMemcpyAsync(w + off[k], host[k], sz[k], hipMemcpyHostToDevice, st) != hipSuccess) return QLAMD_ERR_HIP;
-    s = LegStatePtrs{(const uint8_t *)(w + off[0]), (const uint8_t *)(w + off[1]), (const uint8_t *)(w + off[2]),
-                     (const double *)(w + off[3]), (const double *)(w + off[4]), (int8_t *)(w + off[5]),
-                     (uint8_t *)(w + off[6]), (double *)(w + off[7]), (double *)(w + off[8]), (double *)(w + off[9]),
-                     (uint8_t *)(w + off[10]), (int8_t *)(w + off[11])};
+    s = LegStatePtrs{sg.dev<const uint8_t>(0), sg.dev<const uint8_t>(1), sg.dev<const uint8_t>(2), sg.dev<const double>(3),
+                     sg.dev<const double>(4), sg.dev<int8_t>(5), sg.dev<uint8_t>(6), sg.dev<double>(7), sg.dev<double>(8),
+                     sg.dev<double>(9), sg.dev<uint8_t>(10), sg.dev<int8_t>(11)};
   }
   hipLaunchKernelGGL(leg_state_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, s, index_quirk, batch);
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
-  if (memory == QLAMD_MEM_HOST) {
-    char *w = (char *)ctx->ws;
-    for (int k = 5; k < kN; k++)
-      if (hipMemcpyAsync(host[k], w + off[k], sz[k], hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
-    if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
-  }
+  if (memory == QLAMD_MEM_HOST) return sg.finish(st);
   return QLAMD_OK;
 }
 
@@ -1401,49 +1425,32 @@ int qlamd_robot_state_unpack_batch(qlamd_context *ctx, const uint8_t *messages, 
   const uint8_t *d_msg = messages;
   const int64_t *d_off = offsets;
   int32_t *d_st = status;
-  size_t off[kD + 5];
+  Staged sg;
   if (memory == QLAMD_MEM_HOST) {
     for (size_t k = 0; k < B; k++)
       if (offsets[k + 1] < offsets[k] || offsets[0] < 0) return QLAMD_ERR_INVALID_ARGUMENT;
     const size_t nbytes = (size_t)(offsets[B] - offsets[0]);
-    size_t total = 0;
-    for (int k = 0; k < kD; k++) { off[k] = total; total += align256(hostd[k] ? B * 8 * (size_t)width[k] : 0); }
-    off[kD] = total; total += align256(out->support_leg ? B * 4 : 0);
-    off[kD + 1] = total; total += align256(out->leg_mode ? B * 4 : 0);
-    off[kD + 2] = total; total += align256(B * 4);             // status
-    off[kD + 3] = total; total += align256((B + 1) * 8);       // offsets
-    off[kD + 4] = total; total += align256(nbytes ? nbytes : 1);
-    int rc = ensure_ws(ctx, total);
+    // inputs first, outputs after them: a small call is then one copy each way over a tight span
+    const int i_off = sg.add(offsets, (B + 1) * 8, true, false);
+    const int i_msg = sg.add(messages + offsets[0], nbytes, true, false);
+    int i_d[kD];
+    for (int k = 0; k < kD; k++) i_d[k] = sg.add(hostd[k], B * 8 * (size_t)width[k], false, true);
+    const int i_sup = sg.add(out->support_leg, B * 4, false, true);
+    const int i_mode = sg.add(out->leg_mode, B * 4, false, true);
+    const int i_st = sg.add(status, B * 4, false, true);
+    const int rc = sg.upload(ctx, st);
     if (rc != QLAMD_OK) return rc;
-    char *w = (char *)ctx->ws;
-    if (hipMemcpyAsync(w + off[kD + 3], offsets, (B + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess) return QLAMD_ERR_HIP;
-    if (nbytes && hipMemcpyAsync(w + off[kD + 4], messages + offsets[0], nbytes, hipMemcpyHostToDevice, st) != hipSuccess)
-      return QLAMD_ERR_HIP;
-    double *dd[kD];
-    for (int k = 0; k < kD; k++) dd[k] = hostd[k] ? (double *)(w + off[k]) : nullptr;
-    o = RobotStateOutPtrs{dd[0], dd[1], dd[2], dd[3], dd[4], dd[5], dd[6], dd[7], dd[8], dd[9],
-                          out->support_leg ? (uint8_t *)(w + off[kD]) : nullptr,
-                          out->leg_mode ? (uint8_t *)(w + off[kD + 1]) : nullptr};
-    d_st = (int32_t *)(w + off[kD + 2]);
-    d_off = (const int64_t *)(w + off[kD + 3]);
-    d_msg = (const uint8_t *)(w + off[kD + 4]) - offsets[0]; // the kernel indexes with the caller's offsets
+    o = RobotStateOutPtrs{sg.dev<double>(i_d[0]), sg.dev<double>(i_d[1]), sg.dev<double>(i_d[2]), sg.dev<double>(i_d[3]),
+                          sg.dev<double>(i_d[4]), sg.dev<double>(i_d[5]), sg.dev<double>(i_d[6]), sg.dev<double>(i_d[7]),
+                          sg.dev<double>(i_d[8]), sg.dev<double>(i_d[9]), sg.dev<uint8_t>(i_sup), sg.dev<uint8_t>(i_mode)};
+    d_st = sg.dev<int32_t>(i_st);
+    d_off = sg.dev<const int64_t>(i_off);
+    d_msg = (const uint8_t *)(sg.base + sg.items[i_msg].off) - offsets[0]; // the kernel indexes with the caller's offsets
   }
   hipLaunchKernelGGL(robot_state_unpack_kernel, dim3((unsigned)((batch + kWireMsgsPerBlock - 1) / kWireMsgsPerBlock)),
                      dim3(64), kWireLdsBytes, st, d_msg, d_off, batch, o, d_st);
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
-  if (memory == QLAMD_MEM_HOST) {
-    char *w = (char *)ctx->ws;
-    bool fine = true;
-    for (int k = 0; k < kD; k++)
-      if (hostd[k])
-        fine = fine && hipMemcpyAsync(hostd[k], w + off[k], B * 8 * (size_t)width[k], hipMemcpyDeviceToHost, st) == hipSuccess;
-    if (out->support_leg)
-      fine = fine && hipMemcpyAsync(out->support_leg, w + off[kD], B * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
-    if (out->leg_mode)
-      fine = fine && hipMemcpyAsync(out->leg_mode, w + off[kD + 1], B * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
-    fine = fine && hipMemcpyAsync(status, d_st, B * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
-    if (!fine || hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
-  }
+  if (memory == QLAMD_MEM_HOST) return sg.finish(st);
   return QLAMD_OK;
 }
 

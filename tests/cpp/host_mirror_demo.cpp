@@ -7,6 +7,8 @@
 //   3. the demo QP of qp_solver/src/main.cc:46-101 through QuadraticProblemSolver::minimize.
 // Prints "key v0 v1 ..." lines that tests/test_cpp_mirror.py compares with the oracle.
 // Exit code 3 when no GPU is present (init() returns false: there is no CPU fallback).
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <vector>
@@ -80,6 +82,16 @@ int main(int argc, char **argv) {
     std::printf("tick_effort"); for (int i = 0; i < 12; ++i) std::printf(" %.17g", effort[i]); std::printf("\n");
     std::printf("tick_leg_state"); for (int l = 0; l < 4; ++l) std::printf(" %d", tick.legStateCodes()[l]); std::printf("\n");
     std::printf("tick_qd"); for (int i = 0; i < 12; ++i) std::printf(" %.17g", qd[i]); std::printf("\n");
+    // wall-clock cost of one whole tick (message -> efforts; three host-buffer calls + the balance solve); the
+    // reference's loop runs at 400 Hz, i.e. a 2500 us budget (balance_controller_manager.cpp:48)
+    std::vector<double> us;
+    for (int rep = 0; rep < 300; ++rep) {
+      const auto t0 = std::chrono::steady_clock::now();
+      if (!tick.baseCommandCallback(msg.data(), msg.size()) || !tick.updateFullTick(0.0025)) return 16;
+      us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+    std::sort(us.begin() + 50, us.end());
+    std::printf("tick_latency_us %.1f %.1f\n", us[50 + 125], us[50 + 225]); // median and p90 after 50 warm-up ticks
   }
 
   // ---- 2. pose optimisation ---------------------------------------------------------------------
