@@ -445,3 +445,75 @@ def pose_sqp_batch(pb, hips, leg_order, tol=0.05, max_iter=30, dummy_equality=1,
                                 int(dummy_equality), out.ctypes.data_as(_dp), it.ctypes.data_as(C.POINTER(C.c_int)),
                                 st.ctypes.data_as(C.POINTER(C.c_int)), int(nthreads))
     return out, it, st, problems
+
+
+# ---- whole-body (floating-base) dynamics and QP: oracle_wholebody.c (parity unpinned) ----
+class WbParams(C.Structure):
+    _fields_ = [("force_weights", C.c_double * 6), ("regularizer", C.c_double), ("torque_weight", C.c_double),
+                ("friction", C.c_double), ("min_normal_force", C.c_double), ("torque_limit", C.c_double),
+                ("gravity", C.c_double)]
+
+
+def default_wb_params():
+    p = WbParams()
+    lib().oracle_wb_default_params(C.byref(p))
+    return p
+
+
+def wb_mass_matrix(q):
+    a, ap = _d(q)
+    M = np.zeros((18, 18))
+    lib().oracle_wb_mass_matrix(ap, M.ctypes.data_as(_dp))
+    return M
+
+
+def wb_inverse_dynamics(q, base_quat, nu, nudot, gravity=9.81):
+    a = [_d(v) for v in (q, base_quat, nu, nudot)]
+    out = np.zeros(18)
+    lib().oracle_wb_inverse_dynamics(*[x[1] for x in a], C.c_double(gravity), out.ctypes.data_as(_dp))
+    return out
+
+
+def wb_nonlinear_effects(q, base_quat, nu, gravity=9.81):
+    a = [_d(v) for v in (q, base_quat, nu)]
+    out = np.zeros(18)
+    lib().oracle_wb_nonlinear_effects(*[x[1] for x in a], C.c_double(gravity), out.ctypes.data_as(_dp))
+    return out
+
+
+def wb_contact_jacobian(q):
+    a, ap = _d(q)
+    J = np.zeros((12, 18))
+    lib().oracle_wb_contact_jacobian(ap, J.ctypes.data_as(_dp))
+    return J
+
+
+def wb_kinetic_energy(q, nu):
+    lib().oracle_wb_kinetic_energy.restype = C.c_double
+    a, b = _d(q), _d(nu)
+    return lib().oracle_wb_kinetic_energy(a[1], b[1])
+
+
+def wb_potential_energy(q, base_pos, base_quat, gravity=9.81):
+    lib().oracle_wb_potential_energy.restype = C.c_double
+    a = [_d(v) for v in (q, base_pos, base_quat)]
+    return lib().oracle_wb_potential_energy(*[x[1] for x in a], C.c_double(gravity))
+
+
+def wb_step_batch(s, params=None, nthreads=1):
+    """oracle_wb_step_batch over a state dict with q, qd, base_quat, base_linvel, base_angvel, a_des, stance and
+    optionally qdd_des, normals.  Returns (tau [B,12], grf [B,12], status [B])."""
+    prm = params or default_wb_params()
+    B = s["q"].shape[0]
+    keep = [np.ascontiguousarray(s[k], dtype=np.float64) for k in ("q", "qd", "base_quat", "base_linvel", "base_angvel", "a_des")]
+    qdd = np.ascontiguousarray(s["qdd_des"], dtype=np.float64) if s.get("qdd_des") is not None else None
+    nrm = np.ascontiguousarray(s["normals"], dtype=np.float64) if s.get("normals") is not None else None
+    stance = np.ascontiguousarray(s["stance"], dtype=np.uint8)
+    tau = np.zeros((B, 12)); grf = np.zeros((B, 12)); st = np.zeros(B, np.int32)
+    lib().oracle_wb_step_batch(C.byref(prm), C.c_longlong(B), *[k.ctypes.data_as(_dp) for k in keep],
+                               qdd.ctypes.data_as(_dp) if qdd is not None else None,
+                               stance.ctypes.data_as(C.POINTER(C.c_uint8)),
+                               nrm.ctypes.data_as(_dp) if nrm is not None else None,
+                               tau.ctypes.data_as(_dp), grf.ctypes.data_as(_dp), st.ctypes.data_as(C.POINTER(C.c_int)),
+                               int(nthreads))
+    return tau, grf, st

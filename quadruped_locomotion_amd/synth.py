@@ -165,3 +165,22 @@ def make_swing_inputs(batch, seed=SEED + 9, offset=0):
     tvel = (2.0 * u[:, 36:48] - 1.0) * 0.5
     return dict(q=st["q"], qd=np.ascontiguousarray(qd), qd_old=np.ascontiguousarray(qd_old), dpos=np.ascontiguousarray(dpos),
                 tvel=np.ascontiguousarray(tvel), support=st["stance"])
+
+
+# ---------------------------------------------------------------------------------------------
+# Whole-body (floating-base) states, SURVEY.md section 8 row f4: the control-step states above plus joint
+# velocities and a desired base acceleration [linear ; angular] in base coordinates (what a base-motion
+# controller would ask for); the desired joint accelerations are zero (stance legs hold, swing legs coast).
+def make_wholebody_states(batch, gait="trot", seed=SEED, offset=0):
+    s = make_states(batch, gait, seed, offset)
+    u = _uniform(seed + 17, offset, offset + batch)
+    sym = lambda c, half: (2.0 * u[:, c] - 1.0) * half  # noqa: E731
+    s["qd"] = np.ascontiguousarray(np.stack([sym(k, 0.5) for k in range(12)], axis=1))
+    lin = np.stack([sym(12 + k, 1.0) for k in range(3)], axis=1)
+    ang = np.stack([sym(15 + k, 2.0) for k in range(3)], axis=1)
+    if gait == "trot":  # a horizontal push that loads the friction pyramid, like the velocity error of the trot states
+        ratio, theta = 0.2 + 0.7 * u[:, 18], 2.0 * np.pi * u[:, 19]
+        lin[:, 0] = 9.81 * ratio * np.cos(theta)
+        lin[:, 1] = 9.81 * ratio * np.sin(theta)
+    s["a_des"] = np.ascontiguousarray(np.concatenate([lin, ang], axis=1))
+    return s
