@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 #define QLAMD_VERSION_MAJOR 0
-#define QLAMD_VERSION_MINOR 1
+#define QLAMD_VERSION_MINOR 2
 
 /* ---- return codes of the API calls ------------------------------------- */
 #define QLAMD_OK 0
@@ -80,6 +80,10 @@ typedef struct qlamd_robot_model {
   double link_mass[4][4];
   double link_com[4][4][3];
   double link_inertia[4][4][6]; /* about the com, link frame: ixx ixy ixz iyy iyz izz (swing-leg dynamics) */
+  /* base_link inertial (urdf/quadruped_model.urdf:7-23): only the whole-body (floating-base) entries read it */
+  double base_mass;
+  double base_com[3];
+  double base_inertia[6];       /* about the com, base frame: ixx ixy ixz iyy iyz izz */
 } qlamd_robot_model;
 
 /* The reference robot, quadruped_model/urdf/quadruped_model.urdf. */
@@ -200,7 +204,7 @@ int qlamd_leg_kinematics_batch(qlamd_context *ctx, const double *joint_position,
 
 /* ---- dense QP batch -------------------------------------------------
  * min 1/2 x'Gx + g0'x  s.t.  CE'x + ce0 = 0,  CI'x + ci0 >= 0, one problem per batch entry, all
- * of the same shape (n <= 12, p <= 2, m <= 24), row-major, one constraint per COLUMN of CE / CI as
+ * of the same shape (n <= 12, p <= 2, m <= 24; with p <= 1 up to m = 48), row-major, one constraint per COLUMN of CE / CI as
  * in quadprogpp::solve_quadprog(G, g0, CE, ce0, CI, ci0, x) (qp_solver/include/qp_solver/QuadProg++.h:69-72),
  * which this replaces together with qp_solver::QuadraticProblemSolver::minimize
  * (qp_solver/src/quadraticproblemsolver.cpp:65-97; its wrapper passes CI = -A', ci0 = b for A x <= b,
@@ -407,6 +411,57 @@ void qlamd_joint_pid_default_params(qlamd_joint_pid_params *p);
 int qlamd_swing_branch_batch(qlamd_context *ctx, const qlamd_swing_params *params, const qlamd_joint_pid_params *pid,
                              const qlamd_swing_batch *in, const qlamd_swing_branch_extra *extra, double period,
                              int64_t batch, double *joint_effort, int memory, void *stream);
+
+/* ---- whole-body (floating-base) dynamics and QP ---------------------------------
+ * What BASELINE.json's north_star describes and the reference does NOT contain (no mass
+ * matrix / NonlinearEffects / CalcPointJacobian call anywhere; RBDL only drives one swing leg,
+ * single_leg_test/lib/model_test_header.cpp:229-244,460).  There is therefore no reference interface to cite; the
+ * entries follow the conventions of the rest of this header.  Model: the whole urdf/quadruped_model.urdf tree --
+ * base_link + 4 x (3 revolute links + fixed foot link), 18 degrees of freedom.
+ *
+ * Generalised velocity nu = [ v (3) ; w (3) ; qd (12) ]: velocity of the base origin and angular velocity of the
+ * base, both in BASE coordinates, then the joint rates (LF, RF, RH, LH).  nu' = d nu / dt componentwise.
+ *     M(q) nu' + h(q, nu) = [0 ; tau] + Jc' f
+ * f [12]: forces the ground applies on the four feet (base coordinates); Jc [12][18]: rows 3l..3l+2 =
+ * [ 1 , -[r_l]x , 0 .. J_leg(l) .. 0 ].  Gravity g_W = (0, 0, -gravity). */
+typedef struct qlamd_wholebody_batch {
+  const double *joint_position;        /* [B][12] */
+  const double *joint_velocity;        /* [B][12] */
+  const double *base_orientation;      /* [B][4]  (w,x,y,z) base -> world */
+  const double *base_linear_velocity;  /* [B][3]  world, like the control-step state batch */
+  const double *base_angular_velocity; /* [B][3]  base */
+  const double *desired_base_acceleration;  /* [B][6]  [v' ; w'] in base coordinates (solve entry only) */
+  const double *desired_joint_acceleration; /* [B][12] or NULL = 0                  (solve entry only) */
+  const uint8_t *support_leg;          /* [B][4]                                    (solve entry only) */
+  const double *surface_normal;        /* [B][4][3] world or NULL, like the control-step state batch (solve entry only) */
+} qlamd_wholebody_batch;
+
+typedef struct qlamd_wholebody_params {
+  double torque_weight;   /* w_tau */
+  double torque_limit;    /* tau_max, a constraint of the QP here (the reference clamps afterwards, :451-454) */
+  double gravity;
+} qlamd_wholebody_params;
+
+void qlamd_wholebody_default_params(qlamd_wholebody_params *p);
+
+/* Composite-rigid-body mass matrix, bias forces (Coriolis, centrifugal, gravity) and the contact Jacobian of the
+ * four feet.  mass_matrix [B][18][18], nonlinear_effects [B][18], contact_jacobian [B][12][18]: each may be NULL. */
+int qlamd_wholebody_dynamics_batch(qlamd_context *ctx, const qlamd_wholebody_batch *in, double gravity, int64_t batch,
+                                   double *mass_matrix, double *nonlinear_effects, double *contact_jacobian,
+                                   int memory, void *stream);
+
+/* One whole-body control step per robot.  With [b ; tau0] = M nu'_des + h (inverse dynamics for the desired
+ * accelerations), A = the reference's force-to-wrench map (ContactForceDistribution.cpp:168-206) and S, w_reg, mu,
+ * f_min the context's force-distribution parameters:
+ *     min (A f - b)' S (A f - b) + w_reg |f|^2 + w_tau |tau|^2
+ *     s.t. tau = tau0 - J_leg' f (stance legs),  friction pyramid and minimal normal force on f
+ *          (ContactForceDistribution.cpp:210-336),  |tau| <= tau_max
+ * i.e. 6 nS variables, 3 nS equalities and 11 nS inequalities; the torques are eliminated on the device.
+ * joint_effort [B][12] (swing legs: tau0), contact_force [B][12] or NULL, status [B] (QLAMD_STATUS_*; on failure the
+ * robot's efforts and forces are 0). */
+int qlamd_wholebody_solve_batch(qlamd_context *ctx, const qlamd_wholebody_params *params,
+                                const qlamd_wholebody_batch *in, int64_t batch, double *joint_effort,
+                                double *contact_force, int32_t *status, int memory, void *stream);
 
 const char *qlamd_strerror(int code);
 int qlamd_version(void);

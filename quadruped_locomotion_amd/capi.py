@@ -26,6 +26,7 @@ EXPORTS = (
     "qlamd_base_auto_optimize_pose_batch", "qlamd_leg_state_machine_batch", "qlamd_robot_state_unpack_batch",
     "qlamd_ik_default_params", "qlamd_leg_inverse_kinematics_batch",
     "qlamd_joint_pid_default_params", "qlamd_swing_branch_batch",
+    "qlamd_wholebody_default_params", "qlamd_wholebody_dynamics_batch", "qlamd_wholebody_solve_batch",
 )
 
 
@@ -46,6 +47,7 @@ class RobotModel(C.Structure):
         ("joint_xyz", ((C.c_double * 3) * 4) * 4), ("joint_rpy", ((C.c_double * 3) * 4) * 4),
         ("link_mass", (C.c_double * 4) * 4), ("link_com", ((C.c_double * 3) * 4) * 4),
         ("link_inertia", ((C.c_double * 6) * 4) * 4),
+        ("base_mass", C.c_double), ("base_com", C.c_double * 3), ("base_inertia", C.c_double * 6),
     ]
 
 
@@ -76,6 +78,23 @@ class JointPidParams(C.Structure):
 
 class SwingBranchExtra(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("base_orientation", "joint_command", "leg_mode", "pid_error_last", "pid_error_integral")]
+
+
+class WholebodyBatch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("joint_position", "joint_velocity", "base_orientation", "base_linear_velocity",
+                                           "base_angular_velocity", "desired_base_acceleration",
+                                           "desired_joint_acceleration", "support_leg", "surface_normal")]
+
+
+class WholebodyParams(C.Structure):
+    _fields_ = [("torque_weight", C.c_double), ("torque_limit", C.c_double), ("gravity", C.c_double)]
+
+
+# key of a synth.make_wholebody_states dict -> field of qlamd_wholebody_batch
+WHOLEBODY_FIELDS = (("q", "joint_position"), ("qd", "joint_velocity"), ("base_quat", "base_orientation"),
+                    ("base_linvel", "base_linear_velocity"), ("base_angvel", "base_angular_velocity"),
+                    ("a_des", "desired_base_acceleration"), ("qdd_des", "desired_joint_acceleration"),
+                    ("stance", "support_leg"), ("normals", "surface_normal"))
 
 
 class IkParams(C.Structure):
@@ -184,6 +203,12 @@ def lib():
                                                    C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_pose_sqp_batch.argtypes = [C.c_void_p, C.POINTER(PoseParams), C.POINTER(PoseBatch), C.c_int64,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.qlamd_wholebody_default_params.argtypes = [C.POINTER(WholebodyParams)]
+        L.qlamd_wholebody_default_params.restype = None
+        L.qlamd_wholebody_dynamics_batch.argtypes = [C.c_void_p, C.POINTER(WholebodyBatch), C.c_double, C.c_int64, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.qlamd_wholebody_solve_batch.argtypes = [C.c_void_p, C.POINTER(WholebodyParams), C.POINTER(WholebodyBatch), C.c_int64,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -584,3 +609,71 @@ def to_device(state, device="cuda:0"):
     for k, v in state.items():
         out[k] = torch.from_numpy(np.ascontiguousarray(v)).to(device)
     return out
+
+
+def default_wholebody_params():
+    p = WholebodyParams()
+    lib().qlamd_wholebody_default_params(C.byref(p))
+    return p
+
+
+def _wholebody_batch(state, keep):
+    """qlamd_wholebody_batch over numpy arrays (kept alive in `keep`) or torch CUDA tensors."""
+    wb = WholebodyBatch()
+    for key, field in WHOLEBODY_FIELDS:
+        v = state.get(key)
+        if v is None:
+            continue
+        if not hasattr(v, "data_ptr"):
+            v = np.ascontiguousarray(v, dtype=np.uint8 if key == "stance" else np.float64)
+            keep.append(v)
+        setattr(wb, field, _ptr(v))
+    return wb
+
+
+def wholebody_dynamics(ctx, state, gravity=9.81, want=("M", "h", "Jc")):
+    """qlamd_wholebody_dynamics_batch on host buffers -> dict with M [B,18,18], h [B,18], Jc [B,12,18]."""
+    keep = []
+    wb = _wholebody_batch(state, keep)
+    B = state["q"].shape[0]
+    out = dict(M=np.zeros((B, 18, 18)) if "M" in want else None, h=np.zeros((B, 18)) if "h" in want else None,
+               Jc=np.zeros((B, 12, 18)) if "Jc" in want else None)
+    rc = lib().qlamd_wholebody_dynamics_batch(ctx._h, C.byref(wb), C.c_double(gravity), B, _ptr(out["M"]), _ptr(out["h"]),
+                                              _ptr(out["Jc"]), MEM_HOST, None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_wholebody_dynamics_batch")
+    return out
+
+
+def wholebody_solve(ctx, state, params=None):
+    """qlamd_wholebody_solve_batch on host buffers -> (tau [B,12], grf [B,12], status [B])."""
+    prm = params if params is not None else default_wholebody_params()
+    keep = []
+    wb = _wholebody_batch(state, keep)
+    B = state["q"].shape[0]
+    tau = np.zeros((B, 12)); grf = np.zeros((B, 12)); st = np.full(B, -1, np.int32)
+    rc = lib().qlamd_wholebody_solve_batch(ctx._h, C.byref(prm), C.byref(wb), B, _ptr(tau), _ptr(grf), _ptr(st), MEM_HOST, None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_wholebody_solve_batch")
+    return tau, grf, st
+
+
+def wholebody_solve_device(ctx, dstate, tau, grf, status, params=None, stream=None):
+    """Same entry on torch CUDA tensors (dstate: dict from to_device); asynchronous."""
+    prm = params if params is not None else default_wholebody_params()
+    wb = _wholebody_batch(dstate, [])
+    rc = lib().qlamd_wholebody_solve_batch(ctx._h, C.byref(prm), C.byref(wb), dstate["q"].shape[0], tau.data_ptr(),
+                                           grf.data_ptr() if grf is not None else None, status.data_ptr(), MEM_DEVICE,
+                                           C.c_void_p(stream) if stream else None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_wholebody_solve_batch")
+
+
+def wholebody_dynamics_device(ctx, dstate, M, h, Jc, gravity=9.81, stream=None):
+    wb = _wholebody_batch(dstate, [])
+    rc = lib().qlamd_wholebody_dynamics_batch(ctx._h, C.byref(wb), C.c_double(gravity), dstate["q"].shape[0],
+                                              M.data_ptr() if M is not None else None, h.data_ptr() if h is not None else None,
+                                              Jc.data_ptr() if Jc is not None else None, MEM_DEVICE,
+                                              C.c_void_p(stream) if stream else None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_wholebody_dynamics_batch")

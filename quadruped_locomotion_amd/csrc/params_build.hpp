@@ -40,6 +40,9 @@ inline void default_robot_model(qlamd_robot_model *m) {
   memcpy(m->link_mass, QLAMD_LINK_MASS, sizeof(m->link_mass));
   memcpy(m->link_com, QLAMD_LINK_COM, sizeof(m->link_com));
   memcpy(m->link_inertia, QLAMD_LINK_INERTIA, sizeof(m->link_inertia));
+  m->base_mass = QLAMD_BASE_MASS;
+  memcpy(m->base_com, QLAMD_BASE_COM, sizeof(m->base_com));
+  memcpy(m->base_inertia, QLAMD_BASE_INERTIA, sizeof(m->base_inertia));
 }
 
 // URDF fixed-axis rpy: R = Rz(yaw) Ry(pitch) Rx(roll)  (kdl_parser)

@@ -2,11 +2,12 @@
 //
 // Replaces quadprogpp::solve_quadprog / qp_solver::QuadraticProblemSolver::minimize
 // (qp_solver/src/QuadProg++.cc:52-446, qp_solver/src/quadraticproblemsolver.cpp:65-97) for
-//   min 1/2 x'Gx + g0'x   s.t.  CE'x + ce0 = 0,  CI'x + ci0 >= 0,     n <= N, at most one equality, m <= 24,
+//   min 1/2 x'Gx + g0'x   s.t.  CE'x + ce0 = 0,  CI'x + ci0 >= 0,     n <= N, at most one equality,
+//   m <= 24 with two inequalities per lane (KC = 2), m <= 48 with three (KC = 3, the whole-body QP),
 // with the Goldfarb-Idnani method in the explicit-operator form of balance_coop.hpp / pose_coop.hpp:
 //   lane i < n      variable lane: component i of x, g0, z; row i of G and of the projector H
 //   lane k < n      slot lane: row k of N*, multiplier and constraint id of active-set slot k
-//   lane j          constraint lane: inequality j and (for m > 16) inequality j + 16: normal, ci0, slack
+//   lane j          constraint lane: inequalities j, j + 16 (and j + 32 for KC = 3): normal, ci0, slack
 // Rows n..N-1 are padded with the identity (their variables stay 0).  Pivot rule, step lengths and the
 // termination test are QuadProg++'s; exact ties between equally violated constraints go to the lowest lane.
 //
@@ -22,17 +23,22 @@ namespace qlamd {
 namespace coop {
 
 constexpr int kQpCoopRows = 4;
-template <int N>
-struct QpCoopLds { enum { kCt = 0, kNrow = 24 * N, kNst = 24 * N + N, kTotal = 24 * N + N + N * N }; };
+template <int N, int KC = 2>
+struct QpCoopLds {
+  enum { kRows = KC == 2 ? 24 : 16 * KC, kCt = 0, kNrow = kRows * N, kNst = kRows * N + N, kTotal = kRows * N + N + N * N };
+};
 
-// Gm: row lr of G (identity row for n <= lr < N, zero for lr >= N); g0: component lr; ne: component lr of the
-// equality normal (has_eq), ce0 its offset; a0/b0/v0: inequality lr, a1/b1/v1: inequality lr + 16.
+// Gm: row lr of G (identity row for a variable that is not free, zero for lr >= N); g0: component lr; ne: component
+// lr of the equality normal (has_eq), ce0 its offset; a[s]/b[s]/v[s]: normal, offset and validity of inequality
+// lr + 16 s.  n_free: dimension of the subspace the constraints act on (= n unless some rows of G are identity
+// padding in the middle, as for the swing legs of the whole-body QP); it only enters the empty-null-space rule.
 // Returns the status; x_out = component lr of the minimiser, f_out = objective value (replicated).
-template <int N>
-__device__ __forceinline__ int qp_coop(const double (&Gm)[N], double g0, int n, int m, bool has_eq, double ne, double ce0,
-                                       const double (&a0)[N], double b0, bool v0, const double (&a1)[N], double b1, bool v1,
-                                       bool skip, double *lds_row, double &x_out, double &f_out) {
-  typedef QpCoopLds<N> L;
+template <int N, int KC>
+__device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, int n, int n_free, int m, bool has_eq, double ne,
+                                            double ce0, const double (&a)[KC][N], const double (&b)[KC], const bool (&v)[KC],
+                                            bool skip, double *lds_row, double &x_out, double &f_out) {
+  typedef QpCoopLds<N, KC> L;
+  typedef typename std::conditional<(KC > 2), unsigned long long, unsigned>::type mask_t;
   const int lr = threadIdx.x & 15;
   const bool var = lr < n;
   const double eps = 2.220446049250313e-16;
@@ -40,14 +46,12 @@ __device__ __forceinline__ int qp_coop(const double (&Gm)[N], double g0, int n, 
   double *ct = lds_row + L::kCt, *nrow = lds_row + L::kNrow, *nst = lds_row + L::kNst;
 
   // normals by constraint into LDS: variable lane i reads a_p[i] = ct[N p + i]
-  if (lr < m) {
 #pragma unroll
-    for (int i = 0; i < N; i++) ct[N * lr + i] = a0[i];
-  }
-  if (lr + 16 < m) {
+  for (int s = 0; s < KC; s++)
+    if (lr + 16 * s < m) {
 #pragma unroll
-    for (int i = 0; i < N; i++) ct[N * (lr + 16) + i] = a1[i];
-  }
+      for (int i = 0; i < N; i++) ct[N * (lr + 16 * s) + i] = a[s][i];
+    }
   double diag = 0.0;
 #pragma unroll
   for (int j = 0; j < N; j++) diag = sel(lr == j, Gm[j], diag);
@@ -106,7 +110,9 @@ __device__ __forceinline__ int qp_coop(const double (&Gm)[N], double g0, int n, 
   for (int j = 0; j < N; j++) Ns[j] = 0.0;
   double u = 0.0;
   int idk = 0;
-  unsigned used = 0, act_mask = 0, excl = 0;
+  unsigned used = 0;
+  mask_t act_mask = 0, excl = 0;
+  const mask_t one = 1;
   int q = 0, iters = 0, status = kStatusOk;
   const double psi_tol = (double)m * eps * c1 * c2 * 100.0;
   double rnorm2 = 1.0;
@@ -115,30 +121,46 @@ __device__ __forceinline__ int qp_coop(const double (&Gm)[N], double g0, int n, 
   double sp = 0.0, ucand = 0.0;
   if (bad && !skip) { status = kStatusNotPd; done = true; }
 
+  const auto slacks = [&](double xx, double (&sl)[KC]) {
+#pragma unroll
+    for (int s = 0; s < KC; s++) sl[s] = b[s];
+    static_for<N>([&](auto I) {
+      constexpr int i = I;
+      fmac_bc<i, i == 0>(sl[0], xx, a[0][i]);
+#pragma unroll
+      for (int s = 1; s < KC; s++) fmac_bc<i>(sl[s], xx, a[s][i]);
+    });
+  };
+
   for (int tick = 0; tick < 40 * kMaxOuter; tick++) {
     if (__all(done)) break;
     if (!done && need_select) {
       if (fresh) { iters++; excl = 0; }
-      double s0 = b0, s1 = b1;
-      static_for<N>([&](auto I) {
-        constexpr int i = I;
-        fmac_bc<i, i == 0>(s0, x, a0[i]);
-        fmac_bc<i>(s1, x, a1[i]);
-      });
-      const float viol = (v0 ? (float)vmin(0.0, s0) : 0.0f) + (v1 ? (float)vmin(0.0, s1) : 0.0f);
+      double sl[KC];
+      slacks(x, sl);
+      float viol = 0.0f;
+#pragma unroll
+      for (int s = 0; s < KC; s++) viol += v[s] ? (float)vmin(0.0, sl[s]) : 0.0f;
       const double psi = (double)row_sum_f32(viol);
-      const unsigned blocked = act_mask | excl;
-      double v = sel(v0 && !((blocked >> lr) & 1u) && s0 < 0.0, s0, inf);
-      const bool second = v1 && !((blocked >> (lr + 16)) & 1u) && s1 < 0.0 && s1 < v;
-      v = sel(second, s1, v);
-      const double vbest = row_min(v);
-      const int wl = row_first(v == vbest && v < 0.0);
-      const bool wsecond = ((unsigned)(__ballot(second) >> ((threadIdx.x & 48) + (wl & 15))) & 1u) != 0;
+      const mask_t blocked = act_mask | excl;
+      double vv = sel(v[0] && !((blocked >> lr) & 1u) && sl[0] < 0.0, sl[0], inf);
+      int which = 0;
+#pragma unroll
+      for (int s = 1; s < KC; s++) {
+        const bool better = v[s] && !((blocked >> (lr + 16 * s)) & 1u) && sl[s] < 0.0 && sl[s] < vv;
+        vv = sel(better, sl[s], vv);
+        which = better ? s : which;
+      }
+      const double vbest = row_min(vv);
+      const int wl = row_first(vv == vbest && vv < 0.0);
+      const int sh = (threadIdx.x & 48) + (wl & 15);
+      int wset = (int)((unsigned)(__ballot(which & 1) >> sh) & 1u);
+      if constexpr (KC > 2) wset |= (int)((unsigned)(__ballot((which & 2) != 0) >> sh) & 1u) << 1;
       const bool feasible = fresh && (fabs(psi) <= psi_tol);     // QuadProg++.cc:246-250
       const bool stop = feasible || !(vbest < 0.0) || iters > kMaxOuter; // :271-274
       status = (stop && iters > kMaxOuter) ? kStatusMaxIter : status;
       done = stop;
-      ip = stop ? ip : (wl + (wsecond ? 16 : 0));
+      ip = stop ? ip : (wl + 16 * wset);
       sp = sel(stop, sp, vbest);
       ucand = sel(stop, ucand, 0.0);
       need_select = stop;
@@ -163,7 +185,7 @@ __device__ __forceinline__ int qp_coop(const double (&Gm)[N], double g0, int n, 
       const double t2v = -sp * rcp_nr(zn);
       // with n - (equality) constraints active the null space is empty and z is exactly 0 in the reference (J2 has
       // no columns); the explicit projector only leaves ~1e-7 of drift there, which must not pass for a direction
-      const bool exhausted = q + (has_eq ? 1 : 0) >= n;
+      const bool exhausted = q + (has_eq ? 1 : 0) >= n_free;
       const double t2 = sel(!exhausted && fabs(zz) > eps && !(t2v < 0.0), t2v, inf);
       const double t = vmin(t1, t2);
       const bool infeasible = !(t < inf);                          // :339-344
@@ -187,10 +209,10 @@ __device__ __forceinline__ int qp_coop(const double (&Gm)[N], double g0, int n, 
       u = newslot ? ucand : u;
       idk = newslot ? ip : idk;
       used |= is_add ? (1u << newlane) : 0u;
-      act_mask |= is_add ? (1u << ip) : 0u;
+      act_mask |= is_add ? (one << ip) : (mask_t)0;
       rnorm2 = is_add ? fmax(rnorm2, zn) : rnorm2;
       q += is_add ? 1 : 0;
-      excl |= degenerate ? (1u << ip) : 0u;
+      excl |= degenerate ? (one << ip) : (mask_t)0;
       need_select = need_select || full;
       fresh = is_add ? true : (degenerate ? false : fresh);
       if (is_drop) {
@@ -210,7 +232,7 @@ __device__ __forceinline__ int qp_coop(const double (&Gm)[N], double g0, int n, 
         hc = nt_me * einv;
         nc = -coef * einv;
         const int drop_id = __shfl(idk, lpos, 16);
-        act_mask &= ~(1u << drop_id);
+        act_mask &= ~(one << drop_id);
         used &= ~(1u << lpos);
         if (lr == lpos) u = 0.0;
         q--;
@@ -244,15 +266,16 @@ __device__ __forceinline__ int qp_coop(const double (&Gm)[N], double g0, int n, 
     double corr = 0.0;
     static_for<N>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(corr, grad, H[j]); });
     x -= corr;
-    double s0 = b0, s1 = b1;
-    static_for<N>([&](auto I) {
-      constexpr int i = I;
-      fmac_bc<i, i == 0>(s0, x, a0[i]);
-      fmac_bc<i>(s1, x, a1[i]);
-    });
+    double sl[KC];
+    slacks(x, sl);
     const int src = myslot ? (idk & 15) : 0;
-    const double sv0 = __shfl(s0, src, 16), sv1 = __shfl(s1, src, 16);
-    const double rho = sel(myslot, -sel(idk >= 16, sv1, sv0), 0.0);
+    double sv = __shfl(sl[0], src, 16);
+#pragma unroll
+    for (int s = 1; s < KC; s++) {
+      const double t = __shfl(sl[s], src, 16);
+      sv = sel((idk >> 4) == s, t, sv);
+    }
+    const double rho = sel(myslot, -sv, 0.0);
     double dx = 0.0;
     static_for<N>([&](auto K) { constexpr int k = K; fmac_bc<k, k == 0>(dx, rho, NsT[k]); });
     x += dx;
@@ -266,6 +289,19 @@ __device__ __forceinline__ int qp_coop(const double (&Gm)[N], double g0, int n, 
   }
   x_out = x;
   return status;
+}
+
+// two inequalities per lane (m <= 24): the shape qlamd_qp_solve_batch uses
+template <int N>
+__device__ __forceinline__ int qp_coop(const double (&Gm)[N], double g0, int n, int m, bool has_eq, double ne, double ce0,
+                                       const double (&a0)[N], double b0, bool v0, const double (&a1)[N], double b1, bool v1,
+                                       bool skip, double *lds_row, double &x_out, double &f_out) {
+  double a[2][N];
+#pragma unroll
+  for (int i = 0; i < N; i++) { a[0][i] = a0[i]; a[1][i] = a1[i]; }
+  const double b[2] = {b0, b1};
+  const bool v[2] = {v0, v1};
+  return qp_coop_impl<N, 2>(Gm, g0, n, n, m, has_eq, ne, ce0, a, b, v, skip, lds_row, x_out, f_out);
 }
 
 } // namespace coop
