@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="robots per GPU")
     ap.add_argument("--gait", default="static", choices=["static", "trot"])
-    ap.add_argument("--workload", default="balance", choices=["balance", "pose_sqp"],
-                    help="pose_sqp = BASELINE config 5 (reported separately; single GPU)")
+    ap.add_argument("--workload", default="balance", choices=["balance", "pose_sqp", "wholebody", "wholebody_dynamics"],
+                    help="pose_sqp = BASELINE config 5; wholebody / wholebody_dynamics = SURVEY 8 row f4 "
+                         "(all reported separately from the headline metric; single GPU)")
     ap.add_argument("--rpw", type=int, default=0, help="robots per wavefront (0 = auto)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph of K steps")
     ap.add_argument("--force-collective", action="store_true",
@@ -153,10 +154,87 @@ def bench_pose_sqp(args):
         **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
 
 
+def bench_wholebody(args):
+    """SURVEY.md section 8 row f4 (no counterpart in the reference): `wholebody` = one whole-body control step per robot
+    (inverse dynamics -> force/torque QP -> joint efforts), `wholebody_dynamics` = mass matrix + bias forces + contact
+    Jacobian per robot (the HBM-bound kernel: 4464 B written per robot)."""
+    import torch
+    from quadruped_locomotion_amd import capi, synth
+    B, solve = args.batch, args.workload == "wholebody"
+    gait = "trot" if args.gait == "trot" else "static"
+    s = synth.make_wholebody_states(B, gait)
+    ctx = capi.Context(device=0)
+    d = capi.to_device(s)
+    dev = dict(dtype=torch.float64, device="cuda:0")
+    tau, grf, st = torch.zeros(B, 12, **dev), torch.zeros(B, 12, **dev), torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    M, h, Jc = torch.zeros(B, 18, 18, **dev), torch.zeros(B, 18, **dev), torch.zeros(B, 12, 18, **dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def launch():
+        if solve:
+            capi.wholebody_solve_device(ctx, d, tau, grf, st, stream=stream)
+        else:
+            capi.wholebody_dynamics_device(ctx, d, M, h, Jc, stream=stream)
+
+    for _ in range(args.warmup):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = e0.elapsed_time(e1) / args.steps
+    # algorithmic bytes per robot: q, qd (2 x 96), quaternion 32, twists 48 in; solve: + a_des 48 + stance 4 in, torques 96 +
+    # forces 96 + status 4 out; dynamics: M 2592 + h 144 + Jc 1728 out
+    per = (272 + 52 + 196) if solve else (272 + 4464)
+    achieved = per * B / (kernel_ms * 1e-3) / 1e9
+    cpu = None
+    if solve and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+        def rate(threads, budget):
+            n, t0 = 0, time.perf_counter()
+            while True:
+                O.wb_step_batch(s, nthreads=threads)
+                n += 1
+                dt = time.perf_counter() - t0
+                if dt >= budget:
+                    return n * B / dt, n, dt
+        cands = [c for c in sorted({1, 8, 32, visible} | ({visible // 2} if visible >= 4 else set())) if 1 <= c <= visible]
+        probe = {c: rate(c, 0.4)[0] for c in cands}
+        best = max(probe, key=probe.get)
+        v, n, dt = rate(best, min(args.cpu_seconds, 8.0))
+        cpu = {"value": v, "unit": "whole-body control steps/s", "cores": best, "kind": "port", "single_thread_value": probe.get(1),
+               "visible_cores": visible, "sample": "%d passes over the same %d robots (%.1f s), the oracle's %d-variable QP with "
+               "equalities, OpenMP over robots, %d threads (fastest of %s)" % (n, B, dt, 24, best, cands)}
+    print(json.dumps({
+        "metric": ("whole-body control steps/sec" if solve else "whole-body dynamics evaluations/sec") +
+                  " (SURVEY 8 row f4, reported separately from the headline metric)",
+        "value": B * args.steps / elapsed, "unit": "steps/s" if solve else "evaluations/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": ("batch=%d robots, %s, whole-body step: 18-DoF inverse dynamics -> force/torque QP (12 variables "
+                                "after eliminating the torques, up to 44 inequality rows) -> 12 joint efforts" if solve else
+                                "batch=%d robots, %s, 18x18 mass matrix + bias forces + 12x18 contact Jacobian") % (B, gait),
+                   **({"all_status_ok": bool((st == 0).all().item())} if solve else {})},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "wholebody_solve_kernel" if solve else "wholebody_dynamics_kernel",
+                     "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": per * B},
+        **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
+
+
 def main():
     args = parse()
     if args.workload == "pose_sqp":
         return bench_pose_sqp(args)
+    if args.workload in ("wholebody", "wholebody_dynamics"):
+        return bench_wholebody(args)
     import numpy as np
     import torch
     import torch.distributed as dist

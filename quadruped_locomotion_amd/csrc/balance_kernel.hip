@@ -963,7 +963,7 @@ __global__ __launch_bounds__(64) void wholebody_dynamics_kernel(const DevicePara
                                                                 double *__restrict__ ho, double *__restrict__ Jo) {
   using namespace coop;
   __shared__ double tab[4 * kTabPerLeg];
-  __shared__ double outb[4 * kWbOutDoubles];
+  __shared__ double outb[4 * kWbStage]; // staged twice: M, then h and Jc
   const DeviceParams &P = *Pp;
   TabStage ts;
   ts.issue(P);
@@ -973,8 +973,8 @@ __global__ __launch_bounds__(64) void wholebody_dynamics_kernel(const DevicePara
   WbLaneIn in;
   in.load(s, i, 3 * leg + (c < 3 ? c : 2));
   ts.commit(tab);
-  double *ob = outb + kWbOutDoubles * row;
-  for (int e = lr; e < kWbOutDoubles; e += 16) ob[e] = 0.0;
+  double *ob = outb + kWbStage * row;
+  for (int e = lr; e < kWbStage; e += 16) ob[e] = 0.0;
 
   double Rm[9], gB[3];
   quat_to_matrix(in.quat, Rm);
@@ -996,8 +996,10 @@ __global__ __launch_bounds__(64) void wholebody_dynamics_kernel(const DevicePara
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_s_waitcnt(0xC07F);
 
-  // base block, interface order [linear ; angular]:  [[m 1, -[h]x], [[h]x, I]]
-  {
+  const int64_t r0 = (int64_t)blockIdx.x * 4;
+  const int nrob = (int)((B - r0) < 4 ? (B - r0) : 4);
+  // ---- pass 1: the mass matrix.  Base block, interface order [linear ; angular]:  [[m 1, -[h]x], [[h]x, I]]
+  if (Mo) {
     static_for<36>([&](auto E) {
       constexpr int e = E, a = e / 6, b = e % 6;
       double val = 0.0;
@@ -1016,38 +1018,45 @@ __global__ __launch_bounds__(64) void wholebody_dynamics_kernel(const DevicePara
       }
       ob[kWbM + 18 * a + b] = val; // replicated value: every lane of the row stores it
     });
-    static_for<6>([&](auto E) { constexpr int e = E; ob[kWbH + e] = gb[e]; });
-  }
-  if (c < 3) {
-    const int j = 6 + 3 * leg + c;
+    if (c < 3) {
+      const int j = 6 + 3 * leg + c;
 #pragma unroll
-    for (int a = 0; a < 3; a++) { // my column / row of the base block: [force ; moment]
-      ob[kWbM + 18 * a + j] = Fcol[3 + a]; ob[kWbM + 18 * j + a] = Fcol[3 + a];
-      ob[kWbM + 18 * (3 + a) + j] = Fcol[a]; ob[kWbM + 18 * j + 3 + a] = Fcol[a];
-      ob[kWbM + 18 * j + 6 + 3 * leg + a] = Mleg[a];
+      for (int a = 0; a < 3; a++) { // my column / row of the base block: [force ; moment]
+        ob[kWbM + 18 * a + j] = Fcol[3 + a]; ob[kWbM + 18 * j + a] = Fcol[3 + a];
+        ob[kWbM + 18 * (3 + a) + j] = Fcol[a]; ob[kWbM + 18 * j + 3 + a] = Fcol[a];
+        ob[kWbM + 18 * j + 6 + 3 * leg + a] = Mleg[a];
+      }
     }
-    ob[kWbH + j] = tau;
-    double d[3] = {L.pf[0] - L.p[0], L.pf[1] - L.p[1], L.pf[2] - L.p[2]}, col[3];
-    cross3(L.z, d, col);
-#pragma unroll
-    for (int a = 0; a < 3; a++) ob[kWbJc + 18 * (3 * leg + a) + j] = col[a];
-  } else {
-    // the foot lane writes [1 , -[r]x] of its leg's three rows
-    double *jr = ob + kWbJc + 18 * 3 * leg;
-    jr[0] = 1.0; jr[18 + 1] = 1.0; jr[36 + 2] = 1.0;
-    jr[4] = L.pf[2]; jr[5] = -L.pf[1];            // -[r]x
-    jr[18 + 3] = -L.pf[2]; jr[18 + 5] = L.pf[0];
-    jr[36 + 3] = L.pf[1]; jr[36 + 4] = -L.pf[0];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 324 * nrob; e += 64) Mo[r0 * 324 + e] = outb[e]; // kWbStage == 324: robots are contiguous
+    __syncthreads();
+    if (ho || Jo)
+      for (int e = lr; e < 18 + 216; e += 16) ob[e] = 0.0;
   }
-  __syncthreads();
-  const int64_t r0 = (int64_t)blockIdx.x * 4;
-  const int nrob = (int)((B - r0) < 4 ? (B - r0) : 4);
-  if (Mo)
-    for (int e = threadIdx.x; e < 324 * nrob; e += 64) Mo[r0 * 324 + e] = outb[kWbOutDoubles * (e / 324) + kWbM + e % 324];
-  if (ho)
-    for (int e = threadIdx.x; e < 18 * nrob; e += 64) ho[r0 * 18 + e] = outb[kWbOutDoubles * (e / 18) + kWbH + e % 18];
-  if (Jo)
-    for (int e = threadIdx.x; e < 216 * nrob; e += 64) Jo[r0 * 216 + e] = outb[kWbOutDoubles * (e / 216) + kWbJc + e % 216];
+  // ---- pass 2: bias forces and the contact Jacobian
+  if (ho || Jo) {
+    static_for<6>([&](auto E) { constexpr int e = E; ob[kWbH + e] = gb[e]; });
+    if (c < 3) {
+      const int j = 6 + 3 * leg + c;
+      ob[kWbH + j] = tau;
+      double d[3] = {L.pf[0] - L.p[0], L.pf[1] - L.p[1], L.pf[2] - L.p[2]}, col[3];
+      cross3(L.z, d, col);
+#pragma unroll
+      for (int a = 0; a < 3; a++) ob[kWbJc + 18 * (3 * leg + a) + j] = col[a];
+    } else {
+      // the foot lane writes [1 , -[r]x] of its leg's three rows
+      double *jr = ob + kWbJc + 18 * 3 * leg;
+      jr[0] = 1.0; jr[18 + 1] = 1.0; jr[36 + 2] = 1.0;
+      jr[4] = L.pf[2]; jr[5] = -L.pf[1];            // -[r]x
+      jr[18 + 3] = -L.pf[2]; jr[18 + 5] = L.pf[0];
+      jr[36 + 3] = L.pf[1]; jr[36 + 4] = -L.pf[0];
+    }
+    __syncthreads();
+    if (ho)
+      for (int e = threadIdx.x; e < 18 * nrob; e += 64) ho[r0 * 18 + e] = outb[kWbStage * (e / 18) + kWbH + e % 18];
+    if (Jo)
+      for (int e = threadIdx.x; e < 216 * nrob; e += 64) Jo[r0 * 216 + e] = outb[kWbStage * (e / 216) + kWbJc + e % 216];
+  }
 }
 
 // One whole-body control step per robot: inverse dynamics for the desired accelerations -> force/torque QP over the

@@ -222,8 +222,9 @@ __device__ __forceinline__ void wb_crba(const WbParamsDev &W, const WbLink &L, i
   for (int a = 0; a < 6; a++) total.I[a] = W.base_I[a] + row_sum(sel(c == 0, Xc.I[a], 0.0));
 }
 
-// Layout of one robot's staging block in LDS for the dynamics kernel: M [18][18], h [18], Jc [12][18]
-constexpr int kWbM = 0, kWbH = 324, kWbJc = 342, kWbOutDoubles = 558;
+// Layout of one robot's staging block in LDS for the dynamics kernel: M [18][18]; then h [18], Jc [12][18]
+// (the kernel stages M first and, after writing it out, h and Jc in the same block)
+constexpr int kWbM = 0, kWbStage = 324, kWbH = 0, kWbJc = 18;
 
 // Layout of the exchange block of the whole-body solve (quad-lane results -> variable / constraint lanes)
 constexpr int kWxTau0 = 0, kWxJ = 12 /* [leg][a][k] */, kWxR = 48 /* [leg][3] */, kWxN = 60 /* [leg][n,t1,t2][3] */,

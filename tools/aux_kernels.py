@@ -7,6 +7,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
+import torch  # before the C-ABI library: both bring a HIP runtime, torch's must be the one that initialises
 
 from quadruped_locomotion_amd import capi, synth
 
@@ -61,4 +62,16 @@ for tag in ("n12", "n6"):                      # the golden force QPs (n = 12, m
 for _ in range(REPS):
     ctx.balance_solve_host(st)
     ctx.balance_solve_host(synth.make_states(B, "static"))
+
+# whole-body row (f4): dynamics kernel and the fused step, trot and static states, device-resident inputs
+for gait in ("trot", "static"):
+    d = capi.to_device(synth.make_wholebody_states(B, gait))
+    tau = torch.zeros(B, 12, dtype=torch.float64, device="cuda:0"); grf = torch.zeros_like(tau)
+    stt = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    M = torch.zeros(B, 18, 18, dtype=torch.float64, device="cuda:0"); h = torch.zeros(B, 18, dtype=torch.float64, device="cuda:0")
+    Jc = torch.zeros(B, 12, 18, dtype=torch.float64, device="cuda:0")
+    for _ in range(REPS):
+        capi.wholebody_solve_device(ctx, d, tau, grf, stt)
+        capi.wholebody_dynamics_device(ctx, d, M, h, Jc)
+    torch.cuda.synchronize()
 print("done")
