@@ -224,7 +224,9 @@ def bench_wholebody(args):
                                 "batch=%d robots, %s, 18x18 mass matrix + bias forces + 12x18 contact Jacobian") % (B, gait),
                    **({"all_status_ok": bool((st == 0).all().item())} if solve else {})},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "wholebody_solve_kernel" if solve else "wholebody_dynamics_kernel",
+                     # HBM bytes per launch from rocprofv3 --pmc (profiles/r1/pmc_dynamics_b65536.json), measured at 65536 robots
+                     "traffic": int((10361.5 + 285696.0) * 1024) if (not solve and B == 65536) else None,
+                     "kernel": "wholebody_solve_kernel" if solve else "wholebody_dynamics_kernel",
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": per * B},
         **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
 
