@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "balance_controller/RosBalanceController.hpp"
+#include "balance_controller/WholeBodyController.hpp"
 #include "free_gait_core/PoseConstraintsChecker.hpp"
 #include "free_gait_core/PoseOptimizationGeometric.hpp"
 #include "free_gait_core/PoseOptimizationQP.hpp"
@@ -59,6 +60,23 @@ int main(int argc, char **argv) {
   std::printf("cfd_effort"); for (double v : state->getAllJointEfforts()) std::printf(" %.17g", v); std::printf("\n");
   qlamd::Force f_lf; cfd.getForceForLeg(qlamd::LimbEnum::LF_LEG, f_lf);
   std::printf("cfd_force_lf %.17g %.17g %.17g\n", f_lf(0), f_lf(1), f_lf(2));
+
+  // ---- 1a. the whole-body controller on the same stance scenario (an extension, no reference counterpart)
+  {
+    state->setBaseStateFromFeedback(qlamd::LinearVelocity(linvel[0], linvel[1], linvel[2]),
+                                    qlamd::LocalAngularVelocity(angvel[0], angvel[1], angvel[2]));
+    balance_controller::WholeBodyController wbc(ctx, state);
+    if (wbc.compute()) return 17;                                      // parameters not loaded
+    wbc.loadParameters();
+    std::array<double, 12> wqd; for (int i = 0; i < 12; ++i) wqd[i] = 0.2 * std::cos(0.7 * i);
+    wbc.setJointVelocities(wqd);
+    wbc.setDesiredBaseAcceleration({0.5, -0.3, 0.8, 0.2, -0.1, 0.4});
+    wbc.setTorqueLimit(60.0);
+    if (!wbc.compute()) return 18;
+    std::printf("wbc_qd"); for (double v : wqd) std::printf(" %.17g", v); std::printf("\n");
+    std::printf("wbc_effort"); for (double v : state->getAllJointEfforts()) std::printf(" %.17g", v); std::printf("\n");
+    std::printf("wbc_grf"); for (double v : wbc.getContactForces()) std::printf(" %.17g", v); std::printf("\n");
+  }
 
   // ---- 1b. the whole tick from a serialised /desired_robot_state message (argv[1], written by the test) -----
   if (argc > 1) {

@@ -67,6 +67,15 @@ def test_mirror_matches_oracle(oracle):
                           + oracle.leg_gravity(l, out["state"][3 * l:3 * l + 3], gB) for l in range(4)])
     assert np.abs(out["cfd_effort"] - np.clip(tau, -300, 300)).max() < 1e-6
     assert np.abs(out["cfd_force_lf"] + x[:3]).max() < 1e-6      # desiredContactForce_ = -x
+    # 1a. WholeBodyController::compute against the whole-body oracle on the same scenario
+    wb = dict(q=out["state"][None], qd=out["wbc_qd"][None], base_quat=quat, base_linvel=np.array([[0.01, -0.02, 0.0]]),
+              base_angvel=np.array([[0.0, 0.01, 0.02]]), a_des=np.array([[0.5, -0.3, 0.8, 0.2, -0.1, 0.4]]),
+              stance=np.ones((1, 4), np.uint8))
+    wprm = oracle.default_wb_params()
+    wprm.torque_limit = 60.0
+    wt, wg, wst = oracle.wb_step_batch(wb, wprm)
+    assert wst[0] == 0
+    assert np.abs(out["wbc_effort"] - wt[0]).max() < 1e-6 and np.abs(out["wbc_grf"] - wg[0]).max() < 1e-6
     # 2. PoseOptimizationSQPTest.cpp:111-150
     assert np.allclose(out["pose"], [0, 0, 0.3, 1, 0, 0, 0], atol=1e-3)
     # PoseOptimizationQpTest.cpp:20-52 and the checker on an inside / outside pose
