@@ -42,7 +42,7 @@ __device__ unsigned long long g_stamps[64];
     __builtin_amdgcn_sched_barrier(0);                                                      \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
     __builtin_amdgcn_sched_barrier(0);                                                      \
-    if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[k] = t_;                              \
+    if (blockIdx.x == 0 && threadIdx.x == 0) ::qlamd::coop::g_stamps[k] = t_;                              \
   } while (0)
 #else
 #define QL_STAMP(k)

@@ -650,12 +650,18 @@ struct LdsBytes {
 // chain: every string / array length decides where the next field starts) and notes where the wanted payload
 // sits; pass 2 reads the payload at those anchors with independent loads.  Same results as robot_state_unpack
 // (wire_core.hpp), which stays the reference implementation for the host build and the global-memory fallback.
+constexpr int kTplMaxFields = 128; // length fields a layout template can hold (a reference message has ~95)
 struct WireSkeleton {
   const LdsBytes &p;
   uint32_t pos, cap; // cap = len + 1; pos saturates there ("bad")
+  uint32_t *log;     // global (position, value) pairs of the layout template, or NULL: only block 0's first message logs
+  uint32_t nf;
   __device__ __forceinline__ void skip(uint32_t n) { pos = min(pos + min(n, cap), cap); }
   __device__ __forceinline__ uint32_t len_field() { // read a uint32 at pos, step over it
-    const uint32_t v = p.u32(min(pos, cap - 1));
+    const uint32_t at = min(pos, cap - 1);
+    const uint32_t v = p.u32(at);
+    if (log && nf < (uint32_t)kTplMaxFields) { log[2 * nf] = at; log[2 * nf + 1] = v; }
+    nf++;
     skip(4);
     return v;
   }
@@ -674,10 +680,13 @@ enum WireAnchor : int { // uint32 slots per message
   kAnCount = 37
 };
 
-__device__ __forceinline__ int wire_lds_unpack(const LdsBytes &src, int64_t len64, RobotStateFields &f, uint32_t *an) {
+// Pass 1.  Returns the status; nf = number of length fields met, end_pos = position after the last field.
+__device__ __forceinline__ int wire_lds_skeleton(const LdsBytes &src, int64_t len64, uint32_t *an, uint32_t *log, uint32_t &nf,
+                                                 uint32_t &end_pos) {
+  nf = 0u; end_pos = 0u;
   if (len64 < 0 || len64 > 0x7FFFFFF0ll) return kWireTruncated;
   const uint32_t len = (uint32_t)len64;
-  WireSkeleton c{src, 0u, len + 1u};
+  WireSkeleton c{src, 0u, len + 1u, log, 0u};
   bool missing = false;
   // ---- pass 1: skeleton
 #pragma nounroll
@@ -728,71 +737,91 @@ __device__ __forceinline__ int wire_lds_unpack(const LdsBytes &src, int64_t len6
     c.header();
     c.skip(24 + 2);                 // surface_normal.vector, ignore_contact, ignore_for_pose_adaptation
   }
+  nf = c.nf; end_pos = c.pos;
   if (c.pos >= c.cap) return kWireTruncated; // some field ran past the end: the record stays cleared
-  // ---- pass 2: payload (independent reads)
+  return missing ? kWireMissingField : kWireOk;
+}
+
+// Pass 2: payload at the anchors, by the 16 lanes of the message's row.  The 77 doubles of a record are numbered in the
+// order of RobotStateFields (des_pos 0-2, des_quat 3-6, des_linvel 7-9, des_angvel 10-12, joint_command 13-24,
+// foot_position / velocity / acceleration 25-60, surface_normal 61-72, phase 73-76); lane lr takes entries lr, lr + 16, ...
+// All of a lane's reads are issued before its first store (a store into the record would otherwise fence the reads:
+// the record and the staged bytes are both LDS).  Lanes 0-3 also decode leg lr's mode name and support flag.
+__device__ __forceinline__ void wire_lds_extract_row(const LdsBytes &src, RobotStateFields &f, const uint32_t *an, int lr) {
+  double val[5];
+  bool put[5];
 #pragma unroll
-  for (int l = 0; l < 4; l++) {
-    const uint32_t at = an[kAnJointPos + l];
-    const uint32_t np = an[kAnJointCnt + l]; // fewer than 3 entries: flagged missing, keep what exists
-    if (np > 0) f.joint_command[3 * l] = src.f64(at);
-    if (np > 1) f.joint_command[3 * l + 1] = src.f64(at + 8);
-    if (np > 2) f.joint_command[3 * l + 2] = src.f64(at + 16);
+  for (int t = 0; t < 5; t++) {
+    const int e = lr + 16 * t;
+    uint32_t slot = kAnOdomPose, off = 0u;
+    bool ok = e < 77;
+    if (e < 3) { off = 8u * e; }                                                   // des_pos
+    else if (e < 7) { const int k = (e - 3 + 3) & 3; off = 24u + 8u * k; }          // des_quat (w,x,y,z) <- wire (x,y,z,w)
+    else if (e < 13) { off = 56u + 288u + 8u * (e - 7); }                          // des_linvel, des_angvel
+    else if (e < 25) { const int l = (e - 13) / 3, j = (e - 13) - 3 * l;           // joint_command
+      slot = kAnJointPos + l; off = 8u * j; ok = (uint32_t)j < an[kAnJointCnt + l]; }
+    else if (e < 61) { const int t9 = e - 25, arr = t9 / 12, r = t9 - 12 * arr, l = r / 3, j = r - 3 * l; // foot_* [arr][leg][j]
+      slot = kAnTarget + 3 * l + arr; off = 8u * j; ok = an[slot] != 0u; }
+    else if (e < 73) { const int l = (e - 61) / 3, j = (e - 61) - 3 * l; slot = kAnModeNormal + l; off = 8u * j; }
+    else { slot = kAnModeFlag + (e - 73 < 4 ? e - 73 : 0); off = 9u; }               // phase
+    put[t] = ok;
+    val[t] = src.f64(an[ok ? slot : (uint32_t)kAnOdomPose] + (ok ? off : 0u));
   }
+  int mode = kModeOther;
+  uint8_t sup = 0;
   {
-    const uint32_t at = an[kAnOdomPose];
-    f.des_pos[0] = src.f64(at); f.des_pos[1] = src.f64(at + 8); f.des_pos[2] = src.f64(at + 16);
-    f.des_quat[1] = src.f64(at + 24); f.des_quat[2] = src.f64(at + 32); f.des_quat[3] = src.f64(at + 40); f.des_quat[0] = src.f64(at + 48);
-    const uint32_t tw = at + 56 + 288;
-    f.des_linvel[0] = src.f64(tw); f.des_linvel[1] = src.f64(tw + 8); f.des_linvel[2] = src.f64(tw + 16);
-    f.des_angvel[0] = src.f64(tw + 24); f.des_angvel[1] = src.f64(tw + 32); f.des_angvel[2] = src.f64(tw + 40);
-  }
-#pragma unroll
-  for (int l = 0; l < 4; l++) {
+    const int l = lr & 3;
     const uint32_t nm = an[kAnModeName + l], nl = an[kAnModeLen + l];
     // "joint" 5, "leg_mode" 8, "cartesian" 9, "footstep" 8: compare 12 bytes read as three words against the literals
     const uint32_t w0 = src.u32(nm), w1 = src.u32(nm + 4), w2 = src.u32(nm + 8);
-    int mode = kModeOther;
     if (nl == 5 && w0 == 0x6E696F6Au && (w1 & 0xFFu) == 0x74u) mode = kModeJoint;                    // "join" "t"
     else if (nl == 8 && w0 == 0x5F67656Cu && w1 == 0x65646F6Du) mode = kModeLegMode;                // "leg_" "mode"
     else if (nl == 9 && w0 == 0x74726163u && w1 == 0x61697365u && (w2 & 0xFFu) == 0x6Eu) mode = kModeCartesian; // "cart" "esia" "n"
     else if (nl == 8 && w0 == 0x746F6F66u && w1 == 0x70657473u) mode = kModeFootstep;               // "foot" "step"
-    f.leg_mode[l] = (uint8_t)mode;
-    const uint32_t fl = an[kAnModeFlag + l];
-    f.support_leg[l] = src.u8(fl) != 0;
-    f.phase[l] = src.f64(fl + 9);
-    const uint32_t nv = an[kAnModeNormal + l];
-    f.surface_normal[3 * l] = src.f64(nv); f.surface_normal[3 * l + 1] = src.f64(nv + 8); f.surface_normal[3 * l + 2] = src.f64(nv + 16);
+    sup = src.u8(an[kAnModeFlag + l]) != 0;
   }
+  double *rec = reinterpret_cast<double *>(&f);
 #pragma unroll
-  for (int l = 0; l < 4; l++) {
-#pragma unroll
-    for (int arr = 0; arr < 3; arr++) {
-      const uint32_t at = an[kAnTarget + 3 * l + arr];
-      if (at == 0u) continue; // empty array (flagged missing): nothing to copy
-      double *dst = arr == 0 ? f.foot_position : arr == 1 ? f.foot_velocity : f.foot_acceleration;
-      dst[3 * l] = src.f64(at); dst[3 * l + 1] = src.f64(at + 8); dst[3 * l + 2] = src.f64(at + 16);
-    }
-  }
-  return missing ? kWireMissingField : kWireOk;
+  for (int t = 0; t < 5; t++)
+    if (put[t]) rec[lr + 16 * t] = val[t];
+  if (lr < 4) { f.leg_mode[lr] = (uint8_t)mode; f.support_leg[lr] = sup; }
 }
 
-constexpr int kWireMsgsPerBlock = 4;          // messages parsed per 64-lane block (one lane each)
+constexpr int kWireMsgsPerBlock = 4;          // messages parsed per 64-lane block (one 16-lane row each)
 constexpr int kWireLdsBytes = 32 * 1024;      // staging window; longer runs are parsed straight from global memory
+// Layout template: the (position, value) of every length field of one well-formed message plus the anchors its walk
+// produced.  A message whose length fields hold the template's values AT the template's positions has, by induction
+// along the walk, exactly the template's layout -- so its anchors are known without walking.
+constexpr uint32_t kTplMagic = 0x51574C54u;   // "TLWQ"
+constexpr int kTplValid = 0, kTplEnd = 1, kTplMissing = 2, kTplFields = 3, kTplAnchors = 4, kTplPairs = kTplAnchors + kAnCount,
+              kTplWords = kTplPairs + 2 * kTplMaxFields;
 
 // One block = kWireMsgsPerBlock consecutive messages: the block copies their contiguous byte range into LDS with
-// coalesced 16-byte loads, one lane per message walks the length-prefixed fields out of LDS (the walk is a chain
-// of dependent reads: ~100 cycles each from LDS instead of a DRAM round trip each from global memory) into a
-// per-message record in LDS, and the whole block writes the records out.
+// coalesced 16-byte loads; each message then belongs to one 16-lane row.  The row first checks the message against
+// the layout template of the previous launch (tpl_in): its lanes compare the ~95 length fields in parallel.  On a hit
+// the anchors are the template's; on a miss the row's first lane walks the length-prefixed fields (a chain of
+// dependent LDS reads, ~15 us for a message).  The payload is then read at the anchors into a per-message record
+// in LDS and the whole block writes the records out.  Block 0 leaves the template for the next launch in tpl_out
+// (the layout of its first message if that one had to be walked, else the template it used).  Results never depend
+// on the template, only the time does: streams from one publisher keep one layout.
 __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *__restrict__ messages,
                                                                 const int64_t *__restrict__ offsets, int64_t B,
-                                                                const RobotStateOutPtrs o, int32_t *__restrict__ status) {
+                                                                const RobotStateOutPtrs o, int32_t *__restrict__ status,
+                                                                const uint32_t *__restrict__ tpl_in,
+                                                                uint32_t *__restrict__ tpl_out) {
   extern __shared__ uint32_t wire_lds[];
   __shared__ RobotStateFields rec[kWireMsgsPerBlock];
   __shared__ uint32_t anchors[kWireMsgsPerBlock][kAnCount];
+  __shared__ uint32_t tpl[kTplWords];
   const int tid = threadIdx.x;
   const int64_t i0 = (int64_t)blockIdx.x * kWireMsgsPerBlock;
   const int n = (int)((B - i0) < kWireMsgsPerBlock ? (B - i0) : kWireMsgsPerBlock);
+  QL_STAMP(20);
   const int64_t a = offsets[i0], b = offsets[i0 + n];
+  // the template's loads go out first, its LDS stores follow the staging loop
+  uint32_t tplv[(kTplWords + 63) / 64];
+#pragma unroll
+  for (int j = 0; j < (kTplWords + 63) / 64; j++) tplv[j] = tpl_in[min(tid + 64 * j, kTplWords - 1)];
   const uintptr_t src = (uintptr_t)(messages + a);
   const uintptr_t src_al = src & ~(uintptr_t)15;
   const int64_t lead = (int64_t)(src - src_al), nbytes = lead + (b - a);
@@ -801,32 +830,101 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
     const int64_t full = nbytes >> 4;
     const uint4 *g = (const uint4 *)src_al;
     uint4 *l4 = (uint4 *)wire_lds;
-    // eight 16-byte loads in flight per lane before the first LDS store (a load-store-load-store chain would
-    // pay one DRAM latency per kilobyte)
-    int64_t k = tid;
-    for (; k + 64 * 7 < full; k += 64 * 8) {
-      const uint4 v0 = g[k], v1 = g[k + 64], v2 = g[k + 128], v3 = g[k + 192], v4 = g[k + 256], v5 = g[k + 320],
-                  v6 = g[k + 384], v7 = g[k + 448];
-      l4[k] = v0; l4[k + 64] = v1; l4[k + 128] = v2; l4[k + 192] = v3; l4[k + 256] = v4; l4[k + 320] = v5;
-      l4[k + 384] = v6; l4[k + 448] = v7;
+    // sixteen 16-byte loads in flight per lane (a 16 KB window: four typical messages) before the first LDS store:
+    // one DRAM round trip for the block instead of one per kilobyte
+    for (int64_t k0 = tid; k0 - tid < full; k0 += 64 * 16) {
+      const int64_t last = full - 1;
+      const uint4 v0 = g[min(k0 + 0, last)], v1 = g[min(k0 + 64, last)], v2 = g[min(k0 + 128, last)], v3 = g[min(k0 + 192, last)], v4 = g[min(k0 + 256, last)], v5 = g[min(k0 + 320, last)], v6 = g[min(k0 + 384, last)], v7 = g[min(k0 + 448, last)], v8 = g[min(k0 + 512, last)], v9 = g[min(k0 + 576, last)], v10 = g[min(k0 + 640, last)], v11 = g[min(k0 + 704, last)], v12 = g[min(k0 + 768, last)], v13 = g[min(k0 + 832, last)], v14 = g[min(k0 + 896, last)], v15 = g[min(k0 + 960, last)];
+      if (k0 + 0 < full) l4[k0 + 0] = v0;
+      if (k0 + 64 < full) l4[k0 + 64] = v1;
+      if (k0 + 128 < full) l4[k0 + 128] = v2;
+      if (k0 + 192 < full) l4[k0 + 192] = v3;
+      if (k0 + 256 < full) l4[k0 + 256] = v4;
+      if (k0 + 320 < full) l4[k0 + 320] = v5;
+      if (k0 + 384 < full) l4[k0 + 384] = v6;
+      if (k0 + 448 < full) l4[k0 + 448] = v7;
+      if (k0 + 512 < full) l4[k0 + 512] = v8;
+      if (k0 + 576 < full) l4[k0 + 576] = v9;
+      if (k0 + 640 < full) l4[k0 + 640] = v10;
+      if (k0 + 704 < full) l4[k0 + 704] = v11;
+      if (k0 + 768 < full) l4[k0 + 768] = v12;
+      if (k0 + 832 < full) l4[k0 + 832] = v13;
+      if (k0 + 896 < full) l4[k0 + 896] = v14;
+      if (k0 + 960 < full) l4[k0 + 960] = v15;
     }
-    for (; k < full; k += 64) l4[k] = g[k];
     const int64_t tail0 = full << 4;                 // last partial chunk byte by byte: never read past the blob
     if (tid < nbytes - tail0) ((uint8_t *)wire_lds)[tail0 + tid] = ((const uint8_t *)src_al)[tail0 + tid];
   }
+#pragma unroll
+  for (int j = 0; j < (kTplWords + 63) / 64; j++)
+    if (tid + 64 * j < kTplWords) tpl[tid + 64 * j] = tplv[j];
   // clear the records (fields a malformed message never reaches read as zero)
   for (int w = tid; w < (int)(sizeof(rec) / 4); w += 64) ((uint32_t *)rec)[w] = 0u;
   for (int w = tid; w < kWireMsgsPerBlock * kAnCount; w += 64) (&anchors[0][0])[w] = 0u;
   __syncthreads();
-  if (tid < n) {
-    const int64_t ma = offsets[i0 + tid], mb = offsets[i0 + tid + 1];
-    int st;
-    if (ma < a || mb > b || mb < ma) st = kWireTruncated; // offsets not ascending: nothing to parse
-    else if (staged) st = wire_lds_unpack(LdsBytes{wire_lds, (uint32_t)(lead + (ma - a))}, mb - ma, rec[tid], anchors[tid]);
-    else st = robot_state_unpack(PlainBytes{messages + ma}, mb - ma, rec[tid]);
-    status[i0 + tid] = st;
+  QL_STAMP(21);
+  const int row = tid >> 4, lr = tid & 15;
+  const bool mine = row < n;
+  const int64_t ma = offsets[i0 + (mine ? row : 0)], mb = offsets[i0 + (mine ? row : 0) + 1];
+  const bool sane = mine && !(ma < a || mb > b || mb < ma); // offsets not ascending: nothing to parse
+  const LdsBytes msg{wire_lds, (uint32_t)(lead + (ma - a))};
+  // ---- template check, 16 lanes per message
+  const uint32_t tnf = tpl[kTplFields];
+  bool same = sane && staged && tpl[kTplValid] == kTplMagic && tnf <= (uint32_t)kTplMaxFields &&
+              (mb - ma) <= 0x7FFFFFF0ll && (uint64_t)(mb - ma) >= (uint64_t)tpl[kTplEnd];
+  {
+    // eight length fields per lane, all reads independent (positions inside the message: <= end <= length)
+    uint32_t at[kTplMaxFields / 16], want[kTplMaxFields / 16], got[kTplMaxFields / 16];
+#pragma unroll
+    for (int t = 0; t < kTplMaxFields / 16; t++) {
+      const uint32_t k = lr + 16u * t;
+      const bool on = same && k < tnf;
+      at[t] = on ? tpl[kTplPairs + 2 * k] : 0u;
+      want[t] = on ? tpl[kTplPairs + 2 * k + 1] : 0u;
+    }
+#pragma unroll
+    for (int t = 0; t < kTplMaxFields / 16; t++) got[t] = msg.u32(same ? at[t] : 0u);
+#pragma unroll
+    for (int t = 0; t < kTplMaxFields / 16; t++) same = same && (lr + 16u * t >= tnf || got[t] == want[t]);
+  }
+  const bool hit = ((unsigned)(__ballot(same) >> (tid & 48)) & 0xFFFFu) == 0xFFFFu;
+  if (hit)
+    for (int k = lr; k < kAnCount; k += 16) anchors[row][k] = tpl[kTplAnchors + k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  QL_STAMP(22);
+  uint32_t nf = 0u, end_pos = 0u;
+  int st = kWireTruncated;
+  const bool logger = blockIdx.x == 0 && row == 0; // this message's layout becomes the next launch's template
+  if (lr == 0 && mine) {
+    if (!sane) st = kWireTruncated;
+    else if (hit) st = tpl[kTplMissing] ? kWireMissingField : kWireOk;
+    else if (staged) st = wire_lds_skeleton(msg, mb - ma, anchors[row], logger ? tpl_out + kTplPairs : nullptr, nf, end_pos);
+    else st = robot_state_unpack(PlainBytes{messages + ma}, mb - ma, rec[row]);
+    status[i0 + row] = st;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  const int st_row = __shfl(st, 0, 16);
+  if (mine && sane && staged && st_row != kWireTruncated) wire_lds_extract_row(msg, rec[row], anchors[row], lr);
+  QL_STAMP(23);
+  // ---- the template for the next launch (block 0, first message)
+  if (logger) {
+    const uint32_t nf0 = __shfl(nf, 0, 16), end0 = __shfl(end_pos, 0, 16);
+    if (hit) {
+      for (int k = lr; k < kTplWords; k += 16) tpl_out[k] = tpl[k]; // still in force
+    } else {
+      // the walk has already left its (position, value) pairs in tpl_out; valid only if the message was well-formed
+      const bool good = sane && staged && st_row != kWireTruncated && nf0 <= (uint32_t)kTplMaxFields;
+      if (lr == 0) {
+        tpl_out[kTplValid] = good ? kTplMagic : 0u; tpl_out[kTplEnd] = end0;
+        tpl_out[kTplMissing] = st_row == kWireMissingField ? 1u : 0u; tpl_out[kTplFields] = nf0;
+      }
+      for (int k = lr; k < kAnCount; k += 16) tpl_out[kTplAnchors + k] = anchors[0][k];
+    }
   }
   __syncthreads();
+  QL_STAMP(24);
   // write-out: message m's k doubles of each field are contiguous in the output arrays
   const auto put = [&](double *dst, int width, size_t field_off) {
     if (!dst) return;
@@ -847,6 +945,7 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
     if (o.support_leg) o.support_leg[4 * i0 + tid] = rec[m].support_leg[l];
     if (o.leg_mode) o.leg_mode[4 * i0 + tid] = rec[m].leg_mode[l];
   }
+  QL_STAMP(25);
 }
 
 // ---- dense QP batch: one problem per lane, 8 problems per wavefront, arrays in LDS ------------
@@ -958,6 +1057,9 @@ struct WbLaneIn {
 };
 
 // M [B][18][18], h [B][18], Jc [B][12][18] (any of them may be NULL): staged per robot in LDS, written out coalesced.
+// kM: the composite-rigid-body pass and M; kHJ: the Newton-Euler pass, h and Jc (a caller that wants only one of the two
+// does not pay for the other).
+template <bool kM, bool kHJ>
 __global__ __launch_bounds__(64) void wholebody_dynamics_kernel(const DeviceParams *__restrict__ Pp, const coop::WbParamsDev W,
                                                                 const WbPtrs s, int64_t B, double *__restrict__ Mo,
                                                                 double *__restrict__ ho, double *__restrict__ Jo) {
@@ -988,18 +1090,18 @@ __global__ __launch_bounds__(64) void wholebody_dynamics_kernel(const DevicePara
   wb_link(CoopTab{tab + kTabPerLeg * leg}, c, sj, cj, L);
   const double V0[6] = {in.angvel[0], in.angvel[1], in.angvel[2], vB[0], vB[1], vB[2]};
   const double A0[6] = {0.0, 0.0, 0.0, -gB[0], -gB[1], -gB[2]};
-  double tau, gb[6];
-  wb_inverse_dynamics(W, L, c, V0, A0, c < 3 ? in.qdj : 0.0, 0.0, tau, gb);
-  WbInertia T;
-  double Fcol[6], Mleg[3];
-  wb_crba(W, L, c, T, Fcol, Mleg);
+  double tau = 0.0, gb[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if constexpr (kHJ) wb_inverse_dynamics(W, L, c, V0, A0, c < 3 ? in.qdj : 0.0, 0.0, tau, gb);
+  WbInertia T{};
+  double Fcol[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, Mleg[3] = {0.0, 0.0, 0.0};
+  if constexpr (kM) wb_crba(W, L, c, T, Fcol, Mleg);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_s_waitcnt(0xC07F);
 
   const int64_t r0 = (int64_t)blockIdx.x * 4;
   const int nrob = (int)((B - r0) < 4 ? (B - r0) : 4);
   // ---- pass 1: the mass matrix.  Base block, interface order [linear ; angular]:  [[m 1, -[h]x], [[h]x, I]]
-  if (Mo) {
+  if (kM && Mo) {
     static_for<36>([&](auto E) {
       constexpr int e = E, a = e / 6, b = e % 6;
       double val = 0.0;
@@ -1030,11 +1132,11 @@ __global__ __launch_bounds__(64) void wholebody_dynamics_kernel(const DevicePara
     __syncthreads();
     for (int e = threadIdx.x; e < 324 * nrob; e += 64) Mo[r0 * 324 + e] = outb[e]; // kWbStage == 324: robots are contiguous
     __syncthreads();
-    if (ho || Jo)
+    if (kHJ && (ho || Jo))
       for (int e = lr; e < 18 + 216; e += 16) ob[e] = 0.0;
   }
   // ---- pass 2: bias forces and the contact Jacobian
-  if (ho || Jo) {
+  if (kHJ && (ho || Jo)) {
     static_for<6>([&](auto E) { constexpr int e = E; ob[kWbH + e] = gb[e]; });
     if (c < 3) {
       const int j = 6 + 3 * leg + c;
@@ -1242,6 +1344,8 @@ struct qlamd_context {
   int rpw_override;
   int num_cu;
   double base_m, base_h[3], base_I[6]; // base_link about the base origin (whole-body entries)
+  uint32_t *wire_tpl;  // two layout templates of robot_state_unpack_kernel (read one, write the other), or NULL
+  int wire_flip;
   // HOST-memory mode staging (grown on demand)
   void *ws;
   size_t ws_bytes;
@@ -1749,8 +1853,15 @@ int qlamd_robot_state_unpack_batch(qlamd_context *ctx, const uint8_t *messages, 
     d_off = sg.dev<const int64_t>(i_off);
     d_msg = (const uint8_t *)(sg.base + sg.items[i_msg].off) - offsets[0]; // the kernel indexes with the caller's offsets
   }
+  if (!ctx->wire_tpl) { // zero = "no template yet": the first launch walks every message
+    if (hipMalloc((void **)&ctx->wire_tpl, 2 * kTplWords * sizeof(uint32_t)) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;
+    if (hipMemsetAsync(ctx->wire_tpl, 0, 2 * kTplWords * sizeof(uint32_t), st) != hipSuccess) return QLAMD_ERR_HIP;
+  }
+  const uint32_t *tpl_in = ctx->wire_tpl + kTplWords * ctx->wire_flip;
+  uint32_t *tpl_out = ctx->wire_tpl + kTplWords * (ctx->wire_flip ^ 1);
+  ctx->wire_flip ^= 1;
   hipLaunchKernelGGL(robot_state_unpack_kernel, dim3((unsigned)((batch + kWireMsgsPerBlock - 1) / kWireMsgsPerBlock)),
-                     dim3(64), kWireLdsBytes, st, d_msg, d_off, batch, o, d_st);
+                     dim3(64), kWireLdsBytes, st, d_msg, d_off, batch, o, d_st, tpl_in, tpl_out);
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   if (memory == QLAMD_MEM_HOST) return sg.finish(st);
   return QLAMD_OK;
@@ -1911,8 +2022,21 @@ int qlamd_wholebody_dynamics_batch(qlamd_context *ctx, const qlamd_wholebody_bat
     dM = sg.dev<double>(5); dh = sg.dev<double>(6); dJ = sg.dev<double>(7);
   }
   const coop::WbParamsDev W = wb_params_of(ctx, 0.0, 0.0, gravity);
-  hipLaunchKernelGGL(wholebody_dynamics_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(64), 0, st, ctx->d_params, W, s, batch,
-                     dM, dh, dJ);
+  const dim3 grid((unsigned)((batch + 3) / 4));
+  // One launch for everything.  Two launches (M; h and Jc) need 140 / 158 instead of 204 registers, i.e. three waves
+  // per SIMD instead of two, but repeat the link kinematics: measured 9 % slower at 65 536 robots, 30 % at 4096
+  // (QLAMD_WB_SPLIT=1 selects them, for measurement).
+  const bool fused = getenv("QLAMD_WB_SPLIT") == nullptr;
+  if (fused && dM && (dh || dJ)) {
+    hipLaunchKernelGGL((wholebody_dynamics_kernel<true, true>), grid, dim3(64), 0, st, ctx->d_params, W, s, batch, dM, dh, dJ);
+  } else {
+    if (dM)
+      hipLaunchKernelGGL((wholebody_dynamics_kernel<true, false>), grid, dim3(64), 0, st, ctx->d_params, W, s, batch, dM,
+                         (double *)nullptr, (double *)nullptr);
+    if (dh || dJ)
+      hipLaunchKernelGGL((wholebody_dynamics_kernel<false, true>), grid, dim3(64), 0, st, ctx->d_params, W, s, batch,
+                         (double *)nullptr, dh, dJ);
+  }
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   if (memory == QLAMD_MEM_HOST) return sg.finish(st);
   return QLAMD_OK;
@@ -2007,6 +2131,8 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
   ctx->ws_bytes = 0;
   ctx->pinned = nullptr;
   ctx->pinned_bytes = 0;
+  ctx->wire_tpl = nullptr;
+  ctx->wire_flip = 0;
   qlamd_robot_model m;
   if (model) m = *model; else default_robot_model(&m);
   build_device_params(*params, m, &ctx->params);
@@ -2035,6 +2161,7 @@ void qlamd_context_destroy(qlamd_context *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->wire_tpl) (void)hipFree(ctx->wire_tpl);
   if (ctx->d_params) (void)hipFree(ctx->d_params);
   delete ctx;
 }

@@ -52,6 +52,15 @@ blob, off, _ = batch_of_messages(B, 1)
 print("wire bytes per message: %.0f" % (len(blob) / B))
 for _ in range(REPS):
     capi.robot_state_unpack(ctx, blob, off)
+# a stream of one layout (one publisher): after the first launch every message hits the layout template
+from test_wire_format import random_message
+one, _ = random_message(np.random.default_rng(3), ragged=True)
+blob1 = one * B
+off1 = np.arange(B + 1, dtype=np.int64) * len(one)
+print("uniform stream: %d bytes per message" % len(one))
+ctx_u = capi.Context()
+for _ in range(REPS + 1):
+    capi.robot_state_unpack(ctx_u, blob1, off1)
 
 g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "qp_goldens.npz"))
 for tag in ("n12", "n6"):                      # the golden force QPs (n = 12, m = 20 and n = 6, m = 10), tiled to 4096
