@@ -120,7 +120,7 @@ __device__ __forceinline__ double row_min(double x) {
 }
 // lowest lane of my row for which `pred` holds (16 if none)
 __device__ __forceinline__ int row_first(bool pred) {
-  const unsigned long long m = __ballot(pred);
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
   const unsigned bits = (unsigned)(m >> (threadIdx.x & 48)) & 0xFFFFu;
   return bits ? (__ffs(bits) - 1) : 16;
 }
@@ -464,7 +464,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   };
 
   for (int tick = 0; tick < 40 * kMaxOuter; tick++) {
-    if (__all(done)) break;
+    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
     if (!done && need_select) {
       if (fresh) { iters++; excl = 0; }
       double s_min, s_fric;
@@ -481,7 +481,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       v = sel(cand_min, s_min, v);
       const double vbest = row_min(v);
       const int wl = row_first(v == vbest && v < 0.0);
-      const bool wmin = ((unsigned)(__ballot(cand_min) >> ((threadIdx.x & 48) + (wl & 15))) & 1u) != 0;
+      const bool wmin = ((unsigned)(__builtin_amdgcn_ballot_w64(cand_min) >> ((threadIdx.x & 48) + (wl & 15))) & 1u) != 0;
       v = vbest;
       const int key = 5 * (wl >> 2) + (wmin ? 0 : (wl & 3) + 1);
       const bool feasible = fresh && (fabs(psi) <= psi_tol); // QuadProg++.cc:246-250
