@@ -351,3 +351,18 @@ done:
   free(buf); free(ibuf); free(bbuf);
   return status;
 }
+
+/* `count` problems of one shape, `reps` passes: timing loop for tools/cpu_qp_calibration.py (no Python in the loop). */
+int oracle_solve_quadprog_batch(int n, int p, int m, int count, int reps, const double *G, const double *g0,
+                                const double *CI, const double *ci0, double *x) {
+  int bad = 0, active[64], nact, iters;
+  double f, Gw[12 * 12];
+  if (n > 12 || m + p > 63) return -1;
+  for (int r = 0; r < reps; r++)
+    for (int k = 0; k < count; k++) {
+      memcpy(Gw, G + (size_t)k * n * n, sizeof(double) * (size_t)n * (size_t)n); /* the solver factorises G in place */
+      bad += oracle_solve_quadprog(n, p, m, Gw, g0 + (size_t)k * n, NULL, NULL, CI + (size_t)k * n * m, ci0 + (size_t)k * m,
+                                   x + (size_t)k * n, &f, active, &nact, &iters) != 0;
+    }
+  return bad;
+}

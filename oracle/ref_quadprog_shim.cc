@@ -39,3 +39,15 @@ extern "C" int ref_solve_quadprog(int n, int p, int m, const double *G, const do
   *f_out = f;
   return std::isinf(f) ? 1 : 0;
 }
+
+/* `count` problems of one shape, `reps` passes: timing loop for tools/cpu_qp_calibration.py (no Python in the loop). */
+extern "C" int ref_solve_quadprog_batch(int n, int p, int m, int count, int reps, const double *G, const double *g0,
+                                        const double *CI, const double *ci0, double *x) {
+  int bad = 0;
+  double f;
+  for (int r = 0; r < reps; r++)
+    for (int k = 0; k < count; k++)
+      bad += ref_solve_quadprog(n, p, m, G + (size_t)k * n * n, g0 + (size_t)k * n, nullptr, nullptr, CI + (size_t)k * n * m,
+                                ci0 + (size_t)k * m, x + (size_t)k * n, &f) != 0;
+  return bad;
+}
