@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="robots per GPU")
     ap.add_argument("--gait", default="static", choices=["static", "trot"])
-    ap.add_argument("--workload", default="balance", choices=["balance", "pose_sqp", "wholebody", "wholebody_dynamics"],
-                    help="pose_sqp = BASELINE config 5; wholebody / wholebody_dynamics = SURVEY 8 row f4 "
+    ap.add_argument("--workload", default="balance", choices=["balance", "pose_sqp", "wholebody", "wholebody_dynamics", "full_tick"],
+                    help="pose_sqp = BASELINE config 5; wholebody / wholebody_dynamics = SURVEY 8 row f4; full_tick = the "
+                         "whole update() from a serialised message to 12 efforts (rows a1 + f1 + f2) "
                          "(all reported separately from the headline metric; single GPU)")
     ap.add_argument("--rpw", type=int, default=0, help="robots per wavefront (0 = auto)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph of K steps")
@@ -55,6 +56,7 @@ def parse():
                     help="capture the gathers on a second stream even with one rank (self-test of the multi-rank graph)")
     ap.add_argument("--no-gather", action="store_true",
                     help="several ranks without the per-step all-gather of the torques (scaling with / without it)")
+    ap.add_argument("--ragged", action="store_true", help="full_tick: every message with its own layout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -231,8 +233,74 @@ def bench_wholebody(args):
         **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
 
 
+def bench_full_tick(args):
+    """The plugin's whole tick for every robot: serialised /desired_robot_state message -> leg state machine -> balance
+    solve -> swing branch -> 12 efforts (qlamd_full_tick_batch).  Messages: one per robot; by default copies of one
+    message (one publisher's layout: the layout template of the unpack kernel hits from the second launch on, the
+    measured states still differ per robot); --ragged gives every message its own layout and payload (every message
+    is walked)."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from quadruped_locomotion_amd import capi, synth
+    from test_wire_format import random_message
+    B = args.batch
+    rng = np.random.default_rng(11)
+    if args.ragged:
+        raws = [random_message(rng, ragged=True)[0] for _ in range(B)]
+    else:
+        base = bytearray(random_message(np.random.default_rng(3), ragged=True)[0])
+        raws = [bytes(base)] * B
+    off = np.zeros(B + 1, np.int64)
+    off[1:] = np.cumsum([len(r) for r in raws])
+    s = synth.make_states(B, "trot")
+    host = dict(messages=np.frombuffer(b"".join(raws), np.uint8).copy(), offsets=off, joint_position=s["q"],
+                joint_velocity=rng.normal(scale=0.3, size=(B, 12)), joint_velocity_oldest=rng.normal(scale=0.3, size=(B, 12)),
+                base_position=s["base_pos"], base_orientation=s["base_quat"], base_linear_velocity=np.ascontiguousarray(s["base_linvel"]),
+                base_angular_velocity=np.ascontiguousarray(s["base_angvel"]), contact=rng.integers(0, 2, (B, 4)).astype(np.uint8),
+                limb_state=np.zeros((B, 4), np.int8), store_flag=np.zeros((B, 4), np.uint8), stored_joint_position=np.zeros((B, 12)),
+                leg_mode=np.zeros((B, 4), np.uint8), pid_error_last=np.zeros((B, 12)), pid_error_integral=np.zeros((B, 12)),
+                joint_effort=np.zeros((B, 12)), leg_state_code=np.zeros((B, 4), np.int8), status=np.full(B, -1, np.int32),
+                message_status=np.full(B, -1, np.int32))
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to("cuda:0") for k, v in host.items()}
+    ctx = capi.Context(device=0)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(max(args.warmup, 2)):
+        capi.full_tick(ctx, dev, 0.0025, memory=capi.MEM_DEVICE, stream=stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        capi.full_tick(ctx, dev, 0.0025, memory=capi.MEM_DEVICE, stream=stream)
+    e1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tick_ms = e0.elapsed_time(e1) / args.steps
+    nbytes = int(off[-1])
+    # algorithmic bytes per robot: its message + measured state (q, qd, qd_oldest 288, base pose / twist 104, contact 4) +
+    # persistent state read and written (2 x (4 + 4 + 96 + 4 + 96 + 96)) + efforts 96 + codes / statuses 12
+    per = 288 + 104 + 4 + 2 * 300 + 96 + 12
+    algo = nbytes + per * B
+    achieved = algo / (tick_ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "whole control ticks/sec, message to efforts (SURVEY 8 rows a1 + f1 + f2, reported separately from the headline metric)",
+        "value": B * args.steps / elapsed, "unit": "ticks/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "batch=%d robots, one serialised free_gait_msgs/RobotState (%d B on average, %s) per robot and tick, "
+                               "trot states: unpack -> leg state machine -> balance solve -> swing branch" %
+                               (B, nbytes // B, "ragged layouts" if args.ragged else "one layout"),
+                   "messages_ok": int((dev["message_status"] == 0).sum().item()), "solves_ok": int((dev["status"] == 0).sum().item())},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "five kernels per tick (unpack, leg mode, leg state, balance, swing branch)",
+                     "kernel_ms": tick_ms, "algorithmic_bytes_per_launch": algo}}), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "full_tick":
+        return bench_full_tick(args)
     if args.workload == "pose_sqp":
         return bench_pose_sqp(args)
     if args.workload in ("wholebody", "wholebody_dynamics"):

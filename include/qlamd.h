@@ -463,6 +463,47 @@ int qlamd_wholebody_solve_batch(qlamd_context *ctx, const qlamd_wholebody_params
                                 const qlamd_wholebody_batch *in, int64_t batch, double *joint_effort,
                                 double *contact_force, int32_t *status, int memory, void *stream);
 
+/* ---- the whole control tick in one call (SURVEY.md section 8 row a1 with rows f1 and f2) -----------------------
+ * What the plugin does between one /desired_robot_state message and 12 effort commands:
+ *   baseCommandCallback (ros_balance_controller.cpp:761-1083)   message -> desired base state, leg modes, targets
+ *   footContactsCallback + the switch of update() (:1084-1135, :234-380)   leg state machine -> support legs
+ *   update() :384-454   balance solve for the support legs (virtual-model wrench -> force QP -> torques, clamped)
+ *   update() :467-603   swing branch for the others (joint PID / gravity compensation / swing-leg inverse dynamics)
+ * i.e. qlamd_robot_state_unpack_batch -> qlamd_leg_state_machine_batch -> qlamd_balance_solve_batch ->
+ * qlamd_swing_branch_batch with the intermediate arrays kept in device memory by the context.  A leg mode name the
+ * plugin does not know leaves that leg's mode as it was (:876-964); a message that cannot be parsed (message_status
+ * != QLAMD_WIRE_OK) leaves the robot's desired state zeroed for this tick, as qlamd_robot_state_unpack_batch does.
+ * All arrays [B][k]; persistent arrays are caller-owned so that a controller can be checkpointed. */
+typedef struct qlamd_tick_batch {
+  /* in: this tick */
+  const uint8_t *messages;              /* serialised free_gait_msgs/RobotState, concatenated */
+  const int64_t *offsets;               /* [B+1] */
+  const double *joint_position;         /* [B][12] measured */
+  const double *joint_velocity;         /* [B][12] measured */
+  const double *joint_velocity_oldest;  /* [B][12] ten ticks ago (MyRobotSolver's queue, model_test_header.cpp:417-431) */
+  const double *base_position;          /* [B][3]  measured */
+  const double *base_orientation;       /* [B][4]  */
+  const double *base_linear_velocity;   /* [B][3]  */
+  const double *base_angular_velocity;  /* [B][3]  */
+  const uint8_t *contact;               /* [B][4]  foot contact sensors */
+  /* in/out: what the plugin keeps between ticks */
+  int8_t *limb_state;                   /* [B][4]  */
+  uint8_t *store_flag;                  /* [B][4]  */
+  double *stored_joint_position;        /* [B][12] */
+  uint8_t *leg_mode;                    /* [B][4]  QLAMD_LEG_MODE_* in force */
+  double *pid_error_last;               /* [B][12] */
+  double *pid_error_integral;           /* [B][12] */
+  /* out */
+  double *joint_effort;                 /* [B][12] */
+  int8_t *leg_state_code;               /* [B][4]  or NULL */
+  int32_t *status;                      /* [B]     QLAMD_STATUS_* of the balance solve */
+  int32_t *message_status;              /* [B]     QLAMD_WIRE_* */
+} qlamd_tick_batch;
+
+int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, const qlamd_joint_pid_params *pid,
+                          const qlamd_tick_batch *io, double period, int index_quirk, int64_t batch, int memory,
+                          void *stream);
+
 const char *qlamd_strerror(int code);
 int qlamd_version(void);
 

@@ -27,6 +27,7 @@ EXPORTS = (
     "qlamd_ik_default_params", "qlamd_leg_inverse_kinematics_batch",
     "qlamd_joint_pid_default_params", "qlamd_swing_branch_batch",
     "qlamd_wholebody_default_params", "qlamd_wholebody_dynamics_batch", "qlamd_wholebody_solve_batch",
+    "qlamd_full_tick_batch",
 )
 
 
@@ -78,6 +79,18 @@ class JointPidParams(C.Structure):
 
 class SwingBranchExtra(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("base_orientation", "joint_command", "leg_mode", "pid_error_last", "pid_error_integral")]
+
+
+TICK_FIELDS = (("messages", np.uint8), ("offsets", np.int64), ("joint_position", np.float64), ("joint_velocity", np.float64),
+               ("joint_velocity_oldest", np.float64), ("base_position", np.float64), ("base_orientation", np.float64),
+               ("base_linear_velocity", np.float64), ("base_angular_velocity", np.float64), ("contact", np.uint8),
+               ("limb_state", np.int8), ("store_flag", np.uint8), ("stored_joint_position", np.float64), ("leg_mode", np.uint8),
+               ("pid_error_last", np.float64), ("pid_error_integral", np.float64), ("joint_effort", np.float64),
+               ("leg_state_code", np.int8), ("status", np.int32), ("message_status", np.int32))
+
+
+class TickBatch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n, _ in TICK_FIELDS]
 
 
 class WholebodyBatch(C.Structure):
@@ -157,6 +170,12 @@ def lib():
     """Load libqlamd.so; raise loudly if the HIP extension was not built."""
     global _lib
     if _lib is None:
+        # torch (device tensors, streams) carries its own HIP runtime: it has to be the one that initialises, or a later
+        # `import torch` in the same process finds no GPU.  Plumbing only -- nothing of torch is used by the library.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 "HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`). "
@@ -203,6 +222,8 @@ def lib():
                                                    C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_pose_sqp_batch.argtypes = [C.c_void_p, C.POINTER(PoseParams), C.POINTER(PoseBatch), C.c_int64,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.qlamd_full_tick_batch.argtypes = [C.c_void_p, C.POINTER(SwingParams), C.POINTER(JointPidParams), C.POINTER(TickBatch),
+                                            C.c_double, C.c_int, C.c_int64, C.c_int, C.c_void_p]
         L.qlamd_wholebody_default_params.argtypes = [C.POINTER(WholebodyParams)]
         L.qlamd_wholebody_default_params.restype = None
         L.qlamd_wholebody_dynamics_batch.argtypes = [C.c_void_p, C.POINTER(WholebodyBatch), C.c_double, C.c_int64, C.c_void_p,
@@ -677,3 +698,25 @@ def wholebody_dynamics_device(ctx, dstate, M, h, Jc, gravity=9.81, stream=None):
                                               C.c_void_p(stream) if stream else None)
     if rc != OK:
         raise QlamdError(rc, "qlamd_wholebody_dynamics_batch")
+
+
+def full_tick(ctx, io, period, index_quirk=1, params=None, pid=None, memory=MEM_HOST, stream=None):
+    """qlamd_full_tick_batch.  `io`: dict with the fields of qlamd_tick_batch (TICK_FIELDS: C-contiguous numpy arrays of
+    those dtypes for host memory, torch CUDA tensors for device memory; `leg_state_code` may be None); in/out and out
+    arrays are updated in place."""
+    prm = params if params is not None else default_swing_params()
+    pidp = pid if pid is not None else default_joint_pid_params()
+    tb = TickBatch()
+    for name, dt in TICK_FIELDS:
+        a = io.get(name)
+        if a is None:
+            continue
+        if memory == MEM_HOST:
+            assert a.dtype == dt and a.flags["C_CONTIGUOUS"], name
+        setattr(tb, name, _ptr(a))
+    B = int(io["offsets"].shape[0]) - 1
+    rc = lib().qlamd_full_tick_batch(ctx._h, C.byref(prm), C.byref(pidp), C.byref(tb), float(period), int(index_quirk), B, memory,
+                                     C.c_void_p(stream) if stream else None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_full_tick_batch")
+    return io

@@ -1333,6 +1333,17 @@ __global__ __launch_bounds__(64) void wholebody_solve_kernel(const DeviceParams 
   if (lr == 0 && live) status_out[i] = st;
 }
 
+// ---- the whole tick: a known leg-mode name replaces the mode in force, anything else leaves it (:876-964) ----------
+__global__ void tick_leg_mode_kernel(const uint8_t *__restrict__ msg_mode, uint8_t *__restrict__ leg_mode,
+                                     uint8_t *__restrict__ is_footstep, int64_t n) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint8_t m = msg_mode[t];
+  const uint8_t cur = m != kModeOther ? m : leg_mode[t];
+  leg_mode[t] = cur;
+  is_footstep[t] = cur == kModeFootstep ? 1 : 0;
+}
+
 } // namespace
 
 // ------------------------------------------------------------------ C-ABI ---
@@ -1344,6 +1355,8 @@ struct qlamd_context {
   int rpw_override;
   int num_cu;
   double base_m, base_h[3], base_I[6]; // base_link about the base origin (whole-body entries)
+  void *tick_ws;       // intermediates of qlamd_full_tick_batch (grown on demand)
+  size_t tick_ws_bytes;
   uint32_t *wire_tpl;  // two layout templates of robot_state_unpack_kernel (read one, write the other), or NULL
   int wire_flip;
   // HOST-memory mode staging (grown on demand)
@@ -2093,6 +2106,99 @@ int qlamd_wholebody_solve_batch(qlamd_context *ctx, const qlamd_wholebody_params
   return QLAMD_OK;
 }
 
+int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, const qlamd_joint_pid_params *pid,
+                          const qlamd_tick_batch *io, double period, int index_quirk, int64_t batch, int memory,
+                          void *stream) {
+  if (!ctx || !io || batch < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!swing || !pid) return QLAMD_ERR_NOT_LOADED;
+  if (!io->messages || !io->offsets || !io->joint_position || !io->joint_velocity || !io->joint_velocity_oldest ||
+      !io->base_position || !io->base_orientation || !io->base_linear_velocity || !io->base_angular_velocity ||
+      !io->contact || !io->limb_state || !io->store_flag || !io->stored_joint_position || !io->leg_mode ||
+      !io->pid_error_last || !io->pid_error_integral || !io->joint_effort || !io->status || !io->message_status)
+    return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+  qlamd_tick_batch d = *io;
+  Staged sg;
+  if (memory == QLAMD_MEM_HOST) {
+    for (size_t k = 0; k < B; k++)
+      if (io->offsets[k + 1] < io->offsets[k] || io->offsets[0] < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+    const size_t nbytes = (size_t)(io->offsets[B] - io->offsets[0]);
+    const int i_off = sg.add(io->offsets, (B + 1) * 8, true, false);
+    const int i_msg = sg.add(io->messages + io->offsets[0], nbytes ? nbytes : 1, true, false);
+    const int i_in[8] = {sg.add(io->joint_position, B * 96, true, false), sg.add(io->joint_velocity, B * 96, true, false),
+                         sg.add(io->joint_velocity_oldest, B * 96, true, false), sg.add(io->base_position, B * 24, true, false),
+                         sg.add(io->base_orientation, B * 32, true, false), sg.add(io->base_linear_velocity, B * 24, true, false),
+                         sg.add(io->base_angular_velocity, B * 24, true, false), sg.add(io->contact, B * 4, true, false)};
+    const int i_io[6] = {sg.add(io->limb_state, B * 4, true, true), sg.add(io->store_flag, B * 4, true, true),
+                         sg.add(io->stored_joint_position, B * 96, true, true), sg.add(io->leg_mode, B * 4, true, true),
+                         sg.add(io->pid_error_last, B * 96, true, true), sg.add(io->pid_error_integral, B * 96, true, true)};
+    const int i_out[4] = {sg.add(io->joint_effort, B * 96, false, true), sg.add(io->leg_state_code, B * 4, false, true),
+                          sg.add(io->status, B * 4, false, true), sg.add(io->message_status, B * 4, false, true)};
+    const int rc = sg.upload(ctx, st);
+    if (rc != QLAMD_OK) return rc;
+    d.offsets = sg.dev<const int64_t>(i_off);
+    d.messages = (const uint8_t *)(sg.base + sg.items[i_msg].off) - io->offsets[0];
+    d.joint_position = sg.dev<const double>(i_in[0]); d.joint_velocity = sg.dev<const double>(i_in[1]);
+    d.joint_velocity_oldest = sg.dev<const double>(i_in[2]); d.base_position = sg.dev<const double>(i_in[3]);
+    d.base_orientation = sg.dev<const double>(i_in[4]); d.base_linear_velocity = sg.dev<const double>(i_in[5]);
+    d.base_angular_velocity = sg.dev<const double>(i_in[6]); d.contact = sg.dev<const uint8_t>(i_in[7]);
+    d.limb_state = sg.dev<int8_t>(i_io[0]); d.store_flag = sg.dev<uint8_t>(i_io[1]);
+    d.stored_joint_position = sg.dev<double>(i_io[2]); d.leg_mode = sg.dev<uint8_t>(i_io[3]);
+    d.pid_error_last = sg.dev<double>(i_io[4]); d.pid_error_integral = sg.dev<double>(i_io[5]);
+    d.joint_effort = sg.dev<double>(i_out[0]); d.leg_state_code = sg.dev<int8_t>(i_out[1]);
+    d.status = sg.dev<int32_t>(i_out[2]); d.message_status = sg.dev<int32_t>(i_out[3]);
+  }
+  // intermediates: what the message delivers and what the state machine decides
+  enum { kPos, kQuat, kLin, kAng, kCmd, kFootP, kFootV, kPhase, kMsgSup, kMsgMode, kFootstep, kSupport, kCode, kN };
+  const size_t sz[kN] = {B * 24, B * 32, B * 24, B * 24, B * 96, B * 96, B * 96, B * 32, B * 4, B * 4, B * 4, B * 4, B * 4};
+  size_t off[kN], total = 0;
+  for (int k = 0; k < kN; k++) { off[k] = total; total += align256(sz[k]); }
+  if (ctx->tick_ws_bytes < total) {
+    if (ctx->tick_ws) (void)hipFree(ctx->tick_ws);
+    ctx->tick_ws = nullptr; ctx->tick_ws_bytes = 0;
+    if (hipMalloc(&ctx->tick_ws, total) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;
+    ctx->tick_ws_bytes = total;
+  }
+  char *w = (char *)ctx->tick_ws;
+  const auto D = [&](int k) { return (double *)(w + off[k]); };
+  const auto U = [&](int k) { return (uint8_t *)(w + off[k]); };
+  int rc;
+  // 1. baseCommandCallback: message -> desired state, targets, leg modes
+  qlamd_robot_state_fields f{};
+  f.des_pos = D(kPos); f.des_quat = D(kQuat); f.des_linvel = D(kLin); f.des_angvel = D(kAng);
+  f.joint_command = D(kCmd); f.foot_position = D(kFootP); f.foot_velocity = D(kFootV); f.phase = D(kPhase);
+  f.support_leg = U(kMsgSup); f.leg_mode = U(kMsgMode);
+  rc = qlamd_robot_state_unpack_batch(ctx, d.messages, d.offsets, batch, &f, d.message_status, QLAMD_MEM_DEVICE, stream);
+  if (rc != QLAMD_OK) return rc;
+  hipLaunchKernelGGL(tick_leg_mode_kernel, dim3((unsigned)((4 * batch + 255) / 256)), dim3(256), 0, st, U(kMsgMode), d.leg_mode,
+                     U(kFootstep), 4 * batch);
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  // 2. footContactsCallback + the switch of update(): support legs, held joint commands, nudged foot targets
+  qlamd_leg_state_batch ls{U(kMsgSup), D(kPhase), U(kFootstep), d.contact, d.joint_position, d.limb_state, d.store_flag,
+                           d.stored_joint_position, D(kCmd), D(kFootP), U(kSupport),
+                           d.leg_state_code ? d.leg_state_code : (int8_t *)(w + off[kCode])};
+  rc = qlamd_leg_state_machine_batch(ctx, &ls, index_quirk, batch, QLAMD_MEM_DEVICE, stream);
+  if (rc != QLAMD_OK) return rc;
+  // 3. balance solve for the support legs (all 12 efforts written: 0 for the others)
+  qlamd_state_batch sb{d.joint_position, d.base_position, d.base_orientation, d.base_linear_velocity, d.base_angular_velocity,
+                       D(kPos), D(kQuat), D(kLin), D(kAng), U(kSupport), nullptr};
+  rc = qlamd_balance_solve_batch(ctx, &sb, batch, d.joint_effort, nullptr, d.status, QLAMD_MEM_DEVICE, stream);
+  if (rc != QLAMD_OK) return rc;
+  // 4. swing branch for the legs that do not support
+  qlamd_swing_params sp = *swing;
+  sp.period = period;
+  const qlamd_swing_batch sw{d.joint_position, d.joint_velocity, d.joint_velocity_oldest, D(kFootP), D(kFootV), U(kSupport), nullptr};
+  const qlamd_swing_branch_extra ex{d.base_orientation, D(kCmd), d.leg_mode, d.pid_error_last, d.pid_error_integral};
+  rc = qlamd_swing_branch_batch(ctx, &sp, pid, &sw, &ex, period, batch, d.joint_effort, QLAMD_MEM_DEVICE, stream);
+  if (rc != QLAMD_OK) return rc;
+  if (memory == QLAMD_MEM_HOST) return sg.finish(st);
+  return QLAMD_OK;
+}
+
 #ifdef QLAMD_STAMPS
 int qlamd_debug_stamps(unsigned long long *out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(qlamd::coop::g_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
@@ -2133,6 +2239,8 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
   ctx->pinned_bytes = 0;
   ctx->wire_tpl = nullptr;
   ctx->wire_flip = 0;
+  ctx->tick_ws = nullptr;
+  ctx->tick_ws_bytes = 0;
   qlamd_robot_model m;
   if (model) m = *model; else default_robot_model(&m);
   build_device_params(*params, m, &ctx->params);
@@ -2162,6 +2270,7 @@ void qlamd_context_destroy(qlamd_context *ctx) {
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->wire_tpl) (void)hipFree(ctx->wire_tpl);
+  if (ctx->tick_ws) (void)hipFree(ctx->tick_ws);
   if (ctx->d_params) (void)hipFree(ctx->d_params);
   delete ctx;
 }

@@ -120,6 +120,25 @@ class RosBalanceController {
       return false;
     return solved;
   }
+  // The same tick through ONE call of the C-ABI (qlamd_full_tick_batch, batch 1): message bytes in, 12 efforts out.
+  // Equivalent to baseCommandCallback(msg) + footContactsCallback + updateFullTick(period) when every tick brings a
+  // message; what stays between ticks (limb states, stored joints, leg modes, PID errors, velocity queue) lives here.
+  bool tick(const uint8_t *msg, size_t len, double period) {
+    for (int i = 0; i < 12; ++i) {
+      for (int k = 10; k > 0; --k) qd_queue_[k][i] = qd_queue_[k - 1][i];
+      qd_queue_[0][i] = hw_.joint_velocity_read ? hw_.joint_velocity_read[i] : 0.0;
+    }
+    const int64_t off[2] = {0, static_cast<int64_t>(len)};
+    qlamd_swing_params sp; qlamd_swing_default_params(&sp);
+    qlamd_joint_pid_params pid; qlamd_joint_pid_default_params(&pid);
+    int32_t status = -1, message_status = -1;
+    qlamd_tick_batch io{msg, off, hw_.joint_position_read, qd_queue_[0].data(), qd_queue_[10].data(), hw_.position,
+                        hw_.orientation, hw_.linear_velocity, hw_.angular_velocity, contact_, limb_state_, store_flag_,
+                        stored_joint_position_.data(), leg_mode_, pid_error_last_.data(), pid_error_integral_.data(),
+                        hw_.joint_effort_write, leg_state_code_, &status, &message_status};
+    if (qlamd_full_tick_batch(ctx_->get(), &sp, &pid, &io, period, 1, 1, QLAMD_MEM_HOST, nullptr) != QLAMD_OK) return false;
+    return message_status == QLAMD_WIRE_OK && status == QLAMD_STATUS_OK;
+  }
   const int8_t *legStateCodes() const { return leg_state_code_; }
   const int8_t *limbStates() const { return limb_state_; }
 

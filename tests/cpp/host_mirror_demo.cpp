@@ -110,6 +110,23 @@ int main(int argc, char **argv) {
     }
     std::sort(us.begin() + 50, us.end());
     std::printf("tick_latency_us %.1f %.1f\n", us[50 + 125], us[50 + 225]); // median and p90 after 50 warm-up ticks
+    // the same first tick through the one-call entry on a fresh controller: identical efforts; then its latency
+    double effort1[12] = {0};
+    balance_controller::RobotStateHandleData hw1 = hw;
+    hw1.joint_effort_write = effort1;
+    balance_controller::RosBalanceController one;
+    if (!one.init(hw1, params, 0)) return 19;
+    one.footContactsCallback(touching);
+    if (!one.tick(msg.data(), msg.size(), 0.0025)) return 20;
+    std::printf("tick1_effort"); for (int i = 0; i < 12; ++i) std::printf(" %.17g", effort1[i]); std::printf("\n");
+    std::vector<double> us1;
+    for (int rep = 0; rep < 300; ++rep) {
+      const auto t0 = std::chrono::steady_clock::now();
+      if (!one.tick(msg.data(), msg.size(), 0.0025)) return 21;
+      us1.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+    std::sort(us1.begin() + 50, us1.end());
+    std::printf("tick1_latency_us %.1f %.1f\n", us1[50 + 125], us1[50 + 225]);
   }
 
   // ---- 2. pose optimisation ---------------------------------------------------------------------

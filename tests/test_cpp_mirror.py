@@ -123,6 +123,9 @@ def test_mirror_full_tick_matches_oracle(oracle, tmp_path):
     swing = oracle.swing_branch_leg(0, 4, quat, q[:3], q[:3], qd[:3], np.zeros(3), foot_t[0], foot_v[0], cmd_q[:3], 0.0025, el, ei)
     assert np.abs(out["tick_effort"][:3] - swing).max() < 1e-8
     # the whole tick (message -> 12 efforts, host buffers, batch 1) fits the reference's 400 Hz loop many times over
+    # the one-call tick (qlamd_full_tick_batch) gives the same efforts as the four-call tick
+    assert np.array_equal(out["tick1_effort"], out["tick_effort"])
+    print("one-call tick latency: median %.1f us, p90 %.1f us" % tuple(out["tick1_latency_us"]))
     med, p90 = out["tick_latency_us"]
     print("full tick latency: median %.1f us, p90 %.1f us" % (med, p90))
     assert med < 1250.0

@@ -1,0 +1,89 @@
+"""qlamd_full_tick_batch (message -> leg state machine -> balance solve -> swing branch in one call) against the same
+four entries called one after the other -- each of which has its own oracle parity test -- over several ticks with the
+persistent controller state carried along.  Bitwise equality is expected: the same kernels run on the same data."""
+import numpy as np
+import pytest
+
+from quadruped_locomotion_amd import synth
+from test_wire_format import random_message
+
+pytestmark = pytest.mark.gpu
+
+
+def make_tick_inputs(B, rng, tick):
+    raws = []
+    for i in range(B):
+        raw, _ = random_message(rng, ragged=(i % 3 != 0))
+        raws.append(raw if not (i == 5 and tick == 1) else raw[:40])          # one unparsable message on the second tick
+    off = np.zeros(B + 1, np.int64)
+    off[1:] = np.cumsum([len(r) for r in raws])
+    s = synth.make_states(B, "trot", offset=1000 * tick)
+    return dict(messages=np.frombuffer(b"".join(raws), np.uint8).copy(), offsets=off, joint_position=s["q"],
+                joint_velocity=np.ascontiguousarray(rng.normal(scale=0.3, size=(B, 12))),
+                joint_velocity_oldest=np.ascontiguousarray(rng.normal(scale=0.3, size=(B, 12))),
+                base_position=s["base_pos"], base_orientation=s["base_quat"], base_linear_velocity=np.ascontiguousarray(s["base_linvel"]),
+                base_angular_velocity=np.ascontiguousarray(s["base_angvel"]), contact=rng.integers(0, 2, (B, 4)).astype(np.uint8))
+
+
+def test_full_tick_equals_the_four_entries(oracle):
+    from quadruped_locomotion_amd import capi
+    ctx, ctx2 = capi.Context(), capi.Context()
+    rng = np.random.default_rng(2027)
+    B, period = 333, 0.0025
+    fresh = lambda: dict(limb_state=np.zeros((B, 4), np.int8), store_flag=np.zeros((B, 4), np.uint8),  # noqa: E731
+                         stored_joint_position=np.zeros((B, 12)), leg_mode=np.zeros((B, 4), np.uint8),
+                         pid_error_last=np.zeros((B, 12)), pid_error_integral=np.zeros((B, 12)))
+    keep_a, keep_b = fresh(), fresh()
+    for tick in range(4):
+        tin = make_tick_inputs(B, rng, tick)
+        # ---- one call
+        io = dict(tin, **keep_a, joint_effort=np.zeros((B, 12)), leg_state_code=np.zeros((B, 4), np.int8),
+                  status=np.full(B, -1, np.int32), message_status=np.full(B, -1, np.int32))
+        capi.full_tick(ctx, io, period)
+        # ---- the four entries, one after the other (host buffers)
+        f, mst = capi.robot_state_unpack(ctx2, tin["messages"], tin["offsets"])
+        known = f["leg_mode"] != 0
+        keep_b["leg_mode"][known] = f["leg_mode"][known]
+        ls = dict(support_leg=f["support_leg"], phase=f["phase"], is_footstep=(keep_b["leg_mode"] == 4).astype(np.uint8),
+                  contact=tin["contact"], joint_position=tin["joint_position"], limb_state=keep_b["limb_state"],
+                  store_flag=keep_b["store_flag"], stored_joint_position=keep_b["stored_joint_position"],
+                  joint_command=f["joint_command"], foot_target=f["foot_position"], support=np.zeros((B, 4), np.uint8),
+                  leg_state_code=np.zeros((B, 4), np.int8))
+        capi.leg_state_machine(ctx2, ls)
+        state = dict(q=tin["joint_position"], base_pos=tin["base_position"], base_quat=tin["base_orientation"],
+                     base_linvel=tin["base_linear_velocity"], base_angvel=tin["base_angular_velocity"], des_pos=f["des_pos"],
+                     des_quat=f["des_quat"], des_linvel=f["des_linvel"], des_angvel=f["des_angvel"], stance=ls["support"])
+        tau, _, st = ctx2.balance_solve_host(state)
+        effort = np.ascontiguousarray(tau)
+        capi.swing_branch(ctx2, effort, tin["joint_position"], tin["joint_velocity"], tin["joint_velocity_oldest"], ls["foot_target"],
+                          f["foot_velocity"], ls["support"], tin["base_orientation"], ls["joint_command"], keep_b["leg_mode"],
+                          keep_b["pid_error_last"], keep_b["pid_error_integral"], period)
+        assert np.array_equal(io["message_status"], mst) and np.array_equal(io["status"], st)
+        assert np.array_equal(io["leg_state_code"], ls["leg_state_code"])
+        assert np.array_equal(io["joint_effort"], effort), np.abs(io["joint_effort"] - effort).max()
+        for k in keep_a:
+            assert np.array_equal(io[k], keep_b[k]), k
+        assert (mst != 0).sum() >= (1 if tick == 1 else 0)
+    assert np.abs(io["joint_effort"]).max() > 1.0 and (io["status"] == 0).sum() > B // 2
+
+
+def test_full_tick_device_buffers_and_errors():
+    import torch
+    from quadruped_locomotion_amd import capi
+    ctx = capi.Context()
+    rng = np.random.default_rng(5)
+    B = 130
+    tin = make_tick_inputs(B, rng, 0)
+    host = dict(tin, limb_state=np.zeros((B, 4), np.int8), store_flag=np.zeros((B, 4), np.uint8), stored_joint_position=np.zeros((B, 12)),
+                leg_mode=np.zeros((B, 4), np.uint8), pid_error_last=np.zeros((B, 12)), pid_error_integral=np.zeros((B, 12)),
+                joint_effort=np.zeros((B, 12)), leg_state_code=np.zeros((B, 4), np.int8), status=np.full(B, -1, np.int32),
+                message_status=np.full(B, -1, np.int32))
+    dev = {k: torch.from_numpy(v.copy()).to("cuda:0") for k, v in host.items()}
+    capi.full_tick(ctx, host, 0.0025)
+    capi.full_tick(ctx, dev, 0.0025, memory=capi.MEM_DEVICE)
+    torch.cuda.synchronize()
+    for k in ("joint_effort", "status", "message_status", "leg_state_code", "limb_state", "pid_error_integral"):
+        assert np.array_equal(dev[k].cpu().numpy(), host[k]), k
+    bad = dict(host); bad["contact"] = None
+    with pytest.raises(capi.QlamdError):
+        capi.full_tick(ctx, bad, 0.0025)
