@@ -259,8 +259,8 @@ def bench_full_tick(args):
                 base_position=s["base_pos"], base_orientation=s["base_quat"], base_linear_velocity=np.ascontiguousarray(s["base_linvel"]),
                 base_angular_velocity=np.ascontiguousarray(s["base_angvel"]), contact=rng.integers(0, 2, (B, 4)).astype(np.uint8),
                 limb_state=np.zeros((B, 4), np.int8), store_flag=np.zeros((B, 4), np.uint8), stored_joint_position=np.zeros((B, 12)),
-                leg_mode=np.zeros((B, 4), np.uint8), pid_error_last=np.zeros((B, 12)), pid_error_integral=np.zeros((B, 12)),
-                joint_effort=np.zeros((B, 12)), leg_state_code=np.zeros((B, 4), np.int8), status=np.full(B, -1, np.int32),
+                leg_mode=np.zeros((B, 4), np.uint8), support=np.ones((B, 4), np.uint8), pid_error_last=np.zeros((B, 12)),
+                pid_error_integral=np.zeros((B, 12)), joint_effort=np.zeros((B, 12)), leg_state_code=np.zeros((B, 4), np.int8), status=np.full(B, -1, np.int32),
                 message_status=np.full(B, -1, np.int32))
     dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to("cuda:0") for k, v in host.items()}
     ctx = capi.Context(device=0)
@@ -279,8 +279,8 @@ def bench_full_tick(args):
     tick_ms = e0.elapsed_time(e1) / args.steps
     nbytes = int(off[-1])
     # algorithmic bytes per robot: its message + measured state (q, qd, qd_oldest 288, base pose / twist 104, contact 4) +
-    # persistent state read and written (2 x (4 + 4 + 96 + 4 + 96 + 96)) + efforts 96 + codes / statuses 12
-    per = 288 + 104 + 4 + 2 * 300 + 96 + 12
+    # persistent state read and written (2 x (4 + 4 + 96 + 4 + 4 + 96 + 96)) + efforts 96 + codes / statuses 12
+    per = 288 + 104 + 4 + 2 * 304 + 96 + 12
     algo = nbytes + per * B
     achieved = algo / (tick_ms * 1e-3) / 1e9
     print(json.dumps({

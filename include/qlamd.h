@@ -491,6 +491,7 @@ typedef struct qlamd_tick_batch {
   uint8_t *store_flag;                  /* [B][4]  */
   double *stored_joint_position;        /* [B][12] */
   uint8_t *leg_mode;                    /* [B][4]  QLAMD_LEG_MODE_* in force */
+  uint8_t *support;                     /* [B][4]  State::isSupportLeg (two leg states have no case in update() and leave it) */
   double *pid_error_last;               /* [B][12] */
   double *pid_error_integral;           /* [B][12] */
   /* out */

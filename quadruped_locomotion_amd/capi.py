@@ -84,7 +84,7 @@ class SwingBranchExtra(C.Structure):
 TICK_FIELDS = (("messages", np.uint8), ("offsets", np.int64), ("joint_position", np.float64), ("joint_velocity", np.float64),
                ("joint_velocity_oldest", np.float64), ("base_position", np.float64), ("base_orientation", np.float64),
                ("base_linear_velocity", np.float64), ("base_angular_velocity", np.float64), ("contact", np.uint8),
-               ("limb_state", np.int8), ("store_flag", np.uint8), ("stored_joint_position", np.float64), ("leg_mode", np.uint8),
+               ("limb_state", np.int8), ("store_flag", np.uint8), ("stored_joint_position", np.float64), ("leg_mode", np.uint8), ("support", np.uint8),
                ("pid_error_last", np.float64), ("pid_error_integral", np.float64), ("joint_effort", np.float64),
                ("leg_state_code", np.int8), ("status", np.int32), ("message_status", np.int32))
 

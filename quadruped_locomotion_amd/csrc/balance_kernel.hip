@@ -1428,7 +1428,7 @@ constexpr size_t kSmallHostCall = 256 * 1024; // below this a host-buffer call g
 // one copy down (the span of the outputs) instead of one pageable copy per array.
 struct Staged {
   struct Item { void *host; size_t bytes; bool in, out; size_t off; };
-  Item items[20];
+  Item items[24];
   int n = 0;
   char *base = nullptr;
   char *slab = nullptr; // pinned mirror of the workspace for small calls
@@ -2113,7 +2113,7 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
   if (!swing || !pid) return QLAMD_ERR_NOT_LOADED;
   if (!io->messages || !io->offsets || !io->joint_position || !io->joint_velocity || !io->joint_velocity_oldest ||
       !io->base_position || !io->base_orientation || !io->base_linear_velocity || !io->base_angular_velocity ||
-      !io->contact || !io->limb_state || !io->store_flag || !io->stored_joint_position || !io->leg_mode ||
+      !io->contact || !io->limb_state || !io->store_flag || !io->stored_joint_position || !io->leg_mode || !io->support ||
       !io->pid_error_last || !io->pid_error_integral || !io->joint_effort || !io->status || !io->message_status)
     return QLAMD_ERR_INVALID_ARGUMENT;
   if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
@@ -2133,9 +2133,10 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
                          sg.add(io->joint_velocity_oldest, B * 96, true, false), sg.add(io->base_position, B * 24, true, false),
                          sg.add(io->base_orientation, B * 32, true, false), sg.add(io->base_linear_velocity, B * 24, true, false),
                          sg.add(io->base_angular_velocity, B * 24, true, false), sg.add(io->contact, B * 4, true, false)};
-    const int i_io[6] = {sg.add(io->limb_state, B * 4, true, true), sg.add(io->store_flag, B * 4, true, true),
+    const int i_io[7] = {sg.add(io->limb_state, B * 4, true, true), sg.add(io->store_flag, B * 4, true, true),
                          sg.add(io->stored_joint_position, B * 96, true, true), sg.add(io->leg_mode, B * 4, true, true),
-                         sg.add(io->pid_error_last, B * 96, true, true), sg.add(io->pid_error_integral, B * 96, true, true)};
+                         sg.add(io->pid_error_last, B * 96, true, true), sg.add(io->pid_error_integral, B * 96, true, true),
+                         sg.add(io->support, B * 4, true, true)};
     const int i_out[4] = {sg.add(io->joint_effort, B * 96, false, true), sg.add(io->leg_state_code, B * 4, false, true),
                           sg.add(io->status, B * 4, false, true), sg.add(io->message_status, B * 4, false, true)};
     const int rc = sg.upload(ctx, st);
@@ -2149,12 +2150,13 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
     d.limb_state = sg.dev<int8_t>(i_io[0]); d.store_flag = sg.dev<uint8_t>(i_io[1]);
     d.stored_joint_position = sg.dev<double>(i_io[2]); d.leg_mode = sg.dev<uint8_t>(i_io[3]);
     d.pid_error_last = sg.dev<double>(i_io[4]); d.pid_error_integral = sg.dev<double>(i_io[5]);
+    d.support = sg.dev<uint8_t>(i_io[6]);
     d.joint_effort = sg.dev<double>(i_out[0]); d.leg_state_code = sg.dev<int8_t>(i_out[1]);
     d.status = sg.dev<int32_t>(i_out[2]); d.message_status = sg.dev<int32_t>(i_out[3]);
   }
   // intermediates: what the message delivers and what the state machine decides
-  enum { kPos, kQuat, kLin, kAng, kCmd, kFootP, kFootV, kPhase, kMsgSup, kMsgMode, kFootstep, kSupport, kCode, kN };
-  const size_t sz[kN] = {B * 24, B * 32, B * 24, B * 24, B * 96, B * 96, B * 96, B * 32, B * 4, B * 4, B * 4, B * 4, B * 4};
+  enum { kPos, kQuat, kLin, kAng, kCmd, kFootP, kFootV, kPhase, kMsgSup, kMsgMode, kFootstep, kCode, kN };
+  const size_t sz[kN] = {B * 24, B * 32, B * 24, B * 24, B * 96, B * 96, B * 96, B * 32, B * 4, B * 4, B * 4, B * 4};
   size_t off[kN], total = 0;
   for (int k = 0; k < kN; k++) { off[k] = total; total += align256(sz[k]); }
   if (ctx->tick_ws_bytes < total) {
@@ -2179,19 +2181,19 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   // 2. footContactsCallback + the switch of update(): support legs, held joint commands, nudged foot targets
   qlamd_leg_state_batch ls{U(kMsgSup), D(kPhase), U(kFootstep), d.contact, d.joint_position, d.limb_state, d.store_flag,
-                           d.stored_joint_position, D(kCmd), D(kFootP), U(kSupport),
+                           d.stored_joint_position, D(kCmd), D(kFootP), d.support,
                            d.leg_state_code ? d.leg_state_code : (int8_t *)(w + off[kCode])};
   rc = qlamd_leg_state_machine_batch(ctx, &ls, index_quirk, batch, QLAMD_MEM_DEVICE, stream);
   if (rc != QLAMD_OK) return rc;
   // 3. balance solve for the support legs (all 12 efforts written: 0 for the others)
   qlamd_state_batch sb{d.joint_position, d.base_position, d.base_orientation, d.base_linear_velocity, d.base_angular_velocity,
-                       D(kPos), D(kQuat), D(kLin), D(kAng), U(kSupport), nullptr};
+                       D(kPos), D(kQuat), D(kLin), D(kAng), d.support, nullptr};
   rc = qlamd_balance_solve_batch(ctx, &sb, batch, d.joint_effort, nullptr, d.status, QLAMD_MEM_DEVICE, stream);
   if (rc != QLAMD_OK) return rc;
   // 4. swing branch for the legs that do not support
   qlamd_swing_params sp = *swing;
   sp.period = period;
-  const qlamd_swing_batch sw{d.joint_position, d.joint_velocity, d.joint_velocity_oldest, D(kFootP), D(kFootV), U(kSupport), nullptr};
+  const qlamd_swing_batch sw{d.joint_position, d.joint_velocity, d.joint_velocity_oldest, D(kFootP), D(kFootV), d.support, nullptr};
   const qlamd_swing_branch_extra ex{d.base_orientation, D(kCmd), d.leg_mode, d.pid_error_last, d.pid_error_integral};
   rc = qlamd_swing_branch_batch(ctx, &sp, pid, &sw, &ex, period, batch, d.joint_effort, QLAMD_MEM_DEVICE, stream);
   if (rc != QLAMD_OK) return rc;

@@ -134,7 +134,7 @@ class RosBalanceController {
     int32_t status = -1, message_status = -1;
     qlamd_tick_batch io{msg, off, hw_.joint_position_read, qd_queue_[0].data(), qd_queue_[10].data(), hw_.position,
                         hw_.orientation, hw_.linear_velocity, hw_.angular_velocity, contact_, limb_state_, store_flag_,
-                        stored_joint_position_.data(), leg_mode_, pid_error_last_.data(), pid_error_integral_.data(),
+                        stored_joint_position_.data(), leg_mode_, support_, pid_error_last_.data(), pid_error_integral_.data(),
                         hw_.joint_effort_write, leg_state_code_, &status, &message_status};
     if (qlamd_full_tick_batch(ctx_->get(), &sp, &pid, &io, period, 1, 1, QLAMD_MEM_HOST, nullptr) != QLAMD_OK) return false;
     return message_status == QLAMD_WIRE_OK && status == QLAMD_STATUS_OK;

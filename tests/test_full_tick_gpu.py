@@ -32,7 +32,7 @@ def test_full_tick_equals_the_four_entries(oracle):
     B, period = 333, 0.0025
     fresh = lambda: dict(limb_state=np.zeros((B, 4), np.int8), store_flag=np.zeros((B, 4), np.uint8),  # noqa: E731
                          stored_joint_position=np.zeros((B, 12)), leg_mode=np.zeros((B, 4), np.uint8),
-                         pid_error_last=np.zeros((B, 12)), pid_error_integral=np.zeros((B, 12)))
+                         support=np.ones((B, 4), np.uint8), pid_error_last=np.zeros((B, 12)), pid_error_integral=np.zeros((B, 12)))
     keep_a, keep_b = fresh(), fresh()
     for tick in range(4):
         tin = make_tick_inputs(B, rng, tick)
@@ -47,7 +47,7 @@ def test_full_tick_equals_the_four_entries(oracle):
         ls = dict(support_leg=f["support_leg"], phase=f["phase"], is_footstep=(keep_b["leg_mode"] == 4).astype(np.uint8),
                   contact=tin["contact"], joint_position=tin["joint_position"], limb_state=keep_b["limb_state"],
                   store_flag=keep_b["store_flag"], stored_joint_position=keep_b["stored_joint_position"],
-                  joint_command=f["joint_command"], foot_target=f["foot_position"], support=np.zeros((B, 4), np.uint8),
+                  joint_command=f["joint_command"], foot_target=f["foot_position"], support=keep_b["support"],
                   leg_state_code=np.zeros((B, 4), np.int8))
         capi.leg_state_machine(ctx2, ls)
         state = dict(q=tin["joint_position"], base_pos=tin["base_position"], base_quat=tin["base_orientation"],
@@ -75,8 +75,8 @@ def test_full_tick_device_buffers_and_errors():
     B = 130
     tin = make_tick_inputs(B, rng, 0)
     host = dict(tin, limb_state=np.zeros((B, 4), np.int8), store_flag=np.zeros((B, 4), np.uint8), stored_joint_position=np.zeros((B, 12)),
-                leg_mode=np.zeros((B, 4), np.uint8), pid_error_last=np.zeros((B, 12)), pid_error_integral=np.zeros((B, 12)),
-                joint_effort=np.zeros((B, 12)), leg_state_code=np.zeros((B, 4), np.int8), status=np.full(B, -1, np.int32),
+                leg_mode=np.zeros((B, 4), np.uint8), support=np.ones((B, 4), np.uint8), pid_error_last=np.zeros((B, 12)),
+                pid_error_integral=np.zeros((B, 12)), joint_effort=np.zeros((B, 12)), leg_state_code=np.zeros((B, 4), np.int8), status=np.full(B, -1, np.int32),
                 message_status=np.full(B, -1, np.int32))
     dev = {k: torch.from_numpy(v.copy()).to("cuda:0") for k, v in host.items()}
     capi.full_tick(ctx, host, 0.0025)
