@@ -10,10 +10,15 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB = os.path.join(_PKG, "libqlamd.so")
-SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("balance_kernel.hip",)]
-HEADERS = [os.path.join(_PKG, "csrc", f) for f in ("balance_core.hpp", "balance_coop.hpp", "pose_coop.hpp", "qp_coop.hpp", "params_build.hpp", "gi_core.hpp",
-                                                     "gi6_core.hpp", "pose_core.hpp", "swing_core.hpp", "leg_state_core.hpp", "wire_core.hpp")] + [
-    os.path.join(_ROOT, "include", f) for f in ("qlamd.h", "qlamd_robot_constants.h")]
+SOURCE_NAMES = ("balance_kernel.hip", "pose_kernel.hip", "tick_kernel.hip", "wholebody_kernel.hip")
+SOURCES = [os.path.join(_PKG, "csrc", f) for f in SOURCE_NAMES]
+OBJ_DIR = os.path.join(_PKG, "csrc", "_obj")
+
+
+def headers():
+    csrc = os.path.join(_PKG, "csrc")
+    return [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".hpp")] + [
+        os.path.join(_ROOT, "include", f) for f in ("qlamd.h", "qlamd_robot_constants.h")]
 
 
 def hipcc():
@@ -27,19 +32,43 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(f) > t for f in SOURCES + headers())
 
 
-def build(force=False, verbose=False):
-    if not (force or needs_build()):
-        return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_PKG, "csrc"),
-           "-o", LIB] + SOURCES
+def build(force=False, verbose=False, defines=(), lib=None):
+    """One object per translation unit (compiled side by side), then one link.  `defines` / `lib` build a variant
+    (e.g. defines=("QLAMD_STAMPS",) for the diagnostic build) without touching the product library."""
+    out = lib or LIB
+    if not (force or lib or needs_build()):
+        return out
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = OBJ_DIR if not lib else OBJ_DIR + "_" + os.path.basename(out)
+    os.makedirs(obj_dir, exist_ok=True)
+    common = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(_ROOT, "include"),
+              "-I" + os.path.join(_PKG, "csrc")] + ["-D" + d for d in defines]
+    sources = SOURCES
+    if "QLAMD_STAMPS" in defines:
+        # the diagnostic build keeps its stamp buffer in one device variable: one translation unit
+        unity = os.path.join(obj_dir, "unity.hip")
+        with open(unity, "w") as f:
+            f.write("".join('#include "%s"\n' % src for src in SOURCES))
+        sources = [unity]
+    objs = [os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o") for src in sources]
+
+    def compile_one(pair):
+        src, obj = pair
+        cmd = common + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=len(sources)) as pool:
+        list(pool.map(compile_one, zip(sources, objs)))
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB
+        print(" ".join(link))
+    subprocess.check_call(link)
+    return out
 
 
 if __name__ == "__main__":

@@ -1,0 +1,170 @@
+// What every translation unit of libqlamd.so shares on the host side: the context behind the opaque handle of
+// include/qlamd.h, its device workspaces, the staging of host-buffer calls, and the LDS staging of the model table
+// that the per-leg kernels use.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "balance_core.hpp"
+#include "qlamd.h"
+
+struct qlamd_context {
+  int device;
+  qlamd::DeviceParams params;
+  qlamd::DeviceParams *d_params; // device copy, read through scalar loads
+  int rpw_override;
+  int num_cu;
+  double base_m, base_h[3], base_I[6]; // base_link about the base origin (whole-body entries)
+  void *tick_ws;       // intermediates of qlamd_full_tick_batch (grown on demand)
+  size_t tick_ws_bytes;
+  uint32_t *wire_tpl;  // two layout templates of robot_state_unpack_kernel (read one, write the other), or NULL
+  int wire_flip;
+  // HOST-memory mode staging (grown on demand)
+  void *ws;
+  size_t ws_bytes;
+  void *pinned;        // page-locked mirror of the head of ws, for small host-buffer calls (one copy each way)
+  size_t pinned_bytes;
+};
+
+
+namespace qlamd {
+namespace rt {
+
+// Per-robot run-time indexed arrays in LDS, [element][robot-in-wave]: a lane's
+// bank depends on the lane only, so divergent element indices never conflict.
+struct LdsScratch {
+  double *base;
+  int stride;
+  __device__ __forceinline__ double &at(int e) { return base[e * stride]; }
+};
+
+struct LdsTab { // one leg's 64-double block of the model table, staged in LDS
+  const double *p;
+  __device__ __forceinline__ double operator[](int i) const { return p[i]; }
+};
+
+
+// The per-leg kernels below read ~60 model constants per lane.  Straight from global memory the compiler
+// interleaves those reads with the arithmetic, a memory round trip every few dozen instructions; instead the
+// 4 x 88-double table is staged in LDS once per block: its six loads per lane are issued first, the lane's own
+// inputs right behind them, then the table is stored and the block synchronises -- one round trip in all.
+struct TabStage {
+  double v[6];
+  __device__ __forceinline__ void issue(const DeviceParams &P) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const int idx = (int)threadIdx.x + 64 * j;
+      v[j] = P.legtab[idx < 4 * kTabPerLeg ? idx : 4 * kTabPerLeg - 1];
+    }
+  }
+  __device__ __forceinline__ void commit(double *lds_tab) const {
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const int idx = (int)threadIdx.x + 64 * j;
+      if (idx < 4 * kTabPerLeg) lds_tab[idx] = v[j];
+    }
+    __syncthreads();
+  }
+};
+__device__ __forceinline__ void load3(const double *p, int64_t t, double o[3]) {
+  o[0] = p[3 * t]; o[1] = p[3 * t + 1]; o[2] = p[3 * t + 2];
+}
+
+
+inline int ensure_ws(qlamd_context *ctx, size_t bytes) {
+  if (ctx->ws_bytes >= bytes) return QLAMD_OK;
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  ctx->ws = nullptr;
+  ctx->ws_bytes = 0;
+  if (hipMalloc(&ctx->ws, bytes) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;
+  ctx->ws_bytes = bytes;
+  return QLAMD_OK;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+inline int ensure_pinned(qlamd_context *ctx, size_t bytes) {
+  if (ctx->pinned_bytes >= bytes) return QLAMD_OK;
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  ctx->pinned = nullptr;
+  ctx->pinned_bytes = 0;
+  if (hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;
+  ctx->pinned_bytes = bytes;
+  return QLAMD_OK;
+}
+constexpr size_t kSmallHostCall = 256 * 1024; // below this a host-buffer call goes through one pinned slab
+
+// Host-buffer calls: the listed arrays are laid out in the context workspace, inputs copied up front,
+// outputs copied back (and the stream synchronised) by finish().  Calls whose arrays total at most
+// kSmallHostCall bytes go through the context's pinned slab: one copy up (the span of the inputs) and
+// one copy down (the span of the outputs) instead of one pageable copy per array.
+struct Staged {
+  struct Item { void *host; size_t bytes; bool in, out; size_t off; };
+  Item items[24];
+  int n = 0;
+  char *base = nullptr;
+  char *slab = nullptr; // pinned mirror of the workspace for small calls
+  int add(const void *host, size_t bytes, bool in, bool out) {
+    items[n] = Item{const_cast<void *>(host), host ? bytes : 0, in, out, 0};
+    return n++;
+  }
+  void span(bool want_out, size_t *lo, size_t *hi) const {
+    *lo = ~(size_t)0; *hi = 0;
+    for (int k = 0; k < n; k++) {
+      if (!items[k].bytes || !(want_out ? items[k].out : items[k].in)) continue;
+      if (items[k].off < *lo) *lo = items[k].off;
+      if (items[k].off + items[k].bytes > *hi) *hi = items[k].off + items[k].bytes;
+    }
+  }
+  int upload(qlamd_context *ctx, hipStream_t st) {
+    size_t total = 0;
+    for (int k = 0; k < n; k++) { items[k].off = total; total += align256(items[k].bytes); }
+    int rc = ensure_ws(ctx, total ? total : 256);
+    if (rc != QLAMD_OK) return rc;
+    base = (char *)ctx->ws;
+    if (total && total <= kSmallHostCall) {
+      rc = ensure_pinned(ctx, kSmallHostCall);
+      if (rc != QLAMD_OK) return rc;
+      slab = (char *)ctx->pinned;
+      for (int k = 0; k < n; k++)
+        if (items[k].in && items[k].bytes) memcpy(slab + items[k].off, items[k].host, items[k].bytes);
+      size_t lo, hi;
+      span(false, &lo, &hi);
+      if (hi > lo && hipMemcpyAsync(base + lo, slab + lo, hi - lo, hipMemcpyHostToDevice, st) != hipSuccess)
+        return QLAMD_ERR_HIP;
+      return QLAMD_OK;
+    }
+    for (int k = 0; k < n; k++)
+      if (items[k].in && items[k].bytes &&
+          hipMemcpyAsync(base + items[k].off, items[k].host, items[k].bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+        return QLAMD_ERR_HIP;
+    return QLAMD_OK;
+  }
+  template <class T> T *dev(int k) const { return items[k].host ? (T *)(base + items[k].off) : nullptr; }
+  int finish(hipStream_t st) {
+    if (slab) {
+      size_t lo, hi;
+      span(true, &lo, &hi);
+      if (hi > lo && hipMemcpyAsync(slab + lo, base + lo, hi - lo, hipMemcpyDeviceToHost, st) != hipSuccess)
+        return QLAMD_ERR_HIP;
+      if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
+      for (int k = 0; k < n; k++)
+        if (items[k].out && items[k].bytes) memcpy(items[k].host, slab + items[k].off, items[k].bytes);
+      return QLAMD_OK;
+    }
+    for (int k = 0; k < n; k++)
+      if (items[k].out && items[k].bytes &&
+          hipMemcpyAsync(items[k].host, base + items[k].off, items[k].bytes, hipMemcpyDeviceToHost, st) != hipSuccess)
+        return QLAMD_ERR_HIP;
+    return hipStreamSynchronize(st) == hipSuccess ? QLAMD_OK : QLAMD_ERR_HIP;
+  }
+};
+
+
+} // namespace rt
+} // namespace qlamd

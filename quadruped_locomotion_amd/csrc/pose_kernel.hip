@@ -1,0 +1,524 @@
+// HIP kernels (gfx950) of the pose optimisation (rows a16/a17, f3) and of the dense QP batch (rows a14/a15) and their
+// part of the C-ABI of include/qlamd.h.
+#include "pose_coop.hpp"
+#include "qp_coop.hpp"
+#include "pose_core.hpp"
+#include "context.hpp"
+
+using namespace qlamd;
+using namespace qlamd::rt;
+
+namespace {
+
+// ---- config 5: one pose-optimisation problem per lane, 16 problems per wavefront --------------
+struct PosePtrs {
+  const double *stance, *nominal, *polygon, *rcom, *maxlen, *pose;
+  const uint8_t *mask;
+  const int32_t *nverts;
+};
+constexpr int kPosePerWave = 16;
+
+// Every load of a problem is issued unconditionally and before the first use: an absent optional array is read
+// through `stance` (always present and at least as long) and its value replaced afterwards, so that no load sits
+// behind a branch and the whole problem costs one memory round trip.
+__device__ __forceinline__ void load_pose_problem(const PoseParamsDev &P, const PosePtrs &s, int64_t i, PoseProblem &pb,
+                                                  double pose[7]) {
+  const uint8_t *maskp = s.mask ? s.mask : reinterpret_cast<const uint8_t *>(s.stance);
+  const double *rcomp = s.rcom ? s.rcom : s.stance;
+  const int32_t *nvp = s.nverts ? s.nverts : reinterpret_cast<const int32_t *>(s.stance);
+  const double *posep = s.pose ? s.pose : s.stance;
+  const uint32_t m4 = *reinterpret_cast<const uint32_t *>(maskp + 4 * i);
+  const int32_t nv = nvp[i];
+  double rc[3], ps[7], poly[8];
+#pragma unroll
+  for (int a = 0; a < 3; a++) rc[a] = rcomp[3 * i + a];
+#pragma unroll
+  for (int a = 0; a < 7; a++) ps[a] = posep[7 * i + a];
+  {
+    const double2 *p2 = reinterpret_cast<const double2 *>(s.polygon + 8 * i);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const double2 v = p2[k]; poly[2 * k] = v.x; poly[2 * k + 1] = v.y; }
+  }
+  pose_problem_load_legs(
+      P, pb, [&](int l, int a) { return s.stance[12 * i + 3 * l + a]; },
+      [&](int l, int a) { return s.nominal[12 * i + 3 * l + a]; }, [&](int l) { return s.maxlen[4 * i + l]; },
+      [&]() {
+        unsigned limb_mask = 0xFu;
+        if (s.mask) {
+          limb_mask = 0;
+#pragma unroll
+          for (int l = 0; l < 4; l++) limb_mask |= ((m4 >> (8 * l)) & 0xFFu) ? (1u << l) : 0u;
+        }
+        return limb_mask;
+      });
+#pragma unroll
+  for (int l = 0; l < 4; l++) { pb.polygon[l][0] = poly[2 * l]; pb.polygon[l][1] = poly[2 * l + 1]; }
+#pragma unroll
+  for (int a = 0; a < 3; a++) pb.r_com[a] = s.rcom ? rc[a] : 0.0;
+  pb.n_vertices = s.nverts ? nv : 4;
+#pragma unroll
+  for (int a = 0; a < 7; a++) pose[a] = s.pose ? ps[a] : (a == 3 ? 1.0 : 0.0);
+}
+
+__global__ __launch_bounds__(64) void pose_sqp_kernel(const PoseParamsDev P, const PosePtrs s, int64_t B,
+                                                      double *__restrict__ pose_out, int32_t *__restrict__ iters,
+                                                      int32_t *__restrict__ status) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * kPosePerWave + lane;
+  // the problem data lives in LDS (one record per lane): it is read a few values at a time over the whole SQP
+  // loop, and holding its 60 doubles in registers next to the QP's made the compiler spill each freshly loaded
+  // value to scratch, one memory round trip after the other
+  __shared__ PoseProblem pbs[kPosePerWave];
+  if (lane >= kPosePerWave || i >= B) return;
+  PoseProblem &pb = pbs[lane];
+  double pose[7];
+  load_pose_problem(P, s, i, pb, pose);
+  LdsScratch scr{lds + lane, kPosePerWave};
+  int it = 0;
+  const int st = pose_sqp6(P, pb, scr, pose, &it); // register-resident inner QP (gi6_core.hpp)
+#pragma unroll
+  for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
+  if (iters) iters[i] = it;
+  status[i] = st;
+}
+
+// Lane-cooperative form (csrc/pose_coop.hpp): 16 lanes per problem, 4 problems per wavefront -- the default.
+__global__ __launch_bounds__(64) void pose_sqp_coop_kernel(const PoseParamsDev P, const PosePtrs s, int64_t B,
+                                                           double *__restrict__ pose_out, int32_t *__restrict__ iters,
+                                                           int32_t *__restrict__ status) {
+  __shared__ PoseProblem pbs[coop::kPoseCoopRows];
+  __shared__ double pose0[coop::kPoseCoopRows][8];
+  __shared__ double rows[coop::kPoseCoopRows * coop::kPoseCoopLdsDoubles];
+  const int row = threadIdx.x >> 4, lr = threadIdx.x & 15;
+  int64_t i = (int64_t)blockIdx.x * coop::kPoseCoopRows + row;
+  const bool live = i < B;
+  if (!live) i = B - 1;
+  if (lr == 0) { // one lane per problem fetches the record; the row reads it back from LDS
+    double ps[7];
+    load_pose_problem(P, s, i, pbs[row], ps);
+#pragma unroll
+    for (int a = 0; a < 7; a++) pose0[row][a] = ps[a];
+  }
+  __syncthreads();
+  double pose[7];
+#pragma unroll
+  for (int a = 0; a < 7; a++) pose[a] = pose0[row][a];
+  int it = 0;
+  const int st = coop::pose_sqp_coop(P, pbs[row], live, rows + row * coop::kPoseCoopLdsDoubles, pose, it);
+  if (lr == 0 && live) {
+#pragma unroll
+    for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
+    if (iters) iters[i] = it;
+    status[i] = st;
+  }
+}
+
+// PoseOptimizationQP (position only) and PoseConstraintsChecker, same problem layout
+__global__ __launch_bounds__(64) void pose_qp_kernel(const PoseParamsDev P, const PosePtrs s, int64_t B,
+                                                     double *__restrict__ pose_out, int32_t *__restrict__ status) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * kPosePerWave + lane;
+  if (lane >= kPosePerWave || i >= B) return;
+  PoseProblem pb;
+  double pose[7];
+  load_pose_problem(P, s, i, pb, pose);
+  LdsScratch scr{lds + lane, kPosePerWave};
+  const int st = pose_qp(P, pb, scr, pose);
+#pragma unroll
+  for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
+  status[i] = st;
+}
+
+__global__ __launch_bounds__(64) void pose_check_kernel(const PoseParamsDev P, const PosePtrs s,
+                                                        const double *__restrict__ min_len, double leg_tol, int64_t B,
+                                                        uint8_t *__restrict__ ok) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= B) return;
+  PoseProblem pb;
+  double pose[7], mn[4];
+  load_pose_problem(P, s, i, pb, pose);
+#pragma unroll
+  for (int k = 0; k < 4; k++) mn[k] = min_len ? min_len[4 * i + P.leg_order[k]] : 0.0;
+  ok[i] = pose_check(pb, pose, mn, leg_tol) ? 1 : 0;
+}
+
+__device__ __forceinline__ void load_sfo(const PosePtrs &s, const double *__restrict__ sfo_in, int64_t i, double sfo[4][3]) {
+  const double *src = sfo_in ? sfo_in : s.stance; // default: the stance itself (all four limbs needed, :76-77)
+#pragma unroll
+  for (int l = 0; l < 4; l++)
+#pragma unroll
+    for (int a = 0; a < 3; a++) sfo[l][a] = src[12 * i + 3 * l + a];
+}
+
+__global__ __launch_bounds__(64) void pose_geometric_kernel(const PoseParamsDev P, const PosePtrs s,
+                                                            const double *__restrict__ sfo_in, int64_t B,
+                                                            double *__restrict__ pose_out) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= B) return;
+  PoseProblem pb;
+  double pose[7], sfo[4][3];
+  load_pose_problem(P, s, i, pb, pose);
+  load_sfo(s, sfo_in, i, sfo);
+  pose_geometric(pb, sfo, pose);
+#pragma unroll
+  for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
+}
+
+// BaseAuto::optimizePose: geometric -> QP -> check -> SQP for the problems the check rejects
+__global__ __launch_bounds__(64) void base_auto_pose_kernel(const PoseParamsDev P, const PosePtrs s,
+                                                            const double *__restrict__ sfo_in,
+                                                            const double *__restrict__ min_len, double leg_tol, int64_t B,
+                                                            double *__restrict__ pose_out, int32_t *__restrict__ stage,
+                                                            int32_t *__restrict__ iters, int32_t *__restrict__ status) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * kPosePerWave + lane;
+  __shared__ PoseProblem pbs[kPosePerWave]; // see pose_sqp_kernel
+  if (lane >= kPosePerWave || i >= B) return;
+  PoseProblem &pb = pbs[lane];
+  double pose[7], sfo[4][3], mn[4];
+  load_pose_problem(P, s, i, pb, pose);
+  load_sfo(s, sfo_in, i, sfo);
+#pragma unroll
+  for (int k = 0; k < 4; k++) mn[k] = min_len ? min_len[4 * i + P.leg_order[k]] : 0.0;
+  LdsScratch scr{lds + lane, kPosePerWave};
+  int stg = 0, it = 0;
+  const int st = base_auto_optimize_pose(P, pb, sfo, mn, leg_tol, scr, pose, &stg, &it);
+#pragma unroll
+  for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
+  if (stage) stage[i] = stg;
+  if (iters) iters[i] = it;
+  status[i] = st;
+}
+
+// ---- dense QP batch: one problem per lane, 8 problems per wavefront, arrays in LDS ------------
+typedef GiLayout<12, 2, 24> QpGi;
+constexpr int kQpPerWave = 8;
+
+__global__ __launch_bounds__(64) void qp_solve_kernel(int n, int p, int m, const double *__restrict__ G,
+                                                      const double *__restrict__ g0, const double *__restrict__ CE,
+                                                      const double *__restrict__ ce0, const double *__restrict__ CI,
+                                                      const double *__restrict__ ci0, int64_t B,
+                                                      double *__restrict__ x, double *__restrict__ obj,
+                                                      int32_t *__restrict__ status) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * kQpPerWave + lane;
+  if (lane >= kQpPerWave || i >= B) return;
+  LdsScratch s{lds + lane, kQpPerWave};
+  for (int k = 0; k < n * n; k++) s.at(QpGi::G + k) = G[(size_t)i * n * n + k];
+  for (int k = 0; k < n; k++) s.at(QpGi::G0 + k) = g0[(size_t)i * n + k];
+  for (int k = 0; k < n * p; k++) s.at(QpGi::CE + k) = CE[(size_t)i * n * p + k];
+  for (int k = 0; k < p; k++) s.at(QpGi::CE0 + k) = ce0[(size_t)i * p + k];
+  for (int k = 0; k < n * m; k++) s.at(QpGi::CI + k) = CI[(size_t)i * n * m + k];
+  for (int k = 0; k < m; k++) s.at(QpGi::CI0 + k) = ci0[(size_t)i * m + k];
+  double f;
+  const int st = gi_solve<12, 2, 24>(s, n, p, m, &f, nullptr);
+  for (int k = 0; k < n; k++) x[(size_t)i * n + k] = s.at(QpGi::X + k);
+  if (obj) obj[i] = f;
+  status[i] = st;
+}
+
+// Lane-cooperative dense QP batch (csrc/qp_coop.hpp): 16 lanes per problem, 4 problems per wavefront.
+// N = 6 for n <= 6, N = 12 otherwise; KC = 2 inequalities per lane for m <= 24, 3 for m <= 48; at most one equality
+// column (two go to qp_solve_kernel).
+template <int N, int KC>
+__global__ __launch_bounds__(64) void qp_coop_kernel(int n, int p, int m, const double *__restrict__ G,
+                                                     const double *__restrict__ g0, const double *__restrict__ CE,
+                                                     const double *__restrict__ ce0, const double *__restrict__ CI,
+                                                     const double *__restrict__ ci0, int64_t B, double *__restrict__ x,
+                                                     double *__restrict__ obj, int32_t *__restrict__ status) {
+  typedef coop::QpCoopLds<N, KC> L;
+  __shared__ double rows[coop::kQpCoopRows * L::kTotal];
+  const int row = threadIdx.x >> 4, lr = threadIdx.x & 15;
+  int64_t i = (int64_t)blockIdx.x * coop::kQpCoopRows + row;
+  const bool live = i < B;
+  if (!live) i = B - 1;
+  // every load is issued unconditionally with a clamped index; values outside the problem are replaced afterwards
+  const int rv = lr < n ? lr : 0;               // my variable (row of G)
+  int cs[KC];                                   // my inequalities
+  bool v[KC];
+#pragma unroll
+  for (int s = 0; s < KC; s++) { v[s] = lr + 16 * s < m; cs[s] = v[s] ? lr + 16 * s : 0; }
+  double Gm[N], a[KC][N], b[KC];
+  const double *Gp = G + (size_t)i * n * n + (size_t)rv * n;
+  const double *Cp = CI ? CI + (size_t)i * n * m : G;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const int kk = k < n ? k : 0;
+    Gm[k] = Gp[kk];
+#pragma unroll
+    for (int s = 0; s < KC; s++) a[s][k] = Cp[(size_t)kk * (m > 0 ? m : 1) + cs[s]];
+  }
+  double gl = g0[(size_t)i * n + rv];
+#pragma unroll
+  for (int s = 0; s < KC; s++) b[s] = m > 0 ? ci0[(size_t)i * m + cs[s]] : 0.0;
+  double ne = p > 0 ? CE[((size_t)i * n + rv) * p] : 0.0, e0 = p > 0 ? ce0[(size_t)i * p] : 0.0;
+  const bool var = lr < n;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const bool in = var && k < n;
+    Gm[k] = in ? Gm[k] : ((lr == k && lr < N) ? 1.0 : 0.0); // identity padding for rows n..N-1
+#pragma unroll
+    for (int s = 0; s < KC; s++) a[s][k] = (v[s] && k < n) ? a[s][k] : 0.0;
+  }
+  gl = var ? gl : 0.0;
+  ne = var ? ne : 0.0;
+#pragma unroll
+  for (int s = 0; s < KC; s++) b[s] = v[s] ? b[s] : 0.0;
+  double xo, fo;
+  const int st = coop::qp_coop_impl<N, KC>(Gm, gl, n, n, m, p > 0, ne, e0, a, b, v, !live, rows + row * L::kTotal, xo, fo);
+  if (live) {
+    if (var) x[(size_t)i * n + lr] = xo;
+    if (lr == 0) {
+      if (obj) obj[i] = fo;
+      status[i] = st;
+    }
+  }
+}
+
+} // namespace
+
+extern "C" {
+
+void qlamd_pose_default_params(qlamd_pose_params *p) {
+  if (!p) return;
+  // free_gait_core/test/AdapterDummy.cpp:111-125 (same values as quadruped_state.cpp:83-97), LF RF RH LH
+  const double hips[4][3] = {{0.42, 0.075, 0.0}, {0.42, -0.075, 0.0}, {-0.42, -0.075, 0.0}, {-0.42, 0.075, 0.0}};
+  memcpy(p->hip_in_base, hips, sizeof(hips));
+  p->com_weight = 2.0;     // PoseOptimizationObjectiveFunction.cpp:17
+  p->tolerance = 0.05;     // PoseOptimizationSQP.cpp:99
+  p->max_iterations = 30;
+  p->dummy_equality = 1;   // sequencequadraticproblemsolver.cpp:25-26
+  p->leg_order[0] = 2; p->leg_order[1] = 3; p->leg_order[2] = 1; p->leg_order[3] = 0;
+}
+
+// One driver for the pose entries; what differs per entry is the kernel and which optional arrays exist.
+enum PoseMode { kPoseSqp = 0, kPoseQp = 1, kPoseCheck = 2, kPoseGeometric = 3, kPoseBaseAuto = 4 };
+struct PoseCall {
+  PoseMode mode;
+  double *pose_out = nullptr;        // [B][7]   (all but check)
+  int32_t *iterations = nullptr;     // [B]      (sqp, base_auto; optional)
+  int32_t *status = nullptr;         // [B]      (sqp, qp, base_auto)
+  int32_t *stage = nullptr;          // [B]      (base_auto; optional)
+  uint8_t *ok = nullptr;             // [B]      (check)
+  const double *min_len = nullptr;   // [B][4]   (check, base_auto; optional)
+  const double *sfo = nullptr;       // [B][12]  (geometric, base_auto; optional -> stance)
+  double leg_tol = 0.0;
+};
+
+static int pose_impl(const PoseCall &call, qlamd_context *ctx, const qlamd_pose_params *params,
+                     const qlamd_pose_batch *in, int64_t batch, int memory, void *stream) {
+  const PoseMode mode = call.mode;
+  if (!ctx || !in || batch < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (mode == kPoseCheck ? !call.ok : !call.pose_out) return QLAMD_ERR_INVALID_ARGUMENT;
+  const bool has_status = mode == kPoseSqp || mode == kPoseQp || mode == kPoseBaseAuto;
+  if (has_status && !call.status) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!params) return QLAMD_ERR_NOT_LOADED;
+  if (!in->stance || !in->nominal_stance || !in->support_polygon || !in->max_limb_length) return QLAMD_ERR_INVALID_ARGUMENT;
+  const bool needs_pose = mode != kPoseGeometric && mode != kPoseBaseAuto; // those two start from scratch
+  if (needs_pose && !in->pose) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (params->max_iterations < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+  for (int k = 0; k < 4; k++)
+    if (params->leg_order[k] < 0 || params->leg_order[k] > 3) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+  PoseParamsDev P;
+  memcpy(P.hips, params->hip_in_base, sizeof(P.hips));
+  P.com_weight = params->com_weight; P.tol = params->tolerance; P.max_iter = params->max_iterations;
+  P.dummy_equality = params->dummy_equality;
+  for (int k = 0; k < 4; k++) P.leg_order[k] = params->leg_order[k];
+
+  PosePtrs s{in->stance, in->nominal_stance, in->support_polygon, in->center_of_mass, in->max_limb_length,
+             in->pose, in->stance_mask, in->n_vertices};
+  double *d_out = call.pose_out;
+  int32_t *d_it = call.iterations, *d_st = call.status, *d_stage = call.stage;
+  const double *d_min = call.min_len, *d_sfo = call.sfo;
+  uint8_t *d_ok = call.ok;
+  if (memory == QLAMD_MEM_HOST) {
+    enum { kIn = 10 };
+    const size_t sz[kIn] = {B * 96, B * 96, B * 64, in->center_of_mass ? B * 24 : 0, B * 32, in->pose ? B * 56 : 0,
+                            in->stance_mask ? B * 4 : 0, in->n_vertices ? B * 4 : 0, call.min_len ? B * 32 : 0,
+                            call.sfo ? B * 96 : 0};
+    const void *src[kIn] = {in->stance, in->nominal_stance, in->support_polygon, in->center_of_mass,
+                            in->max_limb_length, in->pose, in->stance_mask, in->n_vertices, call.min_len, call.sfo};
+    size_t off[kIn + 5], total = 0;
+    for (int k = 0; k < kIn; k++) { off[k] = total; total += align256(sz[k]); }
+    const size_t osz[5] = {B * 56, B * 4, B * 4, B * 4, B};
+    for (int k = 0; k < 5; k++) { off[kIn + k] = total; total += align256(osz[k]); }
+    int rc = ensure_ws(ctx, total);
+    if (rc != QLAMD_OK) return rc;
+    char *w = (char *)ctx->ws;
+    for (int k = 0; k < kIn; k++)
+      if (sz[k] && hipMemcpyAsync(w + off[k], src[k], sz[k], hipMemcpyHostToDevice, st) != hipSuccess)
+        return QLAMD_ERR_HIP;
+    s = PosePtrs{(const double *)(w + off[0]), (const double *)(w + off[1]), (const double *)(w + off[2]),
+                 in->center_of_mass ? (const double *)(w + off[3]) : nullptr, (const double *)(w + off[4]),
+                 in->pose ? (const double *)(w + off[5]) : nullptr,
+                 in->stance_mask ? (const uint8_t *)(w + off[6]) : nullptr,
+                 in->n_vertices ? (const int32_t *)(w + off[7]) : nullptr};
+    d_min = call.min_len ? (const double *)(w + off[8]) : nullptr;
+    d_sfo = call.sfo ? (const double *)(w + off[9]) : nullptr;
+    d_out = (double *)(w + off[kIn]);
+    d_it = (int32_t *)(w + off[kIn + 1]);
+    d_st = (int32_t *)(w + off[kIn + 2]);
+    d_stage = (int32_t *)(w + off[kIn + 3]);
+    d_ok = (uint8_t *)(w + off[kIn + 4]);
+  }
+  const unsigned grid = (unsigned)((batch + kPosePerWave - 1) / kPosePerWave);
+  const size_t lds6 = (size_t)kPosePerWave * Gi6Layout::kTotal * sizeof(double);
+  const size_t lds3 = (size_t)kPosePerWave * PoseQpGi::kTotal * sizeof(double);
+  switch (mode) {
+    case kPoseSqp:
+      if (getenv("QLAMD_POSE_ONE_LANE")) // the one-lane-per-problem form, kept as a second implementation
+        hipLaunchKernelGGL(pose_sqp_kernel, dim3(grid), dim3(64), lds6, st, P, s, batch, d_out, d_it, d_st);
+      else
+        hipLaunchKernelGGL(pose_sqp_coop_kernel,
+                           dim3((unsigned)((batch + coop::kPoseCoopRows - 1) / coop::kPoseCoopRows)), dim3(64), 0, st, P, s,
+                           batch, d_out, d_it, d_st);
+      break;
+    case kPoseQp:
+      hipLaunchKernelGGL(pose_qp_kernel, dim3(grid), dim3(64), lds3, st, P, s, batch, d_out, d_st);
+      break;
+    case kPoseCheck:
+      hipLaunchKernelGGL(pose_check_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, P, s, d_min,
+                         call.leg_tol, batch, d_ok);
+      break;
+    case kPoseGeometric:
+      hipLaunchKernelGGL(pose_geometric_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, P, s, d_sfo, batch,
+                         d_out);
+      break;
+    case kPoseBaseAuto:
+      hipLaunchKernelGGL(base_auto_pose_kernel, dim3(grid), dim3(64), lds6 > lds3 ? lds6 : lds3, st, P, s, d_sfo, d_min,
+                         call.leg_tol, batch, d_out, d_stage, d_it, d_st);
+      break;
+  }
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  if (memory == QLAMD_MEM_HOST) {
+    const auto back = [&](void *dst, const void *srcp, size_t n) {
+      return !dst || hipMemcpyAsync(dst, srcp, n, hipMemcpyDeviceToHost, st) == hipSuccess;
+    };
+    bool fine = true;
+    if (mode != kPoseCheck) fine = fine && back(call.pose_out, d_out, B * 56);
+    if (mode == kPoseSqp || mode == kPoseBaseAuto) fine = fine && back(call.iterations, d_it, B * 4);
+    if (has_status) fine = fine && back(call.status, d_st, B * 4);
+    if (mode == kPoseBaseAuto) fine = fine && back(call.stage, d_stage, B * 4);
+    if (mode == kPoseCheck) fine = fine && back(call.ok, d_ok, B);
+    if (!fine || hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
+  }
+  return QLAMD_OK;
+}
+
+int qlamd_pose_sqp_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
+                         int64_t batch, double *pose_out, int32_t *iterations, int32_t *status, int memory,
+                         void *stream) {
+  PoseCall c{kPoseSqp};
+  c.pose_out = pose_out; c.iterations = iterations; c.status = status;
+  return pose_impl(c, ctx, params, in, batch, memory, stream);
+}
+
+int qlamd_pose_qp_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in, int64_t batch,
+                        double *pose_out, int32_t *status, int memory, void *stream) {
+  PoseCall c{kPoseQp};
+  c.pose_out = pose_out; c.status = status;
+  return pose_impl(c, ctx, params, in, batch, memory, stream);
+}
+
+int qlamd_pose_check_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
+                           const double *min_limb_length, double leg_length_tolerance, int64_t batch, uint8_t *ok,
+                           int memory, void *stream) {
+  PoseCall c{kPoseCheck};
+  c.ok = ok; c.min_len = min_limb_length; c.leg_tol = leg_length_tolerance;
+  return pose_impl(c, ctx, params, in, batch, memory, stream);
+}
+
+int qlamd_pose_geometric_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
+                               const double *stance_for_orientation, int64_t batch, double *pose_out, int memory,
+                               void *stream) {
+  PoseCall c{kPoseGeometric};
+  c.pose_out = pose_out; c.sfo = stance_for_orientation;
+  return pose_impl(c, ctx, params, in, batch, memory, stream);
+}
+
+int qlamd_base_auto_optimize_pose_batch(qlamd_context *ctx, const qlamd_pose_params *params, const qlamd_pose_batch *in,
+                                        const double *stance_for_orientation, const double *min_limb_length,
+                                        double leg_length_tolerance, int64_t batch, double *pose_out, int32_t *stage,
+                                        int32_t *iterations, int32_t *status, int memory, void *stream) {
+  PoseCall c{kPoseBaseAuto};
+  c.pose_out = pose_out; c.stage = stage; c.iterations = iterations; c.status = status;
+  c.sfo = stance_for_orientation; c.min_len = min_limb_length; c.leg_tol = leg_length_tolerance;
+  return pose_impl(c, ctx, params, in, batch, memory, stream);
+}
+
+int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *G, const double *g0,
+                         const double *CE, const double *ce0, const double *CI, const double *ci0,
+                         int64_t batch, double *x, double *objective, int32_t *status, int memory,
+                         void *stream) {
+  if (!ctx || batch < 0 || !G || !g0 || !x || !status) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (n < 1 || n > 12 || p < 0 || p > 2 || m < 0 || m > 48) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (m > 24 && (p > 1 || getenv("QLAMD_QP_ONE_LANE"))) return QLAMD_ERR_INVALID_ARGUMENT; // 25..48 rows: cooperative kernel only
+  if ((p > 0 && (!CE || !ce0)) || (m > 0 && (!CI || !ci0))) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+  const double *dG = G, *dg0 = g0, *dCE = CE, *dce0 = ce0, *dCI = CI, *dci0 = ci0;
+  double *dx = x, *dobj = objective;
+  int32_t *dst = status;
+  if (memory == QLAMD_MEM_HOST) {
+    const size_t sz[6] = {B * n * n * 8, B * n * 8, B * n * p * 8, B * p * 8, B * n * m * 8, B * m * 8};
+    const void *src[6] = {G, g0, CE, ce0, CI, ci0};
+    size_t off[9], total = 0;
+    for (int k = 0; k < 6; k++) { off[k] = total; total += align256(sz[k]); }
+    off[6] = total; total += align256(B * n * 8);
+    off[7] = total; total += align256(B * 8);
+    off[8] = total; total += align256(B * 4);
+    int rc = ensure_ws(ctx, total);
+    if (rc != QLAMD_OK) return rc;
+    char *w = (char *)ctx->ws;
+    for (int k = 0; k < 6; k++)
+      if (sz[k] && hipMemcpyAsync(w + off[k], src[k], sz[k], hipMemcpyHostToDevice, st) != hipSuccess)
+        return QLAMD_ERR_HIP;
+    dG = (const double *)(w + off[0]); dg0 = (const double *)(w + off[1]); dCE = (const double *)(w + off[2]);
+    dce0 = (const double *)(w + off[3]); dCI = (const double *)(w + off[4]); dci0 = (const double *)(w + off[5]);
+    dx = (double *)(w + off[6]); dobj = objective ? (double *)(w + off[7]) : nullptr; dst = (int32_t *)(w + off[8]);
+  }
+  if (p <= 1 && !getenv("QLAMD_QP_ONE_LANE")) {
+    // lane-cooperative kernel (at most one equality column: what every caller in the reference passes)
+    const unsigned cgrid = (unsigned)((batch + coop::kQpCoopRows - 1) / coop::kQpCoopRows);
+    auto launch = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(cgrid), dim3(64), 0, st, n, p, m, dG, dg0, dCE, dce0, dCI, dci0, batch, dx, dobj, dst);
+    };
+    if (m > 24) {
+      if (n <= 6) launch(qp_coop_kernel<6, 3>); else launch(qp_coop_kernel<12, 3>);
+    } else {
+      if (n <= 6) launch(qp_coop_kernel<6, 2>); else launch(qp_coop_kernel<12, 2>);
+    }
+  } else {
+    // one lane per problem, following solve_quadprog step by step (two equality columns, or on request)
+    const size_t lds = (size_t)kQpPerWave * QpGi::kTotal * sizeof(double);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute((const void *)qp_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return QLAMD_ERR_HIP;
+    const unsigned grid = (unsigned)((batch + kQpPerWave - 1) / kQpPerWave);
+    hipLaunchKernelGGL(qp_solve_kernel, dim3(grid), dim3(64), lds, st, n, p, m, dG, dg0, dCE, dce0, dCI, dci0, batch, dx,
+                       dobj, dst);
+  }
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  if (memory == QLAMD_MEM_HOST) {
+    if (hipMemcpyAsync(x, dx, B * n * 8, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
+    if (objective && hipMemcpyAsync(objective, dobj, B * 8, hipMemcpyDeviceToHost, st) != hipSuccess)
+      return QLAMD_ERR_HIP;
+    if (hipMemcpyAsync(status, dst, B * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
+  }
+  return QLAMD_OK;
+}
+
+} // extern "C"

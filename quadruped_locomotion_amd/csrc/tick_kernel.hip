@@ -1,0 +1,878 @@
+// HIP kernels (gfx950) of the steps either side of the balance solve in a control tick (rows a18, f1, f2, leg IK of
+// f4): swing-leg torque and swing branch, leg state machine, message unpacking, analytic leg IK, and the whole tick
+// composed of them; with their part of the C-ABI of include/qlamd.h.
+#include "balance_coop.hpp"
+#include "swing_core.hpp"
+#include "leg_state_core.hpp"
+#include "wire_core.hpp"
+#include "context.hpp"
+
+using namespace qlamd;
+using namespace qlamd::rt;
+
+namespace {
+
+// ---- analytic leg IK (row f4), one lane per (robot, leg) -------------------------------------------------
+struct IkGeom { double g[3]; uint8_t config[4]; };
+
+__global__ __launch_bounds__(64) void leg_ik_kernel(const DeviceParams *__restrict__ Pp, const IkGeom G,
+                                                    const double *__restrict__ foot, const double *__restrict__ q_last,
+                                                    int64_t B, double *__restrict__ q_out, uint8_t *__restrict__ ok) {
+  const DeviceParams &P = *Pp;
+  const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (t >= 4 * B) return;
+  const int leg = (int)(t & 3);
+  // the hip frame (12 constants) and the inputs, all loads issued before the first use
+  const double *tb = P.legtab + kTabPerLeg * leg;
+  double hip[12];
+#pragma unroll
+  for (int k = 0; k < 9; k++) hip[k] = tb[kTabR0 + k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) hip[9 + k] = tb[kTabXyz + k];
+  double p[3], last[3] = {0.0, 0.0, 0.0};
+  load3(foot, t, p);
+  if (q_last) load3(q_last, t, last);
+  struct HipTab { // kTabR0 + k -> hip[k], kTabXyz + k -> hip[9 + k]: the only entries the IK reads
+    const double *h;
+    __device__ __forceinline__ double operator[](int i) const { return i < kTabXyz ? h[i - kTabR0] : h[9 + i - kTabXyz]; }
+  };
+  double q[3];
+  const bool good = leg_inverse_kinematics(HipTab{hip}, p, G.config[leg], G.g, q);
+  // on failure the caller's previous joint positions are kept (quadruped_state.cpp:289-294)
+#pragma unroll
+  for (int k = 0; k < 3; k++) q_out[3 * t + k] = good ? q[k] : (q_last ? last[k] : q[k]);
+  if (ok) ok[t] = good ? 1 : 0;
+}
+
+// ---- row a18: swing-leg torque, one lane per (robot, leg) -------------------------------------
+struct SwingPtrs {
+  const double *q, *qd, *qd_old, *tpos, *tvel, *q_id;
+  const uint8_t *support;
+};
+
+__global__ __launch_bounds__(64) void swing_leg_kernel(const DeviceParams *__restrict__ Pp, const SwingParamsDev SP,
+                                                       const SwingPtrs s, int64_t B, double *__restrict__ tau) {
+  __shared__ double tab[4 * kTabPerLeg];
+  const DeviceParams &P = *Pp;
+  TabStage ts;
+  ts.issue(P);
+  const int64_t t0 = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool live = t0 < 4 * B;
+  const int64_t t = live ? t0 : 4 * B - 1;
+  const int leg = (int)(t & 3);
+  double q[3], qd[3], qo[3], tp[3], tv[3], qi[3];
+  load3(s.q, t, q); load3(s.qd, t, qd); load3(s.qd_old, t, qo); load3(s.tpos, t, tp); load3(s.tvel, t, tv);
+  load3(s.q_id ? s.q_id : s.q, t, qi);
+  const bool support = s.support[t] != 0;
+  ts.commit(tab);
+  double out[3] = {0.0, 0.0, 0.0};
+  if (!support) swing_leg_torque(LdsTab{tab + kTabPerLeg * leg}, SP, qi, q, qd, qo, tp, tv, out);
+  if (!live) return;
+  tau[3 * t] = out[0]; tau[3 * t + 1] = out[1]; tau[3 * t + 2] = out[2];
+}
+
+// ---- swing branch of update(): PID / gravity compensation / swing torque per leg mode ---------------------
+struct SwingBranchPtrs {
+  const double *quat, *cmd;
+  const uint8_t *mode;
+  double *e_last, *e_int;
+};
+
+__global__ __launch_bounds__(64) void swing_branch_kernel(const DeviceParams *__restrict__ Pp, const SwingParamsDev SP,
+                                                          const PidParamsDev pid, const SwingPtrs s,
+                                                          const SwingBranchPtrs b, double period, int64_t B,
+                                                          double *__restrict__ effort) {
+  __shared__ double tab[4 * kTabPerLeg];
+  const DeviceParams &P = *Pp;
+  TabStage ts;
+  ts.issue(P);
+  const int64_t t0 = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool live = t0 < 4 * B;
+  const int64_t t = live ? t0 : 4 * B - 1;
+  const int64_t i = t >> 2;
+  const int leg = (int)(t & 3);
+  double q[3], qd[3], qo[3], tp[3], tv[3], cmd[3], qi[3], el[3], ei[3];
+  load3(s.q, t, q); load3(s.qd, t, qd); load3(s.qd_old, t, qo); load3(s.tpos, t, tp); load3(s.tvel, t, tv);
+  load3(b.cmd, t, cmd); load3(s.q_id ? s.q_id : s.q, t, qi); load3(b.e_last, t, el); load3(b.e_int, t, ei);
+  const double quat[4] = {b.quat[4 * i], b.quat[4 * i + 1], b.quat[4 * i + 2], b.quat[4 * i + 3]};
+  const int mode = (b.mode ? b.mode : s.support)[t];
+  const bool support = s.support[t] != 0;
+  PidLeg pl; // this leg's gains out of the kernel arguments, fetched with everything else
+  pid_leg_of(pid, leg, pl);
+  ts.commit(tab);
+  if (support || !live) return; // support legs keep the clamped QP torque already in `effort` (:497-502)
+  double out[3];
+  swing_branch_leg(LdsTab{tab + kTabPerLeg * leg}, SP, pl, b.mode ? mode : 0, quat, qi, q, qd, qo, tp, tv, cmd, period, el,
+                   ei, out);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { effort[3 * t + k] = out[k]; b.e_last[3 * t + k] = el[k]; b.e_int[3 * t + k] = ei[k]; }
+}
+
+// ---- leg state machine (row f2): one robot per lane, flags and a few doubles in, flags out ----------
+struct LegStatePtrs {
+  const uint8_t *support_leg, *is_footstep, *contact;
+  const double *phase, *joint_position;
+  int8_t *limb_state;
+  uint8_t *store_flag;
+  double *stored_joint_position, *joint_command, *foot_target;
+  uint8_t *support;
+  int8_t *code;
+};
+
+__global__ __launch_bounds__(256) void leg_state_kernel(const LegStatePtrs s, int index_quirk, int64_t B) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B) return;
+  LegStateRobot r;
+  // four flags per robot travel as one 32-bit word
+  const uint32_t sup = *reinterpret_cast<const uint32_t *>(s.support_leg + 4 * i);
+  const uint32_t fst = *reinterpret_cast<const uint32_t *>(s.is_footstep + 4 * i);
+  const uint32_t con = *reinterpret_cast<const uint32_t *>(s.contact + 4 * i);
+  const uint32_t lst = *reinterpret_cast<const uint32_t *>(s.limb_state + 4 * i);
+  const uint32_t sto = *reinterpret_cast<const uint32_t *>(s.store_flag + 4 * i);
+  const double2 p01 = *reinterpret_cast<const double2 *>(s.phase + 4 * i);
+  const double2 p23 = *reinterpret_cast<const double2 *>(s.phase + 4 * i + 2);
+  const double ph[4] = {p01.x, p01.y, p23.x, p23.y};
+#pragma unroll
+  for (int l = 0; l < 4; l++) {
+    r.support_leg[l] = ((sup >> (8 * l)) & 0xFFu) != 0;
+    r.is_footstep[l] = ((fst >> (8 * l)) & 0xFFu) != 0;
+    r.contact[l] = ((con >> (8 * l)) & 0xFFu) != 0;
+    r.limb_state[l] = (int)(int8_t)((lst >> (8 * l)) & 0xFFu);
+    r.store_flag[l] = ((sto >> (8 * l)) & 0xFFu) != 0;
+    r.phase[l] = ph[l];
+  }
+  // every array the tick may touch is fetched up front (independent 16-byte loads, one round trip); what
+  // the state machine decides only selects which values are written back
+  double jp[12], sj[12], ft[12];
+  {
+    const double2 *pj = reinterpret_cast<const double2 *>(s.joint_position + 12 * i);
+    const double2 *ps = reinterpret_cast<const double2 *>(s.stored_joint_position + 12 * i);
+    const double2 *pf = reinterpret_cast<const double2 *>(s.foot_target + 12 * i);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const double2 a = pj[k], b = ps[k], c = pf[k];
+      jp[2 * k] = a.x; jp[2 * k + 1] = a.y; sj[2 * k] = b.x; sj[2 * k + 1] = b.y; ft[2 * k] = c.x; ft[2 * k + 1] = c.y;
+    }
+  }
+  const uint32_t sup_i = *reinterpret_cast<const uint32_t *>(s.support + 4 * i);
+  leg_state_machine(r, index_quirk != 0);
+  uint32_t lst_o = 0, sto_o = 0, code_o = 0;
+  uint32_t sup_o = sup_i;
+#pragma unroll
+  for (int l = 0; l < 4; l++) {
+    lst_o |= (uint32_t)(uint8_t)(int8_t)r.limb_state[l] << (8 * l);
+    sto_o |= (r.store_flag[l] ? 1u : 0u) << (8 * l);
+    code_o |= (uint32_t)(uint8_t)(int8_t)r.code[l] << (8 * l);
+    if (r.support_written[l]) sup_o = (sup_o & ~(0xFFu << (8 * l))) | ((r.support[l] ? 1u : 0u) << (8 * l));
+    if (r.nudge_bumped[l]) { s.foot_target[12 * i + 3 * l] = ft[3 * l] - 0.005; s.foot_target[12 * i + 3 * l + 2] = ft[3 * l + 2] + 0.02; }
+    if (r.nudge_late[l]) s.foot_target[12 * i + 3 * l + 2] = ft[3 * l + 2] - 0.01;
+    if (r.capture[l]) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) s.stored_joint_position[12 * i + 3 * l + k] = jp[3 * l + k];
+    }
+    if (r.hold[l]) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) s.joint_command[12 * i + 3 * l + k] = sj[3 * l + k];
+    }
+  }
+  *reinterpret_cast<uint32_t *>(s.limb_state + 4 * i) = lst_o;
+  *reinterpret_cast<uint32_t *>(s.store_flag + 4 * i) = sto_o;
+  *reinterpret_cast<uint32_t *>(s.support + 4 * i) = sup_o;
+  *reinterpret_cast<uint32_t *>(s.code + 4 * i) = code_o;
+}
+
+// ---- free_gait_msgs/RobotState wire format -> SoA (row f2): one message per lane ---------------------
+struct RobotStateOutPtrs {
+  double *des_pos, *des_quat, *des_linvel, *des_angvel, *joint_command, *foot_position, *foot_velocity,
+      *foot_acceleration, *surface_normal, *phase;
+  uint8_t *support_leg, *leg_mode;
+};
+
+// Byte source in LDS: aligned 32-bit reads joined with v_alignbyte (fields sit at arbitrary byte offsets).
+struct LdsBytes {
+  static constexpr bool kOverread = true; // the staging window extends 16 bytes past the last message
+  const uint32_t *w; // LDS, word-aligned base
+  uint32_t shift;    // byte position of message offset 0 relative to w
+  __device__ __forceinline__ uint32_t u32(uint32_t at) const {
+    const uint32_t b = at + shift;
+    const uint32_t lo = w[b >> 2], hi = w[(b >> 2) + 1];
+    return __builtin_amdgcn_alignbyte(hi, lo, b & 3u);
+  }
+  __device__ __forceinline__ uint8_t u8(uint32_t at) const {
+    const uint32_t b = at + shift;
+    return (uint8_t)(w[b >> 2] >> (8 * (b & 3u)));
+  }
+  __device__ __forceinline__ double f64(uint32_t at) const {
+    const uint32_t b = at + shift;
+    const uint32_t w0 = w[b >> 2], w1 = w[(b >> 2) + 1], w2 = w[(b >> 2) + 2];
+    const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, b & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, b & 3u);
+    return __hiloint2double((int)hi, (int)lo);
+  }
+};
+
+// Two-pass walk over a message staged in LDS.  Pass 1 follows only the length fields (the one true dependency
+// chain: every string / array length decides where the next field starts) and notes where the wanted payload
+// sits; pass 2 reads the payload at those anchors with independent loads.  Same results as robot_state_unpack
+// (wire_core.hpp), which stays the reference implementation for the host build and the global-memory fallback.
+constexpr int kTplMaxFields = 128; // length fields a layout template can hold (a reference message has ~95)
+struct WireSkeleton {
+  const LdsBytes &p;
+  uint32_t pos, cap; // cap = len + 1; pos saturates there ("bad")
+  uint32_t *log;     // global (position, value) pairs of the layout template, or NULL: only block 0's first message logs
+  uint32_t nf;
+  __device__ __forceinline__ void skip(uint32_t n) { pos = min(pos + min(n, cap), cap); }
+  __device__ __forceinline__ uint32_t len_field() { // read a uint32 at pos, step over it
+    const uint32_t at = min(pos, cap - 1);
+    const uint32_t v = p.u32(at);
+    if (log && nf < (uint32_t)kTplMaxFields) { log[2 * nf] = at; log[2 * nf + 1] = v; }
+    nf++;
+    skip(4);
+    return v;
+  }
+  __device__ __forceinline__ void header() { skip(12); skip(len_field()); }
+};
+
+enum WireAnchor : int { // uint32 slots per message
+  kAnJointPos = 0,      // [4] start of *_leg_joints.position data
+  kAnOdomPose = 4,      // start of base_pose.pose.pose.position
+  kAnModeName = 5,      // [4] start of *_leg_mode.name bytes
+  kAnModeLen = 9,       // [4] its length
+  kAnModeFlag = 13,     // [4] support_leg byte
+  kAnModeNormal = 17,   // [4] surface_normal.vector
+  kAnTarget = 21,       // [4][3] target_{position,velocity,acceleration}[0] payload
+  kAnJointCnt = 33,     // [4] number of entries in *_leg_joints.position
+  kAnCount = 37
+};
+
+// Pass 1.  Returns the status; nf = number of length fields met, end_pos = position after the last field.
+__device__ __forceinline__ int wire_lds_skeleton(const LdsBytes &src, int64_t len64, uint32_t *an, uint32_t *log, uint32_t &nf,
+                                                 uint32_t &end_pos) {
+  nf = 0u; end_pos = 0u;
+  if (len64 < 0 || len64 > 0x7FFFFFF0ll) return kWireTruncated;
+  const uint32_t len = (uint32_t)len64;
+  WireSkeleton c{src, 0u, len + 1u, log, 0u};
+  bool missing = false;
+  // ---- pass 1: skeleton
+#pragma nounroll
+  for (int l = 0; l < 4; l++) { // sensor_msgs/JointState
+    c.header();
+    uint32_t nn = c.len_field();
+#pragma nounroll
+    for (; nn > 0 && c.pos < c.cap; nn--) c.skip(c.len_field());
+    const uint32_t np = c.len_field();
+    missing = missing || np < 3;
+    an[kAnJointPos + l] = c.pos;
+    an[kAnJointCnt + l] = np;
+    c.skip(np > 0x0FFFFFFFu ? 0xFFFFFFFFu : 8u * np);
+    const uint32_t nv = c.len_field(); c.skip(nv > 0x0FFFFFFFu ? 0xFFFFFFFFu : 8u * nv);
+    const uint32_t ne = c.len_field(); c.skip(ne > 0x0FFFFFFFu ? 0xFFFFFFFFu : 8u * ne);
+  }
+  c.header();                       // nav_msgs/Odometry
+  c.skip(c.len_field());            // child_frame_id
+  an[kAnOdomPose] = c.pos;
+  c.skip(56 + 288 + 48 + 288);
+#pragma nounroll
+  for (int l = 0; l < 4; l++) {     // free_gait_msgs/LegMode
+    const uint32_t n = c.len_field();
+    an[kAnModeName + l] = c.pos;
+    an[kAnModeLen + l] = n;
+    c.skip(n);
+    an[kAnModeFlag + l] = c.pos;
+    c.skip(1 + 8 + 8);              // support_leg, duration, phase
+    c.header();
+    an[kAnModeNormal + l] = c.pos;
+    c.skip(24 + 1);
+  }
+#pragma nounroll
+  for (int l = 0; l < 4; l++) {     // free_gait_msgs/EndEffectorTarget
+    c.skip(c.len_field());          // name
+#pragma nounroll
+    for (int arr = 0; arr < 4; arr++) {
+      uint32_t n = c.len_field();
+      if (arr < 3) missing = missing || n == 0;
+#pragma nounroll
+      for (uint32_t k = 0; k < n && c.pos < c.cap; k++) {
+        c.header();
+        if (k == 0 && arr < 3) an[kAnTarget + 3 * l + arr] = c.pos;
+        c.skip(24);
+      }
+    }
+    c.skip(8);                      // average_velocity
+    c.header();
+    c.skip(24 + 2);                 // surface_normal.vector, ignore_contact, ignore_for_pose_adaptation
+  }
+  nf = c.nf; end_pos = c.pos;
+  if (c.pos >= c.cap) return kWireTruncated; // some field ran past the end: the record stays cleared
+  return missing ? kWireMissingField : kWireOk;
+}
+
+// Pass 2: payload at the anchors, by the 16 lanes of the message's row.  The 77 doubles of a record are numbered in the
+// order of RobotStateFields (des_pos 0-2, des_quat 3-6, des_linvel 7-9, des_angvel 10-12, joint_command 13-24,
+// foot_position / velocity / acceleration 25-60, surface_normal 61-72, phase 73-76); lane lr takes entries lr, lr + 16, ...
+// All of a lane's reads are issued before its first store (a store into the record would otherwise fence the reads:
+// the record and the staged bytes are both LDS).  Lanes 0-3 also decode leg lr's mode name and support flag.
+__device__ __forceinline__ void wire_lds_extract_row(const LdsBytes &src, RobotStateFields &f, const uint32_t *an, int lr) {
+  double val[5];
+  bool put[5];
+#pragma unroll
+  for (int t = 0; t < 5; t++) {
+    const int e = lr + 16 * t;
+    uint32_t slot = kAnOdomPose, off = 0u;
+    bool ok = e < 77;
+    if (e < 3) { off = 8u * e; }                                                   // des_pos
+    else if (e < 7) { const int k = (e - 3 + 3) & 3; off = 24u + 8u * k; }          // des_quat (w,x,y,z) <- wire (x,y,z,w)
+    else if (e < 13) { off = 56u + 288u + 8u * (e - 7); }                          // des_linvel, des_angvel
+    else if (e < 25) { const int l = (e - 13) / 3, j = (e - 13) - 3 * l;           // joint_command
+      slot = kAnJointPos + l; off = 8u * j; ok = (uint32_t)j < an[kAnJointCnt + l]; }
+    else if (e < 61) { const int t9 = e - 25, arr = t9 / 12, r = t9 - 12 * arr, l = r / 3, j = r - 3 * l; // foot_* [arr][leg][j]
+      slot = kAnTarget + 3 * l + arr; off = 8u * j; ok = an[slot] != 0u; }
+    else if (e < 73) { const int l = (e - 61) / 3, j = (e - 61) - 3 * l; slot = kAnModeNormal + l; off = 8u * j; }
+    else { slot = kAnModeFlag + (e - 73 < 4 ? e - 73 : 0); off = 9u; }               // phase
+    put[t] = ok;
+    val[t] = src.f64(an[ok ? slot : (uint32_t)kAnOdomPose] + (ok ? off : 0u));
+  }
+  int mode = kModeOther;
+  uint8_t sup = 0;
+  {
+    const int l = lr & 3;
+    const uint32_t nm = an[kAnModeName + l], nl = an[kAnModeLen + l];
+    // "joint" 5, "leg_mode" 8, "cartesian" 9, "footstep" 8: compare 12 bytes read as three words against the literals
+    const uint32_t w0 = src.u32(nm), w1 = src.u32(nm + 4), w2 = src.u32(nm + 8);
+    if (nl == 5 && w0 == 0x6E696F6Au && (w1 & 0xFFu) == 0x74u) mode = kModeJoint;                    // "join" "t"
+    else if (nl == 8 && w0 == 0x5F67656Cu && w1 == 0x65646F6Du) mode = kModeLegMode;                // "leg_" "mode"
+    else if (nl == 9 && w0 == 0x74726163u && w1 == 0x61697365u && (w2 & 0xFFu) == 0x6Eu) mode = kModeCartesian; // "cart" "esia" "n"
+    else if (nl == 8 && w0 == 0x746F6F66u && w1 == 0x70657473u) mode = kModeFootstep;               // "foot" "step"
+    sup = src.u8(an[kAnModeFlag + l]) != 0;
+  }
+  double *rec = reinterpret_cast<double *>(&f);
+#pragma unroll
+  for (int t = 0; t < 5; t++)
+    if (put[t]) rec[lr + 16 * t] = val[t];
+  if (lr < 4) { f.leg_mode[lr] = (uint8_t)mode; f.support_leg[lr] = sup; }
+}
+
+constexpr int kWireMsgsPerBlock = 4;          // messages parsed per 64-lane block (one 16-lane row each)
+constexpr int kWireLdsBytes = 32 * 1024;      // staging window; longer runs are parsed straight from global memory
+// Layout template: the (position, value) of every length field of one well-formed message plus the anchors its walk
+// produced.  A message whose length fields hold the template's values AT the template's positions has, by induction
+// along the walk, exactly the template's layout -- so its anchors are known without walking.
+constexpr uint32_t kTplMagic = 0x51574C54u;   // "TLWQ"
+constexpr int kTplValid = 0, kTplEnd = 1, kTplMissing = 2, kTplFields = 3, kTplAnchors = 4, kTplPairs = kTplAnchors + kAnCount,
+              kTplWords = kTplPairs + 2 * kTplMaxFields;
+
+// One block = kWireMsgsPerBlock consecutive messages: the block copies their contiguous byte range into LDS with
+// coalesced 16-byte loads; each message then belongs to one 16-lane row.  The row first checks the message against
+// the layout template of the previous launch (tpl_in): its lanes compare the ~95 length fields in parallel.  On a hit
+// the anchors are the template's; on a miss the row's first lane walks the length-prefixed fields (a chain of
+// dependent LDS reads, ~15 us for a message).  The payload is then read at the anchors into a per-message record
+// in LDS and the whole block writes the records out.  Block 0 leaves the template for the next launch in tpl_out
+// (the layout of its first message if that one had to be walked, else the template it used).  Results never depend
+// on the template, only the time does: streams from one publisher keep one layout.
+__global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *__restrict__ messages,
+                                                                const int64_t *__restrict__ offsets, int64_t B,
+                                                                const RobotStateOutPtrs o, int32_t *__restrict__ status,
+                                                                const uint32_t *__restrict__ tpl_in,
+                                                                uint32_t *__restrict__ tpl_out) {
+  extern __shared__ uint32_t wire_lds[];
+  __shared__ RobotStateFields rec[kWireMsgsPerBlock];
+  __shared__ uint32_t anchors[kWireMsgsPerBlock][kAnCount];
+  __shared__ uint32_t tpl[kTplWords];
+  const int tid = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.x * kWireMsgsPerBlock;
+  const int n = (int)((B - i0) < kWireMsgsPerBlock ? (B - i0) : kWireMsgsPerBlock);
+  QL_STAMP(20);
+  const int64_t a = offsets[i0], b = offsets[i0 + n];
+  // the template's loads go out first, its LDS stores follow the staging loop
+  uint32_t tplv[(kTplWords + 63) / 64];
+#pragma unroll
+  for (int j = 0; j < (kTplWords + 63) / 64; j++) tplv[j] = tpl_in[min(tid + 64 * j, kTplWords - 1)];
+  const uintptr_t src = (uintptr_t)(messages + a);
+  const uintptr_t src_al = src & ~(uintptr_t)15;
+  const int64_t lead = (int64_t)(src - src_al), nbytes = lead + (b - a);
+  const bool staged = nbytes + 16 <= kWireLdsBytes; // +16: u32 / f64 reads may touch the next two words
+  if (staged) {
+    const int64_t full = nbytes >> 4;
+    const uint4 *g = (const uint4 *)src_al;
+    uint4 *l4 = (uint4 *)wire_lds;
+    // sixteen 16-byte loads in flight per lane (a 16 KB window: four typical messages) before the first LDS store:
+    // one DRAM round trip for the block instead of one per kilobyte
+    for (int64_t k0 = tid; k0 - tid < full; k0 += 64 * 16) {
+      const int64_t last = full - 1;
+      const uint4 v0 = g[min(k0 + 0, last)], v1 = g[min(k0 + 64, last)], v2 = g[min(k0 + 128, last)], v3 = g[min(k0 + 192, last)], v4 = g[min(k0 + 256, last)], v5 = g[min(k0 + 320, last)], v6 = g[min(k0 + 384, last)], v7 = g[min(k0 + 448, last)], v8 = g[min(k0 + 512, last)], v9 = g[min(k0 + 576, last)], v10 = g[min(k0 + 640, last)], v11 = g[min(k0 + 704, last)], v12 = g[min(k0 + 768, last)], v13 = g[min(k0 + 832, last)], v14 = g[min(k0 + 896, last)], v15 = g[min(k0 + 960, last)];
+      if (k0 + 0 < full) l4[k0 + 0] = v0;
+      if (k0 + 64 < full) l4[k0 + 64] = v1;
+      if (k0 + 128 < full) l4[k0 + 128] = v2;
+      if (k0 + 192 < full) l4[k0 + 192] = v3;
+      if (k0 + 256 < full) l4[k0 + 256] = v4;
+      if (k0 + 320 < full) l4[k0 + 320] = v5;
+      if (k0 + 384 < full) l4[k0 + 384] = v6;
+      if (k0 + 448 < full) l4[k0 + 448] = v7;
+      if (k0 + 512 < full) l4[k0 + 512] = v8;
+      if (k0 + 576 < full) l4[k0 + 576] = v9;
+      if (k0 + 640 < full) l4[k0 + 640] = v10;
+      if (k0 + 704 < full) l4[k0 + 704] = v11;
+      if (k0 + 768 < full) l4[k0 + 768] = v12;
+      if (k0 + 832 < full) l4[k0 + 832] = v13;
+      if (k0 + 896 < full) l4[k0 + 896] = v14;
+      if (k0 + 960 < full) l4[k0 + 960] = v15;
+    }
+    const int64_t tail0 = full << 4;                 // last partial chunk byte by byte: never read past the blob
+    if (tid < nbytes - tail0) ((uint8_t *)wire_lds)[tail0 + tid] = ((const uint8_t *)src_al)[tail0 + tid];
+  }
+#pragma unroll
+  for (int j = 0; j < (kTplWords + 63) / 64; j++)
+    if (tid + 64 * j < kTplWords) tpl[tid + 64 * j] = tplv[j];
+  // clear the records (fields a malformed message never reaches read as zero)
+  for (int w = tid; w < (int)(sizeof(rec) / 4); w += 64) ((uint32_t *)rec)[w] = 0u;
+  for (int w = tid; w < kWireMsgsPerBlock * kAnCount; w += 64) (&anchors[0][0])[w] = 0u;
+  __syncthreads();
+  QL_STAMP(21);
+  const int row = tid >> 4, lr = tid & 15;
+  const bool mine = row < n;
+  const int64_t ma = offsets[i0 + (mine ? row : 0)], mb = offsets[i0 + (mine ? row : 0) + 1];
+  const bool sane = mine && !(ma < a || mb > b || mb < ma); // offsets not ascending: nothing to parse
+  const LdsBytes msg{wire_lds, (uint32_t)(lead + (ma - a))};
+  // ---- template check, 16 lanes per message
+  const uint32_t tnf = tpl[kTplFields];
+  bool same = sane && staged && tpl[kTplValid] == kTplMagic && tnf <= (uint32_t)kTplMaxFields &&
+              (mb - ma) <= 0x7FFFFFF0ll && (uint64_t)(mb - ma) >= (uint64_t)tpl[kTplEnd];
+  {
+    // eight length fields per lane, all reads independent (positions inside the message: <= end <= length)
+    uint32_t at[kTplMaxFields / 16], want[kTplMaxFields / 16], got[kTplMaxFields / 16];
+#pragma unroll
+    for (int t = 0; t < kTplMaxFields / 16; t++) {
+      const uint32_t k = lr + 16u * t;
+      const bool on = same && k < tnf;
+      at[t] = on ? tpl[kTplPairs + 2 * k] : 0u;
+      want[t] = on ? tpl[kTplPairs + 2 * k + 1] : 0u;
+    }
+#pragma unroll
+    for (int t = 0; t < kTplMaxFields / 16; t++) got[t] = msg.u32(same ? at[t] : 0u);
+#pragma unroll
+    for (int t = 0; t < kTplMaxFields / 16; t++) same = same && (lr + 16u * t >= tnf || got[t] == want[t]);
+  }
+  const bool hit = ((unsigned)(__ballot(same) >> (tid & 48)) & 0xFFFFu) == 0xFFFFu;
+  if (hit)
+    for (int k = lr; k < kAnCount; k += 16) anchors[row][k] = tpl[kTplAnchors + k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  QL_STAMP(22);
+  uint32_t nf = 0u, end_pos = 0u;
+  int st = kWireTruncated;
+  const bool logger = blockIdx.x == 0 && row == 0; // this message's layout becomes the next launch's template
+  if (lr == 0 && mine) {
+    if (!sane) st = kWireTruncated;
+    else if (hit) st = tpl[kTplMissing] ? kWireMissingField : kWireOk;
+    else if (staged) st = wire_lds_skeleton(msg, mb - ma, anchors[row], logger ? tpl_out + kTplPairs : nullptr, nf, end_pos);
+    else st = robot_state_unpack(PlainBytes{messages + ma}, mb - ma, rec[row]);
+    status[i0 + row] = st;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  const int st_row = __shfl(st, 0, 16);
+  if (mine && sane && staged && st_row != kWireTruncated) wire_lds_extract_row(msg, rec[row], anchors[row], lr);
+  QL_STAMP(23);
+  // ---- the template for the next launch (block 0, first message)
+  if (logger) {
+    const uint32_t nf0 = __shfl(nf, 0, 16), end0 = __shfl(end_pos, 0, 16);
+    if (hit) {
+      for (int k = lr; k < kTplWords; k += 16) tpl_out[k] = tpl[k]; // still in force
+    } else {
+      // the walk has already left its (position, value) pairs in tpl_out; valid only if the message was well-formed
+      const bool good = sane && staged && st_row != kWireTruncated && nf0 <= (uint32_t)kTplMaxFields;
+      if (lr == 0) {
+        tpl_out[kTplValid] = good ? kTplMagic : 0u; tpl_out[kTplEnd] = end0;
+        tpl_out[kTplMissing] = st_row == kWireMissingField ? 1u : 0u; tpl_out[kTplFields] = nf0;
+      }
+      for (int k = lr; k < kAnCount; k += 16) tpl_out[kTplAnchors + k] = anchors[0][k];
+    }
+  }
+  __syncthreads();
+  QL_STAMP(24);
+  // write-out: message m's k doubles of each field are contiguous in the output arrays
+  const auto put = [&](double *dst, int width, size_t field_off) {
+    if (!dst) return;
+    for (int e = tid; e < n * width; e += 64) {
+      const int m = e / width, k2 = e - m * width;
+      dst[(int64_t)width * i0 + e] = ((const double *)((const char *)&rec[m] + field_off))[k2];
+    }
+  };
+  put(o.des_pos, 3, offsetof(RobotStateFields, des_pos)); put(o.des_quat, 4, offsetof(RobotStateFields, des_quat));
+  put(o.des_linvel, 3, offsetof(RobotStateFields, des_linvel)); put(o.des_angvel, 3, offsetof(RobotStateFields, des_angvel));
+  put(o.joint_command, 12, offsetof(RobotStateFields, joint_command));
+  put(o.foot_position, 12, offsetof(RobotStateFields, foot_position));
+  put(o.foot_velocity, 12, offsetof(RobotStateFields, foot_velocity));
+  put(o.foot_acceleration, 12, offsetof(RobotStateFields, foot_acceleration));
+  put(o.surface_normal, 12, offsetof(RobotStateFields, surface_normal)); put(o.phase, 4, offsetof(RobotStateFields, phase));
+  if (tid < 4 * n) {
+    const int m = tid >> 2, l = tid & 3;
+    if (o.support_leg) o.support_leg[4 * i0 + tid] = rec[m].support_leg[l];
+    if (o.leg_mode) o.leg_mode[4 * i0 + tid] = rec[m].leg_mode[l];
+  }
+  QL_STAMP(25);
+}
+
+// ---- the whole tick: a known leg-mode name replaces the mode in force, anything else leaves it (:876-964) ----------
+__global__ void tick_leg_mode_kernel(const uint8_t *__restrict__ msg_mode, uint8_t *__restrict__ leg_mode,
+                                     uint8_t *__restrict__ is_footstep, int64_t n) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint8_t m = msg_mode[t];
+  const uint8_t cur = m != kModeOther ? m : leg_mode[t];
+  leg_mode[t] = cur;
+  is_footstep[t] = cur == kModeFootstep ? 1 : 0;
+}
+
+} // namespace
+
+extern "C" {
+
+void qlamd_swing_default_params(qlamd_swing_params *p) {
+  if (!p) return;
+  for (int i = 0; i < 3; i++) { p->kp[i] = 300.0; p->kd[i] = 20.0; } // controller_gains.yaml:42-51
+  p->period = 0.0025;      // balance_controller_manager.cpp:48
+  p->accel_window = 10.0;  // model_test_header.cpp:418
+  p->accel_scale = 0.5;    // model_test_header.cpp:460
+  p->gravity = 9.81;
+}
+
+int qlamd_swing_leg_torque_batch(qlamd_context *ctx, const qlamd_swing_params *params, const qlamd_swing_batch *in,
+                                 int64_t batch, double *joint_effort, int memory, void *stream) {
+  if (!ctx || !in || batch < 0 || !joint_effort) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!params) return QLAMD_ERR_NOT_LOADED;
+  if (!in->joint_position || !in->joint_velocity || !in->joint_velocity_oldest || !in->target_foot_position ||
+      !in->target_foot_velocity || !in->support_leg)
+    return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!(params->period > 0.0) || !(params->accel_window > 0.0)) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+  SwingParamsDev SP;
+  for (int i = 0; i < 3; i++) { SP.kp[i] = params->kp[i]; SP.kd[i] = params->kd[i]; }
+  SP.period = params->period; SP.accel_window = params->accel_window; SP.accel_scale = params->accel_scale;
+  SP.gravity = params->gravity;
+  SwingPtrs s{in->joint_position, in->joint_velocity, in->joint_velocity_oldest, in->target_foot_position,
+              in->target_foot_velocity, in->id_joint_position, in->support_leg};
+  double *d_tau = joint_effort;
+  Staged sg;
+  if (memory == QLAMD_MEM_HOST) {
+    sg.add(in->joint_position, B * 96, true, false);
+    sg.add(in->joint_velocity, B * 96, true, false);
+    sg.add(in->joint_velocity_oldest, B * 96, true, false);
+    sg.add(in->target_foot_position, B * 96, true, false);
+    sg.add(in->target_foot_velocity, B * 96, true, false);
+    sg.add(in->id_joint_position, B * 96, true, false);
+    sg.add(in->support_leg, B * 4, true, false);
+    sg.add(joint_effort, B * 96, false, true);
+    const int rc = sg.upload(ctx, st);
+    if (rc != QLAMD_OK) return rc;
+    s = SwingPtrs{sg.dev<const double>(0), sg.dev<const double>(1), sg.dev<const double>(2), sg.dev<const double>(3),
+                  sg.dev<const double>(4), sg.dev<const double>(5), sg.dev<const uint8_t>(6)};
+    d_tau = sg.dev<double>(7);
+  }
+  const unsigned grid = (unsigned)((4 * batch + 63) / 64);
+  hipLaunchKernelGGL(swing_leg_kernel, dim3(grid), dim3(64), 0, st, ctx->d_params, SP, s, batch, d_tau);
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  if (memory == QLAMD_MEM_HOST) return sg.finish(st);
+  return QLAMD_OK;
+}
+
+void qlamd_joint_pid_default_params(qlamd_joint_pid_params *p) {
+  if (!p) return;
+  for (int j = 0; j < 12; j++) { // balance_controller/config/control.yaml:18-29; limits quadruped_model.urdf:53-57
+    p->p[j] = 300.0; p->i[j] = 0.01; p->d[j] = 3.0;
+    p->i_max[j] = 0.0; p->i_min[j] = 0.0;
+    p->lower[j] = -3.0; p->upper[j] = 3.0;
+  }
+  p->antiwindup = 0;
+}
+
+int qlamd_swing_branch_batch(qlamd_context *ctx, const qlamd_swing_params *params, const qlamd_joint_pid_params *pid,
+                             const qlamd_swing_batch *in, const qlamd_swing_branch_extra *extra, double period,
+                             int64_t batch, double *joint_effort, int memory, void *stream) {
+  if (!ctx || !in || !extra || batch < 0 || !joint_effort) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!params || !pid) return QLAMD_ERR_NOT_LOADED;
+  if (!in->joint_position || !in->joint_velocity || !in->joint_velocity_oldest || !in->target_foot_position ||
+      !in->target_foot_velocity || !in->support_leg || !extra->base_orientation || !extra->joint_command ||
+      !extra->pid_error_last || !extra->pid_error_integral)
+    return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!(params->period > 0.0) || !(params->accel_window > 0.0)) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+  SwingParamsDev SP;
+  for (int i = 0; i < 3; i++) { SP.kp[i] = params->kp[i]; SP.kd[i] = params->kd[i]; }
+  SP.period = params->period; SP.accel_window = params->accel_window; SP.accel_scale = params->accel_scale;
+  SP.gravity = params->gravity;
+  PidParamsDev PD;
+  memcpy(PD.p, pid->p, sizeof(PD.p)); memcpy(PD.i, pid->i, sizeof(PD.i)); memcpy(PD.d, pid->d, sizeof(PD.d));
+  memcpy(PD.i_max, pid->i_max, sizeof(PD.i_max)); memcpy(PD.i_min, pid->i_min, sizeof(PD.i_min));
+  memcpy(PD.lower, pid->lower, sizeof(PD.lower)); memcpy(PD.upper, pid->upper, sizeof(PD.upper));
+  PD.antiwindup = pid->antiwindup;
+  SwingPtrs s{in->joint_position, in->joint_velocity, in->joint_velocity_oldest, in->target_foot_position,
+              in->target_foot_velocity, in->id_joint_position, in->support_leg};
+  SwingBranchPtrs sb{extra->base_orientation, extra->joint_command, extra->leg_mode, extra->pid_error_last,
+                     extra->pid_error_integral};
+  double *d_eff = joint_effort;
+  Staged sg;
+  if (memory == QLAMD_MEM_HOST) {
+    const int a0 = sg.add(in->joint_position, B * 96, true, false), a1 = sg.add(in->joint_velocity, B * 96, true, false);
+    const int a2 = sg.add(in->joint_velocity_oldest, B * 96, true, false);
+    const int a3 = sg.add(in->target_foot_position, B * 96, true, false);
+    const int a4 = sg.add(in->target_foot_velocity, B * 96, true, false);
+    const int a5 = sg.add(in->id_joint_position, B * 96, true, false), a6 = sg.add(in->support_leg, B * 4, true, false);
+    const int b0 = sg.add(extra->base_orientation, B * 32, true, false), b1 = sg.add(extra->joint_command, B * 96, true, false);
+    const int b2 = sg.add(extra->leg_mode, B * 4, true, false);
+    const int b3 = sg.add(extra->pid_error_last, B * 96, true, true), b4 = sg.add(extra->pid_error_integral, B * 96, true, true);
+    const int e0 = sg.add(joint_effort, B * 96, true, true);
+    const int rc = sg.upload(ctx, st);
+    if (rc != QLAMD_OK) return rc;
+    s = SwingPtrs{sg.dev<const double>(a0), sg.dev<const double>(a1), sg.dev<const double>(a2), sg.dev<const double>(a3),
+                  sg.dev<const double>(a4), sg.dev<const double>(a5), sg.dev<const uint8_t>(a6)};
+    sb = SwingBranchPtrs{sg.dev<const double>(b0), sg.dev<const double>(b1), sg.dev<const uint8_t>(b2), sg.dev<double>(b3),
+                         sg.dev<double>(b4)};
+    d_eff = sg.dev<double>(e0);
+  }
+  hipLaunchKernelGGL(swing_branch_kernel, dim3((unsigned)((4 * batch + 63) / 64)), dim3(64), 0, st, ctx->d_params, SP, PD,
+                     s, sb, period, batch, d_eff);
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  return memory == QLAMD_MEM_HOST ? sg.finish(st) : QLAMD_OK;
+}
+
+int qlamd_leg_state_machine_batch(qlamd_context *ctx, const qlamd_leg_state_batch *io, int index_quirk, int64_t batch,
+                                  int memory, void *stream) {
+  if (!ctx || !io || batch < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!io->support_leg || !io->phase || !io->is_footstep || !io->contact || !io->joint_position || !io->limb_state ||
+      !io->store_flag || !io->stored_joint_position || !io->joint_command || !io->foot_target || !io->support ||
+      !io->leg_state_code)
+    return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+  LegStatePtrs s{io->support_leg, io->is_footstep, io->contact, io->phase, io->joint_position, io->limb_state,
+                 io->store_flag, io->stored_joint_position, io->joint_command, io->foot_target, io->support,
+                 io->leg_state_code};
+  // host staging: every array goes up except leg_state_code; the in/out and out arrays come back
+  Staged sg;
+  if (memory == QLAMD_MEM_HOST) {
+    sg.add(io->support_leg, B * 4, true, false);
+    sg.add(io->is_footstep, B * 4, true, false);
+    sg.add(io->contact, B * 4, true, false);
+    sg.add(io->phase, B * 32, true, false);
+    sg.add(io->joint_position, B * 96, true, false);
+    sg.add(io->limb_state, B * 4, true, true);
+    sg.add(io->store_flag, B * 4, true, true);
+    sg.add(io->stored_joint_position, B * 96, true, true);
+    sg.add(io->joint_command, B * 96, true, true);
+    sg.add(io->foot_target, B * 96, true, true);
+    sg.add(io->support, B * 4, true, true);
+    sg.add(io->leg_state_code, B * 4, false, true);
+    const int rc = sg.upload(ctx, st);
+    if (rc != QLAMD_OK) return rc;
+    s = LegStatePtrs{sg.dev<const uint8_t>(0), sg.dev<const uint8_t>(1), sg.dev<const uint8_t>(2), sg.dev<const double>(3),
+                     sg.dev<const double>(4), sg.dev<int8_t>(5), sg.dev<uint8_t>(6), sg.dev<double>(7), sg.dev<double>(8),
+                     sg.dev<double>(9), sg.dev<uint8_t>(10), sg.dev<int8_t>(11)};
+  }
+  hipLaunchKernelGGL(leg_state_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, s, index_quirk, batch);
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  if (memory == QLAMD_MEM_HOST) return sg.finish(st);
+  return QLAMD_OK;
+}
+
+int qlamd_robot_state_unpack_batch(qlamd_context *ctx, const uint8_t *messages, const int64_t *offsets, int64_t batch,
+                                   const qlamd_robot_state_fields *out, int32_t *status, int memory, void *stream) {
+  if (!ctx || !messages || !offsets || !out || !status || batch < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+  enum { kD = 10 };
+  const int width[kD] = {3, 4, 3, 3, 12, 12, 12, 12, 12, 4};
+  double *hostd[kD] = {out->des_pos, out->des_quat, out->des_linvel, out->des_angvel, out->joint_command,
+                       out->foot_position, out->foot_velocity, out->foot_acceleration, out->surface_normal, out->phase};
+  RobotStateOutPtrs o{out->des_pos, out->des_quat, out->des_linvel, out->des_angvel, out->joint_command,
+                      out->foot_position, out->foot_velocity, out->foot_acceleration, out->surface_normal, out->phase,
+                      out->support_leg, out->leg_mode};
+  const uint8_t *d_msg = messages;
+  const int64_t *d_off = offsets;
+  int32_t *d_st = status;
+  Staged sg;
+  if (memory == QLAMD_MEM_HOST) {
+    for (size_t k = 0; k < B; k++)
+      if (offsets[k + 1] < offsets[k] || offsets[0] < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+    const size_t nbytes = (size_t)(offsets[B] - offsets[0]);
+    // inputs first, outputs after them: a small call is then one copy each way over a tight span
+    const int i_off = sg.add(offsets, (B + 1) * 8, true, false);
+    const int i_msg = sg.add(messages + offsets[0], nbytes, true, false);
+    int i_d[kD];
+    for (int k = 0; k < kD; k++) i_d[k] = sg.add(hostd[k], B * 8 * (size_t)width[k], false, true);
+    const int i_sup = sg.add(out->support_leg, B * 4, false, true);
+    const int i_mode = sg.add(out->leg_mode, B * 4, false, true);
+    const int i_st = sg.add(status, B * 4, false, true);
+    const int rc = sg.upload(ctx, st);
+    if (rc != QLAMD_OK) return rc;
+    o = RobotStateOutPtrs{sg.dev<double>(i_d[0]), sg.dev<double>(i_d[1]), sg.dev<double>(i_d[2]), sg.dev<double>(i_d[3]),
+                          sg.dev<double>(i_d[4]), sg.dev<double>(i_d[5]), sg.dev<double>(i_d[6]), sg.dev<double>(i_d[7]),
+                          sg.dev<double>(i_d[8]), sg.dev<double>(i_d[9]), sg.dev<uint8_t>(i_sup), sg.dev<uint8_t>(i_mode)};
+    d_st = sg.dev<int32_t>(i_st);
+    d_off = sg.dev<const int64_t>(i_off);
+    d_msg = (const uint8_t *)(sg.base + sg.items[i_msg].off) - offsets[0]; // the kernel indexes with the caller's offsets
+  }
+  if (!ctx->wire_tpl) { // zero = "no template yet": the first launch walks every message
+    if (hipMalloc((void **)&ctx->wire_tpl, 2 * kTplWords * sizeof(uint32_t)) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;
+    if (hipMemsetAsync(ctx->wire_tpl, 0, 2 * kTplWords * sizeof(uint32_t), st) != hipSuccess) return QLAMD_ERR_HIP;
+  }
+  const uint32_t *tpl_in = ctx->wire_tpl + kTplWords * ctx->wire_flip;
+  uint32_t *tpl_out = ctx->wire_tpl + kTplWords * (ctx->wire_flip ^ 1);
+  ctx->wire_flip ^= 1;
+  hipLaunchKernelGGL(robot_state_unpack_kernel, dim3((unsigned)((batch + kWireMsgsPerBlock - 1) / kWireMsgsPerBlock)),
+                     dim3(64), kWireLdsBytes, st, d_msg, d_off, batch, o, d_st, tpl_in, tpl_out);
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  if (memory == QLAMD_MEM_HOST) return sg.finish(st);
+  return QLAMD_OK;
+}
+
+void qlamd_ik_default_params(qlamd_ik_params *p) {
+  if (!p) return;
+  p->d = 0.1; p->l1 = 0.25; p->l2 = 0.25;       // quadrupedkinematics.cpp:383-385
+  // setLimbConfigure("><"), quadruped_state.cpp:61,385-390: LF IN_LEFT, RF OUT_LEFT, RH IN_LEFT, LH OUT_LEFT
+  p->limb_config[0] = QLAMD_IK_IN_LEFT; p->limb_config[1] = QLAMD_IK_OUT_LEFT;
+  p->limb_config[2] = QLAMD_IK_IN_LEFT; p->limb_config[3] = QLAMD_IK_OUT_LEFT;
+}
+
+int qlamd_leg_inverse_kinematics_batch(qlamd_context *ctx, const qlamd_ik_params *params, const double *foot_position,
+                                       const double *joint_position_last, int64_t batch, double *joint_position,
+                                       uint8_t *ok, int memory, void *stream) {
+  if (!ctx || !foot_position || !joint_position || batch < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!params) return QLAMD_ERR_NOT_LOADED;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  IkGeom G;
+  G.g[0] = params->d; G.g[1] = params->l1; G.g[2] = params->l2;
+  for (int l = 0; l < 4; l++) {
+    if (params->limb_config[l] > 3) return QLAMD_ERR_INVALID_ARGUMENT;
+    G.config[l] = params->limb_config[l];
+  }
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+  const double *d_foot = foot_position, *d_last = joint_position_last;
+  double *d_q = joint_position;
+  uint8_t *d_ok = ok;
+  Staged sg;
+  if (memory == QLAMD_MEM_HOST) {
+    const int a = sg.add(foot_position, B * 96, true, false), b2 = sg.add(joint_position_last, B * 96, true, false);
+    const int c = sg.add(joint_position, B * 96, false, true), d = sg.add(ok, B * 4, false, true);
+    const int rc = sg.upload(ctx, st);
+    if (rc != QLAMD_OK) return rc;
+    d_foot = sg.dev<const double>(a); d_last = sg.dev<const double>(b2); d_q = sg.dev<double>(c); d_ok = sg.dev<uint8_t>(d);
+  }
+  hipLaunchKernelGGL(leg_ik_kernel, dim3((unsigned)((4 * batch + 63) / 64)), dim3(64), 0, st, ctx->d_params, G, d_foot,
+                     d_last, batch, d_q, d_ok);
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  return memory == QLAMD_MEM_HOST ? sg.finish(st) : QLAMD_OK;
+}
+
+int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, const qlamd_joint_pid_params *pid,
+                          const qlamd_tick_batch *io, double period, int index_quirk, int64_t batch, int memory,
+                          void *stream) {
+  if (!ctx || !io || batch < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!swing || !pid) return QLAMD_ERR_NOT_LOADED;
+  if (!io->messages || !io->offsets || !io->joint_position || !io->joint_velocity || !io->joint_velocity_oldest ||
+      !io->base_position || !io->base_orientation || !io->base_linear_velocity || !io->base_angular_velocity ||
+      !io->contact || !io->limb_state || !io->store_flag || !io->stored_joint_position || !io->leg_mode || !io->support ||
+      !io->pid_error_last || !io->pid_error_integral || !io->joint_effort || !io->status || !io->message_status)
+    return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)batch;
+  qlamd_tick_batch d = *io;
+  Staged sg;
+  if (memory == QLAMD_MEM_HOST) {
+    for (size_t k = 0; k < B; k++)
+      if (io->offsets[k + 1] < io->offsets[k] || io->offsets[0] < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+    const size_t nbytes = (size_t)(io->offsets[B] - io->offsets[0]);
+    const int i_off = sg.add(io->offsets, (B + 1) * 8, true, false);
+    const int i_msg = sg.add(io->messages + io->offsets[0], nbytes ? nbytes : 1, true, false);
+    const int i_in[8] = {sg.add(io->joint_position, B * 96, true, false), sg.add(io->joint_velocity, B * 96, true, false),
+                         sg.add(io->joint_velocity_oldest, B * 96, true, false), sg.add(io->base_position, B * 24, true, false),
+                         sg.add(io->base_orientation, B * 32, true, false), sg.add(io->base_linear_velocity, B * 24, true, false),
+                         sg.add(io->base_angular_velocity, B * 24, true, false), sg.add(io->contact, B * 4, true, false)};
+    const int i_io[7] = {sg.add(io->limb_state, B * 4, true, true), sg.add(io->store_flag, B * 4, true, true),
+                         sg.add(io->stored_joint_position, B * 96, true, true), sg.add(io->leg_mode, B * 4, true, true),
+                         sg.add(io->pid_error_last, B * 96, true, true), sg.add(io->pid_error_integral, B * 96, true, true),
+                         sg.add(io->support, B * 4, true, true)};
+    const int i_out[4] = {sg.add(io->joint_effort, B * 96, false, true), sg.add(io->leg_state_code, B * 4, false, true),
+                          sg.add(io->status, B * 4, false, true), sg.add(io->message_status, B * 4, false, true)};
+    const int rc = sg.upload(ctx, st);
+    if (rc != QLAMD_OK) return rc;
+    d.offsets = sg.dev<const int64_t>(i_off);
+    d.messages = (const uint8_t *)(sg.base + sg.items[i_msg].off) - io->offsets[0];
+    d.joint_position = sg.dev<const double>(i_in[0]); d.joint_velocity = sg.dev<const double>(i_in[1]);
+    d.joint_velocity_oldest = sg.dev<const double>(i_in[2]); d.base_position = sg.dev<const double>(i_in[3]);
+    d.base_orientation = sg.dev<const double>(i_in[4]); d.base_linear_velocity = sg.dev<const double>(i_in[5]);
+    d.base_angular_velocity = sg.dev<const double>(i_in[6]); d.contact = sg.dev<const uint8_t>(i_in[7]);
+    d.limb_state = sg.dev<int8_t>(i_io[0]); d.store_flag = sg.dev<uint8_t>(i_io[1]);
+    d.stored_joint_position = sg.dev<double>(i_io[2]); d.leg_mode = sg.dev<uint8_t>(i_io[3]);
+    d.pid_error_last = sg.dev<double>(i_io[4]); d.pid_error_integral = sg.dev<double>(i_io[5]);
+    d.support = sg.dev<uint8_t>(i_io[6]);
+    d.joint_effort = sg.dev<double>(i_out[0]); d.leg_state_code = sg.dev<int8_t>(i_out[1]);
+    d.status = sg.dev<int32_t>(i_out[2]); d.message_status = sg.dev<int32_t>(i_out[3]);
+  }
+  // intermediates: what the message delivers and what the state machine decides
+  enum { kPos, kQuat, kLin, kAng, kCmd, kFootP, kFootV, kPhase, kMsgSup, kMsgMode, kFootstep, kCode, kN };
+  const size_t sz[kN] = {B * 24, B * 32, B * 24, B * 24, B * 96, B * 96, B * 96, B * 32, B * 4, B * 4, B * 4, B * 4};
+  size_t off[kN], total = 0;
+  for (int k = 0; k < kN; k++) { off[k] = total; total += align256(sz[k]); }
+  if (ctx->tick_ws_bytes < total) {
+    if (ctx->tick_ws) (void)hipFree(ctx->tick_ws);
+    ctx->tick_ws = nullptr; ctx->tick_ws_bytes = 0;
+    if (hipMalloc(&ctx->tick_ws, total) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;
+    ctx->tick_ws_bytes = total;
+  }
+  char *w = (char *)ctx->tick_ws;
+  const auto D = [&](int k) { return (double *)(w + off[k]); };
+  const auto U = [&](int k) { return (uint8_t *)(w + off[k]); };
+  int rc;
+  // 1. baseCommandCallback: message -> desired state, targets, leg modes
+  qlamd_robot_state_fields f{};
+  f.des_pos = D(kPos); f.des_quat = D(kQuat); f.des_linvel = D(kLin); f.des_angvel = D(kAng);
+  f.joint_command = D(kCmd); f.foot_position = D(kFootP); f.foot_velocity = D(kFootV); f.phase = D(kPhase);
+  f.support_leg = U(kMsgSup); f.leg_mode = U(kMsgMode);
+  rc = qlamd_robot_state_unpack_batch(ctx, d.messages, d.offsets, batch, &f, d.message_status, QLAMD_MEM_DEVICE, stream);
+  if (rc != QLAMD_OK) return rc;
+  hipLaunchKernelGGL(tick_leg_mode_kernel, dim3((unsigned)((4 * batch + 255) / 256)), dim3(256), 0, st, U(kMsgMode), d.leg_mode,
+                     U(kFootstep), 4 * batch);
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  // 2. footContactsCallback + the switch of update(): support legs, held joint commands, nudged foot targets
+  qlamd_leg_state_batch ls{U(kMsgSup), D(kPhase), U(kFootstep), d.contact, d.joint_position, d.limb_state, d.store_flag,
+                           d.stored_joint_position, D(kCmd), D(kFootP), d.support,
+                           d.leg_state_code ? d.leg_state_code : (int8_t *)(w + off[kCode])};
+  rc = qlamd_leg_state_machine_batch(ctx, &ls, index_quirk, batch, QLAMD_MEM_DEVICE, stream);
+  if (rc != QLAMD_OK) return rc;
+  // 3. balance solve for the support legs (all 12 efforts written: 0 for the others)
+  qlamd_state_batch sb{d.joint_position, d.base_position, d.base_orientation, d.base_linear_velocity, d.base_angular_velocity,
+                       D(kPos), D(kQuat), D(kLin), D(kAng), d.support, nullptr};
+  rc = qlamd_balance_solve_batch(ctx, &sb, batch, d.joint_effort, nullptr, d.status, QLAMD_MEM_DEVICE, stream);
+  if (rc != QLAMD_OK) return rc;
+  // 4. swing branch for the legs that do not support
+  qlamd_swing_params sp = *swing;
+  sp.period = period;
+  const qlamd_swing_batch sw{d.joint_position, d.joint_velocity, d.joint_velocity_oldest, D(kFootP), D(kFootV), d.support, nullptr};
+  const qlamd_swing_branch_extra ex{d.base_orientation, D(kCmd), d.leg_mode, d.pid_error_last, d.pid_error_integral};
+  rc = qlamd_swing_branch_batch(ctx, &sp, pid, &sw, &ex, period, batch, d.joint_effort, QLAMD_MEM_DEVICE, stream);
+  if (rc != QLAMD_OK) return rc;
+  if (memory == QLAMD_MEM_HOST) return sg.finish(st);
+  return QLAMD_OK;
+}
+
+} // extern "C"

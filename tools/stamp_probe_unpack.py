@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from quadruped_locomotion_amd import capi
+# diagnostic build: python -c "from quadruped_locomotion_amd import build; build.build(defines=('QLAMD_STAMPS',), lib='scratch_bin/libqlamd_stamps.so')"
 capi.LIB_PATH = os.path.join(ROOT, "scratch_bin", "libqlamd_stamps.so")
 from test_wire_format import random_message, batch_of_messages
 B = 4096
