@@ -117,6 +117,10 @@ struct LegStatePtrs {
   double *stored_joint_position, *joint_command, *foot_target;
   uint8_t *support;
   int8_t *code;
+  // the whole tick only: this tick's mode names as decoded from the message and the modes in force (in/out); a known
+  // name replaces the mode in force, anything else leaves it (:876-964), and is_footstep is derived from the result
+  const uint8_t *msg_mode;
+  uint8_t *leg_mode;
 };
 
 __global__ __launch_bounds__(256) void leg_state_kernel(const LegStatePtrs s, int index_quirk, int64_t B) {
@@ -125,7 +129,23 @@ __global__ __launch_bounds__(256) void leg_state_kernel(const LegStatePtrs s, in
   LegStateRobot r;
   // four flags per robot travel as one 32-bit word
   const uint32_t sup = *reinterpret_cast<const uint32_t *>(s.support_leg + 4 * i);
-  const uint32_t fst = *reinterpret_cast<const uint32_t *>(s.is_footstep + 4 * i);
+  uint32_t fst;
+  if (s.msg_mode) {
+    const uint32_t mm = *reinterpret_cast<const uint32_t *>(s.msg_mode + 4 * i);
+    const uint32_t cur = *reinterpret_cast<const uint32_t *>(s.leg_mode + 4 * i);
+    uint32_t merged = 0;
+    fst = 0;
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+      const uint32_t m = (mm >> (8 * l)) & 0xFFu, c = (cur >> (8 * l)) & 0xFFu;
+      const uint32_t v = m != (uint32_t)kModeOther ? m : c;
+      merged |= v << (8 * l);
+      fst |= (v == (uint32_t)kModeFootstep ? 1u : 0u) << (8 * l);
+    }
+    *reinterpret_cast<uint32_t *>(s.leg_mode + 4 * i) = merged;
+  } else {
+    fst = *reinterpret_cast<const uint32_t *>(s.is_footstep + 4 * i);
+  }
   const uint32_t con = *reinterpret_cast<const uint32_t *>(s.contact + 4 * i);
   const uint32_t lst = *reinterpret_cast<const uint32_t *>(s.limb_state + 4 * i);
   const uint32_t sto = *reinterpret_cast<const uint32_t *>(s.store_flag + 4 * i);
@@ -512,17 +532,6 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   QL_STAMP(25);
 }
 
-// ---- the whole tick: a known leg-mode name replaces the mode in force, anything else leaves it (:876-964) ----------
-__global__ void tick_leg_mode_kernel(const uint8_t *__restrict__ msg_mode, uint8_t *__restrict__ leg_mode,
-                                     uint8_t *__restrict__ is_footstep, int64_t n) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const uint8_t m = msg_mode[t];
-  const uint8_t cur = m != kModeOther ? m : leg_mode[t];
-  leg_mode[t] = cur;
-  is_footstep[t] = cur == kModeFootstep ? 1 : 0;
-}
-
 } // namespace
 
 extern "C" {
@@ -657,7 +666,7 @@ int qlamd_leg_state_machine_batch(qlamd_context *ctx, const qlamd_leg_state_batc
   const size_t B = (size_t)batch;
   LegStatePtrs s{io->support_leg, io->is_footstep, io->contact, io->phase, io->joint_position, io->limb_state,
                  io->store_flag, io->stored_joint_position, io->joint_command, io->foot_target, io->support,
-                 io->leg_state_code};
+                 io->leg_state_code, nullptr, nullptr};
   // host staging: every array goes up except leg_state_code; the in/out and out arrays come back
   Staged sg;
   if (memory == QLAMD_MEM_HOST) {
@@ -677,7 +686,7 @@ int qlamd_leg_state_machine_batch(qlamd_context *ctx, const qlamd_leg_state_batc
     if (rc != QLAMD_OK) return rc;
     s = LegStatePtrs{sg.dev<const uint8_t>(0), sg.dev<const uint8_t>(1), sg.dev<const uint8_t>(2), sg.dev<const double>(3),
                      sg.dev<const double>(4), sg.dev<int8_t>(5), sg.dev<uint8_t>(6), sg.dev<double>(7), sg.dev<double>(8),
-                     sg.dev<double>(9), sg.dev<uint8_t>(10), sg.dev<int8_t>(11)};
+                     sg.dev<double>(9), sg.dev<uint8_t>(10), sg.dev<int8_t>(11), nullptr, nullptr};
   }
   hipLaunchKernelGGL(leg_state_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, s, index_quirk, batch);
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
@@ -829,8 +838,8 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
     d.status = sg.dev<int32_t>(i_out[2]); d.message_status = sg.dev<int32_t>(i_out[3]);
   }
   // intermediates: what the message delivers and what the state machine decides
-  enum { kPos, kQuat, kLin, kAng, kCmd, kFootP, kFootV, kPhase, kMsgSup, kMsgMode, kFootstep, kCode, kN };
-  const size_t sz[kN] = {B * 24, B * 32, B * 24, B * 24, B * 96, B * 96, B * 96, B * 32, B * 4, B * 4, B * 4, B * 4};
+  enum { kPos, kQuat, kLin, kAng, kCmd, kFootP, kFootV, kPhase, kMsgSup, kMsgMode, kCode, kN };
+  const size_t sz[kN] = {B * 24, B * 32, B * 24, B * 24, B * 96, B * 96, B * 96, B * 32, B * 4, B * 4, B * 4};
   size_t off[kN], total = 0;
   for (int k = 0; k < kN; k++) { off[k] = total; total += align256(sz[k]); }
   if (ctx->tick_ws_bytes < total) {
@@ -850,15 +859,13 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
   f.support_leg = U(kMsgSup); f.leg_mode = U(kMsgMode);
   rc = qlamd_robot_state_unpack_batch(ctx, d.messages, d.offsets, batch, &f, d.message_status, QLAMD_MEM_DEVICE, stream);
   if (rc != QLAMD_OK) return rc;
-  hipLaunchKernelGGL(tick_leg_mode_kernel, dim3((unsigned)((4 * batch + 255) / 256)), dim3(256), 0, st, U(kMsgMode), d.leg_mode,
-                     U(kFootstep), 4 * batch);
+  // 2. leg modes in force, footContactsCallback + the switch of update(): support legs, held joint commands, nudged
+  //    foot targets (one launch: the kernel of qlamd_leg_state_machine_batch with the mode merge in front)
+  const LegStatePtrs ls{U(kMsgSup), nullptr, d.contact, D(kPhase), d.joint_position, d.limb_state, d.store_flag,
+                        d.stored_joint_position, D(kCmd), D(kFootP), d.support,
+                        d.leg_state_code ? d.leg_state_code : (int8_t *)(w + off[kCode]), U(kMsgMode), d.leg_mode};
+  hipLaunchKernelGGL(leg_state_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, ls, index_quirk, batch);
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
-  // 2. footContactsCallback + the switch of update(): support legs, held joint commands, nudged foot targets
-  qlamd_leg_state_batch ls{U(kMsgSup), D(kPhase), U(kFootstep), d.contact, d.joint_position, d.limb_state, d.store_flag,
-                           d.stored_joint_position, D(kCmd), D(kFootP), d.support,
-                           d.leg_state_code ? d.leg_state_code : (int8_t *)(w + off[kCode])};
-  rc = qlamd_leg_state_machine_batch(ctx, &ls, index_quirk, batch, QLAMD_MEM_DEVICE, stream);
-  if (rc != QLAMD_OK) return rc;
   // 3. balance solve for the support legs (all 12 efforts written: 0 for the others)
   qlamd_state_batch sb{d.joint_position, d.base_position, d.base_orientation, d.base_linear_velocity, d.base_angular_velocity,
                        D(kPos), D(kQuat), D(kLin), D(kAng), d.support, nullptr};
