@@ -352,7 +352,7 @@ done:
   return status;
 }
 
-/* `count` problems of one shape, `reps` passes: timing loop for tools/cpu_qp_calibration.py (no Python in the loop). */
+/* `count` problems of one shape, `reps` passes: timing loop for tests/tools/cpu_qp_calibration.py (no Python in the loop). */
 int oracle_solve_quadprog_batch(int n, int p, int m, int count, int reps, const double *G, const double *g0,
                                 const double *CI, const double *ci0, double *x) {
   int bad = 0, active[64], nact, iters;

@@ -40,7 +40,7 @@ extern "C" int ref_solve_quadprog(int n, int p, int m, const double *G, const do
   return std::isinf(f) ? 1 : 0;
 }
 
-/* `count` problems of one shape, `reps` passes: timing loop for tools/cpu_qp_calibration.py (no Python in the loop). */
+/* `count` problems of one shape, `reps` passes: timing loop for tests/tools/cpu_qp_calibration.py (no Python in the loop). */
 extern "C" int ref_solve_quadprog_batch(int n, int p, int m, int count, int reps, const double *G, const double *g0,
                                         const double *CI, const double *ci0, double *x) {
   int bad = 0;

@@ -126,7 +126,7 @@ def test_kkt_optimality_on_sample(gpu, oracle):
     s = synth.make_states(256, "trot")
     tau, grf, status = solve_device(gpu, s)
     import sys, os
-    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "tools"))
     from gen_goldens import force_qp_of_state
     for i in range(0, 256, 8):
         legs = [l for l in range(4) if s["stance"][i][l]]

@@ -1,5 +1,5 @@
 """Oracle pinning: the plain-C Goldfarb-Idnani restatement against the golden
-vectors produced by the reference's own compiled QuadProg++ (tools/gen_goldens.py)
+vectors produced by the reference's own compiled QuadProg++ (tests/tools/gen_goldens.py)
 and, where oracle/_ref was built, against that solver live."""
 import numpy as np
 import pytest

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU probe: kernel time vs. per-robot QP iteration count and vs. batch size (tuning aid)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from quadruped_locomotion_amd import capi, synth
 from oracle import oracle as O

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run ONE configuration a few times (for rocprofv3): probe_one.py <gait> <batch> <rpw> [iters_filter]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from quadruped_locomotion_amd import capi, synth
 gait, B, rpw = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
