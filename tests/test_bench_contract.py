@@ -1,0 +1,54 @@
+"""The one-line JSON contract of bench.py: every key the driver reads, with the types and relations it relies on.
+CPU: the committed line of the last measured run (profiles/r1/final_bench_static_b4096.json).  GPU: a short live run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+TOP = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int, "ms_per_step": float,
+       "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict, "roofline": dict}
+ROOFLINE = {"bound": str, "achieved": float, "peak": float, "unit": str, "frac": float}
+CPU = {"value": float, "unit": str, "cores": int, "kind": str, "sample": str}
+
+
+def check(line, want_cpu=True):
+    d = json.loads(line)
+    for k, t in TOP.items():
+        assert isinstance(d[k], t), k
+    assert "vs_baseline" in d and d["vs_baseline"] is None            # BASELINE.md holds no published number for this metric
+    assert d["metric"].startswith("control-step QP solves/sec") and d["unit"] == "solves/s"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["n_gpus"] * d["config"]["robots_per_gpu"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    for k, t in ROOFLINE.items():
+        assert isinstance(r[k], t), k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and "traffic" in r
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["peak"] == 8000.0
+    if want_cpu:
+        c = d["cpu_baseline"]
+        for k, t in CPU.items():
+            assert isinstance(c[k], t), k
+        assert c["kind"] in ("reference", "port") and c["cores"] >= 1
+    return d
+
+
+def test_committed_bench_line_follows_the_contract():
+    path = os.path.join(ROOT, "profiles", "r1", "final_bench_static_b4096.json")
+    d = check(open(path).read().strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["config"]["robots_per_gpu"] == 4096 and d["config"]["all_status_ok"] is True
+
+
+@pytest.mark.gpu
+def test_live_bench_line_follows_the_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--cpu-seconds", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "bench.py must print exactly one line"
+    d = check(lines[0])
+    assert d["steps"] == 20 and d["warmup"] == 3 and d["config"]["all_status_ok"] is True
