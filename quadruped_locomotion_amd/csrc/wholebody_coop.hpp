@@ -45,6 +45,14 @@ __device__ __forceinline__ double quad_prefix(double x, int c) {
   return y;
 }
 
+// sum over the four legs of the value held by the lanes c == 0 (the legs' root bodies), replicated on all 16 lanes:
+// two rotations add the lanes of equal c, the quad broadcast then picks c == 0 -- no masking needed
+__device__ __forceinline__ double legs_root_sum(double x) {
+  x += dpp<0x128>(x); // row_ror:8
+  x += dpp<0x124>(x); // row_ror:4
+  return quad_bc<0>(x);
+}
+
 __device__ __forceinline__ void sym_mul(const double I[6], const double v[3], double o[3]) {
   o[0] = I[0] * v[0] + I[1] * v[1] + I[2] * v[2];
   o[1] = I[1] * v[0] + I[3] * v[1] + I[4] * v[2];
@@ -186,8 +194,8 @@ __device__ __forceinline__ void wb_inverse_dynamics(const WbParamsDev &W, const 
   cross3(V0, fv0, d3);
 #pragma unroll
   for (int a = 0; a < 3; a++) {
-    gb[a] = (f0[a] + d3[a]) + row_sum(sel(c == 0, Fc[3 + a], 0.0));
-    gb[3 + a] = (n0[a] + d1[a] + d2[a]) + row_sum(sel(c == 0, Fc[a], 0.0));
+    gb[a] = (f0[a] + d3[a]) + legs_root_sum(Fc[3 + a]);
+    gb[3 + a] = (n0[a] + d1[a] + d2[a]) + legs_root_sum(Fc[a]);
   }
 }
 
@@ -215,16 +223,16 @@ __device__ __forceinline__ void wb_crba(const WbParamsDev &W, const WbLink &L, i
     }
     Mleg[j] = sel(j <= c, dot_own, dot_other);
   });
-  total.m = W.base_m + row_sum(sel(c == 0, Xc.m, 0.0));
+  total.m = W.base_m + legs_root_sum(Xc.m);
 #pragma unroll
-  for (int a = 0; a < 3; a++) total.h[a] = W.base_h[a] + row_sum(sel(c == 0, Xc.h[a], 0.0));
+  for (int a = 0; a < 3; a++) total.h[a] = W.base_h[a] + legs_root_sum(Xc.h[a]);
 #pragma unroll
-  for (int a = 0; a < 6; a++) total.I[a] = W.base_I[a] + row_sum(sel(c == 0, Xc.I[a], 0.0));
+  for (int a = 0; a < 6; a++) total.I[a] = W.base_I[a] + legs_root_sum(Xc.I[a]);
 }
 
 // Layout of one robot's staging block in LDS for the dynamics kernel: M [18][18]; then h [18], Jc [12][18]
 // (the kernel stages M first and, after writing it out, h and Jc in the same block)
-constexpr int kWbM = 0, kWbStage = 324, kWbH = 0, kWbJc = 18;
+constexpr int kWbM = 0, kWbStage = 324; // pass 2: h of the block's 4 robots [4][18], then Jc [4][216]
 
 // Layout of the exchange block of the whole-body solve (quad-lane results -> variable / constraint lanes)
 constexpr int kWxTau0 = 0, kWxJ = 12 /* [leg][a][k] */, kWxR = 48 /* [leg][3] */, kWxN = 60 /* [leg][n,t1,t2][3] */,

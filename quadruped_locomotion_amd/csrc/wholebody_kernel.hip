@@ -30,6 +30,14 @@ struct WbLaneIn {
   }
 };
 
+// n doubles from LDS to global memory by the 64 lanes of the block, 16 bytes per lane and instruction (both sides are
+// 16-byte aligned: every per-robot record here is a multiple of 16 bytes and n is even)
+__device__ __forceinline__ void copy_out(double *__restrict__ dst, const double *src, int n) {
+  const double2 *s2 = reinterpret_cast<const double2 *>(src);
+  double2 *d2 = reinterpret_cast<double2 *>(dst);
+  for (int e = threadIdx.x; e < (n >> 1); e += 64) d2[e] = s2[e];
+}
+
 // M [B][18][18], h [B][18], Jc [B][12][18] (any of them may be NULL): staged per robot in LDS, written out coalesced.
 // kM: the composite-rigid-body pass and M; kHJ: the Newton-Euler pass, h and Jc (a caller that wants only one of the two
 // does not pay for the other).
@@ -50,7 +58,12 @@ __global__ __launch_bounds__(64) void wholebody_dynamics_kernel(const DevicePara
   in.load(s, i, 3 * leg + (c < 3 ? c : 2));
   ts.commit(tab);
   double *ob = outb + kWbStage * row;
-  for (int e = lr; e < kWbStage; e += 16) ob[e] = 0.0;
+  const double2 zero2 = {0.0, 0.0};
+  if (kM && Mo) {
+    for (int e = lr; e < kWbStage / 2; e += 16) reinterpret_cast<double2 *>(ob)[e] = zero2;
+  } else {
+    for (int e = threadIdx.x; e < 2 * (18 + 216); e += 64) reinterpret_cast<double2 *>(outb)[e] = zero2;
+  }
 
   double Rm[9], gB[3];
   quat_to_matrix(in.quat, Rm);
@@ -104,34 +117,35 @@ __global__ __launch_bounds__(64) void wholebody_dynamics_kernel(const DevicePara
       }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 324 * nrob; e += 64) Mo[r0 * 324 + e] = outb[e]; // kWbStage == 324: robots are contiguous
+    copy_out(Mo + r0 * 324, outb, 324 * nrob); // kWbStage == 324: robots are contiguous
     __syncthreads();
     if (kHJ && (ho || Jo))
-      for (int e = lr; e < 18 + 216; e += 16) ob[e] = 0.0;
+      for (int e = threadIdx.x; e < 2 * (18 + 216); e += 64) reinterpret_cast<double2 *>(outb)[e] = zero2;
   }
-  // ---- pass 2: bias forces and the contact Jacobian
+  // ---- pass 2: bias forces and the contact Jacobian; the block holds h of its 4 robots, then Jc of its 4 robots, so
+  //      that both go out as plain contiguous copies
   if (kHJ && (ho || Jo)) {
-    static_for<6>([&](auto E) { constexpr int e = E; ob[kWbH + e] = gb[e]; });
+    double *hb = outb + 18 * row, *jb = outb + 4 * 18 + 216 * row;
+    __syncthreads(); // the block-wide zero fill is complete
+    static_for<6>([&](auto E) { constexpr int e = E; hb[e] = gb[e]; });
     if (c < 3) {
       const int j = 6 + 3 * leg + c;
-      ob[kWbH + j] = tau;
+      hb[j] = tau;
       double d[3] = {L.pf[0] - L.p[0], L.pf[1] - L.p[1], L.pf[2] - L.p[2]}, col[3];
       cross3(L.z, d, col);
 #pragma unroll
-      for (int a = 0; a < 3; a++) ob[kWbJc + 18 * (3 * leg + a) + j] = col[a];
+      for (int a = 0; a < 3; a++) jb[18 * (3 * leg + a) + j] = col[a];
     } else {
       // the foot lane writes [1 , -[r]x] of its leg's three rows
-      double *jr = ob + kWbJc + 18 * 3 * leg;
+      double *jr = jb + 18 * 3 * leg;
       jr[0] = 1.0; jr[18 + 1] = 1.0; jr[36 + 2] = 1.0;
       jr[4] = L.pf[2]; jr[5] = -L.pf[1];            // -[r]x
       jr[18 + 3] = -L.pf[2]; jr[18 + 5] = L.pf[0];
       jr[36 + 3] = L.pf[1]; jr[36 + 4] = -L.pf[0];
     }
     __syncthreads();
-    if (ho)
-      for (int e = threadIdx.x; e < 18 * nrob; e += 64) ho[r0 * 18 + e] = outb[kWbStage * (e / 18) + kWbH + e % 18];
-    if (Jo)
-      for (int e = threadIdx.x; e < 216 * nrob; e += 64) Jo[r0 * 216 + e] = outb[kWbStage * (e / 216) + kWbJc + e % 216];
+    if (ho) copy_out(ho + r0 * 18, outb, 18 * nrob);
+    if (Jo) copy_out(Jo + r0 * 216, outb + 4 * 18, 216 * nrob);
   }
 }
 
