@@ -77,8 +77,6 @@ __global__ __launch_bounds__(64) void wholebody_dynamics_kernel(const DevicePara
   wb_link(CoopTab{tab + kTabPerLeg * leg}, c, sj, cj, L);
   const double V0[6] = {in.angvel[0], in.angvel[1], in.angvel[2], vB[0], vB[1], vB[2]};
   const double A0[6] = {0.0, 0.0, 0.0, -gB[0], -gB[1], -gB[2]};
-  double tau = 0.0, gb[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  if constexpr (kHJ) wb_inverse_dynamics(W, L, c, V0, A0, c < 3 ? in.qdj : 0.0, 0.0, tau, gb);
   WbInertia T{};
   double Fcol[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, Mleg[3] = {0.0, 0.0, 0.0};
   if constexpr (kM) wb_crba(W, L, c, T, Fcol, Mleg);
@@ -123,8 +121,11 @@ __global__ __launch_bounds__(64) void wholebody_dynamics_kernel(const DevicePara
       for (int e = threadIdx.x; e < 2 * (18 + 216); e += 64) reinterpret_cast<double2 *>(outb)[e] = zero2;
   }
   // ---- pass 2: bias forces and the contact Jacobian; the block holds h of its 4 robots, then Jc of its 4 robots, so
-  //      that both go out as plain contiguous copies
+  //      that both go out as plain contiguous copies.  The Newton-Euler pass runs HERE, after the mass matrix has been
+  //      handed to the memory system: its arithmetic overlaps the drain of those stores.
   if (kHJ && (ho || Jo)) {
+    double tau = 0.0, gb[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    wb_inverse_dynamics(W, L, c, V0, A0, c < 3 ? in.qdj : 0.0, 0.0, tau, gb);
     double *hb = outb + 18 * row, *jb = outb + 4 * 18 + 216 * row;
     __syncthreads(); // the block-wide zero fill is complete
     static_for<6>([&](auto E) { constexpr int e = E; hb[e] = gb[e]; });
