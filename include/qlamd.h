@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 #define QLAMD_VERSION_MAJOR 0
-#define QLAMD_VERSION_MINOR 2
+#define QLAMD_VERSION_MINOR 3
 
 /* ---- return codes of the API calls ------------------------------------- */
 #define QLAMD_OK 0
