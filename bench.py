@@ -28,12 +28,12 @@ ALGO_BYTES_PER_STEP = 408   # 304 B state + 4 B stance in, 96 B 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP64_VALU_PEAK_TFLOPS = 78.6
 # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), see
-# profiles/r1/hbm_traffic_and_sq_pmc_bench_static_b4096_coop_v3.json; None for configurations not profiled.
-MEASURED_TRAFFIC_BYTES = {(4096, "static"): int((1108.6 + 416.0) * 1024)}
+# profiles/r1/hbm_traffic_and_sq_pmc_bench_static_b4096_final.json; None for configurations not profiled.
+MEASURED_TRAFFIC_BYTES = {(4096, "static"): int((1108.5 + 416.0) * 1024)}
 # VALU wave-instructions per launch from the same file (SQ_INSTS_VALU, its own pass).  A wave64 VALU instruction
 # occupies its SIMD16 for 4 cycles, so insts * 4 / (SIMDs * kernel cycles) is the fraction of the chip's VALU
 # issue slots the launch used -- the resource this FP64 path is actually bound by.
-MEASURED_VALU_INSTS = {(4096, "static"): 1764530}
+MEASURED_VALU_INSTS = {(4096, "static"): 1743876}
 N_SIMD, SHADER_CLOCK_HZ = 1024, 2.4e9
 
 
