@@ -47,3 +47,30 @@ def test_no_cpu_fallback(capi):
     assert "no CPU fallback" in capi.strerror(capi.ERR_NO_DEVICE)
     h = C.c_void_p()
     assert capi.lib().qlamd_context_create(None, None, 0, C.byref(h)) == capi.ERR_NOT_LOADED
+
+
+def test_header_is_plain_c_and_links_from_c(capi, tmp_path):
+    """include/qlamd.h is a C header (C11, -pedantic) and a C program links against the library: the boundary is a
+    C ABI, not a C++ one.  Without a GPU qlamd_context_create must fail with QLAMD_ERR_NO_DEVICE, never crash."""
+    import subprocess
+    from conftest import ROOT, has_gpu
+    from quadruped_locomotion_amd import build
+    build.build()
+    src = tmp_path / "c_abi.c"
+    src.write_text('#include <stdio.h>\n#include "qlamd.h"\n'
+                   "int main(void) {\n"
+                   "  qlamd_balance_params p; qlamd_balance_default_params(&p);\n"
+                   "  qlamd_context *ctx = NULL;\n"
+                   "  int rc = qlamd_context_create(&p, NULL, 0, &ctx);\n"
+                   '  printf("%d %s %d\\n", rc, qlamd_strerror(rc), qlamd_version());\n'
+                   "  if (rc == QLAMD_OK) qlamd_context_destroy(ctx);\n"
+                   "  return 0;\n}\n")
+    exe = tmp_path / "c_abi"
+    pkg = os.path.join(ROOT, "quadruped_locomotion_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-I" + os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe), "-L" + pkg, "-lqlamd", "-Wl,-rpath," + pkg])
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rc = int(out.stdout.split()[0])
+    assert rc == (0 if has_gpu() else capi.ERR_NO_DEVICE), out.stdout
