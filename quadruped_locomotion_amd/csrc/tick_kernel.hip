@@ -129,29 +129,28 @@ __global__ __launch_bounds__(256) void leg_state_kernel(const LegStatePtrs s, in
   LegStateRobot r;
   // four flags per robot travel as one 32-bit word
   const uint32_t sup = *reinterpret_cast<const uint32_t *>(s.support_leg + 4 * i);
-  uint32_t fst;
-  if (s.msg_mode) {
-    const uint32_t mm = *reinterpret_cast<const uint32_t *>(s.msg_mode + 4 * i);
-    const uint32_t cur = *reinterpret_cast<const uint32_t *>(s.leg_mode + 4 * i);
-    uint32_t merged = 0;
-    fst = 0;
-#pragma unroll
-    for (int l = 0; l < 4; l++) {
-      const uint32_t m = (mm >> (8 * l)) & 0xFFu, c = (cur >> (8 * l)) & 0xFFu;
-      const uint32_t v = m != (uint32_t)kModeOther ? m : c;
-      merged |= v << (8 * l);
-      fst |= (v == (uint32_t)kModeFootstep ? 1u : 0u) << (8 * l);
-    }
-    *reinterpret_cast<uint32_t *>(s.leg_mode + 4 * i) = merged;
-  } else {
-    fst = *reinterpret_cast<const uint32_t *>(s.is_footstep + 4 * i);
-  }
+  // (the whole tick hands in this tick's mode names instead of is_footstep: both words are loaded here with everything
+  // else, merged below, and the modes in force are written back with the other results)
+  const uint32_t fst_in = *reinterpret_cast<const uint32_t *>((s.msg_mode ? s.support_leg : s.is_footstep) + 4 * i);
+  const uint32_t mm = *reinterpret_cast<const uint32_t *>((s.msg_mode ? s.msg_mode : s.support_leg) + 4 * i);
+  const uint32_t mcur = *reinterpret_cast<const uint32_t *>((s.msg_mode ? (const uint8_t *)s.leg_mode : s.support_leg) + 4 * i);
   const uint32_t con = *reinterpret_cast<const uint32_t *>(s.contact + 4 * i);
   const uint32_t lst = *reinterpret_cast<const uint32_t *>(s.limb_state + 4 * i);
   const uint32_t sto = *reinterpret_cast<const uint32_t *>(s.store_flag + 4 * i);
   const double2 p01 = *reinterpret_cast<const double2 *>(s.phase + 4 * i);
   const double2 p23 = *reinterpret_cast<const double2 *>(s.phase + 4 * i + 2);
   const double ph[4] = {p01.x, p01.y, p23.x, p23.y};
+  uint32_t fst = fst_in, merged = 0;
+  if (s.msg_mode) {
+    fst = 0;
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+      const uint32_t m = (mm >> (8 * l)) & 0xFFu, c = (mcur >> (8 * l)) & 0xFFu;
+      const uint32_t v = m != (uint32_t)kModeOther ? m : c;
+      merged |= v << (8 * l);
+      fst |= (v == (uint32_t)kModeFootstep ? 1u : 0u) << (8 * l);
+    }
+  }
 #pragma unroll
   for (int l = 0; l < 4; l++) {
     r.support_leg[l] = ((sup >> (8 * l)) & 0xFFu) != 0;
@@ -199,6 +198,7 @@ __global__ __launch_bounds__(256) void leg_state_kernel(const LegStatePtrs s, in
   *reinterpret_cast<uint32_t *>(s.store_flag + 4 * i) = sto_o;
   *reinterpret_cast<uint32_t *>(s.support + 4 * i) = sup_o;
   *reinterpret_cast<uint32_t *>(s.code + 4 * i) = code_o;
+  if (s.msg_mode) *reinterpret_cast<uint32_t *>(s.leg_mode + 4 * i) = merged;
 }
 
 // ---- free_gait_msgs/RobotState wire format -> SoA (row f2): one message per lane ---------------------
