@@ -9,10 +9,12 @@ outputs resident in HBM.
   python bench.py [--gpus N] [--steps K] [--warmup W] [--gait static|trot] [--batch B]
 
 N = 1: BASELINE configs[1], batch = 4096 robots, static 4-contact stance.
-N > 1: launched by torch.distributed.run, one rank per GPU; every rank solves its
-own shard of `batch` robots (weak scaling: robots are independent, no data-path
-collective) and the joint torques are all-gathered over RCCL/xGMI for result
-collection, as the north star asks.  Rank 0 prints ONE JSON line.
+N > 1: BASELINE configs[3], 8192 trot robots per GPU (65 536 on 8 GPUs), one rank per GPU; every rank
+solves its own contiguous shard (weak scaling: robots are independent, no data-path collective) and the
+joint torques are all-gathered over RCCL/xGMI for result collection, as the north star asks.  Started
+either by the driver under torch.distributed.run (RANK / WORLD_SIZE in the environment) or from a bare
+shell: `python bench.py --gpus N` then starts the N ranks itself as a child torch.distributed.run (the
+parent never touches a GPU API and exits with the child's code).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -27,14 +29,43 @@ if ROOT not in sys.path:
 ALGO_BYTES_PER_STEP = 408   # 304 B state + 4 B stance in, 96 B torques + 4 B status out
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP64_VALU_PEAK_TFLOPS = 78.6
-# HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), see
-# profiles/r1/hbm_traffic_and_sq_pmc_bench_static_b4096_final.json; None for configurations not profiled.
-MEASURED_TRAFFIC_BYTES = {(4096, "static"): int((1108.5 + 416.0) * 1024)}
-# VALU wave-instructions per launch from the same file (SQ_INSTS_VALU, its own pass).  A wave64 VALU instruction
-# occupies its SIMD16 for 4 cycles, so insts * 4 / (SIMDs * kernel cycles) is the fraction of the chip's VALU
-# issue slots the launch used -- the resource this FP64 path is actually bound by.
-MEASURED_VALU_INSTS = {(4096, "static"): 1743876}
+# HBM bytes and VALU wave-instructions per launch are NOT measured by this script: they come from rocprofv3 --pmc
+# passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU each in its own pass; tools/pmc_collect.py) whose summaries are
+# committed as profiles/r*/pmc_index.json together with a hash of the kernel sources they were taken on.  A record
+# taken on other sources than the ones in this tree is reported as stale and its numbers are dropped.
+# A wave64 VALU instruction occupies its SIMD16 for 4 cycles, so insts * 4 / (SIMDs * kernel cycles) is the fraction
+# of the chip's VALU issue slots the launch used -- the resource this FP64 path is actually bound by.
 N_SIMD, SHADER_CLOCK_HZ = 1024, 2.4e9
+
+
+def source_hash():
+    """sha256 over the kernel sources and the C header (what a PMC record is valid for)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "quadruped_locomotion_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp")))
+    files += [os.path.join(ROOT, "include", "qlamd.h"), os.path.join(ROOT, "include", "qlamd_robot_constants.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_record(kernel, batch, workload):
+    """(record or None, provenance string) from the newest profiles/r*/pmc_index.json."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_index.json")))
+    if not cands:
+        return None, "no profiles/r*/pmc_index.json"
+    idx = json.load(open(cands[-1]))
+    rel = os.path.relpath(cands[-1], ROOT)
+    for rec in idx.get("records", []):
+        if rec["kernel"] == kernel and rec["batch"] == batch and rec["workload"] == workload:
+            if rec.get("source_hash") != source_hash():
+                return None, "%s: record taken on sources %s, this tree is %s (stale, dropped)" % (
+                    rel, rec.get("source_hash"), source_hash())
+            return rec, "%s (%s)" % (rel, rec.get("files", ""))
+    return None, "%s: no record for %s / %d / %s" % (rel, kernel, batch, workload)
 
 
 def parse():
@@ -42,8 +73,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=4096, help="robots per GPU")
-    ap.add_argument("--gait", default="static", choices=["static", "trot"])
+    ap.add_argument("--batch", type=int, default=None, help="robots per GPU (default 4096 with one GPU, 8192 with several)")
+    ap.add_argument("--gait", default=None, choices=["static", "trot"], help="default static with one GPU, trot with several")
+    ap.add_argument("--errors", default="calm", choices=["calm", "survey"],
+                    help="static stance tracking errors: calm = 0.004 m / 0.005 rad / 0.01 m/s (default, DESIGN.md 2), "
+                         "survey = SURVEY.md 8(d)'s literal 0.02 / 0.05 / 0.1")
+    ap.add_argument("--replays", type=int, default=11,
+                    help="timed samples of exactly K steps each (barrier + synchronize on both sides); the median is reported")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU-only check of the multi-rank launcher, sharding and gather layout over gloo: no solve, no measurement")
     ap.add_argument("--workload", default="balance", choices=["balance", "pose_sqp", "wholebody", "wholebody_dynamics", "full_tick"],
                     help="pose_sqp = BASELINE config 5; wholebody / wholebody_dynamics = SURVEY 8 row f4; full_tick = the "
                          "whole update() from a serialised message to 12 efforts (rows a1 + f1 + f2) "
@@ -59,38 +97,78 @@ def parse():
     ap.add_argument("--ragged", action="store_true", help="full_tick: every message with its own layout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 4096 if (args.gpus == 1 or args.workload != "balance") else 8192
+    if args.gait is None:
+        args.gait = "static" if args.gpus == 1 else "trot"
+    return args
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as a child torch.distributed.run and exit with
+    its code.  This parent process must not touch any GPU API (it only counts on the child for that)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(state, seconds):
-    """The oracle (plain-C restatement of the reference path) on the host cores of this box,
-    same workload, bounded sample.  Reported next to the GPU number; not the target.
-    The thread count is the one that runs fastest here (a container's CPU quota can be far
-    below the visible core count); `cores` states it."""
+    """The oracle (plain-C restatement of the reference path) on the host cores of this box, same workload, bounded
+    sample.  Reported next to the GPU number; not the target.  Every pass count runs inside ONE OpenMP region (threads
+    keep their block of robots, no fork / join between passes, active waiting), timed in C between two barriers; all
+    visible cores are tried as well as smaller counts (a container's CPU quota can be below the visible count) and the
+    fastest is `value`; the single-thread and all-core rates are stated beside it."""
+    os.environ.setdefault("OMP_WAIT_POLICY", "active")
+    os.environ.setdefault("OMP_PROC_BIND", "false")
     from oracle import oracle as O
     visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     B = state["q"].shape[0]
+    # at least 64 robots per thread and pass: tile the batch for many-core hosts (same robots, same work per robot)
+    tile = max(1, -(-64 * visible // B))
+    big = {k: (np_tile(v, tile)) for k, v in state.items()}
+    Bb = B * tile
 
     def rate(threads, budget):
-        O.balance_batch(state, nthreads=threads)
-        n, t0 = 0, time.perf_counter()
-        while True:
-            O.balance_batch(state, nthreads=threads)
-            n += 1
-            dt = time.perf_counter() - t0
-            if dt >= budget or n >= 100000:
-                return n * B / dt, n, dt
+        O.balance_batch_repeat(big, 1, threads)
+        dt1 = max(O.balance_batch_repeat(big, 1, threads), 1e-6)
+        passes = max(1, int(budget / dt1))
+        dt = O.balance_batch_repeat(big, passes, threads)
+        return passes * Bb / dt, passes, dt
 
-    cands = sorted({1, 8, 32, visible} | ({visible // 2} if visible >= 4 else set()))
+    cands = sorted({1, 2, 4, 8, 16, 32, 64, 128, visible} | ({visible // 2} if visible >= 4 else set()))
     cands = [c for c in cands if 1 <= c <= visible]
-    probe = {c: rate(c, 0.4)[0] for c in cands}
+    probe = {c: rate(c, 0.3)[0] for c in cands}
     best = max(probe, key=probe.get)
     value, n, dt = rate(best, seconds)
     return {"value": value, "unit": "control-step QP solves/s", "cores": best, "kind": "port",
-            "single_thread_value": probe.get(1), "visible_cores": visible,
-            "sample": "%d passes over the same %d-robot batch (%.1f s), OpenMP over robots, %d threads "
-                      "(fastest of %s)" % (n, B, dt, best, cands)}
+            "single_thread_value": probe.get(1), "all_visible_cores_value": probe.get(visible),
+            "per_core_value": value / best, "visible_cores": visible, "cpu_model": cpu_model(),
+            "thread_sweep": {str(c): probe[c] for c in cands},
+            "sample": "%d passes over the same %d-robot batch%s (%.1f s) inside one OpenMP region, robots blocked over "
+                      "%d threads (fastest of %s)" % (n, B, " tiled x%d" % tile if tile > 1 else "", dt, best, cands)}
+
+
+def np_tile(v, tile):
+    import numpy as np
+    return np.ascontiguousarray(np.concatenate([v] * tile, axis=0)) if tile > 1 else v
 
 
 def bench_pose_sqp(args):
@@ -241,20 +319,12 @@ def bench_full_tick(args):
     is walked)."""
     import numpy as np
     import torch
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from quadruped_locomotion_amd import capi, synth
-    from test_wire_format import random_message
     B = args.batch
     rng = np.random.default_rng(11)
-    if args.ragged:
-        raws = [random_message(rng, ragged=True)[0] for _ in range(B)]
-    else:
-        base = bytearray(random_message(np.random.default_rng(3), ragged=True)[0])
-        raws = [bytes(base)] * B
-    off = np.zeros(B + 1, np.int64)
-    off[1:] = np.cumsum([len(r) for r in raws])
+    blob, off, _ = synth.make_messages(B, ragged=args.ragged)
     s = synth.make_states(B, "trot")
-    host = dict(messages=np.frombuffer(b"".join(raws), np.uint8).copy(), offsets=off, joint_position=s["q"],
+    host = dict(messages=blob, offsets=off, joint_position=s["q"],
                 joint_velocity=rng.normal(scale=0.3, size=(B, 12)), joint_velocity_oldest=rng.normal(scale=0.3, size=(B, 12)),
                 base_position=s["base_pos"], base_orientation=s["base_quat"], base_linear_velocity=np.ascontiguousarray(s["base_linvel"]),
                 base_angular_velocity=np.ascontiguousarray(s["base_angvel"]), contact=rng.integers(0, 2, (B, 4)).astype(np.uint8),
@@ -297,8 +367,43 @@ def bench_full_tick(args):
                      "kernel_ms": tick_ms, "algorithmic_bytes_per_launch": algo}}), flush=True)
 
 
+def selftest_launcher(args):
+    """CPU-only check of what `--gpus N` does around the solve: ranks started by the same launcher, contiguous shards
+    of the seeded generator, the all-gather layout and the max-over-ranks reduction, over gloo.  There is no solve
+    and no measurement here (the product path has no CPU fallback): the gathered quantity is the joint-position
+    shard itself.  Rank 0 prints one JSON line with "selftest": "launcher"."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from quadruped_locomotion_amd import synth
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = args.batch
+    shard = torch.from_numpy(synth.make_states(B, args.gait, offset=rank * B, errors=args.errors)["q"])
+    gathered = torch.zeros(world * B, 12, dtype=torch.float64)
+    dist.all_gather_into_tensor(gathered, shard)
+    ones = torch.ones(1, dtype=torch.int32)
+    dist.all_reduce(ones)
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        whole = synth.make_states(world * B, args.gait, errors=args.errors)["q"]
+        print(json.dumps({"selftest": "launcher", "n_gpus": args.gpus, "world_size": world, "ranks_seen": int(ones.item()),
+                          "max_over_ranks_ok": t.item() == float(world), "robots_per_rank": B, "gait": args.gait,
+                          "gather_layout_ok": bool(np.array_equal(gathered.numpy(), whole)), "value": None}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare shell: this process stays off the GPU and starts the ranks as a child
+        sys.exit(launch_ranks(args))
+    if args.selftest_launcher:
+        return selftest_launcher(args)
     if args.workload == "full_tick":
         return bench_full_tick(args)
     if args.workload == "pose_sqp":
@@ -315,21 +420,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback in the product path)")
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     collective = world > 1 or args.force_collective
+    ranks_seen = 1
     if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        ones = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(ones)  # every rank answers over RCCL
+        ranks_seen = int(ones.item())
+        assert ranks_seen == world == dist.get_world_size(), "RCCL saw %d ranks, expected %d" % (ranks_seen, world)
 
     B = args.batch
     # rank r owns robots [r*B, (r+1)*B) of the global batch (contiguous shards)
-    state = synth.make_states(B, args.gait, offset=rank * B)
+    state = synth.make_states(B, args.gait, offset=rank * B, errors=args.errors)
     ctx = capi.Context(device=local_rank)
     if args.rpw:
         ctx.set_robots_per_wave(args.rpw)
@@ -340,14 +449,14 @@ def main():
     gathered = [torch.zeros(world * B, 12, dtype=torch.float64, device=dev) for _ in range(2)] if gather else None
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step(k, events=None):
+    def step(k, with_gather, events=None):
         buf = k & 1
         if events is not None:
             events[0].record()
         ctx.balance_solve_device(d, tau[buf], None, status, stream=stream)
         if events is not None:
             events[1].record()
-        if gather:
+        if with_gather:
             # result collection only; overlaps with the next step's solve (double-buffered)
             return dist.all_gather_into_tensor(gathered[buf], tau[buf], async_op=True)
         return None
@@ -358,111 +467,139 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    pending = []
     for k in range(args.warmup):
-        w = step(k)
+        w = step(k, gather)
         if w is not None:
             w.wait()
     fence()
 
-    # ---- timed region: exactly K steps -----------------------------------------
-    # The K steps (solve, plus the all-gather of the torques when there are several ranks) are
-    # captured once into a hipGraph (solves on one stream, gathers on a second one) and replayed: a step is a few
-    # tens of microseconds, comparable
-    # to one eager launch from Python.  The graph is built outside the timed region; the timed
-    # region is one replay = K control steps.  If capture fails the steps are launched eagerly,
-    # the all-gather of step k then overlapping the solve of step k+1.
-    use_graph = not args.no_graph
-    graph = None
-    if use_graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=side):
-                    cap = torch.cuda.current_stream().cuda_stream
-                    # The gathers go to a second captured stream: gather k (reads tau[k & 1]) overlaps solve k+1
-                    # (writes the other buffer); solve k+2 waits for gather k before it reuses the buffer.
-                    # (with a single rank the "gather" is a local copy and the extra graph edges cost more than they
-                    # hide -- measured 27.8 vs 22.6 us per step -- so the self-test keeps everything on one stream)
-                    overlap = gather and (world > 1 or args.overlap_gather)
-                    comm = torch.cuda.Stream() if overlap else None
-                    gathered_ev = [None, None]
-                    for k in range(args.steps):
-                        buf = k & 1
-                        if overlap and gathered_ev[buf] is not None:
-                            side.wait_event(gathered_ev[buf])
-                        ctx.balance_solve_device(d, tau[buf], None, status, stream=cap)
-                        if overlap:  # RCCL collectives are capturable; they replay from the graph
-                            solved = torch.cuda.Event()
-                            solved.record(side)
-                            comm.wait_event(solved)
-                            with torch.cuda.stream(comm):
-                                dist.all_gather_into_tensor(gathered[buf], tau[buf])
-                                gathered_ev[buf] = torch.cuda.Event()
-                                gathered_ev[buf].record(comm)
-                        elif gather:
+    # ---- K steps as one hipGraph ----------------------------------------------------------------
+    # The K steps (solve, plus the all-gather of the torques when there are several ranks) are captured once into a
+    # hipGraph (solves on one stream, gathers on a second one) and replayed: a step is a few tens of microseconds,
+    # comparable to one eager launch from Python.  If capture fails the steps are launched eagerly, the all-gather of
+    # step k then overlapping the solve of step k+1.
+    def capture(with_gather):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                cap = torch.cuda.current_stream().cuda_stream
+                # The gathers go to a second captured stream: gather k (reads tau[k & 1]) overlaps solve k+1 (writes
+                # the other buffer); solve k+2 waits for gather k before it reuses the buffer.  (With a single rank
+                # the "gather" is a local copy and the extra graph edges cost more than they hide -- measured 27.8 vs
+                # 22.6 us per step -- so the self-test keeps everything on one stream.)
+                overlap = with_gather and (world > 1 or args.overlap_gather)
+                comm = torch.cuda.Stream() if overlap else None
+                gathered_ev = [None, None]
+                for k in range(args.steps):
+                    buf = k & 1
+                    if overlap and gathered_ev[buf] is not None:
+                        side.wait_event(gathered_ev[buf])
+                    ctx.balance_solve_device(d, tau[buf], None, status, stream=cap)
+                    if overlap:  # RCCL collectives are capturable; they replay from the graph
+                        solved = torch.cuda.Event()
+                        solved.record(side)
+                        comm.wait_event(solved)
+                        with torch.cuda.stream(comm):
                             dist.all_gather_into_tensor(gathered[buf], tau[buf])
-                    if overlap:
-                        side.wait_stream(comm)  # join before the capture ends
-            torch.cuda.current_stream().wait_stream(side)
-        except Exception as e:  # pragma: no cover - fall back to eager launches
-            sys.stderr.write("hipGraph capture failed (%s); eager launches\n" % e)
-            graph = None
-        if collective:
-            # every rank must take the same path, or the collectives would not match up
-            okflag = torch.tensor([1 if graph is not None else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(okflag, op=dist.ReduceOp.MIN)
-            if int(okflag.item()) == 0:
+                            gathered_ev[buf] = torch.cuda.Event()
+                            gathered_ev[buf].record(comm)
+                    elif with_gather:
+                        dist.all_gather_into_tensor(gathered[buf], tau[buf])
+                if overlap:
+                    side.wait_stream(comm)  # join before the capture ends
+        torch.cuda.current_stream().wait_stream(side)
+        return graph
+
+    def build_graph(with_gather):
+        graph = None
+        if not args.no_graph:
+            try:
+                graph = capture(with_gather)
+            except Exception as e:  # pragma: no cover - fall back to eager launches
+                sys.stderr.write("hipGraph capture failed (%s); eager launches\n" % e)
                 graph = None
+            if collective:
+                # every rank must take the same path, or the collectives would not match up
+                okflag = torch.tensor([1 if graph is not None else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(okflag, op=dist.ReduceOp.MIN)
+                if int(okflag.item()) == 0:
+                    graph = None
+            if graph is not None:
+                graph.replay()  # one untimed replay (instantiation / upload)
+                fence()
+        return graph
+
+    def sample(graph, with_gather):
+        """One timed region: exactly K steps between barrier + synchronize on both sides.  Returns (wall seconds,
+        mean solve-kernel ms from HIP events on the launch stream)."""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev, pending = [], []
+        fence()
+        t0 = time.perf_counter()
         if graph is not None:
-            graph.replay()  # one untimed replay (instantiation / upload)
-            fence()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev = []
-    fence()
-    t0 = time.perf_counter()
-    if graph is not None:
-        e0.record()
-        graph.replay()
-        e1.record()
-    else:
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        for k in range(args.steps):
-            w = step(k, ev[k])
-            if w is not None:
-                pending.append(w)
-                if len(pending) > 1:
-                    pending.pop(0).wait()
-        for w in pending:
-            w.wait()
-    fence()
-    elapsed = time.perf_counter() - t0
+            e0.record()
+            graph.replay()
+            e1.record()
+        else:
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+            for k in range(args.steps):
+                w = step(k, with_gather, ev[k])
+                if w is not None:
+                    pending.append(w)
+                    if len(pending) > 1:
+                        pending.pop(0).wait()
+            for w in pending:
+                w.wait()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if graph is not None:
+            # HIP events around the replay: K kernels back to back, so this average includes the ~1.5 us
+            # kernel-to-kernel boundary (an upper bound of the pure kernel duration; the rocprofv3 summary under
+            # profiles/ has the exact figure)
+            kernel_ms = e0.elapsed_time(e1) / args.steps
+        else:
+            kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        return elapsed, kernel_ms
 
-    if collective:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        if rank == 0 and args.steps > 0 and gather:  # the gathered buffer holds every rank's torques in rank order
-            last = (args.steps - 1) & 1
-            assert torch.equal(gathered[last][:B], tau[last]), "all-gather layout"
+    def measure(with_gather):
+        graph = build_graph(with_gather)
+        n = max(1, args.replays)
+        el = np.zeros(n)
+        km = np.zeros(n)
+        for r in range(n):
+            el[r], km[r] = sample(graph, with_gather)
+        if collective:  # a sample lasts as long as its slowest rank
+            t = torch.from_numpy(el).to(dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.cpu().numpy()
+        pick = int(np.argsort(el)[n // 2])  # the median sample is the timed region reported
+        return dict(elapsed=float(el[pick]), kernel_ms=float(np.median(km)), samples_ms=[float(x * 1e3) for x in el],
+                    graph=graph is not None)
 
-    if graph is not None:
-        # HIP events around the replay: K kernels back to back, so this average includes the
-        # ~1.5 us kernel-to-kernel boundary (an upper bound of the pure kernel duration; the
-        # rocprofv3 summary under profiles/ has the exact figure)
-        kernel_ms = e0.elapsed_time(e1) / args.steps
-    else:
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    res = measure(gather)
+    res_plain = measure(False) if (gather and world > 1) else None
+
+    if collective and rank == 0 and args.steps > 0 and gather:  # the gathered buffer holds every rank's torques in rank order
+        last = (args.steps - 1) & 1
+        assert torch.equal(gathered[last][:B], tau[last]), "all-gather layout"
+
     st = status.cpu().numpy()
     ok = bool((st == 0).all())
+    if collective:
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item())
 
     if rank == 0:
+        elapsed, kernel_ms = res["elapsed"], res["kernel_ms"]
         total = world * B * args.steps
         value = total / elapsed
         algo_bytes = ALGO_BYTES_PER_STEP * B
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        wl = "static-%s" % args.errors if args.gait == "static" else "trot"
+        rec, prov = pmc_record("balance_coop_kernel", B, wl)
         line = {
             "metric": "control-step QP solves/sec (18-DoF, 4-contact) at 1/2/4/8 MI355X",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -472,19 +609,31 @@ def main():
                                    "(virtual-model wrench + leg FK + force-distribution QP + torques) per robot"
                                    % (B, "static 4-contact stance" if args.gait == "static"
                                       else "trot gait (2<->4 contacts)"),
-                       "robots_per_gpu": B, "gait": args.gait, "seed": synth.SEED,
+                       "robots_per_gpu": B, "global_batch": world * B, "gait": args.gait, "seed": synth.SEED,
+                       "tracking_error": list(synth.tracking_error(args.gait, args.errors)),
+                       "tracking_error_note": "half-widths of the uniform position (m) / rotation-vector (rad) / twist errors; "
+                                              "SURVEY.md 8(d) lists 0.02 / 0.05 / 0.1 (--errors survey), the static default is "
+                                              "smaller so that constraints are mostly inactive (DESIGN.md 2)",
                        "result_collection": "rccl all_gather of torques" if gather else
                        ("none (--no-gather)" if collective else "none (single GPU)"),
-                       "launch": "hipGraph of K steps" if graph is not None else "eager",
+                       "rccl_ranks": ranks_seen if collective else None,
+                       "launch": "hipGraph of K steps" if res["graph"] else "eager",
+                       "timed_region": "median of %d samples of exactly K steps, each between barrier + synchronize" % len(res["samples_ms"]),
+                       "samples_ms": res["samples_ms"],
                        "all_status_ok": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": MEASURED_TRAFFIC_BYTES.get((B, args.gait)),
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": int(rec["fetch_bytes"] + rec["write_bytes"]) if rec else None, "traffic_source": prov,
                          "kernel": "balance_coop_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
-        insts = MEASURED_VALU_INSTS.get((B, args.gait))
-        if insts is not None:
+        if res_plain is not None:
+            line["without_gather"] = {"value": total / res_plain["elapsed"], "ms_per_step": res_plain["elapsed"] / args.steps * 1e3,
+                                      "samples_ms": res_plain["samples_ms"]}
+        if rec and rec.get("valu_insts"):
+            insts = rec["valu_insts"]
             line["valu_issue"] = {"insts_per_launch": insts, "frac": insts * 4.0 / (N_SIMD * kernel_ms * 1e-3 * SHADER_CLOCK_HZ),
+                                  "source": prov,
                                   "note": "SQ_INSTS_VALU (rocprofv3 --pmc) x 4 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz)"}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(state, args.cpu_seconds)

@@ -215,6 +215,24 @@ def balance_batch(state, params=None, normals_world=None, nthreads=1):
     return tau, grf, status
 
 
+def balance_batch_repeat(state, passes, nthreads, params=None):
+    """`passes` passes over the batch inside one parallel region (bench.py cpu_baseline); returns the wall seconds
+    measured in C between two barriers."""
+    prm = params or default_params()
+    B = int(np.asarray(state["q"]).reshape(-1, 12).shape[0])
+    ptrs, keep = [], []
+    for name, k in STATE_FIELDS:
+        a, p = _d(np.asarray(state[name]).reshape(B, k))
+        keep.append(a)
+        ptrs.append(p)
+    st = np.ascontiguousarray(np.asarray(state["stance"]).reshape(B, 4), dtype=np.uint8)
+    tau, status = np.zeros((B, 12)), np.zeros(B, dtype=np.int32)
+    fn = lib().oracle_balance_batch_repeat
+    fn.restype = C.c_double
+    return float(fn(C.byref(prm), C.c_int64(B), *ptrs, st.ctypes.data_as(C.POINTER(C.c_uint8)), tau.ctypes.data_as(_dp),
+                    status.ctypes.data_as(C.POINTER(C.c_int32)), int(nthreads), int(passes)))
+
+
 def virtual_wrench(state, i=0, params=None):
     prm = params or default_params()
     ptrs, keep = [], []

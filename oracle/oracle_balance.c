@@ -307,3 +307,44 @@ void oracle_balance_batch(const oracle_balance_params *prm, int64_t B,
   }
   (void)nthreads;
 }
+
+/* Timing leg of bench.py's cpu_baseline: `passes` passes over the batch inside ONE parallel region (each thread
+ * keeps its contiguous block of robots, no fork/join between passes), wall time taken between two barriers.
+ * Returns the seconds; the outputs hold the last pass. */
+double oracle_balance_batch_repeat(const oracle_balance_params *prm, int64_t B,
+                                   const double *q, const double *base_pos, const double *base_quat,
+                                   const double *base_linvel, const double *base_angvel,
+                                   const double *des_pos, const double *des_quat,
+                                   const double *des_linvel, const double *des_angvel,
+                                   const uint8_t *stance, double *tau, int32_t *status, int nthreads, int passes) {
+  double t0 = 0.0, t1 = 0.0;
+  if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+  {
+    const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+  {
+    const int tid = 0, nt = 1;
+#endif
+    const int64_t lo = B * tid / nt, hi = B * (tid + 1) / nt;
+#ifdef _OPENMP
+#pragma omp barrier
+#pragma omp master
+    t0 = omp_get_wtime();
+#endif
+    for (int p = 0; p < passes; p++)
+      for (int64_t i = lo; i < hi; i++) {
+        int st = oracle_balance_step(prm, q + 12 * i, base_pos + 3 * i, base_quat + 4 * i, base_linvel + 3 * i,
+                                     base_angvel + 3 * i, des_pos + 3 * i, des_quat + 4 * i, des_linvel + 3 * i,
+                                     des_angvel + 3 * i, stance + 4 * i, NULL, tau + 12 * i, NULL, NULL, NULL, NULL, NULL);
+        status[i] = st;
+      }
+#ifdef _OPENMP
+#pragma omp barrier
+#pragma omp master
+    t1 = omp_get_wtime();
+#endif
+  }
+  return t1 - t0;
+}

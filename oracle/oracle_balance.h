@@ -90,4 +90,12 @@ void oracle_force_qp_assemble(const oracle_balance_params *prm, int nS,
 #ifdef __cplusplus
 }
 #endif
+/* bench.py cpu_baseline: `passes` passes inside one OpenMP region; returns the wall seconds. */
+double oracle_balance_batch_repeat(const oracle_balance_params *prm, int64_t B,
+                                   const double *q, const double *base_pos, const double *base_quat,
+                                   const double *base_linvel, const double *base_angvel,
+                                   const double *des_pos, const double *des_quat,
+                                   const double *des_linvel, const double *des_angvel,
+                                   const uint8_t *stance, double *tau, int32_t *status, int nthreads, int passes);
+
 #endif

@@ -50,7 +50,21 @@ def _quat_exp(rv):
     return np.concatenate([np.cos(0.5 * ang)[..., None], rv * k[..., None]], axis=-1)
 
 
-def make_states(batch, gait="static", seed=SEED, offset=0):
+# Half-widths of the uniform tracking errors (position m, rotation vector rad, twist m/s or rad/s).
+# "calm": a robot holding its pose -- SURVEY.md 8(d) expects "mostly inactive constraints" for the static configs,
+# and with the reference gains (Kd = 5000 N s/m) that needs errors this small.  "survey": the literal half-widths
+# of SURVEY.md 8(d), which saturate the friction pyramid on most robots (about twice the work per control step).
+TRACKING_ERRORS = {"calm": (0.004, 0.005, 0.01), "survey": (0.02, 0.05, 0.1)}
+
+
+def tracking_error(gait, errors=None):
+    """The half-widths make_states uses: static defaults to "calm", trot always takes the survey's."""
+    if gait != "static":
+        return TRACKING_ERRORS["survey"]
+    return TRACKING_ERRORS[errors or "calm"]
+
+
+def make_states(batch, gait="static", seed=SEED, offset=0, errors=None):
     """Return a dict of numpy arrays for robots [offset, offset+batch).
 
     gait = "static": all four feet in stance (BASELINE configs 1-2).
@@ -62,7 +76,7 @@ def make_states(batch, gait="static", seed=SEED, offset=0):
     B = batch
     # static stance: a robot holding its pose (small tracking errors, QP constraints mostly
     # inactive); trot: large tracking errors that load the friction pyramid (active-set churn)
-    e_pos, e_rot, e_twist = (0.004, 0.005, 0.01) if gait == "static" else (0.02, 0.05, 0.1)
+    e_pos, e_rot, e_twist = tracking_error(gait, errors)
     sym = lambda c, half: (2.0 * u[:, c] - 1.0) * half  # noqa: E731
     c = 0
 
@@ -184,3 +198,29 @@ def make_wholebody_states(batch, gait="trot", seed=SEED, offset=0):
         lin[:, 1] = 9.81 * ratio * np.sin(theta)
     s["a_des"] = np.ascontiguousarray(np.concatenate([lin, ang], axis=1))
     return s
+
+
+# ---------------------------------------------------------------------------------------------
+# Serialised /desired_robot_state messages, one per robot: the command side of a tick.
+def make_messages(batch, ragged=False, seed=SEED + 21, mode_names=None):
+    """(blob uint8, offsets int64[B+1], fields) -- `fields` holds what the messages carry, [B][k] arrays.
+    ragged = False: one publisher's layout (every message has the same field offsets, payloads differ);
+    ragged = True: every message has its own string lengths and array counts."""
+    from . import wire
+    rng = np.random.default_rng(seed)
+    names = list(mode_names) if mode_names is not None else list(wire.MODE_NAMES) + ["", "LF_LEG", "footsteps", "Joint"]
+    fields = dict(des_pos=rng.normal(size=(batch, 3)), des_quat=rng.normal(size=(batch, 4)), des_linvel=rng.normal(size=(batch, 3)),
+                  des_angvel=rng.normal(size=(batch, 3)), joint_command=rng.normal(size=(batch, 12)),
+                  foot_position=rng.normal(size=(batch, 12)), foot_velocity=rng.normal(size=(batch, 12)),
+                  foot_acceleration=rng.normal(size=(batch, 12)), surface_normal=rng.normal(size=(batch, 12)),
+                  phase=rng.random((batch, 4)), support_leg=rng.integers(0, 2, (batch, 4)).astype(np.uint8))
+    pick = rng.integers(0, len(names), (batch, 4))
+    fields["leg_mode"] = np.array([[wire.MODE_CODE.get(names[k], 0) for k in row] for row in pick], dtype=np.uint8)
+    one = wire.random_layout(np.random.default_rng(seed + 1))
+    msgs = []
+    for b in range(batch):
+        f = {k: v[b] for k, v in fields.items() if k != "leg_mode"}
+        f["mode_name"] = [names[k] for k in pick[b]]
+        msgs.append(wire.pack_robot_state(f, wire.random_layout(rng) if ragged else one))
+    blob, off = wire.pack_batch(msgs)
+    return blob, off, fields

@@ -55,3 +55,37 @@ def test_two_rank_shards_equal_one_global_batch(oracle, tmp_path):
     whole = synth.make_states(world * B, "trot")
     tau, _, _ = oracle.balance_batch(whole)
     assert np.array_equal(gathered, tau)  # rank order == robot order, bitwise
+
+
+def _run_bench(*argv, env=None):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True,
+                          timeout=600, cwd=ROOT, env=e)
+
+
+def test_bench_launches_its_own_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` without torch.distributed.run around it: the parent starts the two ranks as a child
+    process; here over gloo with the launcher self-test standing in for the solve (no GPU in this container).  The
+    N > 1 defaults are BASELINE configs[3]: 8192 trot robots per GPU."""
+    import json
+    out = _run_bench("--gpus", "2", "--selftest-launcher")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["world_size"] == 2 and d["ranks_seen"] == 2 and d["gather_layout_ok"] and d["max_over_ranks_ok"]
+    assert d["robots_per_rank"] == 8192 and d["gait"] == "trot"
+
+
+def test_bench_reports_a_failed_rank_with_a_nonzero_exit():
+    """Without a GPU the ranks refuse to run (no CPU fallback); the parent must hand that failure on."""
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    out = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64")
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
