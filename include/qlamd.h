@@ -7,6 +7,15 @@
  *
  * The library needs a HIP device (gfx950).  There is NO CPU fallback: without
  * a usable device qlamd_context_create() fails with QLAMD_ERR_NO_DEVICE.
+ *
+ * Threads and streams.  A context is a single-threaded object, like the reference's controller whose
+ * update() and callbacks share one mutex (ros_balance_controller.hpp:142): it owns scratch memory (staging
+ * slab, the intermediates of the whole tick, the layout template of the message parser) that every call
+ * reuses.  Two calls on one context must not overlap: a second thread entering while a call is in progress
+ * gets QLAMD_ERR_BUSY.  QLAMD_MEM_DEVICE calls are asynchronous on `stream`; work queued on one context must
+ * stay ordered, so when a call arrives on another stream than the previous call the library first waits for
+ * the previous stream to drain (not possible while the new stream is being captured into a hipGraph: the
+ * capturing caller orders the graph itself).  Use one context per thread / per concurrent stream.
  */
 #ifndef QLAMD_H
 #define QLAMD_H
@@ -19,7 +28,7 @@ extern "C" {
 #endif
 
 #define QLAMD_VERSION_MAJOR 0
-#define QLAMD_VERSION_MINOR 3
+#define QLAMD_VERSION_MINOR 4
 
 /* ---- return codes of the API calls ------------------------------------- */
 #define QLAMD_OK 0
@@ -30,12 +39,16 @@ extern "C" {
                                          checkIfParametersLoaded() == false,
                                          ContactForceDistribution.cpp:103     */
 #define QLAMD_ERR_OUT_OF_MEMORY (-5)
+#define QLAMD_ERR_BUSY (-6)           /* another thread is inside a call on this context */
 
 /* ---- per-robot status words (int32) ------------------------------------ */
 #define QLAMD_STATUS_OK 0
 #define QLAMD_STATUS_INFEASIBLE 1     /* QuadProg++ returns +inf, QuadProg++.cc:339-344 */
 #define QLAMD_STATUS_NOT_PD 2         /* QuadProg++ throws logic_error, QuadProg++.cc:692-699 */
 #define QLAMD_STATUS_MAX_ITER 3       /* iteration guard hit (no reference counterpart) */
+#define QLAMD_STATUS_NO_COMMAND 4     /* whole tick only: no well-formed command message has reached this robot yet;
+                                         nothing of the robot was read or written (the reference's update() runs on
+                                         the last command baseCommandCallback stored, ros_balance_controller.cpp:761) */
 
 /* ---- where caller buffers live ------------------------------------------ */
 #define QLAMD_MEM_DEVICE 0            /* device pointers, used in place, async on `stream` */
@@ -124,13 +137,33 @@ void qlamd_context_destroy(qlamd_context *ctx);
  * 16 / 64 = one lane per robot (throughput kernel); 0 = choose from the batch size. */
 int qlamd_set_robots_per_wave(qlamd_context *ctx, int robots_per_wave);
 
+/* Context options (set once after creation or between calls; never read from the process environment).
+ *   QLAMD_OPT_ON_FAILURE   what a robot whose QP solve fails (status != QLAMD_STATUS_OK) gets in joint_effort /
+ *                          contact_force: QLAMD_ON_FAILURE_ZERO (default) writes 0 for all 12 entries -- a caller
+ *                          that ignores status[] then commands a limp leg, so check status[]; QLAMD_ON_FAILURE_KEEP
+ *                          leaves the robot's entries untouched: with one effort array reused tick after tick that is
+ *                          the reference's behaviour, whose update() logs "VMC compute failed" and commands the
+ *                          efforts still held in State from the previous tick (ros_balance_controller.cpp:418-424,441-454).
+ *   QLAMD_OPT_REFINE_PASSES  refinement passes of the lane-cooperative force QP on its final working set (default 1)
+ *   QLAMD_OPT_QP_ONE_LANE / QLAMD_OPT_POSE_ONE_LANE / QLAMD_OPT_WHOLEBODY_SPLIT  1 selects the second implementation
+ *                          of the dense QP batch (then m <= 24) / the pose SQP / the two-launch dynamics (diagnostics). */
+#define QLAMD_OPT_ON_FAILURE 1
+#define QLAMD_OPT_REFINE_PASSES 2
+#define QLAMD_OPT_QP_ONE_LANE 3
+#define QLAMD_OPT_POSE_ONE_LANE 4
+#define QLAMD_OPT_WHOLEBODY_SPLIT 5
+#define QLAMD_ON_FAILURE_ZERO 0
+#define QLAMD_ON_FAILURE_KEEP 1
+int qlamd_set_option(qlamd_context *ctx, int option, int value);
+
 /* One control step for `batch` robots: virtual-model wrench -> leg FK ->
  * contact-force-distribution QP -> joint torques, clamped.
  * Replaces VirtualModelController::compute() (VirtualModelController.cpp:89-102)
  * -> ContactForceDistribution::computeForceDistribution() (ContactForceDistribution.cpp:99-136)
  * and the effort read-out + clamp of RosBalanceController::update
  * (ros_balance_controller.cpp:441-454).
- *   joint_effort   [B][12]  out, clamped to +-torque_limit, 0 for non-support legs
+ *   joint_effort   [B][12]  out, clamped to +-torque_limit, 0 for non-support legs; for a robot whose status is
+ *                           not QLAMD_STATUS_OK: all 12 entries 0, or untouched with QLAMD_ON_FAILURE_KEEP
  *   contact_force  [B][12]  out or NULL: QP solution x = ground reaction forces in
  *                           the base frame (desiredContactForce_ = -x,
  *                           ContactForceDistribution.cpp:502-503), 0 for non-support legs
@@ -471,8 +504,13 @@ int qlamd_wholebody_solve_batch(qlamd_context *ctx, const qlamd_wholebody_params
  *   update() :467-603   swing branch for the others (joint PID / gravity compensation / swing-leg inverse dynamics)
  * i.e. qlamd_robot_state_unpack_batch -> qlamd_leg_state_machine_batch -> qlamd_balance_solve_batch ->
  * qlamd_swing_branch_batch with the intermediate arrays kept in device memory by the context.  A leg mode name the
- * plugin does not know leaves that leg's mode as it was (:876-964); a message that cannot be parsed (message_status
- * != QLAMD_WIRE_OK) leaves the robot's desired state zeroed for this tick, as qlamd_robot_state_unpack_batch does.
+ * plugin does not know leaves that leg's mode as it was (:876-964).
+ * A message that cannot be parsed (message_status != QLAMD_WIRE_OK) never reaches baseCommandCallback in the
+ * reference: update() keeps running on the last command stored.  Here the command in force lives in `command`
+ * (caller-owned, opaque, qlamd_tick_command_bytes(batch) bytes, zero-filled before the first tick, in/out): a
+ * well-formed message replaces the robot's stored command, a malformed one leaves it and the tick runs on the stored
+ * one.  A robot that has no stored command yet (or every robot with a malformed message when `command` is NULL) is
+ * skipped: status = QLAMD_STATUS_NO_COMMAND, its joint_effort and all its persistent arrays stay untouched.
  * All arrays [B][k]; persistent arrays are caller-owned so that a controller can be checkpointed. */
 typedef struct qlamd_tick_batch {
   /* in: this tick */
@@ -499,7 +537,11 @@ typedef struct qlamd_tick_batch {
   int8_t *leg_state_code;               /* [B][4]  or NULL */
   int32_t *status;                      /* [B]     QLAMD_STATUS_* of the balance solve */
   int32_t *message_status;              /* [B]     QLAMD_WIRE_* */
+  /* in/out, optional */
+  void *command;                        /* qlamd_tick_command_bytes(B) bytes or NULL: the command in force per robot */
 } qlamd_tick_batch;
+
+size_t qlamd_tick_command_bytes(int64_t batch);
 
 int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, const qlamd_joint_pid_params *pid,
                           const qlamd_tick_batch *io, double period, int index_quirk, int64_t batch, int memory,

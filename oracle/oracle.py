@@ -535,3 +535,33 @@ def wb_step_batch(s, params=None, nthreads=1):
                                tau.ctypes.data_as(_dp), grf.ctypes.data_as(_dp), st.ctypes.data_as(C.POINTER(C.c_int)),
                                int(nthreads))
     return tau, grf, st
+
+
+# ---- the whole control tick (oracle_tick.c) ---------------------------------------------------------------
+class TickState(C.Structure):
+    _fields_ = [("has_command", C.c_int), ("command", RobotStateFields), ("limb_state", C.c_int8 * 4), ("store_flag", C.c_uint8 * 4),
+                ("stored_joint_position", C.c_double * 12), ("leg_mode", C.c_uint8 * 4), ("support", C.c_uint8 * 4),
+                ("pid_error_last", C.c_double * 12), ("pid_error_integral", C.c_double * 12), ("joint_effort", C.c_double * 12)]
+
+
+def new_tick_state():
+    """A controller that has not run yet: all zero, every leg a support leg (State's constructor)."""
+    s = TickState()
+    for l in range(4):
+        s.support[l] = 1
+    return s
+
+
+def full_tick(s, msg, q, qd, qd_oldest, base_pos, base_quat, base_linvel, base_angvel, contact, period, index_quirk=1,
+              keep_on_failure=0, params=None, swing=None, pid=None):
+    """oracle_full_tick on one robot; `s` (TickState) is updated in place.  Returns (status, message_status, leg_state_code)."""
+    prm, sp, pp = params or default_params(), swing or default_swing_params(), pid or default_pid_params()
+    buf = (C.c_uint8 * max(len(msg), 1)).from_buffer_copy(bytes(msg) if len(msg) else b"\0")
+    a = [_d(v) for v in (q, qd, qd_oldest, base_pos, base_quat, base_linvel, base_angvel)]
+    con = np.ascontiguousarray(contact, dtype=np.uint8)
+    code = np.zeros(4, np.int8)
+    mst = C.c_int()
+    st = lib().oracle_full_tick(C.byref(prm), C.byref(sp), C.byref(pp), buf, C.c_size_t(len(msg)), *[x[1] for x in a],
+                                con.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_double(period), int(index_quirk), int(keep_on_failure),
+                                C.byref(s), code.ctypes.data_as(C.POINTER(C.c_int8)), C.byref(mst))
+    return st, mst.value, code

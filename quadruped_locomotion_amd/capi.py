@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libqlamd.so")
 
 OK = 0
-ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_LOADED, ERR_OUT_OF_MEMORY = -1, -2, -3, -4, -5
+ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_LOADED, ERR_OUT_OF_MEMORY, ERR_BUSY = -1, -2, -3, -4, -5, -6
 STATUS_OK, STATUS_INFEASIBLE, STATUS_NOT_PD, STATUS_MAX_ITER = 0, 1, 2, 3
 MEM_DEVICE, MEM_HOST = 0, 1
 
@@ -27,7 +27,7 @@ EXPORTS = (
     "qlamd_ik_default_params", "qlamd_leg_inverse_kinematics_batch",
     "qlamd_joint_pid_default_params", "qlamd_swing_branch_batch",
     "qlamd_wholebody_default_params", "qlamd_wholebody_dynamics_batch", "qlamd_wholebody_solve_batch",
-    "qlamd_full_tick_batch",
+    "qlamd_full_tick_batch", "qlamd_set_option", "qlamd_tick_command_bytes",
 )
 
 
@@ -86,7 +86,7 @@ TICK_FIELDS = (("messages", np.uint8), ("offsets", np.int64), ("joint_position",
                ("base_linear_velocity", np.float64), ("base_angular_velocity", np.float64), ("contact", np.uint8),
                ("limb_state", np.int8), ("store_flag", np.uint8), ("stored_joint_position", np.float64), ("leg_mode", np.uint8), ("support", np.uint8),
                ("pid_error_last", np.float64), ("pid_error_integral", np.float64), ("joint_effort", np.float64),
-               ("leg_state_code", np.int8), ("status", np.int32), ("message_status", np.int32))
+               ("leg_state_code", np.int8), ("status", np.int32), ("message_status", np.int32), ("command", np.uint8))
 
 
 class TickBatch(C.Structure):
@@ -278,6 +278,12 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, option, value):
+        """qlamd_set_option (OPT_* / ON_FAILURE_* below)."""
+        rc = lib().qlamd_set_option(self._h, int(option), int(value))
+        if rc != OK:
+            raise QlamdError(rc, "qlamd_set_option")
 
     def set_robots_per_wave(self, rpw):
         rc = lib().qlamd_set_robots_per_wave(self._h, int(rpw))
@@ -700,10 +706,23 @@ def wholebody_dynamics_device(ctx, dstate, M, h, Jc, gravity=9.81, stream=None):
         raise QlamdError(rc, "qlamd_wholebody_dynamics_batch")
 
 
+OPT_ON_FAILURE, OPT_REFINE_PASSES, OPT_QP_ONE_LANE, OPT_POSE_ONE_LANE, OPT_WHOLEBODY_SPLIT = 1, 2, 3, 4, 5
+ON_FAILURE_ZERO, ON_FAILURE_KEEP = 0, 1
+STATUS_NO_COMMAND = 4
+
+
+def tick_command_bytes(batch):
+    """Size of the opaque `command` block of qlamd_tick_batch (zero-filled before the first tick)."""
+    fn = lib().qlamd_tick_command_bytes
+    fn.restype = C.c_size_t
+    fn.argtypes = [C.c_int64]
+    return int(fn(int(batch)))
+
+
 def full_tick(ctx, io, period, index_quirk=1, params=None, pid=None, memory=MEM_HOST, stream=None):
     """qlamd_full_tick_batch.  `io`: dict with the fields of qlamd_tick_batch (TICK_FIELDS: C-contiguous numpy arrays of
-    those dtypes for host memory, torch CUDA tensors for device memory; `leg_state_code` may be None); in/out and out
-    arrays are updated in place."""
+    those dtypes for host memory, torch CUDA tensors for device memory; `leg_state_code` and `command` may be None);
+    in/out and out arrays are updated in place."""
     prm = params if params is not None else default_swing_params()
     pidp = pid if pid is not None else default_joint_pid_params()
     tb = TickBatch()

@@ -171,6 +171,7 @@ struct CoopPtrs {
   const uint8_t *stance;
   const double *normals;
   const double *wrench; // [B][6] or NULL: externally supplied (F_B, T_B)
+  const uint8_t *live;  // [B] or NULL: 0 = leave this robot alone (whole tick: no command in force), nothing is written
 };
 
 // One robot per 16-lane row.  lds_tab: 256-double model table; lds_row: this robot's private
@@ -178,9 +179,10 @@ struct CoopPtrs {
 constexpr int kCoopLdsDoubles = 12 * 12 + 12;
 
 template <bool kPerLeg>
-__device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs &s, int64_t irobot, bool robot_live,
+__device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs &s, int64_t irobot, bool robot_live_in,
                                            double *lds_tab, double *lds_row, double *__restrict__ tau_out,
                                            double *__restrict__ grf_out, int32_t *__restrict__ status_out) {
+  bool robot_live = robot_live_in;
   const int lr = threadIdx.x & 15;   // lane in row
   const int leg = lr >> 2, c = lr & 3;
   const bool comp = c < 3;           // carries a variable / matrix row
@@ -216,6 +218,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   }
   const uint32_t sm = *reinterpret_cast<const uint32_t *>(s.stance + 4 * i);
   const double qj = s.q[12 * i + (comp ? myidx : 0)];
+  const uint8_t alive = s.live ? s.live[i] : (uint8_t)1;
   double wr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; // externally supplied (F_B, T_B), if any: issued with the rest
   if (s.wrench) {
 #pragma unroll
@@ -224,6 +227,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   double nWl[3] = {0.0, 0.0, 1.0}; // caller-supplied surface normal of my leg (world frame), if any
   if (kPerLeg) { nWl[0] = s.normals[12 * i + 3 * leg]; nWl[1] = s.normals[12 * i + 3 * leg + 1]; nWl[2] = s.normals[12 * i + 3 * leg + 2]; }
   // (all loads above are in flight before the first of them is consumed)
+  robot_live = robot_live && alive != 0;
   const unsigned stance = robot_live ? (((sm & 0xFFu) ? 1u : 0u) | ((sm & 0xFF00u) ? 2u : 0u) |
                                         ((sm & 0xFF0000u) ? 4u : 0u) | ((sm & 0xFF000000u) ? 8u : 0u))
                                      : 0u;
@@ -413,7 +417,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     c2 = row_sum(sel(row_on, rp, 0.0));
     if (bad && nS > 0) {
       if (lr == 0 && robot_live) status_out[i] = kStatusNotPd;
-      if (comp && robot_live) { tau_out[12 * i + myidx] = 0.0; if (grf_out) grf_out[12 * i + myidx] = 0.0; }
+      if (comp && robot_live && !P.keep_on_failure) { tau_out[12 * i + myidx] = 0.0; if (grf_out) grf_out[12 * i + myidx] = 0.0; }
       return;
     }
   }
@@ -634,7 +638,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     double t = sel(c == 0, t0, sel(c == 1, t1, t2));
     t = t > P.tau_max ? P.tau_max : t;
     t = t < -P.tau_max ? -P.tau_max : t;
-    if (comp && robot_live) {
+    if (comp && robot_live && !(P.keep_on_failure && status != kStatusOk)) {
       tau_out[12 * i + myidx] = live ? t : 0.0;
       if (grf_out) grf_out[12 * i + myidx] = live ? x : 0.0;
     }

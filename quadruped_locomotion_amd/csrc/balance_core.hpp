@@ -69,6 +69,7 @@ struct DeviceParams {
   // (ixx ixy ixz iyy iyz izz, link frame); offsets below
   double legtab[4 * 88];
   int refine_passes;           // lane-cooperative kernel: refinement passes on the final working set
+  int keep_on_failure;         // QLAMD_OPT_ON_FAILURE: 1 = leave the efforts / forces of a robot whose solve failed untouched
 };
 constexpr int kTabR0 = 0, kTabXyz = 36, kTabMass = 48, kTabMcom = 52, kTabInertia = 64, kTabPerLeg = 88;
 

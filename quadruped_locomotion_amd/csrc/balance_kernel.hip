@@ -14,6 +14,7 @@ struct StatePtrs {
   const uint8_t *stance;
   const double *normals;
   const double *wrench; // [B][6] or NULL
+  const uint8_t *live;  // [B] or NULL: 0 = robot left alone (nothing written)
 };
 
 __device__ __forceinline__ void load_robot(const StatePtrs &s, int64_t i, RobotIn &in) {
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(64) void balance_step_kernel(const DeviceParams *__
   for (int item = lane; item < 4 * RPW; item += 64) {
     const int rb = item >> 2, leg = item & 3;
     const int64_t i = base + rb;
-    if (i < B) {
+    if (i < B && (!s.live || s.live[i])) {
       const bool support = s.stance[4 * i + leg] != 0;
       const double q3[3] = {s.q[12 * i + 3 * leg], s.q[12 * i + 3 * leg + 1], s.q[12 * i + 3 * leg + 2]};
       const double2 *a2 = reinterpret_cast<const double2 *>(s.quat + 4 * i);
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(64) void balance_step_kernel(const DeviceParams *__
   // ---- phase B
   {
     const int64_t i = base + lane;
-    if (lane < RPW && i < B) {
+    if (lane < RPW && i < B && (!s.live || s.live[i])) {
       RobotIn in;
       load_robot(s, i, in);
       double nw[12];
@@ -114,8 +115,9 @@ __global__ __launch_bounds__(64) void balance_step_kernel(const DeviceParams *__
   for (int item = lane; item < 4 * RPW; item += 64) {
     const int rb = item >> 2, leg = item & 3;
     const int64_t i = base + rb;
-    if (i < B) {
+    if (i < B && (!s.live || s.live[i])) {
       LdsScratch scr{scratch + rb, RPW};
+      if (P.keep_on_failure && scr.at(kScrStatus) != 0.0) continue;
       const bool live = (s.stance[4 * i + leg] != 0) && (scr.at(kScrStatus) == 0.0);
       double t[3], f[3];
       phase_c_leg(leg, live, P.tau_max, scr, t, f);
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(64) void balance_coop_kernel(const DeviceParams *__
   const bool live = i < B;
   if (!live) i = B - 1;
   const coop::CoopPtrs cp{s.q, s.pos, s.quat, s.linvel, s.angvel, s.dpos, s.dquat, s.dlinvel, s.dangvel, s.stance,
-                          s.normals, s.wrench};
+                          s.normals, s.wrench, s.live};
 #ifdef QLAMD_STAMPS
 #pragma unroll 1
   for (int rep = 0; rep < 2; rep++) // second pass runs with a warm instruction cache
@@ -267,6 +269,7 @@ const char *qlamd_strerror(int code) {
     case QLAMD_ERR_HIP: return "HIP runtime error";
     case QLAMD_ERR_NOT_LOADED: return "parameters not loaded";
     case QLAMD_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case QLAMD_ERR_BUSY: return "another thread is inside a call on this context";
     default: return "unknown error";
   }
 }
@@ -295,6 +298,11 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
   ctx->wire_flip = 0;
   ctx->tick_ws = nullptr;
   ctx->tick_ws_bytes = 0;
+  ctx->on_failure = QLAMD_ON_FAILURE_ZERO;
+  ctx->qp_one_lane = ctx->pose_one_lane = ctx->wb_split = 0;
+  ctx->depth = 0;
+  ctx->has_last_stream = false;
+  ctx->last_stream = nullptr;
   qlamd_robot_model m;
   if (model) m = *model; else default_robot_model(&m);
   build_device_params(*params, m, &ctx->params);
@@ -335,8 +343,37 @@ int qlamd_set_robots_per_wave(qlamd_context *ctx, int rpw) {
   return QLAMD_OK;
 }
 
-static int balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, const double *wrench, int64_t batch,
-                        double *joint_effort, double *contact_force, int32_t *status, int memory, void *stream) {
+int qlamd_set_option(qlamd_context *ctx, int option, int value) {
+  if (!ctx) return QLAMD_ERR_INVALID_ARGUMENT;
+  QL_ENTER(ctx, ctx->has_last_stream ? ctx->last_stream : nullptr);
+  switch (option) {
+    case QLAMD_OPT_ON_FAILURE:
+      if (value != QLAMD_ON_FAILURE_ZERO && value != QLAMD_ON_FAILURE_KEEP) return QLAMD_ERR_INVALID_ARGUMENT;
+      ctx->on_failure = value;
+      ctx->params.keep_on_failure = value == QLAMD_ON_FAILURE_KEEP;
+      break;
+    case QLAMD_OPT_REFINE_PASSES:
+      if (value < 0 || value > 4) return QLAMD_ERR_INVALID_ARGUMENT;
+      ctx->params.refine_passes = value;
+      break;
+    case QLAMD_OPT_QP_ONE_LANE: ctx->qp_one_lane = value != 0; return QLAMD_OK;
+    case QLAMD_OPT_POSE_ONE_LANE: ctx->pose_one_lane = value != 0; return QLAMD_OK;
+    case QLAMD_OPT_WHOLEBODY_SPLIT: ctx->wb_split = value != 0; return QLAMD_OK;
+    default: return QLAMD_ERR_INVALID_ARGUMENT;
+  }
+  // the device copy of the parameters: after everything already queued on the context has read the old one
+  if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(ctx->d_params, &ctx->params, sizeof(DeviceParams), hipMemcpyHostToDevice) != hipSuccess)
+    return QLAMD_ERR_HIP;
+  return QLAMD_OK;
+}
+
+} // extern "C"
+
+// live: device pointer [B] or NULL (whole tick, QLAMD_MEM_DEVICE only): robots with 0 are left alone
+int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, const double *wrench, const uint8_t *live,
+                            int64_t batch, double *joint_effort, double *contact_force, int32_t *status, int memory,
+                            void *stream) {
   if (!ctx || !in_user || batch < 0 || !joint_effort || !status) return QLAMD_ERR_INVALID_ARGUMENT;
   qlamd_state_batch filled = *in_user;
   const qlamd_state_batch *in = &filled;
@@ -356,6 +393,7 @@ static int balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, co
   if (batch == 0) return QLAMD_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
+  QL_ENTER(ctx, st);
   const size_t B = (size_t)batch;
 
   StatePtrs s;
@@ -399,7 +437,7 @@ static int balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, co
                   (const double *)(w + off[3]), (const double *)(w + off[4]), (const double *)(w + off[5]),
                   (const double *)(w + off[6]), (const double *)(w + off[7]), (const double *)(w + off[8]),
                   (const uint8_t *)(w + off[9]), in->surface_normal ? (const double *)(w + off[10]) : nullptr,
-                  wrench ? (const double *)(w + off[11]) : nullptr};
+                  wrench ? (const double *)(w + off[11]) : nullptr, nullptr};
     d_tau = (double *)(w + off[12]);
     d_grf = contact_force ? (double *)(w + off[13]) : nullptr;
     d_status = (int32_t *)(w + off[14]);
@@ -407,7 +445,7 @@ static int balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, co
     s = StatePtrs{in->joint_position, in->base_position, in->base_orientation, in->base_linear_velocity,
                   in->base_angular_velocity, in->desired_position, in->desired_orientation,
                   in->desired_linear_velocity, in->desired_angular_velocity, in->support_leg,
-                  in->surface_normal, wrench};
+                  in->surface_normal, wrench, live};
   }
 
   hipError_t e;
@@ -446,9 +484,11 @@ static int balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, co
   return QLAMD_OK;
 }
 
+extern "C" {
+
 int qlamd_balance_solve_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch, double *joint_effort,
                               double *contact_force, int32_t *status, int memory, void *stream) {
-  return balance_impl(ctx, in, nullptr, batch, joint_effort, contact_force, status, memory, stream);
+  return balance_impl(ctx, in, nullptr, nullptr, batch, joint_effort, contact_force, status, memory, stream);
 }
 
 int qlamd_force_distribution_batch(qlamd_context *ctx, const double *joint_position, const double *base_orientation,
@@ -462,7 +502,7 @@ int qlamd_force_distribution_batch(qlamd_context *ctx, const double *joint_posit
   in.base_orientation = base_orientation;
   in.support_leg = support_leg;
   in.surface_normal = surface_normal;
-  return balance_impl(ctx, &in, virtual_wrench, batch, joint_effort, contact_force, status, memory, stream);
+  return balance_impl(ctx, &in, virtual_wrench, nullptr, batch, joint_effort, contact_force, status, memory, stream);
 }
 
 int qlamd_virtual_wrench_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch, double *wrench,
@@ -475,10 +515,11 @@ int qlamd_virtual_wrench_batch(qlamd_context *ctx, const qlamd_state_batch *in, 
   if (batch == 0) return QLAMD_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
+  QL_ENTER(ctx, st);
   const size_t B = (size_t)batch;
   StatePtrs s{in->joint_position, in->base_position, in->base_orientation, in->base_linear_velocity,
               in->base_angular_velocity, in->desired_position, in->desired_orientation,
-              in->desired_linear_velocity, in->desired_angular_velocity, in->support_leg, nullptr, nullptr};
+              in->desired_linear_velocity, in->desired_angular_velocity, in->support_leg, nullptr, nullptr, nullptr};
   double *d_w = wrench;
   Staged sg;
   if (memory == QLAMD_MEM_HOST) {
@@ -491,7 +532,7 @@ int qlamd_virtual_wrench_batch(qlamd_context *ctx, const qlamd_state_batch *in, 
     if (rc != QLAMD_OK) return rc;
     s = StatePtrs{nullptr, sg.dev<const double>(a1), sg.dev<const double>(a2), sg.dev<const double>(a3),
                   sg.dev<const double>(a4), sg.dev<const double>(a5), sg.dev<const double>(a6), sg.dev<const double>(a7),
-                  sg.dev<const double>(a8), nullptr, nullptr, nullptr};
+                  sg.dev<const double>(a8), nullptr, nullptr, nullptr, nullptr};
     d_w = sg.dev<double>(o);
   }
   const unsigned grid = (unsigned)((batch + 63) / 64);
@@ -508,6 +549,7 @@ int qlamd_leg_kinematics_batch(qlamd_context *ctx, const double *joint_position,
   if (batch == 0) return QLAMD_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
+  QL_ENTER(ctx, st);
   const size_t B = (size_t)batch;
   const double *d_q = joint_position, *d_quat = base_orientation;
   double *d_f = foot_position, *d_j = jacobian, *d_g = gravity_torque;

@@ -5,7 +5,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <new>
+#include <thread>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -29,6 +31,15 @@ struct qlamd_context {
   size_t ws_bytes;
   void *pinned;        // page-locked mirror of the head of ws, for small host-buffer calls (one copy each way)
   size_t pinned_bytes;
+  // options (qlamd_set_option): never read from the environment
+  int on_failure, qp_one_lane, pose_one_lane, wb_split;
+  // one call at a time (include/qlamd.h, "Threads and streams"): owner thread and nesting depth of the call in
+  // progress, and the stream of the previous call
+  std::mutex gate;
+  std::thread::id owner;
+  int depth;
+  hipStream_t last_stream;
+  bool has_last_stream;
 };
 
 
@@ -75,6 +86,47 @@ __device__ __forceinline__ void load3(const double *p, int64_t t, double o[3]) {
   o[0] = p[3 * t]; o[1] = p[3 * t + 1]; o[2] = p[3 * t + 2];
 }
 
+
+// Entry guard of every call that uses the context.  A second thread entering while a call is in progress gets
+// QLAMD_ERR_BUSY (the whole tick nests calls on its own thread: allowed).  A call on another stream than the previous
+// one first waits for that stream, so that the scratch memory both calls use is never shared by work in flight;
+// while either stream is being captured into a graph the wait is skipped (it would invalidate the capture): the
+// capturing caller orders the graph.
+struct CallGuard {
+  qlamd_context *c;
+  int rc;
+  CallGuard(qlamd_context *ctx, hipStream_t st) : c(ctx), rc(QLAMD_OK) {
+    const std::thread::id me = std::this_thread::get_id();
+    {
+      std::lock_guard<std::mutex> lk(c->gate);
+      if (c->depth > 0 && c->owner != me) { rc = QLAMD_ERR_BUSY; c = nullptr; return; }
+      c->owner = me;
+      if (c->depth++ > 0) return;
+    }
+    if (c->has_last_stream && c->last_stream != st) {
+      hipStreamCaptureStatus a = hipStreamCaptureStatusNone, b = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(st, &a);
+      (void)hipStreamIsCapturing(c->last_stream, &b);
+      if (a == hipStreamCaptureStatusNone && b == hipStreamCaptureStatusNone) (void)hipStreamSynchronize(c->last_stream);
+      (void)hipGetLastError(); // a stream the caller has destroyed since is not an error of this call
+    }
+    c->last_stream = st;
+    c->has_last_stream = true;
+  }
+  ~CallGuard() {
+    if (!c) return;
+    std::lock_guard<std::mutex> lk(c->gate);
+    c->depth--;
+  }
+};
+#define QL_ENTER(ctx, st)                         \
+  ::qlamd::rt::CallGuard ql_guard_((ctx), (st));  \
+  if (ql_guard_.rc != QLAMD_OK) return ql_guard_.rc
+
+// balance_kernel.hip: the control step behind qlamd_balance_solve_batch / qlamd_force_distribution_batch, with the
+// whole tick's per-robot `live` flags (device pointer or NULL)
+int balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, const double *wrench, const uint8_t *live,
+                 int64_t batch, double *joint_effort, double *contact_force, int32_t *status, int memory, void *stream);
 
 inline int ensure_ws(qlamd_context *ctx, size_t bytes) {
   if (ctx->ws_bytes >= bytes) return QLAMD_OK;

@@ -65,7 +65,7 @@ inline void build_device_params(const qlamd_balance_params &p, const qlamd_robot
   d->w_reg = p.regularizer; d->mu = p.friction; d->f_min = p.min_normal_force; d->tau_max = p.torque_limit;
   d->grav = p.gravity;
   d->refine_passes = 1;
-  if (const char *e = getenv("QLAMD_REFINE_PASSES")) d->refine_passes = atoi(e);
+  d->keep_on_failure = 0;
   double mass = p.torso_mass;
   double arm[3] = {p.torso_mass * p.com_in_base[0], p.torso_mass * p.com_in_base[1], p.torso_mass * p.com_in_base[2]};
   for (int l = 0; l < 4; l++) {

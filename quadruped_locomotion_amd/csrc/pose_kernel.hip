@@ -327,6 +327,7 @@ static int pose_impl(const PoseCall &call, qlamd_context *ctx, const qlamd_pose_
   if (batch == 0) return QLAMD_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
+  QL_ENTER(ctx, st);
   const size_t B = (size_t)batch;
   PoseParamsDev P;
   memcpy(P.hips, params->hip_in_base, sizeof(P.hips));
@@ -375,7 +376,7 @@ static int pose_impl(const PoseCall &call, qlamd_context *ctx, const qlamd_pose_
   const size_t lds3 = (size_t)kPosePerWave * PoseQpGi::kTotal * sizeof(double);
   switch (mode) {
     case kPoseSqp:
-      if (getenv("QLAMD_POSE_ONE_LANE")) // the one-lane-per-problem form, kept as a second implementation
+      if (ctx->pose_one_lane) // the one-lane-per-problem form, kept as a second implementation
         hipLaunchKernelGGL(pose_sqp_kernel, dim3(grid), dim3(64), lds6, st, P, s, batch, d_out, d_it, d_st);
       else
         hipLaunchKernelGGL(pose_sqp_coop_kernel,
@@ -461,12 +462,13 @@ int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *
                          void *stream) {
   if (!ctx || batch < 0 || !G || !g0 || !x || !status) return QLAMD_ERR_INVALID_ARGUMENT;
   if (n < 1 || n > 12 || p < 0 || p > 2 || m < 0 || m > 48) return QLAMD_ERR_INVALID_ARGUMENT;
-  if (m > 24 && (p > 1 || getenv("QLAMD_QP_ONE_LANE"))) return QLAMD_ERR_INVALID_ARGUMENT; // 25..48 rows: cooperative kernel only
+  if (m > 24 && (p > 1 || ctx->qp_one_lane)) return QLAMD_ERR_INVALID_ARGUMENT; // 25..48 rows: cooperative kernel only
   if ((p > 0 && (!CE || !ce0)) || (m > 0 && (!CI || !ci0))) return QLAMD_ERR_INVALID_ARGUMENT;
   if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
   if (batch == 0) return QLAMD_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
+  QL_ENTER(ctx, st);
   const size_t B = (size_t)batch;
   const double *dG = G, *dg0 = g0, *dCE = CE, *dce0 = ce0, *dCI = CI, *dci0 = ci0;
   double *dx = x, *dobj = objective;
@@ -489,7 +491,7 @@ int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *
     dce0 = (const double *)(w + off[3]); dCI = (const double *)(w + off[4]); dci0 = (const double *)(w + off[5]);
     dx = (double *)(w + off[6]); dobj = objective ? (double *)(w + off[7]) : nullptr; dst = (int32_t *)(w + off[8]);
   }
-  if (p <= 1 && !getenv("QLAMD_QP_ONE_LANE")) {
+  if (p <= 1 && !ctx->qp_one_lane) {
     // lane-cooperative kernel (at most one equality column: what every caller in the reference passes)
     const unsigned cgrid = (unsigned)((batch + coop::kQpCoopRows - 1) / coop::kQpCoopRows);
     auto launch = [&](auto kern) {

@@ -76,6 +76,7 @@ struct SwingBranchPtrs {
   const double *quat, *cmd;
   const uint8_t *mode;
   double *e_last, *e_int;
+  const uint8_t *live; // [B] or NULL (whole tick): 0 = robot left alone
 };
 
 __global__ __launch_bounds__(64) void swing_branch_kernel(const DeviceParams *__restrict__ Pp, const SwingParamsDev SP,
@@ -97,10 +98,11 @@ __global__ __launch_bounds__(64) void swing_branch_kernel(const DeviceParams *__
   const double quat[4] = {b.quat[4 * i], b.quat[4 * i + 1], b.quat[4 * i + 2], b.quat[4 * i + 3]};
   const int mode = (b.mode ? b.mode : s.support)[t];
   const bool support = s.support[t] != 0;
+  const bool alive = !b.live || b.live[i] != 0;
   PidLeg pl; // this leg's gains out of the kernel arguments, fetched with everything else
   pid_leg_of(pid, leg, pl);
   ts.commit(tab);
-  if (support || !live) return; // support legs keep the clamped QP torque already in `effort` (:497-502)
+  if (support || !live || !alive) return; // support legs keep the clamped QP torque already in `effort` (:497-502)
   double out[3];
   swing_branch_leg(LdsTab{tab + kTabPerLeg * leg}, SP, pl, b.mode ? mode : 0, quat, qi, q, qd, qo, tp, tv, cmd, period, el,
                    ei, out);
@@ -121,6 +123,9 @@ struct LegStatePtrs {
   // name replaces the mode in force, anything else leaves it (:876-964), and is_footstep is derived from the result
   const uint8_t *msg_mode;
   uint8_t *leg_mode;
+  // the whole tick only: robots without a command in force (live == 0) are left alone and reported in status
+  const uint8_t *live;
+  int32_t *status;
 };
 
 __global__ __launch_bounds__(256) void leg_state_kernel(const LegStatePtrs s, int index_quirk, int64_t B) {
@@ -174,6 +179,10 @@ __global__ __launch_bounds__(256) void leg_state_kernel(const LegStatePtrs s, in
     }
   }
   const uint32_t sup_i = *reinterpret_cast<const uint32_t *>(s.support + 4 * i);
+  if (s.live && !s.live[i]) {
+    s.status[i] = QLAMD_STATUS_NO_COMMAND;
+    return;
+  }
   leg_state_machine(r, index_quirk != 0);
   uint32_t lst_o = 0, sto_o = 0, code_o = 0;
   uint32_t sup_o = sup_i;
@@ -392,8 +401,12 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
                                                                 const int64_t *__restrict__ offsets, int64_t B,
                                                                 const RobotStateOutPtrs o, int32_t *__restrict__ status,
                                                                 const uint32_t *__restrict__ tpl_in,
-                                                                uint32_t *__restrict__ tpl_out) {
+                                                                uint32_t *__restrict__ tpl_out,
+                                                                uint8_t *__restrict__ valid) {
+  // valid != NULL (whole tick): the outputs are the per-robot command in force -- only a well-formed message
+  // replaces a robot's record and sets valid[robot]; a malformed one leaves both as they are.
   extern __shared__ uint32_t wire_lds[];
+  __shared__ int okm[kWireMsgsPerBlock];
   __shared__ RobotStateFields rec[kWireMsgsPerBlock];
   __shared__ uint32_t anchors[kWireMsgsPerBlock][kAnCount];
   __shared__ uint32_t tpl[kTplWords];
@@ -486,6 +499,8 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
     else if (staged) st = wire_lds_skeleton(msg, mb - ma, anchors[row], logger ? tpl_out + kTplPairs : nullptr, nf, end_pos);
     else st = robot_state_unpack(PlainBytes{messages + ma}, mb - ma, rec[row]);
     status[i0 + row] = st;
+    okm[row] = (st == kWireOk || !valid) ? 1 : 0;
+    if (valid && st == kWireOk) valid[i0 + row] = 1;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -496,15 +511,21 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   if (logger) {
     const uint32_t nf0 = __shfl(nf, 0, 16), end0 = __shfl(end_pos, 0, 16);
     if (hit) {
-      for (int k = lr; k < kTplWords; k += 16) tpl_out[k] = tpl[k]; // still in force
+      for (int k = lr; k < kTplWords; k += 16)
+        if (k != kTplValid) tpl_out[k] = tpl[k]; // still in force
+      __threadfence();
+      if (lr == 0) tpl_out[kTplValid] = tpl[kTplValid];
     } else {
       // the walk has already left its (position, value) pairs in tpl_out; valid only if the message was well-formed
       const bool good = sane && staged && st_row != kWireTruncated && nf0 <= (uint32_t)kTplMaxFields;
       if (lr == 0) {
-        tpl_out[kTplValid] = good ? kTplMagic : 0u; tpl_out[kTplEnd] = end0;
+        tpl_out[kTplEnd] = end0;
         tpl_out[kTplMissing] = st_row == kWireMissingField ? 1u : 0u; tpl_out[kTplFields] = nf0;
       }
       for (int k = lr; k < kAnCount; k += 16) tpl_out[kTplAnchors + k] = anchors[0][k];
+      // the valid word goes last, behind a fence: a template is never valid before all of it is in memory
+      __threadfence();
+      if (lr == 0) tpl_out[kTplValid] = good ? kTplMagic : 0u;
     }
   }
   __syncthreads();
@@ -514,7 +535,7 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
     if (!dst) return;
     for (int e = tid; e < n * width; e += 64) {
       const int m = e / width, k2 = e - m * width;
-      dst[(int64_t)width * i0 + e] = ((const double *)((const char *)&rec[m] + field_off))[k2];
+      if (okm[m]) dst[(int64_t)width * i0 + e] = ((const double *)((const char *)&rec[m] + field_off))[k2];
     }
   };
   put(o.des_pos, 3, offsetof(RobotStateFields, des_pos)); put(o.des_quat, 4, offsetof(RobotStateFields, des_quat));
@@ -526,8 +547,8 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   put(o.surface_normal, 12, offsetof(RobotStateFields, surface_normal)); put(o.phase, 4, offsetof(RobotStateFields, phase));
   if (tid < 4 * n) {
     const int m = tid >> 2, l = tid & 3;
-    if (o.support_leg) o.support_leg[4 * i0 + tid] = rec[m].support_leg[l];
-    if (o.leg_mode) o.leg_mode[4 * i0 + tid] = rec[m].leg_mode[l];
+    if (o.support_leg && okm[m]) o.support_leg[4 * i0 + tid] = rec[m].support_leg[l];
+    if (o.leg_mode && okm[m]) o.leg_mode[4 * i0 + tid] = rec[m].leg_mode[l];
   }
   QL_STAMP(25);
 }
@@ -557,6 +578,7 @@ int qlamd_swing_leg_torque_batch(qlamd_context *ctx, const qlamd_swing_params *p
   if (batch == 0) return QLAMD_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
+  QL_ENTER(ctx, st);
   const size_t B = (size_t)batch;
   SwingParamsDev SP;
   for (int i = 0; i < 3; i++) { SP.kp[i] = params->kp[i]; SP.kd[i] = params->kd[i]; }
@@ -598,9 +620,12 @@ void qlamd_joint_pid_default_params(qlamd_joint_pid_params *p) {
   p->antiwindup = 0;
 }
 
-int qlamd_swing_branch_batch(qlamd_context *ctx, const qlamd_swing_params *params, const qlamd_joint_pid_params *pid,
-                             const qlamd_swing_batch *in, const qlamd_swing_branch_extra *extra, double period,
-                             int64_t batch, double *joint_effort, int memory, void *stream) {
+} // extern "C"
+
+// live: device pointer [B] or NULL (whole tick, QLAMD_MEM_DEVICE only): robots with 0 are left alone
+static int swing_branch_impl(qlamd_context *ctx, const qlamd_swing_params *params, const qlamd_joint_pid_params *pid,
+                             const qlamd_swing_batch *in, const qlamd_swing_branch_extra *extra, const uint8_t *live,
+                             double period, int64_t batch, double *joint_effort, int memory, void *stream) {
   if (!ctx || !in || !extra || batch < 0 || !joint_effort) return QLAMD_ERR_INVALID_ARGUMENT;
   if (!params || !pid) return QLAMD_ERR_NOT_LOADED;
   if (!in->joint_position || !in->joint_velocity || !in->joint_velocity_oldest || !in->target_foot_position ||
@@ -612,6 +637,7 @@ int qlamd_swing_branch_batch(qlamd_context *ctx, const qlamd_swing_params *param
   if (batch == 0) return QLAMD_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
+  QL_ENTER(ctx, st);
   const size_t B = (size_t)batch;
   SwingParamsDev SP;
   for (int i = 0; i < 3; i++) { SP.kp[i] = params->kp[i]; SP.kd[i] = params->kd[i]; }
@@ -625,7 +651,7 @@ int qlamd_swing_branch_batch(qlamd_context *ctx, const qlamd_swing_params *param
   SwingPtrs s{in->joint_position, in->joint_velocity, in->joint_velocity_oldest, in->target_foot_position,
               in->target_foot_velocity, in->id_joint_position, in->support_leg};
   SwingBranchPtrs sb{extra->base_orientation, extra->joint_command, extra->leg_mode, extra->pid_error_last,
-                     extra->pid_error_integral};
+                     extra->pid_error_integral, live};
   double *d_eff = joint_effort;
   Staged sg;
   if (memory == QLAMD_MEM_HOST) {
@@ -643,13 +669,21 @@ int qlamd_swing_branch_batch(qlamd_context *ctx, const qlamd_swing_params *param
     s = SwingPtrs{sg.dev<const double>(a0), sg.dev<const double>(a1), sg.dev<const double>(a2), sg.dev<const double>(a3),
                   sg.dev<const double>(a4), sg.dev<const double>(a5), sg.dev<const uint8_t>(a6)};
     sb = SwingBranchPtrs{sg.dev<const double>(b0), sg.dev<const double>(b1), sg.dev<const uint8_t>(b2), sg.dev<double>(b3),
-                         sg.dev<double>(b4)};
+                         sg.dev<double>(b4), nullptr};
     d_eff = sg.dev<double>(e0);
   }
   hipLaunchKernelGGL(swing_branch_kernel, dim3((unsigned)((4 * batch + 63) / 64)), dim3(64), 0, st, ctx->d_params, SP, PD,
                      s, sb, period, batch, d_eff);
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   return memory == QLAMD_MEM_HOST ? sg.finish(st) : QLAMD_OK;
+}
+
+extern "C" {
+
+int qlamd_swing_branch_batch(qlamd_context *ctx, const qlamd_swing_params *params, const qlamd_joint_pid_params *pid,
+                             const qlamd_swing_batch *in, const qlamd_swing_branch_extra *extra, double period,
+                             int64_t batch, double *joint_effort, int memory, void *stream) {
+  return swing_branch_impl(ctx, params, pid, in, extra, nullptr, period, batch, joint_effort, memory, stream);
 }
 
 int qlamd_leg_state_machine_batch(qlamd_context *ctx, const qlamd_leg_state_batch *io, int index_quirk, int64_t batch,
@@ -663,10 +697,11 @@ int qlamd_leg_state_machine_batch(qlamd_context *ctx, const qlamd_leg_state_batc
   if (batch == 0) return QLAMD_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
+  QL_ENTER(ctx, st);
   const size_t B = (size_t)batch;
   LegStatePtrs s{io->support_leg, io->is_footstep, io->contact, io->phase, io->joint_position, io->limb_state,
                  io->store_flag, io->stored_joint_position, io->joint_command, io->foot_target, io->support,
-                 io->leg_state_code, nullptr, nullptr};
+                 io->leg_state_code, nullptr, nullptr, nullptr, nullptr};
   // host staging: every array goes up except leg_state_code; the in/out and out arrays come back
   Staged sg;
   if (memory == QLAMD_MEM_HOST) {
@@ -686,7 +721,7 @@ int qlamd_leg_state_machine_batch(qlamd_context *ctx, const qlamd_leg_state_batc
     if (rc != QLAMD_OK) return rc;
     s = LegStatePtrs{sg.dev<const uint8_t>(0), sg.dev<const uint8_t>(1), sg.dev<const uint8_t>(2), sg.dev<const double>(3),
                      sg.dev<const double>(4), sg.dev<int8_t>(5), sg.dev<uint8_t>(6), sg.dev<double>(7), sg.dev<double>(8),
-                     sg.dev<double>(9), sg.dev<uint8_t>(10), sg.dev<int8_t>(11), nullptr, nullptr};
+                     sg.dev<double>(9), sg.dev<uint8_t>(10), sg.dev<int8_t>(11), nullptr, nullptr, nullptr, nullptr};
   }
   hipLaunchKernelGGL(leg_state_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, s, index_quirk, batch);
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
@@ -694,13 +729,17 @@ int qlamd_leg_state_machine_batch(qlamd_context *ctx, const qlamd_leg_state_batc
   return QLAMD_OK;
 }
 
-int qlamd_robot_state_unpack_batch(qlamd_context *ctx, const uint8_t *messages, const int64_t *offsets, int64_t batch,
-                                   const qlamd_robot_state_fields *out, int32_t *status, int memory, void *stream) {
+} // extern "C"
+
+// valid: device pointer [B] or NULL (whole tick, QLAMD_MEM_DEVICE only), see robot_state_unpack_kernel
+static int unpack_impl(qlamd_context *ctx, const uint8_t *messages, const int64_t *offsets, int64_t batch,
+                       const qlamd_robot_state_fields *out, int32_t *status, uint8_t *valid, int memory, void *stream) {
   if (!ctx || !messages || !offsets || !out || !status || batch < 0) return QLAMD_ERR_INVALID_ARGUMENT;
   if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
   if (batch == 0) return QLAMD_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
+  QL_ENTER(ctx, st);
   const size_t B = (size_t)batch;
   enum { kD = 10 };
   const int width[kD] = {3, 4, 3, 3, 12, 12, 12, 12, 12, 4};
@@ -742,10 +781,17 @@ int qlamd_robot_state_unpack_batch(qlamd_context *ctx, const uint8_t *messages, 
   uint32_t *tpl_out = ctx->wire_tpl + kTplWords * (ctx->wire_flip ^ 1);
   ctx->wire_flip ^= 1;
   hipLaunchKernelGGL(robot_state_unpack_kernel, dim3((unsigned)((batch + kWireMsgsPerBlock - 1) / kWireMsgsPerBlock)),
-                     dim3(64), kWireLdsBytes, st, d_msg, d_off, batch, o, d_st, tpl_in, tpl_out);
+                     dim3(64), kWireLdsBytes, st, d_msg, d_off, batch, o, d_st, tpl_in, tpl_out, valid);
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   if (memory == QLAMD_MEM_HOST) return sg.finish(st);
   return QLAMD_OK;
+}
+
+extern "C" {
+
+int qlamd_robot_state_unpack_batch(qlamd_context *ctx, const uint8_t *messages, const int64_t *offsets, int64_t batch,
+                                   const qlamd_robot_state_fields *out, int32_t *status, int memory, void *stream) {
+  return unpack_impl(ctx, messages, offsets, batch, out, status, nullptr, memory, stream);
 }
 
 void qlamd_ik_default_params(qlamd_ik_params *p) {
@@ -771,6 +817,7 @@ int qlamd_leg_inverse_kinematics_batch(qlamd_context *ctx, const qlamd_ik_params
   if (batch == 0) return QLAMD_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
+  QL_ENTER(ctx, st);
   const size_t B = (size_t)batch;
   const double *d_foot = foot_position, *d_last = joint_position_last;
   double *d_q = joint_position;
@@ -789,6 +836,23 @@ int qlamd_leg_inverse_kinematics_batch(qlamd_context *ctx, const qlamd_ik_params
   return memory == QLAMD_MEM_HOST ? sg.finish(st) : QLAMD_OK;
 }
 
+// Layout of the command block of the whole tick (qlamd_tick_batch.command): per-robot flag "a command is in force",
+// then what the last well-formed message delivered, one array per field like the intermediates they are.
+namespace {
+enum { kCmdValid, kCmdPos, kCmdQuat, kCmdLin, kCmdAng, kCmdJoint, kCmdFootP, kCmdFootV, kCmdPhase, kCmdSup, kCmdMode, kCmdN };
+inline size_t command_layout(size_t B, size_t off[kCmdN]) {
+  const size_t sz[kCmdN] = {B, B * 24, B * 32, B * 24, B * 24, B * 96, B * 96, B * 96, B * 32, B * 4, B * 4};
+  size_t total = 0;
+  for (int k = 0; k < kCmdN; k++) { off[k] = total; total += align256(sz[k]); }
+  return total;
+}
+} // namespace
+
+size_t qlamd_tick_command_bytes(int64_t batch) {
+  size_t off[kCmdN];
+  return batch > 0 ? command_layout((size_t)batch, off) : 0;
+}
+
 int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, const qlamd_joint_pid_params *pid,
                           const qlamd_tick_batch *io, double period, int index_quirk, int64_t batch, int memory,
                           void *stream) {
@@ -803,7 +867,10 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
   if (batch == 0) return QLAMD_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
+  QL_ENTER(ctx, st);
   const size_t B = (size_t)batch;
+  size_t coff[kCmdN];
+  const size_t cmd_bytes = command_layout(B, coff);
   qlamd_tick_batch d = *io;
   Staged sg;
   if (memory == QLAMD_MEM_HOST) {
@@ -811,7 +878,7 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
       if (io->offsets[k + 1] < io->offsets[k] || io->offsets[0] < 0) return QLAMD_ERR_INVALID_ARGUMENT;
     const size_t nbytes = (size_t)(io->offsets[B] - io->offsets[0]);
     const int i_off = sg.add(io->offsets, (B + 1) * 8, true, false);
-    const int i_msg = sg.add(io->messages + io->offsets[0], nbytes ? nbytes : 1, true, false);
+    const int i_msg = sg.add(io->messages + io->offsets[0], nbytes, true, false); // an empty blob stages nothing
     const int i_in[8] = {sg.add(io->joint_position, B * 96, true, false), sg.add(io->joint_velocity, B * 96, true, false),
                          sg.add(io->joint_velocity_oldest, B * 96, true, false), sg.add(io->base_position, B * 24, true, false),
                          sg.add(io->base_orientation, B * 32, true, false), sg.add(io->base_linear_velocity, B * 24, true, false),
@@ -820,8 +887,10 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
                          sg.add(io->stored_joint_position, B * 96, true, true), sg.add(io->leg_mode, B * 4, true, true),
                          sg.add(io->pid_error_last, B * 96, true, true), sg.add(io->pid_error_integral, B * 96, true, true),
                          sg.add(io->support, B * 4, true, true)};
-    const int i_out[4] = {sg.add(io->joint_effort, B * 96, false, true), sg.add(io->leg_state_code, B * 4, false, true),
+    // the efforts travel both ways: robots that are skipped, or whose solve fails under QLAMD_ON_FAILURE_KEEP, keep theirs
+    const int i_out[4] = {sg.add(io->joint_effort, B * 96, true, true), sg.add(io->leg_state_code, B * 4, false, true),
                           sg.add(io->status, B * 4, false, true), sg.add(io->message_status, B * 4, false, true)};
+    const int i_cmd = sg.add(io->command, cmd_bytes, true, true);
     const int rc = sg.upload(ctx, st);
     if (rc != QLAMD_OK) return rc;
     d.offsets = sg.dev<const int64_t>(i_off);
@@ -836,47 +905,49 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
     d.support = sg.dev<uint8_t>(i_io[6]);
     d.joint_effort = sg.dev<double>(i_out[0]); d.leg_state_code = sg.dev<int8_t>(i_out[1]);
     d.status = sg.dev<int32_t>(i_out[2]); d.message_status = sg.dev<int32_t>(i_out[3]);
+    d.command = sg.dev<char>(i_cmd);
   }
-  // intermediates: what the message delivers and what the state machine decides
-  enum { kPos, kQuat, kLin, kAng, kCmd, kFootP, kFootV, kPhase, kMsgSup, kMsgMode, kCode, kN };
-  const size_t sz[kN] = {B * 24, B * 32, B * 24, B * 24, B * 96, B * 96, B * 96, B * 32, B * 4, B * 4, B * 4};
-  size_t off[kN], total = 0;
-  for (int k = 0; k < kN; k++) { off[k] = total; total += align256(sz[k]); }
-  if (ctx->tick_ws_bytes < total) {
+  // context scratch: the leg state codes when the caller does not want them, and the command block when the caller
+  // keeps none (then no command outlives the call: the flags are cleared first)
+  const size_t scratch = align256(B * 4) + (d.command ? 0 : cmd_bytes);
+  if (ctx->tick_ws_bytes < scratch) {
     if (ctx->tick_ws) (void)hipFree(ctx->tick_ws);
     ctx->tick_ws = nullptr; ctx->tick_ws_bytes = 0;
-    if (hipMalloc(&ctx->tick_ws, total) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;
-    ctx->tick_ws_bytes = total;
+    if (hipMalloc(&ctx->tick_ws, scratch) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;
+    ctx->tick_ws_bytes = scratch;
   }
-  char *w = (char *)ctx->tick_ws;
-  const auto D = [&](int k) { return (double *)(w + off[k]); };
-  const auto U = [&](int k) { return (uint8_t *)(w + off[k]); };
+  char *w = (char *)(d.command ? d.command : (char *)ctx->tick_ws + align256(B * 4));
+  if (!d.command && hipMemsetAsync(w + coff[kCmdValid], 0, B, st) != hipSuccess) return QLAMD_ERR_HIP;
+  const auto D = [&](int k) { return (double *)(w + coff[k]); };
+  const auto U = [&](int k) { return (uint8_t *)(w + coff[k]); };
   int rc;
-  // 1. baseCommandCallback: message -> desired state, targets, leg modes
+  // 1. baseCommandCallback: a well-formed message replaces the robot's command in force (desired state, targets, modes)
   qlamd_robot_state_fields f{};
-  f.des_pos = D(kPos); f.des_quat = D(kQuat); f.des_linvel = D(kLin); f.des_angvel = D(kAng);
-  f.joint_command = D(kCmd); f.foot_position = D(kFootP); f.foot_velocity = D(kFootV); f.phase = D(kPhase);
-  f.support_leg = U(kMsgSup); f.leg_mode = U(kMsgMode);
-  rc = qlamd_robot_state_unpack_batch(ctx, d.messages, d.offsets, batch, &f, d.message_status, QLAMD_MEM_DEVICE, stream);
+  f.des_pos = D(kCmdPos); f.des_quat = D(kCmdQuat); f.des_linvel = D(kCmdLin); f.des_angvel = D(kCmdAng);
+  f.joint_command = D(kCmdJoint); f.foot_position = D(kCmdFootP); f.foot_velocity = D(kCmdFootV); f.phase = D(kCmdPhase);
+  f.support_leg = U(kCmdSup); f.leg_mode = U(kCmdMode);
+  const uint8_t *live = U(kCmdValid);
+  rc = unpack_impl(ctx, d.messages, d.offsets, batch, &f, d.message_status, U(kCmdValid), QLAMD_MEM_DEVICE, stream);
   if (rc != QLAMD_OK) return rc;
   // 2. leg modes in force, footContactsCallback + the switch of update(): support legs, held joint commands, nudged
-  //    foot targets (one launch: the kernel of qlamd_leg_state_machine_batch with the mode merge in front)
-  const LegStatePtrs ls{U(kMsgSup), nullptr, d.contact, D(kPhase), d.joint_position, d.limb_state, d.store_flag,
-                        d.stored_joint_position, D(kCmd), D(kFootP), d.support,
-                        d.leg_state_code ? d.leg_state_code : (int8_t *)(w + off[kCode]), U(kMsgMode), d.leg_mode};
+  //    foot targets (one launch: the kernel of qlamd_leg_state_machine_batch with the mode merge in front); robots
+  //    without a command get their status here and are left alone by every kernel of the tick
+  const LegStatePtrs ls{U(kCmdSup), nullptr, d.contact, D(kCmdPhase), d.joint_position, d.limb_state, d.store_flag,
+                        d.stored_joint_position, D(kCmdJoint), D(kCmdFootP), d.support,
+                        d.leg_state_code ? d.leg_state_code : (int8_t *)ctx->tick_ws, U(kCmdMode), d.leg_mode, live, d.status};
   hipLaunchKernelGGL(leg_state_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, ls, index_quirk, batch);
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   // 3. balance solve for the support legs (all 12 efforts written: 0 for the others)
   qlamd_state_batch sb{d.joint_position, d.base_position, d.base_orientation, d.base_linear_velocity, d.base_angular_velocity,
-                       D(kPos), D(kQuat), D(kLin), D(kAng), d.support, nullptr};
-  rc = qlamd_balance_solve_batch(ctx, &sb, batch, d.joint_effort, nullptr, d.status, QLAMD_MEM_DEVICE, stream);
+                       D(kCmdPos), D(kCmdQuat), D(kCmdLin), D(kCmdAng), d.support, nullptr};
+  rc = balance_impl(ctx, &sb, nullptr, live, batch, d.joint_effort, nullptr, d.status, QLAMD_MEM_DEVICE, stream);
   if (rc != QLAMD_OK) return rc;
   // 4. swing branch for the legs that do not support
   qlamd_swing_params sp = *swing;
   sp.period = period;
-  const qlamd_swing_batch sw{d.joint_position, d.joint_velocity, d.joint_velocity_oldest, D(kFootP), D(kFootV), d.support, nullptr};
-  const qlamd_swing_branch_extra ex{d.base_orientation, D(kCmd), d.leg_mode, d.pid_error_last, d.pid_error_integral};
-  rc = qlamd_swing_branch_batch(ctx, &sp, pid, &sw, &ex, period, batch, d.joint_effort, QLAMD_MEM_DEVICE, stream);
+  const qlamd_swing_batch sw{d.joint_position, d.joint_velocity, d.joint_velocity_oldest, D(kCmdFootP), D(kCmdFootV), d.support, nullptr};
+  const qlamd_swing_branch_extra ex{d.base_orientation, D(kCmdJoint), d.leg_mode, d.pid_error_last, d.pid_error_integral};
+  rc = swing_branch_impl(ctx, &sp, pid, &sw, &ex, live, period, batch, d.joint_effort, QLAMD_MEM_DEVICE, stream);
   if (rc != QLAMD_OK) return rc;
   if (memory == QLAMD_MEM_HOST) return sg.finish(st);
   return QLAMD_OK;

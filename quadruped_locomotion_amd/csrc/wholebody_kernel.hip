@@ -353,6 +353,7 @@ int qlamd_wholebody_dynamics_batch(qlamd_context *ctx, const qlamd_wholebody_bat
   if (batch == 0) return QLAMD_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
+  QL_ENTER(ctx, st);
   const size_t B = (size_t)batch;
   WbPtrs s{in->joint_position, in->joint_velocity, in->base_orientation, in->base_linear_velocity,
            in->base_angular_velocity, nullptr, nullptr, nullptr, nullptr};
@@ -378,7 +379,7 @@ int qlamd_wholebody_dynamics_batch(qlamd_context *ctx, const qlamd_wholebody_bat
   // One launch for everything.  Two launches (M; h and Jc) need 140 / 158 instead of 204 registers, i.e. three waves
   // per SIMD instead of two, but repeat the link kinematics: measured 9 % slower at 65 536 robots, 30 % at 4096
   // (QLAMD_WB_SPLIT=1 selects them, for measurement).
-  const bool fused = getenv("QLAMD_WB_SPLIT") == nullptr;
+  const bool fused = !ctx->wb_split;
   if (fused && dM && (dh || dJ)) {
     hipLaunchKernelGGL((wholebody_dynamics_kernel<true, true>), grid, dim3(64), 0, st, ctx->d_params, W, s, batch, dM, dh, dJ);
   } else {
@@ -407,6 +408,7 @@ int qlamd_wholebody_solve_batch(qlamd_context *ctx, const qlamd_wholebody_params
   if (batch == 0) return QLAMD_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
+  QL_ENTER(ctx, st);
   const size_t B = (size_t)batch;
   WbPtrs s{in->joint_position, in->joint_velocity, in->base_orientation, in->base_linear_velocity,
            in->base_angular_velocity, in->desired_base_acceleration, in->desired_joint_acceleration, in->support_leg,

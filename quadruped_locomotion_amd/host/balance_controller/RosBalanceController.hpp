@@ -4,6 +4,8 @@
 // raw pointers owned by the hardware interface, nothing allocated or freed across the boundary.
 #pragma once
 
+#include <vector>
+
 #include "balance_controller/VirtualModelController.hpp"
 
 namespace balance_controller {
@@ -37,6 +39,9 @@ class RosBalanceController {
     } catch (const std::exception &) {
       return false;
     }
+    // a failed solve keeps the efforts of the tick before, as the reference's update() does (:418-424,441-454)
+    if (qlamd_set_option(ctx_->get(), QLAMD_OPT_ON_FAILURE, QLAMD_ON_FAILURE_KEEP) != QLAMD_OK) return false;
+    command_.assign(qlamd_tick_command_bytes(1), 0);
     robot_state_ = std::make_shared<free_gait::State>();
     contact_distribution_ = std::make_shared<ContactForceDistribution>(ctx_, robot_state_);
     virtual_model_controller_ = std::make_shared<VirtualModelController>(ctx_, robot_state_, contact_distribution_);
@@ -121,8 +126,10 @@ class RosBalanceController {
     return solved;
   }
   // The same tick through ONE call of the C-ABI (qlamd_full_tick_batch, batch 1): message bytes in, 12 efforts out.
-  // Equivalent to baseCommandCallback(msg) + footContactsCallback + updateFullTick(period) when every tick brings a
-  // message; what stays between ticks (limb states, stored joints, leg modes, PID errors, velocity queue) lives here.
+  // Equivalent to baseCommandCallback(msg) + footContactsCallback + updateFullTick(period); a message that cannot be
+  // deserialised leaves the command of the last good one in force, as in the reference where it never reaches the
+  // callback.  What stays between ticks (command in force, limb states, stored joints, leg modes, PID errors, velocity
+  // queue) lives here.
   bool tick(const uint8_t *msg, size_t len, double period) {
     for (int i = 0; i < 12; ++i) {
       for (int k = 10; k > 0; --k) qd_queue_[k][i] = qd_queue_[k - 1][i];
@@ -135,7 +142,7 @@ class RosBalanceController {
     qlamd_tick_batch io{msg, off, hw_.joint_position_read, qd_queue_[0].data(), qd_queue_[10].data(), hw_.position,
                         hw_.orientation, hw_.linear_velocity, hw_.angular_velocity, contact_, limb_state_, store_flag_,
                         stored_joint_position_.data(), leg_mode_, support_, pid_error_last_.data(), pid_error_integral_.data(),
-                        hw_.joint_effort_write, leg_state_code_, &status, &message_status};
+                        hw_.joint_effort_write, leg_state_code_, &status, &message_status, command_.data()};
     if (qlamd_full_tick_batch(ctx_->get(), &sp, &pid, &io, period, 1, 1, QLAMD_MEM_HOST, nullptr) != QLAMD_OK) return false;
     return message_status == QLAMD_WIRE_OK && status == QLAMD_STATUS_OK;
   }
@@ -155,6 +162,7 @@ class RosBalanceController {
   std::array<double, 12> joint_command_{}, foot_target_{}, foot_velocity_{}, stored_joint_position_{}, pid_error_last_{},
       pid_error_integral_{};
   std::array<std::array<double, 12>, 11> qd_queue_{};
+  std::vector<uint8_t> command_; // opaque command block of qlamd_full_tick_batch (batch 1)
   double phase_[4] = {0, 0, 0, 0};
   uint8_t support_leg_[4] = {1, 1, 1, 1}, contact_[4] = {1, 1, 1, 1}, store_flag_[4] = {0, 0, 0, 0}, support_[4] = {1, 1, 1, 1};
   uint8_t leg_mode_[4] = {0, 0, 0, 0};

@@ -209,3 +209,52 @@ def test_balance_stress_against_oracle(gpu, oracle):
     assert ok.sum() > B // 2
     assert np.abs(tau[ok] - t0[ok]).max() < TAU_TOL
     print("non-OK:", int((~ok).sum()), "max |dtau|:", np.abs(tau[ok] - t0[ok]).max())
+
+
+def test_survey_literal_tracking_errors_match_oracle(gpu, oracle):
+    """SURVEY.md 8(d)'s literal static-stance errors (0.02 m / 0.05 rad / 0.1 m/s, bench.py --errors survey): most robots
+    saturate the friction pyramid.  Same parity bar as the default (calm) static batch."""
+    state = synth.make_states(4096, "static", errors="survey")
+    tau, grf, st = solve_device(gpu, state)
+    t_ref, g_ref, s_ref = oracle.balance_batch(state, nthreads=8)
+    assert np.array_equal(st, s_ref) and (st == 0).all()
+    assert np.abs(tau - t_ref).max() < TAU_TOL
+    fz, fxy = g_ref[:, 2::3], np.hypot(g_ref[:, 0::3], g_ref[:, 1::3])
+    assert ((fxy > 0.59 * fz).any(axis=1)).mean() > 0.3   # the input really loads the pyramid
+
+
+def test_one_context_refuses_a_second_thread(gpu, oracle):
+    """A context is single-threaded (include/qlamd.h): a call entering while another thread is inside gets
+    QLAMD_ERR_BUSY instead of sharing the staging slab; every call that was admitted returns correct torques."""
+    import threading
+    capi, ctx, torch = gpu
+    big, small = synth.make_states(65536, "static"), synth.make_states(64, "static", offset=7)
+    t_small = oracle.balance_batch(small)[0]
+    stop, busy, wrong = threading.Event(), [0], [0]
+
+    def hammer():
+        while not stop.is_set():
+            try:
+                tau, _, _ = ctx.balance_solve_host(small)
+                if np.abs(tau - t_small).max() > TAU_TOL:
+                    wrong[0] += 1
+            except capi.QlamdError as e:
+                assert e.code == capi.ERR_BUSY
+                busy[0] += 1
+
+    th = threading.Thread(target=hammer)
+    th.start()
+    try:
+        for _ in range(6):
+            try:
+                tau, _, st = ctx.balance_solve_host(big)
+                assert (st == 0).all()
+            except capi.QlamdError as e:
+                assert e.code == capi.ERR_BUSY
+    finally:
+        stop.set()
+        th.join()
+    assert wrong[0] == 0 and busy[0] > 0
+    t_ref = oracle.balance_batch(big, nthreads=8)[0]
+    tau, _, _ = ctx.balance_solve_host(big)
+    assert np.abs(tau - t_ref).max() < TAU_TOL

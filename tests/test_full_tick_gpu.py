@@ -1,89 +1,176 @@
-"""qlamd_full_tick_batch (message -> leg state machine -> balance solve -> swing branch in one call) against the same
-four entries called one after the other -- each of which has its own oracle parity test -- over several ticks with the
-persistent controller state carried along.  Bitwise equality is expected: the same kernels run on the same data."""
+"""qlamd_full_tick_batch (message -> leg state machine -> balance solve -> swing branch in one call) against the
+oracle's chain of the same stages (oracle/oracle_tick.c: oracle_wire -> oracle_leg_state -> oracle_balance ->
+oracle_swing) over several ticks of a thousand robots with ragged messages, the controller state carried along on
+both sides.  Includes what the reference does with a message that cannot be deserialised: it never reaches
+baseCommandCallback (ros_balance_controller.cpp:761), so update() runs on the last command stored; a robot that has
+never received one is left alone."""
 import numpy as np
 import pytest
 
-from quadruped_locomotion_amd import synth
-from test_wire_format import random_message
+from quadruped_locomotion_amd import synth, wire
 
 pytestmark = pytest.mark.gpu
 
+TAU_TOL = 1e-6      # BASELINE north_star: joint torques within 1e-6
+PERSIST = ("limb_state", "store_flag", "stored_joint_position", "leg_mode", "support", "pid_error_last", "pid_error_integral")
 
-def make_tick_inputs(B, rng, tick):
-    raws = []
-    for i in range(B):
-        raw, _ = random_message(rng, ragged=(i % 3 != 0))
-        raws.append(raw if not (i == 5 and tick == 1) else raw[:40])          # one unparsable message on the second tick
-    off = np.zeros(B + 1, np.int64)
-    off[1:] = np.cumsum([len(r) for r in raws])
+
+def make_tick_inputs(B, tick, truncated=()):
+    blob, off, _ = synth.make_messages(B, ragged=True, seed=synth.SEED + 100 + tick)
+    msgs = [bytes(blob[off[b]:off[b + 1]]) for b in range(B)]
+    for b in truncated:
+        msgs[b] = msgs[b][:40 + 7 * (b % 50)]
+    blob, off = wire.pack_batch(msgs)
     s = synth.make_states(B, "trot", offset=1000 * tick)
-    return dict(messages=np.frombuffer(b"".join(raws), np.uint8).copy(), offsets=off, joint_position=s["q"],
-                joint_velocity=np.ascontiguousarray(rng.normal(scale=0.3, size=(B, 12))),
-                joint_velocity_oldest=np.ascontiguousarray(rng.normal(scale=0.3, size=(B, 12))),
-                base_position=s["base_pos"], base_orientation=s["base_quat"], base_linear_velocity=np.ascontiguousarray(s["base_linvel"]),
-                base_angular_velocity=np.ascontiguousarray(s["base_angvel"]), contact=rng.integers(0, 2, (B, 4)).astype(np.uint8))
+    rng = np.random.default_rng(900 + tick)
+    return msgs, dict(messages=blob, offsets=off, joint_position=s["q"],
+                      joint_velocity=np.ascontiguousarray(rng.normal(scale=0.3, size=(B, 12))),
+                      joint_velocity_oldest=np.ascontiguousarray(rng.normal(scale=0.3, size=(B, 12))),
+                      base_position=s["base_pos"], base_orientation=s["base_quat"],
+                      base_linear_velocity=np.ascontiguousarray(s["base_linvel"]),
+                      base_angular_velocity=np.ascontiguousarray(s["base_angvel"]), contact=rng.integers(0, 2, (B, 4)).astype(np.uint8))
 
 
-def test_full_tick_equals_the_four_entries(oracle):
-    from quadruped_locomotion_amd import capi
-    ctx, ctx2 = capi.Context(), capi.Context()
-    rng = np.random.default_rng(2027)
-    B, period = 333, 0.0025
-    fresh = lambda: dict(limb_state=np.zeros((B, 4), np.int8), store_flag=np.zeros((B, 4), np.uint8),  # noqa: E731
-                         stored_joint_position=np.zeros((B, 12)), leg_mode=np.zeros((B, 4), np.uint8),
-                         support=np.ones((B, 4), np.uint8), pid_error_last=np.zeros((B, 12)), pid_error_integral=np.zeros((B, 12)))
-    keep_a, keep_b = fresh(), fresh()
-    for tick in range(4):
-        tin = make_tick_inputs(B, rng, tick)
-        # ---- one call
-        io = dict(tin, **keep_a, joint_effort=np.zeros((B, 12)), leg_state_code=np.zeros((B, 4), np.int8),
-                  status=np.full(B, -1, np.int32), message_status=np.full(B, -1, np.int32))
-        capi.full_tick(ctx, io, period)
-        # ---- the four entries, one after the other (host buffers)
-        f, mst = capi.robot_state_unpack(ctx2, tin["messages"], tin["offsets"])
-        known = f["leg_mode"] != 0
-        keep_b["leg_mode"][known] = f["leg_mode"][known]
-        ls = dict(support_leg=f["support_leg"], phase=f["phase"], is_footstep=(keep_b["leg_mode"] == 4).astype(np.uint8),
-                  contact=tin["contact"], joint_position=tin["joint_position"], limb_state=keep_b["limb_state"],
-                  store_flag=keep_b["store_flag"], stored_joint_position=keep_b["stored_joint_position"],
-                  joint_command=f["joint_command"], foot_target=f["foot_position"], support=keep_b["support"],
-                  leg_state_code=np.zeros((B, 4), np.int8))
-        capi.leg_state_machine(ctx2, ls)
-        state = dict(q=tin["joint_position"], base_pos=tin["base_position"], base_quat=tin["base_orientation"],
-                     base_linvel=tin["base_linear_velocity"], base_angvel=tin["base_angular_velocity"], des_pos=f["des_pos"],
-                     des_quat=f["des_quat"], des_linvel=f["des_linvel"], des_angvel=f["des_angvel"], stance=ls["support"])
-        tau, _, st = ctx2.balance_solve_host(state)
-        effort = np.ascontiguousarray(tau)
-        capi.swing_branch(ctx2, effort, tin["joint_position"], tin["joint_velocity"], tin["joint_velocity_oldest"], ls["foot_target"],
-                          f["foot_velocity"], ls["support"], tin["base_orientation"], ls["joint_command"], keep_b["leg_mode"],
-                          keep_b["pid_error_last"], keep_b["pid_error_integral"], period)
-        assert np.array_equal(io["message_status"], mst) and np.array_equal(io["status"], st)
-        assert np.array_equal(io["leg_state_code"], ls["leg_state_code"])
-        assert np.array_equal(io["joint_effort"], effort), np.abs(io["joint_effort"] - effort).max()
-        for k in keep_a:
-            assert np.array_equal(io[k], keep_b[k]), k
-        assert (mst != 0).sum() >= (1 if tick == 1 else 0)
-    assert np.abs(io["joint_effort"]).max() > 1.0 and (io["status"] == 0).sum() > B // 2
+def fresh_state(B, capi):
+    return dict(limb_state=np.zeros((B, 4), np.int8), store_flag=np.zeros((B, 4), np.uint8), stored_joint_position=np.zeros((B, 12)),
+                leg_mode=np.zeros((B, 4), np.uint8), support=np.ones((B, 4), np.uint8), pid_error_last=np.zeros((B, 12)),
+                pid_error_integral=np.zeros((B, 12)), joint_effort=np.full((B, 12), 7.0), leg_state_code=np.zeros((B, 4), np.int8),
+                status=np.full(B, -1, np.int32), message_status=np.full(B, -1, np.int32),
+                command=np.zeros(capi.tick_command_bytes(B), np.uint8))
 
 
-def test_full_tick_device_buffers_and_errors():
+def run_oracle_tick(oracle, states, msgs, tin, period, keep=0):
+    B = len(msgs)
+    st, mst, code = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros((B, 4), np.int8)
+    for b in range(B):
+        st[b], mst[b], code[b] = oracle.full_tick(
+            states[b], msgs[b], tin["joint_position"][b], tin["joint_velocity"][b], tin["joint_velocity_oldest"][b],
+            tin["base_position"][b], tin["base_orientation"][b], tin["base_linear_velocity"][b], tin["base_angular_velocity"][b],
+            tin["contact"][b], period, keep_on_failure=keep)
+    return st, mst, code
+
+
+def compare(io, states, st, mst, code, tick):
+    B = len(states)
+    assert np.array_equal(io["message_status"], mst), tick
+    assert np.array_equal(io["status"], st), (tick, np.nonzero(io["status"] != st)[0][:8])
+    ran = st != 4
+    assert np.array_equal(io["leg_state_code"][ran], code[ran]), tick
+    for b in range(B):
+        o = states[b]
+        assert np.array_equal(io["limb_state"][b], np.array(o.limb_state[:], np.int8)), (tick, b)
+        assert np.array_equal(io["store_flag"][b], np.array(o.store_flag[:], np.uint8)), (tick, b)
+        assert np.array_equal(io["leg_mode"][b], np.array(o.leg_mode[:], np.uint8)), (tick, b)
+        assert np.array_equal(io["support"][b], np.array(o.support[:], np.uint8)), (tick, b)
+        assert np.array_equal(io["stored_joint_position"][b], np.array(o.stored_joint_position[:])), (tick, b)
+        assert np.abs(io["pid_error_last"][b] - np.array(o.pid_error_last[:])).max() < 1e-12, (tick, b)
+        assert np.abs(io["pid_error_integral"][b] - np.array(o.pid_error_integral[:])).max() < 1e-12, (tick, b)
+        err = np.abs(io["joint_effort"][b] - np.array(o.joint_effort[:])).max()
+        assert err < TAU_TOL, (tick, b, err)
+
+
+@pytest.mark.parametrize("memory", ["host", "device"])
+def test_full_tick_matches_the_oracle_chain(oracle, memory):
     import torch
     from quadruped_locomotion_amd import capi
     ctx = capi.Context()
-    rng = np.random.default_rng(5)
-    B = 130
-    tin = make_tick_inputs(B, rng, 0)
-    host = dict(tin, limb_state=np.zeros((B, 4), np.int8), store_flag=np.zeros((B, 4), np.uint8), stored_joint_position=np.zeros((B, 12)),
-                leg_mode=np.zeros((B, 4), np.uint8), support=np.ones((B, 4), np.uint8), pid_error_last=np.zeros((B, 12)),
-                pid_error_integral=np.zeros((B, 12)), joint_effort=np.zeros((B, 12)), leg_state_code=np.zeros((B, 4), np.int8), status=np.full(B, -1, np.int32),
-                message_status=np.full(B, -1, np.int32))
-    dev = {k: torch.from_numpy(v.copy()).to("cuda:0") for k, v in host.items()}
-    capi.full_tick(ctx, host, 0.0025)
-    capi.full_tick(ctx, dev, 0.0025, memory=capi.MEM_DEVICE)
-    torch.cuda.synchronize()
-    for k in ("joint_effort", "status", "message_status", "leg_state_code", "limb_state", "pid_error_integral"):
-        assert np.array_equal(dev[k].cpu().numpy(), host[k]), k
-    bad = dict(host); bad["contact"] = None
+    B, period, ticks = 1024, 0.0025, 5
+    keep = fresh_state(B, capi)
+    states = [oracle.new_tick_state() for _ in range(B)]
+    for b in range(B):  # the efforts the controller held before the first tick
+        for k in range(12):
+            states[b].joint_effort[k] = 7.0
+    if memory == "device":
+        keep = {k: torch.from_numpy(v).to("cuda:0") for k, v in keep.items()}
+    seen_no_command = seen_stale = 0
+    for tick in range(ticks):
+        # tick 0: robots 3, 77, 500 never got a well-formed message; they stay without one on tick 1 (3 and 77) ...
+        # ticks 2, 3: robots 10..29 lose their message and run on the command stored before
+        truncated = {0: (3, 77, 500), 1: (3, 77), 2: tuple(range(10, 30)) + (3,), 3: tuple(range(20, 30))}.get(tick, ())
+        msgs, tin = make_tick_inputs(B, tick, truncated)
+        if memory == "device":
+            io = dict({k: torch.from_numpy(v).to("cuda:0") for k, v in tin.items()}, **keep)
+            capi.full_tick(ctx, io, period, memory=capi.MEM_DEVICE)
+            torch.cuda.synchronize()
+            got = {k: io[k].cpu().numpy() for k in keep if k != "command"}
+        else:
+            io = dict(tin, **keep)
+            capi.full_tick(ctx, io, period)
+            got = io
+        st, mst, code = run_oracle_tick(oracle, states, msgs, tin, period)
+        compare(got, states, st, mst, code, tick)
+        seen_no_command += int((st == 4).sum())
+        seen_stale += int(((mst != 0) & (st != 4)).sum())
+        for b in np.nonzero(st == 4)[0]:   # a skipped robot: nothing of it was written
+            assert (got["joint_effort"][b] == 7.0).all() and (got["limb_state"][b] == 0).all()
+    assert seen_no_command == 3 + 2 + 1 and seen_stale == 20 + 10
+    assert (st == 0).sum() > B // 2 and np.abs(got["joint_effort"]).max() > 1.0
+
+
+def test_full_tick_without_a_command_block_skips_malformed_messages(oracle):
+    """command == NULL: no command outlives a call, so a malformed message always means QLAMD_STATUS_NO_COMMAND."""
+    from quadruped_locomotion_amd import capi
+    ctx = capi.Context()
+    B = 64
+    keep = fresh_state(B, capi)
+    keep["command"] = None
+    for tick in range(2):
+        msgs, tin = make_tick_inputs(B, tick, truncated=(5,) if tick == 1 else ())
+        io = dict(tin, **keep)
+        capi.full_tick(ctx, io, 0.0025)
+        assert (io["status"] == 4).sum() == (1 if tick == 1 else 0)
+    assert io["status"][5] == 4 and io["message_status"][5] != 0
+
+
+def test_full_tick_keeps_the_previous_efforts_of_a_failed_solve(oracle):
+    """QLAMD_ON_FAILURE_KEEP = the reference's 'VMC compute failed' branch (ros_balance_controller.cpp:418-424,441-454):
+    the support legs of a robot whose solve fails are commanded the efforts of the tick before.  The force QP is always
+    feasible (the pyramid is a cone), so the failure is provoked through the parameters: a negative regulariser makes
+    the Hessian indefinite and the solver reports NOT_PD (QuadProg++.cc:692-699) for every robot."""
+    from quadruped_locomotion_amd import capi
+    B, period = 256, 0.0025
+    bad_c, bad_o = capi.default_params(), oracle.default_params()
+    bad_c.regularizer = bad_o.regularizer = -1e-3
+    for policy in (capi.ON_FAILURE_ZERO, capi.ON_FAILURE_KEEP):
+        good, bad = capi.Context(), capi.Context(params=bad_c)
+        good.set_option(capi.OPT_ON_FAILURE, policy)
+        bad.set_option(capi.OPT_ON_FAILURE, policy)
+        keep = fresh_state(B, capi)
+        states = [oracle.new_tick_state() for _ in range(B)]
+        failed = 0
+        for tick in range(3):
+            msgs, tin = make_tick_inputs(B, tick)
+            io = dict(tin, **keep)
+            capi.full_tick(good if tick == 0 else bad, io, period)
+            st, mst, code = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros((B, 4), np.int8)
+            for b in range(B):
+                st[b], mst[b], code[b] = oracle.full_tick(
+                    states[b], msgs[b], tin["joint_position"][b], tin["joint_velocity"][b], tin["joint_velocity_oldest"][b],
+                    tin["base_position"][b], tin["base_orientation"][b], tin["base_linear_velocity"][b],
+                    tin["base_angular_velocity"][b], tin["contact"][b], period, keep_on_failure=policy,
+                    params=None if tick == 0 else bad_o)
+            compare(io, states, st, mst, code, tick)
+            failed += int((st == 2).sum())
+        assert failed > B
+        stance = io["support"] != 0
+        if policy == capi.ON_FAILURE_KEEP:
+            assert np.abs(io["joint_effort"][np.repeat(stance, 3, axis=1)]).max() > 1.0
+        else:
+            assert (io["joint_effort"][np.repeat(stance, 3, axis=1)] == 0.0).all()
+
+
+def test_full_tick_errors():
+    from quadruped_locomotion_amd import capi
+    ctx = capi.Context()
+    B = 16
+    msgs, tin = make_tick_inputs(B, 0)
+    io = dict(tin, **fresh_state(B, capi))
+    bad = dict(io)
+    bad["contact"] = None
     with pytest.raises(capi.QlamdError):
         capi.full_tick(ctx, bad, 0.0025)
+    # an empty blob: every message has length 0 -> truncated, nobody has a command
+    empty = dict(io, messages=np.zeros(1, np.uint8)[:0].copy(), offsets=np.zeros(B + 1, np.int64))
+    empty["messages"] = np.zeros(0, np.uint8)
+    capi.full_tick(ctx, empty, 0.0025)
+    assert (empty["status"] == 4).all() and (empty["message_status"] != 0).all()

@@ -45,12 +45,14 @@ def test_pose_sqp_4096_matches_oracle(gpu, oracle, tol, max_iter):
 
 
 def test_one_lane_kernel_still_matches_oracle(gpu, oracle, monkeypatch):
-    """The first, one-lane-per-problem kernel stays available as a second implementation (QLAMD_POSE_ONE_LANE)."""
+    """The first, one-lane-per-problem kernel stays available as a second implementation (QLAMD_OPT_POSE_ONE_LANE)."""
     capi, ctx, torch = gpu
-    monkeypatch.setenv("QLAMD_POSE_ONE_LANE", "1")
     pb = synth.make_pose_problems(512)
-    pose, it, st = capi.pose_sqp(ctx, pb)
-    monkeypatch.delenv("QLAMD_POSE_ONE_LANE")
+    ctx.set_option(capi.OPT_POSE_ONE_LANE, 1)
+    try:
+        pose, it, st = capi.pose_sqp(ctx, pb)
+    finally:
+        ctx.set_option(capi.OPT_POSE_ONE_LANE, 0)
     pose2, it2, st2 = capi.pose_sqp(ctx, pb)                      # the cooperative kernel on the same problems
     assert (st == 0).all() and np.array_equal(it, it2) and np.abs(pose - pose2).max() < POSE_TOL
     for i in range(0, 512, 9):
@@ -130,11 +132,11 @@ def test_qp_batch_random_and_error_paths(gpu, oracle):
     CI, ci0 = rng.normal(size=(B, n, m)), rng.normal(size=(B, m)) + 1.0
     zero_eq = (np.zeros((B, n, 1)), np.zeros((B, 1)))              # the reference's dummy column
     xa, fa, sa = capi.qp_solve(ctx, G, g0, *zero_eq, CI, ci0)
-    os.environ["QLAMD_QP_ONE_LANE"] = "1"
+    ctx.set_option(capi.OPT_QP_ONE_LANE, 1)
     try:
         xb, fb, sb = capi.qp_solve(ctx, G, g0, *zero_eq, CI, ci0)
     finally:
-        del os.environ["QLAMD_QP_ONE_LANE"]
+        ctx.set_option(capi.OPT_QP_ONE_LANE, 0)
     assert np.array_equal(sa, sb)
     ok = sa == 0
     assert ok.sum() > 10 and np.abs(xa[ok] - xb[ok]).max() < 1e-8 * max(1.0, np.abs(xb[ok]).max()) and np.allclose(fa[ok], fb[ok], rtol=1e-9)
