@@ -44,8 +44,34 @@ __device__ unsigned long long g_stamps[64];
     __builtin_amdgcn_sched_barrier(0);                                                      \
     if (blockIdx.x == 0 && threadIdx.x == 0) ::qlamd::coop::g_stamps[k] = t_;                              \
   } while (0)
+// segment accumulators inside the active-set loop: QL_SEG(k) adds the time since the previous QL_SEG to slot k
+#define QL_SEG_DECL unsigned long long ql_last_ = 0, ql_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define QL_SEG_START                                                                        \
+  do {                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ql_last_)::"memory");     \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+  } while (0)
+#define QL_SEG(k)                                                                           \
+  do {                                                                                      \
+    unsigned long long t_;                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    ql_acc_[k] += t_ - ql_last_;                                                            \
+    ql_last_ = t_;                                                                          \
+  } while (0)
+#define QL_SEG_STORE                                                                        \
+  do {                                                                                      \
+    if (blockIdx.x == 0 && threadIdx.x == 0)                                                \
+      for (int k_ = 0; k_ < 8; k_++) ::qlamd::coop::g_stamps[16 + k_] = ql_acc_[k_];        \
+  } while (0)
 #else
 #define QL_STAMP(k)
+#define QL_SEG_DECL
+#define QL_SEG_START
+#define QL_SEG(k)
+#define QL_SEG_STORE
 #endif
 
 template <int CTRL>
@@ -111,6 +137,12 @@ __device__ __forceinline__ double vmin(double a, double b) {
   return r;
 }
 
+__device__ __forceinline__ double vmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ double row_min(double x) {
   x = vmin(x, dpp<0x128>(x));
   x = vmin(x, dpp<0x124>(x));
@@ -141,6 +173,11 @@ __device__ __forceinline__ double rcp_nr(double x) {
   y = y + y * (1.0 - x * y);
   y = y + y * (1.0 - x * y);
   return y;
+}
+// one Newton step: 2e-15 relative (the seed has 24 bits, tools/ubench/rcp_accuracy.hip); for ratios that are only compared
+__device__ __forceinline__ double rcp_nr1(double x) {
+  const double y = __builtin_amdgcn_rcp(x);
+  return fma(y, fma(-x, y, 1.0), y);
 }
 __device__ __forceinline__ double rsqrt_nr(double x) {
   double y = __builtin_amdgcn_rsq(x);
@@ -175,12 +212,15 @@ struct CoopPtrs {
 };
 
 // One robot per 16-lane row.  lds_tab: 256-double model table; lds_row: this robot's private
-// LDS block of kCoopLdsDoubles doubles (N* export for the refinement, row export for drops).
+// LDS block of kCoopLdsDoubles doubles (N* export for the refinement, row export for drops); lds_nrm: the wavefront's
+// table of constraint normals, kCoopNrmDoubles doubles ([row kind][lane]).
 constexpr int kCoopLdsDoubles = 12 * 12 + 12;
+constexpr int kCoopNrmDoubles = 5 * 64;
 
 template <bool kPerLeg>
 __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs &s, int64_t irobot, bool robot_live_in,
-                                           double *lds_tab, double *lds_row, double *__restrict__ tau_out,
+                                           double *lds_tab, double *lds_row, double *lds_nrm,
+                                           double *__restrict__ tau_out,
                                            double *__restrict__ grf_out, int32_t *__restrict__ status_out) {
   bool robot_live = robot_live_in;
   const int lr = threadIdx.x & 15;   // lane in row
@@ -331,9 +371,10 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   QL_STAMP(3);
   // ---------------------------------------------------------------- friction pyramid of my leg
   double myn = 0.0, myt1 = 0.0, myt2 = 0.0; // component c of n, t1, t2 (base frame)
+  double nb[3], t1[3], t2[3];               // the whole vectors of my leg
   {
     const double ey[3] = {0.0, 1.0, 0.0}, ez[3] = {0.0, 0.0, 1.0};
-    double yB[3], nW[3], nb[3], t1[3], t2[3];
+    double yB[3], nW[3];
     irot(Rm, ey, yB);
     if (kPerLeg) { nW[0] = nWl[0]; nW[1] = nWl[1]; nW[2] = nWl[2]; }
     else rot(Rm, ez, nW);
@@ -375,9 +416,10 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       Gm[3 * m + 1] = both ? e1 + (c == 1 ? Sfc : 0.0) : 0.0;
       Gm[3 * m + 2] = both ? e2 + (c == 2 ? Sfc : 0.0) : 0.0;
     }
+    // rows of legs that do not support are padding: unit diagonal (they never meet a stance row)
 #pragma unroll
     for (int j = 0; j < 12; j++)
-      if (comp && j == myidx) Gm[j] += P.w_reg;
+      if (comp && j == myidx) Gm[j] += row_on ? P.w_reg : 1.0;
     const double Fc = pick3(b, c);
     const double ST[3] = {P.S[3] * b[3], P.S[4] * b[4], P.S[5] * b[5]};
     const double g0v = -(Sfc * Fc + (a[0] * ST[0] + a[1] * ST[1] + a[2] * ST[2]));
@@ -433,6 +475,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   }
 
   QL_STAMP(6);
+#ifdef QLAMD_COOP_V1
   // ---------------------------------------------------------------- active-set loop
   // Slots are NOT compacted on a drop: a freed slot lane is reused by the next add (the order of the
   // slots only breaks exact ties in the blocking-constraint search).
@@ -509,7 +552,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
         fmac_bc<lane_of(j)>(ra[j % 3], npj, Ns[j]);
       });
       const double z = (za[0] + za[1]) + za[2], r = (ra[0] + ra[1]) + ra[2];
-      const bool slot = (used >> lr) & 1u;
+      const bool slot = (used & lanebit) != 0u;
       const double zn = row_sum(z * npj);
       const float zf = (float)z;
       const double zz = (double)row_sum_f32(zf * zf); // only compared with eps below
@@ -520,7 +563,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       const int lpos = row_first(ratio == t1 && ratio < inf);
       const double t2v = -sp * rcp_nr(zn);
       const bool exhausted = q >= 3 * nS; // empty null space: z is exactly 0 in the reference
-      const double t2 = sel(!exhausted && fabs(zz) > eps && !(t2v < 0.0), t2v, inf);
+      const double t2 = sel((int)(!exhausted) & (int)(fabs(zz) > eps) & (int)(!(t2v < 0.0)), t2v, inf);
       const double t = vmin(t1, t2);
       // what happens this tick (all row-uniform)
       const bool infeasible = !(t < inf);                          // :339-344
@@ -591,6 +634,282 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       }
     }
   }
+
+#else
+  // ---------------------------------------------------------------- active-set loop
+  // One pass of the loop = one step of the dual method (an add or a drop) followed by the rank-one update of H and
+  // N*, with the selection of the next violated constraint (QuadProg++.cc:252-274) computed on the new x in the
+  // shadow of that update: the two are independent, so the broadcast chain of the update fills the wait states of
+  // the selection's cross-lane reduction and vice versa.  Slots are NOT compacted on a drop: a freed slot lane is
+  // reused by the next add (the order of the slots only breaks exact ties in the blocking-constraint search).
+  //
+  // A lone wavefront issues one instruction every ~4.5 cycles whatever its kind (tools/ubench/issue_model.hip), so a
+  // pass costs what it has instructions.  The four robots of a wavefront take different branches of the method, which
+  // makes every state update a predicated select; but the launch lasts as long as its slowest robot, which spends
+  // most of its passes as the only live row of its wavefront.  So the tail of a pass exists three times: all live
+  // rows add (no predication, selection follows), all live rows drop (no selection), and the general predicated form.
+  //
+  // Selection.  Lane (leg, c) watches friction row c + 1 of its leg and, when c = 0, the minimum-force row: with the
+  // three components of x_leg fetched through quad_perm each slack is a 3-term dot product with the lane's own row
+  // vector.  The most violated row is found as the maximum of a 32-bit key per lane: the bits of the slack rounded to
+  // single precision (negative floats order by magnitude as unsigned integers), low five bits replaced by lane and
+  // row kind -- one v_max_u32 with a DPP operand per level instead of two moves and a v_min_f64.  Rows whose slacks
+  // agree to 18 bits are ordered by lane; which of two almost equally violated rows enters first only changes the
+  // path, the minimiser is unique.  Everything that decides a result in double precision stays in double precision:
+  // whether a row is violated at all, the slack of the chosen row (fetched from its lane with ds_bpermute) and the
+  // feasibility test |psi| <= tol (:246), which is only evaluated when the chosen slack is above -tol (psi <= the
+  // most negative slack, so the test cannot pass otherwise).  Component c of the chosen row's normal comes from a
+  // table in LDS ([row kind][lane], written once before the loop), read in the same shadow.
+  double Ns[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) Ns[j] = 0.0;
+  double u = 0.0;            // multiplier of slot lr (free lanes: never read)
+  int idk = 0;               // constraint id of slot lr
+  unsigned used = 0;         // bit k set <=> slot lane k holds an active constraint
+  int q = 0, iters = 0, status = kStatusOk;
+  unsigned act_mask = 0, excl = 0;
+  const double psi_tol = (double)(5 * nS) * eps * c1 * c2 * 100.0;
+  double rnorm2 = 1.0; // R_norm^2
+  bool done = (nS == 0);
+  int ip = 0;
+  double sp = 0.0, ucand = 0.0, npj = 0.0;
+  // rows this lane evaluates
+  const double fa = c == 0 ? 1.0 : c == 1 ? -1.0 : 0.0, fb = c == 2 ? 1.0 : c == 3 ? -1.0 : 0.0;
+  const double Wf0 = mu * nb[0] + (fa * t1[0] + fb * t2[0]), Wf1 = mu * nb[1] + (fa * t1[1] + fb * t2[1]),
+               Wf2 = mu * nb[2] + (fa * t1[2] + fb * t2[2]);
+  const unsigned maskf = on ? (1u << (5 * leg + c + 1)) : 0u, maskm = (on && c == 0) ? (1u << (5 * leg)) : 0u;
+  const unsigned tagf = (unsigned)lr << 1, tagm = tagf | 1u;
+  const int row_addr = ((int)threadIdx.x & 48) << 2; // ds_bpermute byte address of lane 0 of my row
+  const unsigned lanebit = 1u << lr;
+  // table of normals: entry [kind][lane] = component c of my leg's row of that kind (0 minimum force, 1..4 friction)
+  {
+    const double nrm[5] = {myn, mu * myn + myt1, mu * myn - myt1, mu * myn + myt2, mu * myn - myt2};
+#pragma unroll
+    for (int k = 0; k < 5; k++) lds_nrm[64 * k + (int)threadIdx.x] = nrm[k];
+  }
+  const auto slacks = [&](double xx, double &s_min, double &s_fric) {
+    const double x0 = quad_bc<0>(xx), x1 = quad_bc<1>(xx), x2 = quad_bc<2>(xx);
+    s_fric = fma(Wf2, x2, fma(Wf1, x1, Wf0 * x0));
+    s_min = fma(nb[2], x2, fma(nb[1], x1, fma(nb[0], x0, -f_min)));
+  };
+  const auto umax_dpp = [](unsigned k, auto Ctrl) -> unsigned {
+    constexpr int ctrl = decltype(Ctrl)::value;
+    const unsigned o = (unsigned)__builtin_amdgcn_mov_dpp((int)k, ctrl, 0xF, 0xF, true);
+    return k > o ? k : o;
+  };
+
+  // Update of H and N* with the vectors of the step just taken (H[j] += hc * vec_j, N*[j] += nc * vec_j) and
+  // selection of the next constraint at the new x, in one block so that the scheduler can weave the two (and the
+  // bookkeeping of the step in front of them) together.  kMode 0: before the first step (no update; every live row
+  // selects).  kMode 1: general -- rows in `resel` select (`fresh`: after an add, :252-262), the others keep their
+  // candidate.  kMode 2: every live row has just added a constraint.
+  double vec = 0.0, hc = 0.0, nc = 0.0;
+  const auto update_and_select = [&](auto Mode, bool resel, bool fresh) {
+    constexpr int kMode = decltype(Mode)::value;
+    constexpr bool kUpd = kMode != 0;
+    if constexpr (kMode == 1) {
+      iters += (resel && fresh) ? 1 : 0;
+      excl = (resel && fresh) ? 0u : excl;
+    } else {
+      iters += 1;
+      excl = 0u;
+    }
+    const unsigned avail = ~(act_mask | excl);
+    double s_min, s_fric;
+    slacks(x, s_min, s_fric);
+    unsigned kf = __float_as_uint((float)s_fric), km = __float_as_uint((float)s_min);
+    kf = ((avail & maskf) != 0u && s_fric < 0.0) ? ((kf & ~31u) | tagf) : 0u;
+    km = ((avail & maskm) != 0u && s_min < 0.0) ? ((km & ~31u) | tagm) : 0u;
+    const double myv = km > kf ? s_min : s_fric; // the slack behind this lane's key
+    unsigned key = km > kf ? km : kf;
+    if constexpr (kUpd) {
+      static_for<3>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(H[j], vec, hc); fmac_bc<lane_of(j)>(Ns[j], vec, nc); });
+    }
+    key = umax_dpp(key, std::integral_constant<int, 0x128>{});
+    if constexpr (kUpd) {
+      static_for<3>([&](auto J) { constexpr int j = J + 3; fmac_bc<lane_of(j)>(H[j], vec, hc); fmac_bc<lane_of(j)>(Ns[j], vec, nc); });
+    }
+    key = umax_dpp(key, std::integral_constant<int, 0x124>{});
+    if constexpr (kUpd) {
+      static_for<2>([&](auto J) { constexpr int j = J + 6; fmac_bc<lane_of(j)>(H[j], vec, hc); fmac_bc<lane_of(j)>(Ns[j], vec, nc); });
+    }
+    key = umax_dpp(key, std::integral_constant<int, 0x122>{});
+    if constexpr (kUpd) {
+      static_for<2>([&](auto J) { constexpr int j = J + 8; fmac_bc<lane_of(j)>(H[j], vec, hc); fmac_bc<lane_of(j)>(Ns[j], vec, nc); });
+    }
+    key = umax_dpp(key, std::integral_constant<int, 0x121>{});
+    // the chosen row: lane and kind from the low bits, its slack from its lane, its normal from the table
+    const int wl = (int)(key >> 1) & 15;
+    const int addr = row_addr + (wl << 2);
+    const int vlo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(myv));
+    const int vhi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(myv));
+    const int key_kind = (key & 1u) ? 0 : (wl & 3) + 1;
+    const int key_ip = 5 * (wl >> 2) + key_kind;
+    const double np_tab = lds_nrm[64 * key_kind + (int)threadIdx.x];
+    if constexpr (kUpd) {
+      static_for<2>([&](auto J) { constexpr int j = J + 10; fmac_bc<lane_of(j)>(H[j], vec, hc); fmac_bc<lane_of(j)>(Ns[j], vec, nc); });
+    }
+    const double np_new = sel((wl >> 2) == leg, np_tab, 0.0);
+    const bool any = (int)key < 0;                       // a violated row that may enter
+    const double v = __hiloint2double(vhi, vlo);
+    // feasibility, QuadProg++.cc:246-250: only when the worst slack is within the tolerance can the sum be
+    bool feasible = false;
+    const bool close = (kMode != 1 || (resel && fresh)) && any && !(v < -psi_tol);
+    if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
+      const double viol = vmin(0.0, s_fric) + sel(c == 0, vmin(0.0, s_min), 0.0);
+      const double psi = (double)row_sum_f32((float)sel(on, viol, 0.0));
+      feasible = close && (fabs(psi) <= psi_tol);
+    }
+    const bool stop = !any || feasible || iters > kMaxOuter; // :271-274
+    if constexpr (kMode == 1) {
+      status = (resel && stop && iters > kMaxOuter) ? kStatusMaxIter : status;
+      done = done || (resel && stop);
+      const bool take = resel && !stop;
+      ip = take ? key_ip : ip;
+      sp = sel(take, v, sp);
+      ucand = sel(take, 0.0, ucand);
+      npj = sel(take, np_new, npj);
+    } else { // every row here selects: what a stopping row is left with is never read
+      status = (stop && iters > kMaxOuter) ? kStatusMaxIter : status;
+      done = done || stop;
+      ip = key_ip; sp = v; ucand = 0.0; npj = np_new;
+    }
+  };
+  const auto update_only = [&]() {
+    static_for<12>([&](auto J) {
+      constexpr int j = J;
+      fmac_bc<lane_of(j), j == 0>(H[j], vec, hc);
+      fmac_bc<lane_of(j)>(Ns[j], vec, nc);
+    });
+  };
+  // dropping slot lpos (partial or dual-only step): n~ = row lpos of N* reaches the variable lanes through LDS,
+  // then H += n~ n~'/e and N* -= (N* G n~) n~'/e with e = n~'G n~ (row lpos of N* becomes 0)
+  const auto drop_vectors = [&](int lpos) {
+    if (lr == lpos) {
+#pragma unroll
+      for (int j = 0; j < 12; j++) lds_row[144 + j] = Ns[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+    const double nt_me = comp ? lds_row[144 + myidx] : 0.0;
+    const int drop_id = __shfl(idk, lpos, 16);
+    double Gn = 0.0;
+    static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(Gn, nt_me, Gm[j]); });
+    const double einv = rcp_nr1(row_sum(nt_me * Gn));
+    double coef = 0.0;
+    static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(coef, Gn, Ns[j]); });
+    vec = nt_me;
+    hc = nt_me * einv;
+    nc = -coef * einv;
+    return drop_id;
+  };
+
+  update_and_select(std::integral_constant<int, 0>{}, true, true);
+
+  // (terminates: at most kMaxOuter adds, every drop undoes an earlier add, a failed add bans its row until the next add)
+  while (!done) {
+    // ---- directions: z = H n_p (lane i), r = N* n_p (slot lane k; 0 on free lanes, whose rows are 0)
+    // three partial sums per product: consecutive dependent FMAs are 6 instructions apart
+    double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
+    static_for<12>([&](auto J) {
+      constexpr int j = J;
+      fmac_bc<lane_of(j), j == 0>(za[j % 3], npj, H[j]);
+      fmac_bc<lane_of(j)>(ra[j % 3], npj, Ns[j]);
+    });
+    const double z = (za[0] + za[1]) + za[2], r = (ra[0] + ra[1]) + ra[2];
+    const bool slot = (used & lanebit) != 0u;
+    const double zn = row_sum(z * npj);
+    const float zf = (float)z;
+    const double zz = (double)row_sum_f32(zf * zf); // only compared with eps below
+    // ---- step lengths, QuadProg++.cc:304-331
+    const double ur = u * rcp_nr1(r);
+    const double ratio = sel(slot && r > 0.0, ur, inf);
+    const double t1 = row_min(ratio);
+    const double zinv = rcp_nr(zn);
+    const double t2v = -sp * zinv;
+    const bool exhausted = q >= 3 * nS; // empty null space: z is exactly 0 in the reference
+    const double t2 = sel((int)(!exhausted) & (int)(fabs(zz) > eps) & (int)(!(t2v < 0.0)), t2v, inf);
+    const double t = vmin(t1, t2);
+    // what happens this pass (all row-uniform)
+    const bool infeasible = !(t < inf);                          // :339-344
+    const bool dual_only = (t2 >= inf);
+    const bool full = !infeasible && !dual_only && (t2 <= t1);   // :384
+    // add_constraint fails when |R_qq| = sqrt(z'n_p) <= eps * R_norm (:392); compared squared
+    const bool degenerate = full && !(zn > eps * eps * rnorm2);
+    const bool is_add = full && !degenerate;
+    const bool is_drop = !infeasible && !full;                   // partial or dual-only step
+    if (__builtin_amdgcn_ballot_w64(!is_add) == 0ull) {
+      // ---- every live row takes a full step and adds its constraint: H -= z z'/d, N* <- [N* - r z'/d ; z'/d],
+      // the new row goes to the lowest free slot lane
+      x += t * z;
+      u = fma(-t, r, u);
+      const int newlane = __ffs(~used & 0xFFFu) - 1;
+      const bool newslot = lr == newlane;
+      vec = z * zinv;
+      hc = -z;
+      nc = sel(newslot, 1.0, -r);
+      u = sel(newslot, ucand + t, u);
+      idk = newslot ? ip : idk;
+      used |= 1u << newlane;
+      act_mask |= 1u << ip;
+      rnorm2 = vmax(rnorm2, zn);
+      q += 1;
+      update_and_select(std::integral_constant<int, 2>{}, true, true);
+    } else if (__builtin_amdgcn_ballot_w64(!is_drop) == 0ull) {
+      // ---- every live row drops a constraint (partial step, or dual step only when t2 is infinite)
+      const double tp = dual_only ? 0.0 : t;
+      x += tp * z;
+      u = fma(-t, r, u);
+      ucand += t;
+      sp += tp * zn; // slack of ip after a partial step (:436-440, linear in t)
+      const int lpos = row_first(ratio == t1 && ratio < inf);
+      const int drop_id = drop_vectors(lpos);
+      act_mask &= ~(1u << drop_id);
+      used &= ~(1u << lpos);
+      q--;
+      update_only();
+      if (lr == lpos) {
+#pragma unroll
+        for (int j = 0; j < 12; j++) Ns[j] = 0.0;
+      }
+    } else {
+      // ---- general form
+      if (infeasible) { status = kStatusInfeasible; done = true; }
+      const double tp = (infeasible || dual_only || degenerate) ? 0.0 : t;
+      const double td = (infeasible || degenerate) ? 0.0 : t;
+      x += tp * z;
+      u = fma(-td, r, u);
+      ucand += td;
+      sp += tp * zn;
+      // add (predicated).  A numerically dependent normal is skipped and selection repeated.
+      const int newlane = __ffs(~used & 0xFFFu) - 1;
+      const bool newslot = is_add && (lr == newlane);
+      vec = is_add ? z * zinv : 0.0;
+      hc = is_add ? -z : 0.0;
+      nc = sel(newslot, 1.0, sel(is_add, -r, 0.0));
+      u = newslot ? ucand : u;
+      idk = newslot ? ip : idk;
+      used |= is_add ? (1u << newlane) : 0u;
+      act_mask |= is_add ? (1u << ip) : 0u;
+      rnorm2 = is_add ? vmax(rnorm2, zn) : rnorm2;
+      q += is_add ? 1 : 0;
+      excl |= degenerate ? (1u << ip) : 0u;
+      int lpos = 16;
+      if (is_drop) {
+        lpos = row_first(ratio == t1 && ratio < inf);
+        const int drop_id = drop_vectors(lpos);
+        act_mask &= ~(1u << drop_id);
+        used &= ~(1u << lpos);
+        q--;
+      }
+      update_and_select(std::integral_constant<int, 1>{}, full, is_add);
+      if (is_drop && lr == lpos) {
+#pragma unroll
+        for (int j = 0; j < 12; j++) Ns[j] = 0.0;
+      }
+    }
+  }
+#endif
 
   QL_STAMP(7);
   // ---------------------------------------------------------------- refinement on the final working set

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(64) void balance_coop_kernel(const DeviceParams *__
                                                           double *__restrict__ grf, int32_t *__restrict__ status) {
   __shared__ double tab[4 * kTabPerLeg];
   __shared__ double rows[4 * coop::kCoopLdsDoubles];
+  __shared__ double nrm[coop::kCoopNrmDoubles];
   const DeviceParams &P = *Pp;
   const int row = threadIdx.x >> 4;
   int64_t i = (int64_t)blockIdx.x * 4 + row;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(64) void balance_coop_kernel(const DeviceParams *__
 #pragma unroll 1
   for (int rep = 0; rep < 2; rep++) // second pass runs with a warm instruction cache
 #endif
-  coop::coop_robot<kPerLeg>(P, cp, i, live, tab, rows + row * coop::kCoopLdsDoubles, tau, grf, status);
+  coop::coop_robot<kPerLeg>(P, cp, i, live, tab, rows + row * coop::kCoopLdsDoubles, nrm, tau, grf, status);
 }
 
 __global__ __launch_bounds__(64) void virtual_wrench_kernel(const DeviceParams *__restrict__ Pp, const StatePtrs s,

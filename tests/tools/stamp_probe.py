@@ -9,7 +9,7 @@ s = synth.make_states(4096, "trot")
 its = np.array([O.balance_step(s, i)["iters"] for i in range(4096)])
 names = ["load", "wrench", "FK/J/G", "pyramid", "G+GaussJordan", "x0", "loop", "refine", "torque+store"]
 ctx = capi.Context(); ctx.set_robots_per_wave(4)
-for target in (1, 8):
+for target in (1, 4, 8, 11):
     idx = np.where(its == target)[0][:1]
     rep = {k: np.repeat(v[idx], 4096, axis=0) for k, v in s.items()}
     d = capi.to_device(rep)
