@@ -565,3 +565,25 @@ def full_tick(s, msg, q, qd, qd_oldest, base_pos, base_quat, base_linvel, base_a
                                 con.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_double(period), int(index_quirk), int(keep_on_failure),
                                 C.byref(s), code.ctypes.data_as(C.POINTER(C.c_int8)), C.byref(mst))
     return st, mst.value, code
+
+
+# ---- pieces of one SQP iteration (tests/tools/gen_sqp_goldens.py drives the reference's compiled solver with them) ----
+def pose_grad_hess(p, pose):
+    """(g[6], H[6][6]) of a PoseProblem at pose (oracle_pose_grad_hess)."""
+    g, H = np.zeros(6), np.zeros((6, 6))
+    lib().oracle_pose_grad_hess(C.byref(p), (C.c_double * 7)(*pose), g.ctypes.data_as(_dp), H.ctypes.data_as(_dp))
+    return g, H
+
+
+def pose_constraints(p, pose):
+    """(val[m], vmax[m], A[m][6]) of a PoseProblem at pose (oracle_pose_constraints)."""
+    val, vmax, A = np.zeros(8), np.zeros(8), np.zeros((8, 6))
+    m = lib().oracle_pose_constraints(C.byref(p), (C.c_double * 7)(*pose), val.ctypes.data_as(_dp), vmax.ctypes.data_as(_dp),
+                                      A.ctypes.data_as(_dp))
+    return val[:m].copy(), vmax[:m].copy(), A[:m].copy()
+
+
+def quat_box_plus(q, d):
+    out = (C.c_double * 4)()
+    lib().oracle_quat_box_plus((C.c_double * 4)(*q), (C.c_double * 3)(*d), out)
+    return np.array(out[:])

@@ -438,18 +438,25 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     // on the pivot lane f = 1 - 1/d turns the same formula into H_k[j] / d.
     bool bad = false;
     double my_pivot = 1.0; // pivot of my own row, for c2 below
+    // The chain pivot -> reciprocal -> factor -> row updates -> next pivot is serial; the column of the NEXT pivot is
+    // updated first, so that its reciprocal (hardware seed + one Newton step, 2e-15: the final refinement works on
+    // G itself, not on this inverse) is under way while the other ten columns are still being updated.
+    double d = bcv<0>(H[0]);
     static_for<12>([&](auto K) {
       constexpr int k = K;
-      const double d = bcv<k>(H[k]);
       bad = bad || !(d > 0.0);
-      const double p = rcp_nr(d);
+      const double p = rcp_nr1(d);
       const bool piv = comp && (myidx == k);
       my_pivot = piv ? d : my_pivot;
       const double f = piv ? (1.0 - p) : H[k] * p;
       const double nf = -f;
+      if constexpr (k < 11) {
+        fmac_bc<lane_of(k), true>(H[k + 1], H[k + 1], nf);
+        d = bcv<k + 1>(H[k + 1]);
+      }
       static_for<12>([&](auto J) {
         constexpr int j = J;
-        if constexpr (j != k) fmac_bc<lane_of(k), (j == (k == 0 ? 1 : 0))>(H[j], H[j], nf);
+        if constexpr (j != k && j != k + 1) fmac_bc<lane_of(k), (k == 11 && j == 0)>(H[j], H[j], nf);
       });
       H[k] = piv ? p : nf;
     });

@@ -211,3 +211,41 @@ def test_pose_sqp_stress_against_oracle(gpu, oracle):
             n_bad += 1
     assert n_bad < B // 2
     print("non-OK statuses:", n_bad)
+
+
+def test_linearly_dependent_rows_follow_the_reference(gpu, oracle):
+    """Constraint normals that are parallel to rows already in the working set: the reference takes a dual step and
+    swaps the rows (z = 0, QuadProg++.cc:304-331) or reports the pair infeasible (:339-344); its add_constraint failure
+    (:392-421, |R_qq| <= eps R_norm) needs z'z > eps together with z'n <= eps^2 R_norm^2, which z'n >= z'z / lambda_max(H)
+    excludes for a positive semi-definite H.  Scaled duplicates, contradictory pairs and three
+    coplanar normals, with and without the all-zero equality column, against the pinned restatement."""
+    capi, ctx, torch = gpu
+    rng = np.random.default_rng(77)
+    B, n = 96, 6
+    for m, build in ((4, "scaled"), (4, "contradictory"), (5, "coplanar")):
+        M = rng.normal(size=(B, n, n)); G = M @ M.transpose(0, 2, 1) + 0.1 * np.eye(n); g0 = rng.normal(size=(B, n))
+        CI, ci0 = rng.normal(size=(B, n, m)), rng.normal(size=(B, m)) + 0.5
+        x0 = -np.linalg.solve(G, g0[..., None])[..., 0]
+        a = CI[:, :, 0]
+        s_a = (a * x0).sum(1)
+        if build == "scaled":          # row 1 = half of row 0, violated by delta once row 0 is tight
+            ci0[:, 0] = -s_a - 1.0
+            CI[:, :, 1], ci0[:, 1] = 0.5 * a, 0.5 * ci0[:, 0] - 0.01
+        elif build == "contradictory":  # a'x >= c and -a'x >= -c + 1
+            ci0[:, 0] = -s_a - 1.0
+            CI[:, :, 1], ci0[:, 1] = -a, -ci0[:, 0] - 1.0
+        else:                           # rows 0, 1, 2 span a plane: row 2 = row 0 + row 1, each cutting off x0
+            b = CI[:, :, 1]
+            ci0[:, 0], ci0[:, 1] = -s_a - 1.0, -(b * x0).sum(1) - 1.0
+            CI[:, :, 2], ci0[:, 2] = a + b, ci0[:, 0] + ci0[:, 1] - 0.3
+        for dummy in (False, True):
+            CE, ce0 = (np.zeros((B, n, 1)), np.zeros((B, 1))) if dummy else (None, None)
+            x, f, st = capi.qp_solve(ctx, G, g0, CE, ce0, CI, ci0)
+            n_inf = 0
+            for i in range(B):
+                r = oracle.solve_quadprog(G[i], g0[i], None if CE is None else CE[i], None if ce0 is None else ce0[i], CI[i], ci0[i])
+                assert r["status"] == st[i], (build, dummy, i)
+                n_inf += int(st[i] == capi.STATUS_INFEASIBLE)
+                if st[i] == 0:
+                    assert np.abs(r["x"] - x[i]).max() < 1e-8 * max(1.0, np.abs(r["x"]).max()), (build, dummy, i)
+            assert (n_inf == B) == (build == "contradictory")
