@@ -16,6 +16,10 @@ from conftest import ROOT
 from quadruped_locomotion_amd import synth
 
 GOLD = os.path.join(ROOT, "tests", "golden")
+# Contact forces in newtons against the exact minimiser.  The joint torques follow through J' (entries below 0.7 m), so
+# this keeps them an order of magnitude inside the 1e-6 of BASELINE.json's north_star; the reference's own compiled
+# QuadProg++ sits 3e-9 from the exact point on these problems (tests/tools/gen_force_qp_exact.py).
+FORCE_TOL = 1e-7
 HIPS, ORDER = synth.POSE_HIPS, synth.POSE_LEG_ORDER
 
 
@@ -124,13 +128,15 @@ def test_device_force_qp_against_exact_minimisers(gpu, goldens, exact):
     capi, ctx, torch = gpu
     for name in ("n12", "n6"):
         x, f, st = capi.qp_solve(ctx, goldens[name + "_G"], goldens[name + "_g0"], None, None, goldens[name + "_CI"], goldens[name + "_ci0"])
-        assert (st == 0).all() and np.abs(x - exact[name + "_x"]).max() < 1e-8
+        err = np.abs(x - exact[name + "_x"]).max()
+        assert (st == 0).all() and err < FORCE_TOL, (name, err)
     for name, state in zip(("n12", "n6"), golden_states()):
         tau, grf, st = ctx.balance_solve_host(state)
         assert (st == 0).all()
         B = grf.shape[0]
         x = np.stack([grf[b].reshape(4, 3)[state["stance"][b] != 0].ravel() for b in range(B)])
-        assert np.abs(x - exact[name + "_x"]).max() < 1e-8          # forces in newtons; torques follow through J' (< 1)
+        err = np.abs(x - exact[name + "_x"]).max()
+        assert err < FORCE_TOL, (name, err)
 
 
 @pytest.mark.gpu
