@@ -217,7 +217,7 @@ struct CoopPtrs {
 constexpr int kCoopLdsDoubles = 12 * 12 + 12;
 constexpr int kCoopNrmDoubles = 5 * 64;
 
-template <bool kPerLeg>
+template <bool kPerLeg, int kBlock = 64>
 __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs &s, int64_t irobot, bool robot_live_in,
                                            double *lds_tab, double *lds_row, double *lds_nrm,
                                            double *__restrict__ tau_out,
@@ -235,10 +235,11 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   // The model table (4 x 88 doubles) goes to LDS for the leg-indexed reads below.  Its six loads per lane are
   // issued first and unconditionally (clamped index), the robot's own state right behind them, and only then
   // are the table values stored and the barrier taken: one memory round trip instead of seven in a row.
-  double tabv[6];
+  constexpr int kTabLoads = (4 * kTabPerLeg + kBlock - 1) / kBlock;
+  double tabv[kTabLoads];
 #pragma unroll
-  for (int j = 0; j < 6; j++) {
-    const int idx = (int)threadIdx.x + 64 * j;
+  for (int j = 0; j < kTabLoads; j++) {
+    const int idx = (int)threadIdx.x + kBlock * j;
     tabv[j] = P.legtab[idx < 4 * kTabPerLeg ? idx : 4 * kTabPerLeg - 1];
   }
   const int64_t i = irobot;
@@ -274,8 +275,8 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   const int nS = __popc(stance);
   const bool on = ((stance >> leg) & 1u) != 0; // my leg supports
 #pragma unroll
-  for (int j = 0; j < 6; j++) {
-    const int idx = (int)threadIdx.x + 64 * j;
+  for (int j = 0; j < kTabLoads; j++) {
+    const int idx = (int)threadIdx.x + kBlock * j;
     if (idx < 4 * kTabPerLeg) lds_tab[idx] = tabv[j];
   }
   __syncthreads();
@@ -692,7 +693,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   {
     const double nrm[5] = {myn, mu * myn + myt1, mu * myn - myt1, mu * myn + myt2, mu * myn - myt2};
 #pragma unroll
-    for (int k = 0; k < 5; k++) lds_nrm[64 * k + (int)threadIdx.x] = nrm[k];
+    for (int k = 0; k < 5; k++) lds_nrm[64 * k + ((int)threadIdx.x & 63)] = nrm[k];
   }
   const auto slacks = [&](double xx, double &s_min, double &s_fric) {
     const double x0 = quad_bc<0>(xx), x1 = quad_bc<1>(xx), x2 = quad_bc<2>(xx);
@@ -752,7 +753,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     const int vhi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(myv));
     const int key_kind = (key & 1u) ? 0 : (wl & 3) + 1;
     const int key_ip = 5 * (wl >> 2) + key_kind;
-    const double np_tab = lds_nrm[64 * key_kind + (int)threadIdx.x];
+    const double np_tab = lds_nrm[64 * key_kind + ((int)threadIdx.x & 63)];
     if constexpr (kUpd) {
       static_for<2>([&](auto J) { constexpr int j = J + 10; fmac_bc<lane_of(j)>(H[j], vec, hc); fmac_bc<lane_of(j)>(Ns[j], vec, nc); });
     }
