@@ -814,39 +814,43 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
 
   update_and_select(std::integral_constant<int, 0>{}, true, true);
 
-  // (terminates: at most kMaxOuter adds, every drop undoes an earlier add, a failed add bans its row until the next add)
-  while (!done) {
-    // ---- directions: z = H n_p (lane i), r = N* n_p (slot lane k; 0 on free lanes, whose rows are 0)
-    // three partial sums per product: consecutive dependent FMAs are 6 instructions apart
-    double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
-    static_for<12>([&](auto J) {
-      constexpr int j = J;
-      fmac_bc<lane_of(j), j == 0>(za[j % 3], npj, H[j]);
-      fmac_bc<lane_of(j)>(ra[j % 3], npj, Ns[j]);
-    });
-    const double z = (za[0] + za[1]) + za[2], r = (ra[0] + ra[1]) + ra[2];
-    const bool slot = (used & lanebit) != 0u;
-    const double zn = row_sum(z * npj);
-    const float zf = (float)z;
-    const double zz = (double)row_sum_f32(zf * zf); // only compared with eps below
-    // ---- step lengths, QuadProg++.cc:304-331
-    const double ur = u * rcp_nr1(r);
-    const double ratio = sel(slot && r > 0.0, ur, inf);
-    const double t1 = row_min(ratio);
-    const double zinv = rcp_nr(zn);
-    const double t2v = -sp * zinv;
-    const bool exhausted = q >= 3 * nS; // empty null space: z is exactly 0 in the reference
-    const double t2 = sel((int)(!exhausted) & (int)(fabs(zz) > eps) & (int)(!(t2v < 0.0)), t2v, inf);
-    const double t = vmin(t1, t2);
-    // what happens this pass (all row-uniform)
-    const bool infeasible = !(t < inf);                          // :339-344
-    const bool dual_only = (t2 >= inf);
-    const bool full = !infeasible && !dual_only && (t2 <= t1);   // :384
-    // add_constraint fails when |R_qq| = sqrt(z'n_p) <= eps * R_norm (:392); compared squared
-    const bool degenerate = full && !(zn > eps * eps * rnorm2);
-    const bool is_add = full && !degenerate;
-    const bool is_drop = !infeasible && !full;                   // partial or dual-only step
-    if (__builtin_amdgcn_ballot_w64(!is_add) == 0ull) {
+  // Loop structure.  A pass = directions and step lengths, then what the step is.  Passes in which EVERY live row adds
+  // its constraint run in an inner loop that is one straight path: unpredicated bookkeeping, then update + selection.
+  // It is left as soon as some row drops, fails or is infeasible; that pass is finished by the tail below (all rows
+  // drop: unpredicated, no selection; otherwise the general predicated form) and the inner loop is entered again.
+  // (Alternative tails inside ONE loop cost 24 register copies of H and N* on its back edge; and the launch lasts as
+  // long as its slowest robot, which is alone in its wavefront for most of its passes.)
+  // Terminates: at most kMaxOuter adds, every drop undoes an earlier add, a failed add bans its row until the next add.
+  for (;;) {
+    double z = 0.0, r = 0.0, zn = 0.0, zinv = 0.0, t = 0.0, tl1 = 0.0, tl2 = 0.0, ratio = 0.0;
+    bool is_add = false;
+    while (!done) {
+      // ---- directions: z = H n_p (lane i), r = N* n_p (slot lane k; 0 on free lanes, whose rows are 0)
+      // three partial sums per product: consecutive dependent FMAs are 6 instructions apart
+      double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
+      static_for<12>([&](auto J) {
+        constexpr int j = J;
+        fmac_bc<lane_of(j), j == 0>(za[j % 3], npj, H[j]);
+        fmac_bc<lane_of(j)>(ra[j % 3], npj, Ns[j]);
+      });
+      z = (za[0] + za[1]) + za[2];
+      r = (ra[0] + ra[1]) + ra[2];
+      const bool slot = (used & lanebit) != 0u;
+      zn = row_sum(z * npj);
+      const float zf = (float)z;
+      const double zz = (double)row_sum_f32(zf * zf); // only compared with eps below
+      // ---- step lengths, QuadProg++.cc:304-331
+      const double ur = u * rcp_nr1(r);
+      ratio = sel(slot && r > 0.0, ur, inf);
+      tl1 = row_min(ratio);
+      zinv = rcp_nr(zn);
+      const double t2v = -sp * zinv;
+      const bool exhausted = q >= 3 * nS; // empty null space: z is exactly 0 in the reference
+      tl2 = sel((int)(!exhausted) & (int)(fabs(zz) > eps) & (int)(!(t2v < 0.0)), t2v, inf);
+      t = vmin(tl1, tl2);
+      // a full step (:384) whose constraint can be added (:392: |R_qq| = sqrt(z'n_p) > eps * R_norm, compared squared)
+      is_add = (tl2 < inf) && (tl2 <= tl1) && (zn > eps * eps * rnorm2);
+      if (__builtin_amdgcn_ballot_w64(!is_add) != 0ull) break;
       // ---- every live row takes a full step and adds its constraint: H -= z z'/d, N* <- [N* - r z'/d ; z'/d],
       // the new row goes to the lowest free slot lane
       x += t * z;
@@ -863,25 +867,34 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       rnorm2 = vmax(rnorm2, zn);
       q += 1;
       update_and_select(std::integral_constant<int, 2>{}, true, true);
-    } else if (__builtin_amdgcn_ballot_w64(!is_drop) == 0ull) {
-      // ---- every live row drops a constraint (partial step, or dual step only when t2 is infinite)
-      const double tp = dual_only ? 0.0 : t;
-      x += tp * z;
-      u = fma(-t, r, u);
-      ucand += t;
-      sp += tp * zn; // slack of ip after a partial step (:436-440, linear in t)
-      const int lpos = row_first(ratio == t1 && ratio < inf);
-      const int drop_id = drop_vectors(lpos);
-      act_mask &= ~(1u << drop_id);
-      used &= ~(1u << lpos);
-      q--;
-      update_only();
-      if (lr == lpos) {
+    }
+    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+    if (__builtin_amdgcn_ballot_w64(!done && !(tl1 < tl2)) == 0ull) {
+      // ---- every live row drops a constraint (t1 < t2: partial step, or dual step only when t2 is infinite)
+      if (!done) {
+        const double tp = (tl2 >= inf) ? 0.0 : t;
+        x += tp * z;
+        u = fma(-t, r, u);
+        ucand += t;
+        sp += tp * zn; // slack of ip after a partial step (:436-440, linear in t)
+        const int lpos = row_first(ratio == tl1 && ratio < inf);
+        const int drop_id = drop_vectors(lpos);
+        act_mask &= ~(1u << drop_id);
+        used &= ~(1u << lpos);
+        q--;
+        update_only();
+        if (lr == lpos) {
 #pragma unroll
-        for (int j = 0; j < 12; j++) Ns[j] = 0.0;
+          for (int j = 0; j < 12; j++) Ns[j] = 0.0;
+        }
       }
-    } else {
-      // ---- general form
+    } else if (!done) {
+      // ---- the pass of the live rows in general form (all row-uniform)
+      const bool infeasible = !(t < inf);                          // :339-344
+      const bool dual_only = (tl2 >= inf);
+      const bool full = !infeasible && !dual_only && (tl2 <= tl1);   // :384
+      const bool degenerate = full && !is_add;
+      const bool is_drop = !infeasible && !full;                   // partial or dual-only step
       if (infeasible) { status = kStatusInfeasible; done = true; }
       const double tp = (infeasible || dual_only || degenerate) ? 0.0 : t;
       const double td = (infeasible || degenerate) ? 0.0 : t;
@@ -904,7 +917,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       excl |= degenerate ? (1u << ip) : 0u;
       int lpos = 16;
       if (is_drop) {
-        lpos = row_first(ratio == t1 && ratio < inf);
+        lpos = row_first(ratio == tl1 && ratio < inf);
         const int drop_id = drop_vectors(lpos);
         act_mask &= ~(1u << drop_id);
         used &= ~(1u << lpos);

@@ -136,8 +136,9 @@ __global__ __launch_bounds__(64) void balance_step_kernel(const DeviceParams *__
 // shared) costs 2.3 us at 4096 robots and 20 % at 65536 -- the barrier behind the table ties the start of four
 // wavefronts together and workgroups leave their compute unit only when their slowest wavefront has finished.
 constexpr int kCoopWaves = 1;
+// (at least two wavefronts per SIMD, i.e. at most 256 registers: the large-batch throughput halves without it)
 template <bool kPerLeg>
-__global__ __launch_bounds__(64 * kCoopWaves) void balance_coop_kernel(const DeviceParams *__restrict__ Pp, const StatePtrs s,
+__global__ __launch_bounds__(64 * kCoopWaves, 2) void balance_coop_kernel(const DeviceParams *__restrict__ Pp, const StatePtrs s,
                                                                       int64_t B, double *__restrict__ tau,
                                                                       double *__restrict__ grf, int32_t *__restrict__ status) {
   __shared__ double tab[4 * kTabPerLeg];
