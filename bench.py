@@ -221,6 +221,7 @@ def bench_pose_sqp(args):
         cpu = {"value": v, "unit": "pose-SQP solves/s", "cores": best, "kind": "port", "single_thread_value": probe.get(1),
                "visible_cores": visible, "sample": "%d passes over the same %d problems (%.1f s), OpenMP over problems, "
                "%d threads (fastest of %s)" % (n, B, dt, best, cands)}
+    rec, prov = pmc_record("pose_sqp_coop_kernel", B, "pose_sqp")
     print(json.dumps({
         "metric": "pose-SQP solves/sec (config 5, reported separately from the headline metric)",
         "value": B * args.steps / elapsed, "unit": "solves/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -229,7 +230,8 @@ def bench_pose_sqp(args):
         "config": {"workload": "batch=%d pose optimisations, 5 SQP iterations x inner Goldfarb-Idnani QP "
                                "(n=6, m=8, dummy equality)" % B, "all_status_ok": bool((out[2] == 0).all().item())},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "pose_sqp_coop_kernel", "kernel_ms": kernel_ms,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": int(rec["fetch_bytes"] + rec["write_bytes"]) if rec else None,
+                     "traffic_source": prov, "kernel": "pose_sqp_coop_kernel", "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": algo},
         **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
 

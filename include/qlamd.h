@@ -145,12 +145,9 @@ int qlamd_set_robots_per_wave(qlamd_context *ctx, int robots_per_wave);
  *                          the reference's behaviour, whose update() logs "VMC compute failed" and commands the
  *                          efforts still held in State from the previous tick (ros_balance_controller.cpp:418-424,441-454).
  *   QLAMD_OPT_REFINE_PASSES  refinement passes of the lane-cooperative force QP on its final working set (default 1)
- *   QLAMD_OPT_QP_ONE_LANE / QLAMD_OPT_POSE_ONE_LANE / QLAMD_OPT_WHOLEBODY_SPLIT  1 selects the second implementation
- *                          of the dense QP batch (then m <= 24) / the pose SQP / the two-launch dynamics (diagnostics). */
+ *   QLAMD_OPT_WHOLEBODY_SPLIT  1 selects the two-launch form of the whole-body dynamics (diagnostics). */
 #define QLAMD_OPT_ON_FAILURE 1
 #define QLAMD_OPT_REFINE_PASSES 2
-#define QLAMD_OPT_QP_ONE_LANE 3
-#define QLAMD_OPT_POSE_ONE_LANE 4
 #define QLAMD_OPT_WHOLEBODY_SPLIT 5
 #define QLAMD_ON_FAILURE_ZERO 0
 #define QLAMD_ON_FAILURE_KEEP 1
@@ -237,12 +234,13 @@ int qlamd_leg_kinematics_batch(qlamd_context *ctx, const double *joint_position,
 
 /* ---- dense QP batch -------------------------------------------------
  * min 1/2 x'Gx + g0'x  s.t.  CE'x + ce0 = 0,  CI'x + ci0 >= 0, one problem per batch entry, all
- * of the same shape (n <= 12, p <= 2, m <= 24; with p <= 1 up to m = 48), row-major, one constraint per COLUMN of CE / CI as
+ * of the same shape (n <= 12, p <= 2, m <= 48), row-major, one constraint per COLUMN of CE / CI as
  * in quadprogpp::solve_quadprog(G, g0, CE, ce0, CI, ci0, x) (qp_solver/include/qp_solver/QuadProg++.h:69-72),
  * which this replaces together with qp_solver::QuadraticProblemSolver::minimize
  * (qp_solver/src/quadraticproblemsolver.cpp:65-97; its wrapper passes CI = -A', ci0 = b for A x <= b,
  * :164).  The Goldfarb-Idnani iteration is the reference's, including its treatment of an all-zero
- * equality column.  G is not modified.
+ * equality column when p = 1 (with p = 2 both columns have to be genuine, linearly independent normals: an
+ * all-zero or dependent second column is ignored).  G is not modified.
  *   G [B][n][n], g0 [B][n], CE [B][n][p] (NULL if p = 0), ce0 [B][p], CI [B][n][m], ci0 [B][m]
  *   x [B][n] out, objective [B] out or NULL (+inf when infeasible), status [B] out (QLAMD_STATUS_*)
  */

@@ -706,7 +706,7 @@ def wholebody_dynamics_device(ctx, dstate, M, h, Jc, gravity=9.81, stream=None):
         raise QlamdError(rc, "qlamd_wholebody_dynamics_batch")
 
 
-OPT_ON_FAILURE, OPT_REFINE_PASSES, OPT_QP_ONE_LANE, OPT_POSE_ONE_LANE, OPT_WHOLEBODY_SPLIT = 1, 2, 3, 4, 5
+OPT_ON_FAILURE, OPT_REFINE_PASSES, OPT_WHOLEBODY_SPLIT = 1, 2, 5
 ON_FAILURE_ZERO, ON_FAILURE_KEEP = 0, 1
 STATUS_NO_COMMAND = 4
 

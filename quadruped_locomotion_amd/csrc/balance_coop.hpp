@@ -215,7 +215,7 @@ struct CoopPtrs {
 // LDS block of kCoopLdsDoubles doubles (N* export for the refinement, row export for drops); lds_nrm: the wavefront's
 // table of constraint normals, kCoopNrmDoubles doubles ([row kind][lane]).
 constexpr int kCoopLdsDoubles = 12 * 12 + 12;
-constexpr int kCoopNrmDoubles = 5 * 64;
+constexpr int kCoopNrmDoubles = 11 * 64; // 5 row kinds + parked Jacobian row (3) and gravity torque (3)
 
 template <bool kPerLeg, int kBlock = 64>
 __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs &s, int64_t irobot, bool robot_live_in,
@@ -367,6 +367,14 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       const double zh = qcross(zax[k], h);
       Gq[k] = -quad_sum(sel(comp, my_g * zh, 0.0));
     }
+  }
+
+  // Jacobian row and gravity torque are not needed before the torques at the very end: parked in LDS ([k][lane]) so
+  // that the kernel stays within 256 registers without a spill to scratch memory
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    lds_nrm[64 * (5 + k) + ((int)threadIdx.x & 63)] = Jrow[k];
+    lds_nrm[64 * (8 + k) + ((int)threadIdx.x & 63)] = Gq[k];
   }
 
   QL_STAMP(3);
@@ -972,9 +980,15 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   {
     const bool live = on && status == kStatusOk;
     const double fx = live ? -x : 0.0;
-    const double t0 = quad_sum(sel(comp, Jrow[0] * fx, 0.0)) + Gq[0];
-    const double t1 = quad_sum(sel(comp, Jrow[1] * fx, 0.0)) + Gq[1];
-    const double t2 = quad_sum(sel(comp, Jrow[2] * fx, 0.0)) + Gq[2];
+    double Jr[3], Gr[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      Jr[k] = lds_nrm[64 * (5 + k) + ((int)threadIdx.x & 63)];
+      Gr[k] = lds_nrm[64 * (8 + k) + ((int)threadIdx.x & 63)];
+    }
+    const double t0 = quad_sum(sel(comp, Jr[0] * fx, 0.0)) + Gr[0];
+    const double t1 = quad_sum(sel(comp, Jr[1] * fx, 0.0)) + Gr[1];
+    const double t2 = quad_sum(sel(comp, Jr[2] * fx, 0.0)) + Gr[2];
     double t = sel(c == 0, t0, sel(c == 1, t1, t2));
     t = t > P.tau_max ? P.tau_max : t;
     t = t < -P.tau_max ? -P.tau_max : t;

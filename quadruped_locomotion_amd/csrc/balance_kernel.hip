@@ -306,7 +306,7 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
   ctx->tick_ws = nullptr;
   ctx->tick_ws_bytes = 0;
   ctx->on_failure = QLAMD_ON_FAILURE_ZERO;
-  ctx->qp_one_lane = ctx->pose_one_lane = ctx->wb_split = 0;
+  ctx->wb_split = 0;
   ctx->depth = 0;
   ctx->has_last_stream = false;
   ctx->last_stream = nullptr;
@@ -363,8 +363,6 @@ int qlamd_set_option(qlamd_context *ctx, int option, int value) {
       if (value < 0 || value > 4) return QLAMD_ERR_INVALID_ARGUMENT;
       ctx->params.refine_passes = value;
       break;
-    case QLAMD_OPT_QP_ONE_LANE: ctx->qp_one_lane = value != 0; return QLAMD_OK;
-    case QLAMD_OPT_POSE_ONE_LANE: ctx->pose_one_lane = value != 0; return QLAMD_OK;
     case QLAMD_OPT_WHOLEBODY_SPLIT: ctx->wb_split = value != 0; return QLAMD_OK;
     default: return QLAMD_ERR_INVALID_ARGUMENT;
   }

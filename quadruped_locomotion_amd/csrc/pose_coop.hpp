@@ -36,10 +36,13 @@ constexpr int kPoseCoopLdsDoubles = 8 * 6 + 6 + 6 * 6; // per problem: normals b
 // Gm: row lr of G on variable lanes (0 elsewhere); g0: component lr; a, bci0, cvalid: this constraint lane's
 // normal (CI column), ci0 and presence; m: number of inequality constraints present.  Returns the status;
 // x_out = component lr of the minimiser on variable lanes.
+// n: number of real variables (6 for the SQP step; 3 for the position-only QP, whose rows 3..5 of G are identity
+// padding -- those variables stay 0 and do not enter the traces behind the termination tolerance).
 __device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const double (&a)[6], double bci0, bool cvalid,
-                                        int m, bool dummy_eq, bool skip, double *lds_row, double &x_out) {
+                                        int m, bool dummy_eq, bool skip, double *lds_row, double &x_out, int n = 6) {
   const int lr = threadIdx.x & 15;
   const bool var = lr < 6;
+  const bool real = lr < n;
   const int cj = lr - 8; // constraint id on constraint lanes
   const double eps = 2.220446049250313e-16;
   const double inf = INFINITY;
@@ -54,7 +57,7 @@ __device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const 
   double diag = 0.0;
 #pragma unroll
   for (int j = 0; j < 6; j++) diag = sel(lr == j, Gm[j], diag);
-  const double c1 = row_sum(sel(var, diag, 0.0));
+  const double c1 = row_sum(sel(real, diag, 0.0));
   // H = G^-1 by Gauss-Jordan, row per lane (non-variable lanes carry zero rows)
   double H[6];
 #pragma unroll
@@ -77,7 +80,7 @@ __device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const 
     H[k] = piv ? p : nf;
   });
   const double rp = rsqrt_nr(my_pivot);
-  const double c2 = row_sum(sel(var, rp, 0.0));
+  const double c2 = row_sum(sel(real, rp, 0.0));
   // x0 = -G^-1 g0 (the equality below holds there by construction)
   double x = 0.0;
   {
@@ -149,7 +152,7 @@ __device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const 
       const double t1 = row_min(ratio);
       const int lpos = row_first(ratio == t1 && ratio < inf);
       const double t2v = -sp * rcp_nr(zn);
-      const bool exhausted = q + (dummy_eq ? 1 : 0) >= 6; // empty null space: z is exactly 0 in the reference
+      const bool exhausted = q + (dummy_eq ? 1 : 0) >= n; // empty null space: z is exactly 0 in the reference
       const double t2 = sel(!exhausted && fabs(zz) > eps && !(t2v < 0.0), t2v, inf);
       const double t = vmin(t1, t2);
       const bool infeasible = !(t < inf);                          // :339-344
@@ -402,6 +405,220 @@ __device__ __forceinline__ int pose_sqp_coop(const PoseParamsDev &P, const PoseP
   }
   iters_out = k;
   return status;
+}
+
+
+// ---- PoseOptimizationQP::optimize in the row layout (PoseOptimizationQP.cpp:42-140) ---------------------------
+// Position only: min sum |x + R d_i - f_i|^2 s.t. the support half-spaces on (x + R r_com)_xy, with the reference's
+// all-zero equality column -- the n = 3 problem on the six variable lanes of qp6_coop (rows 3..5 identity), the
+// half-spaces on constraint lanes 8..11.  pose: replicated, position replaced on success.
+__device__ __forceinline__ int pose_qp_coop(const PoseParamsDev &P, const PoseProblem &pb, bool live, double *lds_row,
+                                            double pose[7]) {
+  const int lr = threadIdx.x & 15, cj = lr - 8;
+  double R[9], qv[3] = {0.0, 0.0, 0.0};
+  quat_to_matrix(pose + 3, R);
+  const unsigned present = pb.present;
+  const int nl = __popc(present & 0xFu);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (!((present >> k) & 1u)) continue;
+    double Rd[3];
+    rot(R, pb.nominal[k], Rd);
+#pragma unroll
+    for (int i = 0; i < 3; i++) qv[i] += -2.0 * (pb.stance[k][i] - Rd[i]);
+  }
+  double GA[4][2], gb[4], Rr[3];
+  const int m = polygon_halfspaces(pb.n_vertices, pb.polygon, GA, gb);
+  rot(R, pb.r_com, Rr);
+  double Gm[6], a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, g0 = 0.0, bci0 = 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; j++) Gm[j] = lr == j ? (j < 3 ? 2.0 * (double)nl : 1.0) : 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) g0 = sel(lr == i, qv[i], g0);
+  const bool cvalid = lr >= 8 && cj < m;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const bool me = cvalid && cj == j;
+    a[0] = sel(me, -GA[j][0], a[0]);
+    a[1] = sel(me, -GA[j][1], a[1]);
+    bci0 = sel(me, gb[j] - (GA[j][0] * Rr[0] + GA[j][1] * Rr[1]), bci0);
+  }
+  double x;
+  const int st = qp6_coop(Gm, g0, a, bci0, cvalid, m, P.dummy_equality != 0, !live, lds_row, x, 3);
+  const double x0 = bc<0>(x), x1 = bc<1>(x), x2 = bc<2>(x);
+  if (st == kStatusOk) { pose[0] = x0; pose[1] = x1; pose[2] = x2; }
+  return st;
+}
+
+// ---- PoseOptimizationGeometric::optimize in the row layout (PoseOptimizationGeometric.cpp:34-105) --------------
+// Everything but the eigen-problem is a few dozen replicated operations (pose_core.hpp: pose_geometric).  The 4x4
+// symmetric eigen-problem runs on the four lanes of a quad, lane i holding row i of A and of the vectors V: the
+// parallel Jacobi ordering (0,1)(2,3) / (0,2)(1,3) / (0,3)(1,2) rotates two disjoint pairs at once, so a sweep is
+// three rounds instead of six rotations; partners and the other pair's (c, s) arrive through quad_perm.
+template <int kPartner> // quad_perm control that maps lane i to its partner in this round
+__device__ __forceinline__ void jacobi_round(double (&A)[4], double (&V)[4], int c4, bool &rotated) {
+  // this round's pairs: partner = c4 ^ mask with mask 1, 2, 3 for kPartner 0xB1 [1,0,3,2], 0x4E [2,3,0,1], 0x1B [3,2,1,0]
+  constexpr int mask = kPartner == 0xB1 ? 1 : kPartner == 0x4E ? 2 : 3;
+  const int pr = c4 ^ mask;
+  const bool low = c4 < pr;                 // I am p (the smaller index) of my pair
+  // a_pp, a_qq, a_pq of my pair: my diagonal, my partner's diagonal, my element in my partner's column
+  double dme = 0.0, ape = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { dme = sel(c4 == k, A[k], dme); ape = sel(pr == k, A[k], ape); }
+  const double dpa = dpp<kPartner>(dme), apa = dpp<kPartner>(ape);
+  const double app = low ? dme : dpa, aqq = low ? dpa : dme, apq = low ? ape : apa; // both lanes use A[p][q] of lane p
+  // rotation (Rutishauser): t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq).  An
+  // off-diagonal element that no longer registers against both diagonal elements (100 |apq| below their last bit) is
+  // set to zero instead of being rotated away: the sweeps then end by themselves, and theta cannot overflow.
+  const double g100 = 100.0 * fabs(apq);
+  const bool live = apq != 0.0 && !((fabs(app) + g100 == fabs(app)) && (fabs(aqq) + g100 == fabs(aqq)));
+  rotated = rotated || live;
+  const double theta = (aqq - app) * (0.5 * rcp_nr(live ? apq : 1.0));
+  const double th1 = theta * theta + 1.0;
+  const double t = (theta >= 0.0 ? 1.0 : -1.0) * rcp_nr(fabs(theta) + th1 * rsqrt_nr(th1));
+  const double cr = live ? rsqrt_nr(t * t + 1.0) : 1.0, sr = live ? t * cr : 0.0;
+  // (c, s) of the pair that owns column k, for every k: mine for my two columns, the other pair's for the others
+  constexpr int kOther = mask == 1 ? 0x4E : 0xB1; // quad_perm reaching a lane of the other pair
+  const double co = dpp<kOther>(cr), so = dpp<kOther>(sr);
+  // columns: A <- A J, V <- V J with J = product of the two rotations; column pairs (p, q) are compile-time per round
+  const auto cols = [&](double (&M)[4]) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const int q = p ^ mask;
+      if (p > q) continue;
+      // the pair (p, q): its rotation is mine if p or q is my index or my partner's, else the other pair's
+      const bool minep = (p == c4) || (q == c4);
+      const double c = minep ? cr : co, sn = minep ? sr : so;
+      const double mp = M[p], mq = M[q];
+      M[p] = c * mp - sn * mq;
+      M[q] = sn * mp + c * mq;
+    }
+  };
+  cols(A);
+  cols(V);
+  // rows: A <- J' A: my row mixes with my partner's; the element the rotation annihilates is exactly zero afterwards
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const double other_row = dpp<kPartner>(A[k]);
+    const double mixed = low ? cr * A[k] - sr * other_row : sr * other_row + cr * A[k];
+    A[k] = pr == k ? 0.0 : mixed;
+  }
+}
+
+// C: row c4 of the symmetric matrix on every lane of the quad.  Returns component c4 of the eigenvector of the
+// largest eigenvalue, as sym4_eigen + the selection in pose_geometric do.
+__device__ __forceinline__ double sym4_dominant_quad(const double (&Crow)[4], int c4) {
+  double A[4], V[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { A[k] = Crow[k]; V[k] = c4 == k ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 12; sweep++) { // quadratic convergence: 4-6 sweeps, ended by a sweep without a rotation
+    bool rotated = false;
+    jacobi_round<0xB1>(A, V, c4, rotated);
+    jacobi_round<0x4E>(A, V, c4, rotated);
+    jacobi_round<0x1B>(A, V, c4, rotated);
+    if (__builtin_amdgcn_ballot_w64(rotated) == 0ull) break;
+  }
+  // eigenvalue i = A[i][i] on lane i; V[k] on lane r = component r of eigenvector k
+  double w = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) w = sel(c4 == k, A[k], w);
+  const double w0 = quad_bc<0>(w), w1 = quad_bc<1>(w), w2 = quad_bc<2>(w), w3 = quad_bc<3>(w);
+  double wb = w0, comp = V[0];
+  if (w1 > wb) { wb = w1; comp = V[1]; }
+  if (w2 > wb) { wb = w2; comp = V[2]; }
+  if (w3 > wb) { wb = w3; comp = V[3]; }
+  return comp;
+}
+
+// pose: replicated on the row (output).  sfo: stance for orientation by limb id, replicated.
+__device__ __forceinline__ void pose_geometric_coop(const PoseProblem &pb, const double sfo[4][3], double pose[7]) {
+  const int c4 = threadIdx.x & 3;
+  double cen[2];
+  polygon_centroid(pb.n_vertices, pb.polygon, cen);
+  // my row of C = sum_k Ak'Ak ... as pose_geometric, only row c4
+  double z = 0.0, Crow[4] = {0.0, 0.0, 0.0, 0.0}, Am[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) Am[i] = 0.0;
+  int nl = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (!((pb.present >> k) & 1u)) continue;
+    nl++;
+    z += pb.stance[k][2] - pb.nominal[k][2];
+    const double *a = pb.stance[k], *b = pb.nominal[k];
+    const double Ak[16] = {0.0,         -a[0] + b[0], -a[1] + b[1], -a[2] + b[2],
+                           a[0] - b[0], 0.0,          -a[2] - b[2], a[1] + b[1],
+                           a[1] - b[1], a[2] + b[2],  0.0,          -a[0] - b[0],
+                           a[2] - b[2], -a[1] - b[1], a[0] + b[0],  0.0};
+    double arow[4] = {0.0, 0.0, 0.0, 0.0}; // row c4 of Ak
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) arow[j] = sel(c4 == i, Ak[4 * i + j], arow[j]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < 4; m++) acc += arow[m] * Ak[4 * m + j];
+      Crow[j] += acc;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) Am[i] += Ak[i];
+  }
+  const double n = (double)nl, rn = rcp_nr(n);
+  z *= rn;
+#pragma unroll
+  for (int i = 0; i < 16; i++) Am[i] *= rn;
+  {
+    double arow[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) arow[j] = sel(c4 == i, Am[4 * i + j], arow[j]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < 4; m++) acc += arow[m] * Am[4 * m + j];
+      Crow[j] -= n * acc;
+    }
+  }
+  // (C is symmetric to the last bit: Ak is antisymmetric by construction, so (Ak Ak)[i][j] and [j][i] are the same
+  // products summed in the same order; sym4_eigen's 1/2 (C + C') is the identity on it)
+  const double qc = sym4_dominant_quad(Crow, c4);
+  double q[4] = {quad_bc<0>(qc), quad_bc<1>(qc), quad_bc<2>(qc), quad_bc<3>(qc)};
+  const double inq = rsqrt_nr(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] *= inq;
+  { // setUnique: first non-zero component positive
+    bool neg = false, decided = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const bool here = !decided && q[i] != 0.0;
+      neg = here ? q[i] < 0.0 : neg;
+      decided = decided || here;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = neg ? -q[i] : q[i];
+  }
+  pose_geometric_finish(pb, sfo, cen, z, q, pose);
+}
+
+// ---- BaseAuto::optimizePose in the row layout (BaseAuto.cpp:394-400): geometric -> QP -> check -> SQP ------------
+__device__ __forceinline__ int base_auto_coop(const PoseParamsDev &P, const PoseProblem &pb, const double sfo[4][3],
+                                              const double min_len[4], double leg_tol, bool live, double *lds_row,
+                                              double pose[7], int &stage, int &iters) {
+  pose_geometric_coop(pb, sfo, pose);
+  stage = 2;
+  iters = 0;
+  int st = pose_qp_coop(P, pb, live, lds_row, pose);
+  const bool need = live && st == kStatusOk && !pose_check(pb, pose, min_len, leg_tol);
+  if (__builtin_amdgcn_ballot_w64(need) != 0ull) { // the SQP only for the rows the checker rejects
+    int it = 0;
+    const int s2 = pose_sqp_coop(P, pb, need, lds_row, pose, it);
+    if (need) { st = s2; stage = 3; iters = it; }
+  }
+  return st;
 }
 
 } // namespace coop

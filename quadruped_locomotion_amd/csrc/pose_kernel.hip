@@ -10,13 +10,12 @@ using namespace qlamd::rt;
 
 namespace {
 
-// ---- config 5: one pose-optimisation problem per lane, 16 problems per wavefront --------------
+// ---- pose optimisation: problem records --------------------------------------------------
 struct PosePtrs {
   const double *stance, *nominal, *polygon, *rcom, *maxlen, *pose;
   const uint8_t *mask;
   const int32_t *nverts;
 };
-constexpr int kPosePerWave = 16;
 
 // Every load of a problem is issued unconditionally and before the first use: an absent optional array is read
 // through `stance` (always present and at least as long) and its value replaced afterwards, so that no load sits
@@ -60,30 +59,7 @@ __device__ __forceinline__ void load_pose_problem(const PoseParamsDev &P, const 
   for (int a = 0; a < 7; a++) pose[a] = s.pose ? ps[a] : (a == 3 ? 1.0 : 0.0);
 }
 
-__global__ __launch_bounds__(64) void pose_sqp_kernel(const PoseParamsDev P, const PosePtrs s, int64_t B,
-                                                      double *__restrict__ pose_out, int32_t *__restrict__ iters,
-                                                      int32_t *__restrict__ status) {
-  extern __shared__ double lds[];
-  const int lane = threadIdx.x;
-  const int64_t i = (int64_t)blockIdx.x * kPosePerWave + lane;
-  // the problem data lives in LDS (one record per lane): it is read a few values at a time over the whole SQP
-  // loop, and holding its 60 doubles in registers next to the QP's made the compiler spill each freshly loaded
-  // value to scratch, one memory round trip after the other
-  __shared__ PoseProblem pbs[kPosePerWave];
-  if (lane >= kPosePerWave || i >= B) return;
-  PoseProblem &pb = pbs[lane];
-  double pose[7];
-  load_pose_problem(P, s, i, pb, pose);
-  LdsScratch scr{lds + lane, kPosePerWave};
-  int it = 0;
-  const int st = pose_sqp6(P, pb, scr, pose, &it); // register-resident inner QP (gi6_core.hpp)
-#pragma unroll
-  for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
-  if (iters) iters[i] = it;
-  status[i] = st;
-}
-
-// Lane-cooperative form (csrc/pose_coop.hpp): 16 lanes per problem, 4 problems per wavefront -- the default.
+// Lane-cooperative form (csrc/pose_coop.hpp): 16 lanes per problem, 4 problems per wavefront.
 __global__ __launch_bounds__(64) void pose_sqp_coop_kernel(const PoseParamsDev P, const PosePtrs s, int64_t B,
                                                            double *__restrict__ pose_out, int32_t *__restrict__ iters,
                                                            int32_t *__restrict__ status) {
@@ -114,21 +90,32 @@ __global__ __launch_bounds__(64) void pose_sqp_coop_kernel(const PoseParamsDev P
   }
 }
 
-// PoseOptimizationQP (position only) and PoseConstraintsChecker, same problem layout
-__global__ __launch_bounds__(64) void pose_qp_kernel(const PoseParamsDev P, const PosePtrs s, int64_t B,
-                                                     double *__restrict__ pose_out, int32_t *__restrict__ status) {
-  extern __shared__ double lds[];
-  const int lane = threadIdx.x;
-  const int64_t i = (int64_t)blockIdx.x * kPosePerWave + lane;
-  if (lane >= kPosePerWave || i >= B) return;
-  PoseProblem pb;
-  double pose[7];
-  load_pose_problem(P, s, i, pb, pose);
-  LdsScratch scr{lds + lane, kPosePerWave};
-  const int st = pose_qp(P, pb, scr, pose);
+// PoseOptimizationQP (position only) in the row layout, and PoseConstraintsChecker (one lane per problem)
+__global__ __launch_bounds__(64) void pose_qp_coop_kernel(const PoseParamsDev P, const PosePtrs s, int64_t B,
+                                                          double *__restrict__ pose_out, int32_t *__restrict__ status) {
+  __shared__ PoseProblem pbs[coop::kPoseCoopRows];
+  __shared__ double pose0[coop::kPoseCoopRows][8];
+  __shared__ double rows[coop::kPoseCoopRows * coop::kPoseCoopLdsDoubles];
+  const int row = threadIdx.x >> 4, lr = threadIdx.x & 15;
+  int64_t i = (int64_t)blockIdx.x * coop::kPoseCoopRows + row;
+  const bool live = i < B;
+  if (!live) i = B - 1;
+  if (lr == 0) {
+    double ps[7];
+    load_pose_problem(P, s, i, pbs[row], ps);
 #pragma unroll
-  for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
-  status[i] = st;
+    for (int a = 0; a < 7; a++) pose0[row][a] = ps[a];
+  }
+  __syncthreads();
+  double pose[7];
+#pragma unroll
+  for (int a = 0; a < 7; a++) pose[a] = pose0[row][a];
+  const int st = coop::pose_qp_coop(P, pbs[row], live, rows + row * coop::kPoseCoopLdsDoubles, pose);
+  if (lr == 0 && live) {
+#pragma unroll
+    for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
+    status[i] = st;
+  }
 }
 
 __global__ __launch_bounds__(64) void pose_check_kernel(const PoseParamsDev P, const PosePtrs s,
@@ -152,78 +139,82 @@ __device__ __forceinline__ void load_sfo(const PosePtrs &s, const double *__rest
     for (int a = 0; a < 3; a++) sfo[l][a] = src[12 * i + 3 * l + a];
 }
 
-__global__ __launch_bounds__(64) void pose_geometric_kernel(const PoseParamsDev P, const PosePtrs s,
-                                                            const double *__restrict__ sfo_in, int64_t B,
-                                                            double *__restrict__ pose_out) {
-  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= B) return;
-  PoseProblem pb;
-  double pose[7], sfo[4][3];
-  load_pose_problem(P, s, i, pb, pose);
+// PoseOptimizationGeometric and the whole BaseAuto::optimizePose sequence in the row layout
+__device__ __forceinline__ void load_row_problem(const PoseParamsDev &P, const PosePtrs &s, const double *sfo_in,
+                                                 const double *min_len, int64_t i, PoseProblem &pb, double (&io)[24]) {
+  // one lane per problem fetches the record; pose (7), stance for orientation (12) and minimal lengths (4) go through io
+  double ps[7], sfo[4][3];
+  load_pose_problem(P, s, i, pb, ps);
   load_sfo(s, sfo_in, i, sfo);
-  pose_geometric(pb, sfo, pose);
 #pragma unroll
-  for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
+  for (int a = 0; a < 7; a++) io[a] = ps[a];
+#pragma unroll
+  for (int l = 0; l < 4; l++)
+#pragma unroll
+    for (int a = 0; a < 3; a++) io[7 + 3 * l + a] = sfo[l][a];
+#pragma unroll
+  for (int k = 0; k < 4; k++) io[19 + k] = min_len ? min_len[4 * i + P.leg_order[k]] : 0.0;
+}
+
+__global__ __launch_bounds__(64) void pose_geometric_coop_kernel(const PoseParamsDev P, const PosePtrs s,
+                                                                 const double *__restrict__ sfo_in, int64_t B,
+                                                                 double *__restrict__ pose_out) {
+  __shared__ PoseProblem pbs[coop::kPoseCoopRows];
+  __shared__ double io[coop::kPoseCoopRows][24];
+  const int row = threadIdx.x >> 4, lr = threadIdx.x & 15;
+  int64_t i = (int64_t)blockIdx.x * coop::kPoseCoopRows + row;
+  const bool live = i < B;
+  if (!live) i = B - 1;
+  if (lr == 0) load_row_problem(P, s, sfo_in, nullptr, i, pbs[row], io[row]);
+  __syncthreads();
+  double pose[7], sfo[4][3];
+#pragma unroll
+  for (int l = 0; l < 4; l++)
+#pragma unroll
+    for (int a = 0; a < 3; a++) sfo[l][a] = io[row][7 + 3 * l + a];
+  coop::pose_geometric_coop(pbs[row], sfo, pose);
+  if (lr == 0 && live) {
+#pragma unroll
+    for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
+  }
 }
 
 // BaseAuto::optimizePose: geometric -> QP -> check -> SQP for the problems the check rejects
-__global__ __launch_bounds__(64) void base_auto_pose_kernel(const PoseParamsDev P, const PosePtrs s,
+__global__ __launch_bounds__(64) void base_auto_coop_kernel(const PoseParamsDev P, const PosePtrs s,
                                                             const double *__restrict__ sfo_in,
                                                             const double *__restrict__ min_len, double leg_tol, int64_t B,
                                                             double *__restrict__ pose_out, int32_t *__restrict__ stage,
                                                             int32_t *__restrict__ iters, int32_t *__restrict__ status) {
-  extern __shared__ double lds[];
-  const int lane = threadIdx.x;
-  const int64_t i = (int64_t)blockIdx.x * kPosePerWave + lane;
-  __shared__ PoseProblem pbs[kPosePerWave]; // see pose_sqp_kernel
-  if (lane >= kPosePerWave || i >= B) return;
-  PoseProblem &pb = pbs[lane];
+  __shared__ PoseProblem pbs[coop::kPoseCoopRows];
+  __shared__ double io[coop::kPoseCoopRows][24];
+  __shared__ double rows[coop::kPoseCoopRows * coop::kPoseCoopLdsDoubles];
+  const int row = threadIdx.x >> 4, lr = threadIdx.x & 15;
+  int64_t i = (int64_t)blockIdx.x * coop::kPoseCoopRows + row;
+  const bool live = i < B;
+  if (!live) i = B - 1;
+  if (lr == 0) load_row_problem(P, s, sfo_in, min_len, i, pbs[row], io[row]);
+  __syncthreads();
   double pose[7], sfo[4][3], mn[4];
-  load_pose_problem(P, s, i, pb, pose);
-  load_sfo(s, sfo_in, i, sfo);
 #pragma unroll
-  for (int k = 0; k < 4; k++) mn[k] = min_len ? min_len[4 * i + P.leg_order[k]] : 0.0;
-  LdsScratch scr{lds + lane, kPosePerWave};
+  for (int l = 0; l < 4; l++)
+#pragma unroll
+    for (int a = 0; a < 3; a++) sfo[l][a] = io[row][7 + 3 * l + a];
+#pragma unroll
+  for (int k = 0; k < 4; k++) mn[k] = io[row][19 + k];
   int stg = 0, it = 0;
-  const int st = base_auto_optimize_pose(P, pb, sfo, mn, leg_tol, scr, pose, &stg, &it);
+  const int st = coop::base_auto_coop(P, pbs[row], sfo, mn, leg_tol, live, rows + row * coop::kPoseCoopLdsDoubles, pose, stg, it);
+  if (lr == 0 && live) {
 #pragma unroll
-  for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
-  if (stage) stage[i] = stg;
-  if (iters) iters[i] = it;
-  status[i] = st;
-}
-
-// ---- dense QP batch: one problem per lane, 8 problems per wavefront, arrays in LDS ------------
-typedef GiLayout<12, 2, 24> QpGi;
-constexpr int kQpPerWave = 8;
-
-__global__ __launch_bounds__(64) void qp_solve_kernel(int n, int p, int m, const double *__restrict__ G,
-                                                      const double *__restrict__ g0, const double *__restrict__ CE,
-                                                      const double *__restrict__ ce0, const double *__restrict__ CI,
-                                                      const double *__restrict__ ci0, int64_t B,
-                                                      double *__restrict__ x, double *__restrict__ obj,
-                                                      int32_t *__restrict__ status) {
-  extern __shared__ double lds[];
-  const int lane = threadIdx.x;
-  const int64_t i = (int64_t)blockIdx.x * kQpPerWave + lane;
-  if (lane >= kQpPerWave || i >= B) return;
-  LdsScratch s{lds + lane, kQpPerWave};
-  for (int k = 0; k < n * n; k++) s.at(QpGi::G + k) = G[(size_t)i * n * n + k];
-  for (int k = 0; k < n; k++) s.at(QpGi::G0 + k) = g0[(size_t)i * n + k];
-  for (int k = 0; k < n * p; k++) s.at(QpGi::CE + k) = CE[(size_t)i * n * p + k];
-  for (int k = 0; k < p; k++) s.at(QpGi::CE0 + k) = ce0[(size_t)i * p + k];
-  for (int k = 0; k < n * m; k++) s.at(QpGi::CI + k) = CI[(size_t)i * n * m + k];
-  for (int k = 0; k < m; k++) s.at(QpGi::CI0 + k) = ci0[(size_t)i * m + k];
-  double f;
-  const int st = gi_solve<12, 2, 24>(s, n, p, m, &f, nullptr);
-  for (int k = 0; k < n; k++) x[(size_t)i * n + k] = s.at(QpGi::X + k);
-  if (obj) obj[i] = f;
-  status[i] = st;
+    for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
+    if (stage) stage[i] = stg;
+    if (iters) iters[i] = it;
+    status[i] = st;
+  }
 }
 
 // Lane-cooperative dense QP batch (csrc/qp_coop.hpp): 16 lanes per problem, 4 problems per wavefront.
-// N = 6 for n <= 6, N = 12 otherwise; KC = 2 inequalities per lane for m <= 24, 3 for m <= 48; at most one equality
-// column (two go to qp_solve_kernel).
+// N = 6 for n <= 6, N = 12 otherwise; KC = 2 inequalities per lane for m <= 24, 3 for m <= 48; up to two equality
+// columns.
 template <int N, int KC>
 __global__ __launch_bounds__(64) void qp_coop_kernel(int n, int p, int m, const double *__restrict__ G,
                                                      const double *__restrict__ g0, const double *__restrict__ CE,
@@ -256,6 +247,7 @@ __global__ __launch_bounds__(64) void qp_coop_kernel(int n, int p, int m, const 
 #pragma unroll
   for (int s = 0; s < KC; s++) b[s] = m > 0 ? ci0[(size_t)i * m + cs[s]] : 0.0;
   double ne = p > 0 ? CE[((size_t)i * n + rv) * p] : 0.0, e0 = p > 0 ? ce0[(size_t)i * p] : 0.0;
+  double ne2 = p > 1 ? CE[((size_t)i * n + rv) * p + 1] : 0.0, e02 = p > 1 ? ce0[(size_t)i * p + 1] : 0.0;
   const bool var = lr < n;
 #pragma unroll
   for (int k = 0; k < N; k++) {
@@ -266,10 +258,12 @@ __global__ __launch_bounds__(64) void qp_coop_kernel(int n, int p, int m, const 
   }
   gl = var ? gl : 0.0;
   ne = var ? ne : 0.0;
+  ne2 = var ? ne2 : 0.0;
 #pragma unroll
   for (int s = 0; s < KC; s++) b[s] = v[s] ? b[s] : 0.0;
   double xo, fo;
-  const int st = coop::qp_coop_impl<N, KC>(Gm, gl, n, n, m, p > 0, ne, e0, a, b, v, !live, rows + row * L::kTotal, xo, fo);
+  const int st = coop::qp_coop_impl<N, KC>(Gm, gl, n, n, m, p > 0, ne, e0, a, b, v, !live, rows + row * L::kTotal, xo, fo,
+                                           p > 1, ne2, e02);
   if (live) {
     if (var) x[(size_t)i * n + lr] = xo;
     if (lr == 0) {
@@ -371,32 +365,24 @@ static int pose_impl(const PoseCall &call, qlamd_context *ctx, const qlamd_pose_
     d_stage = (int32_t *)(w + off[kIn + 3]);
     d_ok = (uint8_t *)(w + off[kIn + 4]);
   }
-  const unsigned grid = (unsigned)((batch + kPosePerWave - 1) / kPosePerWave);
-  const size_t lds6 = (size_t)kPosePerWave * Gi6Layout::kTotal * sizeof(double);
-  const size_t lds3 = (size_t)kPosePerWave * PoseQpGi::kTotal * sizeof(double);
+  const unsigned rgrid = (unsigned)((batch + coop::kPoseCoopRows - 1) / coop::kPoseCoopRows); // 4 problems per wavefront
   switch (mode) {
     case kPoseSqp:
-      if (ctx->pose_one_lane) // the one-lane-per-problem form, kept as a second implementation
-        hipLaunchKernelGGL(pose_sqp_kernel, dim3(grid), dim3(64), lds6, st, P, s, batch, d_out, d_it, d_st);
-      else
-        hipLaunchKernelGGL(pose_sqp_coop_kernel,
-                           dim3((unsigned)((batch + coop::kPoseCoopRows - 1) / coop::kPoseCoopRows)), dim3(64), 0, st, P, s,
-                           batch, d_out, d_it, d_st);
+      hipLaunchKernelGGL(pose_sqp_coop_kernel, dim3(rgrid), dim3(64), 0, st, P, s, batch, d_out, d_it, d_st);
       break;
     case kPoseQp:
-      hipLaunchKernelGGL(pose_qp_kernel, dim3(grid), dim3(64), lds3, st, P, s, batch, d_out, d_st);
+      hipLaunchKernelGGL(pose_qp_coop_kernel, dim3(rgrid), dim3(64), 0, st, P, s, batch, d_out, d_st);
       break;
     case kPoseCheck:
       hipLaunchKernelGGL(pose_check_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, P, s, d_min,
                          call.leg_tol, batch, d_ok);
       break;
     case kPoseGeometric:
-      hipLaunchKernelGGL(pose_geometric_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, P, s, d_sfo, batch,
-                         d_out);
+      hipLaunchKernelGGL(pose_geometric_coop_kernel, dim3(rgrid), dim3(64), 0, st, P, s, d_sfo, batch, d_out);
       break;
     case kPoseBaseAuto:
-      hipLaunchKernelGGL(base_auto_pose_kernel, dim3(grid), dim3(64), lds6 > lds3 ? lds6 : lds3, st, P, s, d_sfo, d_min,
-                         call.leg_tol, batch, d_out, d_stage, d_it, d_st);
+      hipLaunchKernelGGL(base_auto_coop_kernel, dim3(rgrid), dim3(64), 0, st, P, s, d_sfo, d_min, call.leg_tol, batch, d_out,
+                         d_stage, d_it, d_st);
       break;
   }
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
@@ -462,7 +448,6 @@ int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *
                          void *stream) {
   if (!ctx || batch < 0 || !G || !g0 || !x || !status) return QLAMD_ERR_INVALID_ARGUMENT;
   if (n < 1 || n > 12 || p < 0 || p > 2 || m < 0 || m > 48) return QLAMD_ERR_INVALID_ARGUMENT;
-  if (m > 24 && (p > 1 || ctx->qp_one_lane)) return QLAMD_ERR_INVALID_ARGUMENT; // 25..48 rows: cooperative kernel only
   if ((p > 0 && (!CE || !ce0)) || (m > 0 && (!CI || !ci0))) return QLAMD_ERR_INVALID_ARGUMENT;
   if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
   if (batch == 0) return QLAMD_OK;
@@ -491,8 +476,7 @@ int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *
     dce0 = (const double *)(w + off[3]); dCI = (const double *)(w + off[4]); dci0 = (const double *)(w + off[5]);
     dx = (double *)(w + off[6]); dobj = objective ? (double *)(w + off[7]) : nullptr; dst = (int32_t *)(w + off[8]);
   }
-  if (p <= 1 && !ctx->qp_one_lane) {
-    // lane-cooperative kernel (at most one equality column: what every caller in the reference passes)
+  {
     const unsigned cgrid = (unsigned)((batch + coop::kQpCoopRows - 1) / coop::kQpCoopRows);
     auto launch = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(cgrid), dim3(64), 0, st, n, p, m, dG, dg0, dCE, dce0, dCI, dci0, batch, dx, dobj, dst);
@@ -502,15 +486,6 @@ int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *
     } else {
       if (n <= 6) launch(qp_coop_kernel<6, 2>); else launch(qp_coop_kernel<12, 2>);
     }
-  } else {
-    // one lane per problem, following solve_quadprog step by step (two equality columns, or on request)
-    const size_t lds = (size_t)kQpPerWave * QpGi::kTotal * sizeof(double);
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute((const void *)qp_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return QLAMD_ERR_HIP;
-    const unsigned grid = (unsigned)((batch + kQpPerWave - 1) / kQpPerWave);
-    hipLaunchKernelGGL(qp_solve_kernel, dim3(grid), dim3(64), lds, st, n, p, m, dG, dg0, dCE, dce0, dCI, dci0, batch, dx,
-                       dobj, dst);
   }
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   if (memory == QLAMD_MEM_HOST) {

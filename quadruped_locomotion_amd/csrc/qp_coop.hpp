@@ -2,7 +2,7 @@
 //
 // Replaces quadprogpp::solve_quadprog / qp_solver::QuadraticProblemSolver::minimize
 // (qp_solver/src/QuadProg++.cc:52-446, qp_solver/src/quadraticproblemsolver.cpp:65-97) for
-//   min 1/2 x'Gx + g0'x   s.t.  CE'x + ce0 = 0,  CI'x + ci0 >= 0,     n <= N, at most one equality,
+//   min 1/2 x'Gx + g0'x   s.t.  CE'x + ce0 = 0,  CI'x + ci0 >= 0,     n <= N, at most two equalities,
 //   m <= 24 with two inequalities per lane (KC = 2), m <= 48 with three (KC = 3, the whole-body QP),
 // with the Goldfarb-Idnani method in the explicit-operator form of balance_coop.hpp / pose_coop.hpp:
 //   lane i < n      variable lane: component i of x, g0, z; row i of G and of the projector H
@@ -14,7 +14,10 @@
 // The single equality: a genuine one is stepped onto and projected out (H -= z z'/z'n) before the inequality
 // loop, as QuadProg++ does (:169-210).  An all-zero column -- what the reference's wrapper always passes
 //  -- consumes the first column of J = L^-T there without moving x, i.e. it is the equality
-// (G e1)'(x - x0) = 0: H0 = G^-1 - e1 e1'/G11 (tests/test_oracle_quadprog.py).
+// (G e1)'(x - x0) = 0: H0 = G^-1 - e1 e1'/G11 (tests/test_oracle_quadprog.py).  A second equality column is
+// projected out the same way after the first; it has to be a genuine normal (an all-zero or linearly dependent
+// second column is ignored, where the reference would spend another column of J on it: no caller in the reference
+// passes two columns).
 #pragma once
 
 #include "balance_coop.hpp"
@@ -36,7 +39,8 @@ struct QpCoopLds {
 template <int N, int KC>
 __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, int n, int n_free, int m, bool has_eq, double ne,
                                             double ce0, const double (&a)[KC][N], const double (&b)[KC], const bool (&v)[KC],
-                                            bool skip, double *lds_row, double &x_out, double &f_out) {
+                                            bool skip, double *lds_row, double &x_out, double &f_out, bool has_eq2 = false,
+                                            double ne2 = 0.0, double ce02 = 0.0) {
   typedef QpCoopLds<N, KC> L;
   typedef typename std::conditional<(KC > 2), unsigned long long, unsigned>::type mask_t;
   const int lr = threadIdx.x & 15;
@@ -101,6 +105,17 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
     static_for<N>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(H[j], vec, hc); });
     const double g11 = bc<0>(Gm[0]);
     H[0] = sel(dummy && lr == 0, H[0] - rcp_nr(g11), H[0]);
+  }
+  if (has_eq2) { // the second equality column: stepped onto and projected out of what the first has left
+    double za[3] = {0.0, 0.0, 0.0};
+    static_for<N>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(za[j % 3], ne2, H[j]); });
+    const double z = (za[0] + za[1]) + za[2];
+    const double zn = row_sum(z * ne2), zz = row_sum(z * z), nx = row_sum(ne2 * x);
+    const bool indep = fabs(zz) > eps && zn > 0.0;
+    const double dinv = rcp_nr(indep ? zn : 1.0);
+    x += sel(indep, (-nx - ce02) * dinv * z, 0.0);
+    const double vec = sel(indep, z * dinv, 0.0), hc = sel(indep, -z, 0.0);
+    static_for<N>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(H[j], vec, hc); });
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -185,7 +200,7 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
       const double t2v = -sp * rcp_nr(zn);
       // with n - (equality) constraints active the null space is empty and z is exactly 0 in the reference (J2 has
       // no columns); the explicit projector only leaves ~1e-7 of drift there, which must not pass for a direction
-      const bool exhausted = q + (has_eq ? 1 : 0) >= n_free;
+      const bool exhausted = q + (has_eq ? 1 : 0) + (has_eq2 ? 1 : 0) >= n_free;
       const double t2 = sel(!exhausted && fabs(zz) > eps && !(t2v < 0.0), t2v, inf);
       const double t = vmin(t1, t2);
       const bool infeasible = !(t < inf);                          // :339-344

@@ -44,15 +44,14 @@ class Mirror:
         srcs = [os.path.join(d, "mirror.cpp"),
                 os.path.join(ROOT, "quadruped_locomotion_amd", "csrc", "balance_core.hpp"),
                 os.path.join(ROOT, "quadruped_locomotion_amd", "csrc", "params_build.hpp"),
-                os.path.join(ROOT, "quadruped_locomotion_amd", "csrc", "gi_core.hpp"),
+                os.path.join(d, "gi_core.hpp"), os.path.join(d, "gi6_core.hpp"), os.path.join(d, "pose_one_lane.hpp"),
                 os.path.join(ROOT, "quadruped_locomotion_amd", "csrc", "pose_core.hpp"),
                 os.path.join(ROOT, "quadruped_locomotion_amd", "csrc", "leg_state_core.hpp"),
                 os.path.join(ROOT, "quadruped_locomotion_amd", "csrc", "wire_core.hpp"),
-                os.path.join(ROOT, "quadruped_locomotion_amd", "csrc", "gi6_core.hpp"),
                 os.path.join(ROOT, "quadruped_locomotion_amd", "csrc", "swing_core.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
-                                   "-I" + os.path.join(ROOT, "quadruped_locomotion_amd", "csrc"), "-o", so, srcs[0]])
+                                   "-I" + os.path.join(ROOT, "quadruped_locomotion_amd", "csrc"), "-I" + d, "-o", so, srcs[0]])
         self.L = C.CDLL(so)
 
     def balance(self, O, state, normals=None):

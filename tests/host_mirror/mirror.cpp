@@ -70,7 +70,7 @@ extern "C" void mirror_sincos(double x, double *s, double *c) { sincos_reduced(x
 extern "C" void mirror_default_params(qlamd_balance_params *p) { default_balance_params(p); }
 
 // ---- pose optimisation / dense QP (config 5), host build of gi_core.hpp + pose_core.hpp ----
-#include "pose_core.hpp"
+#include "pose_one_lane.hpp"
 
 template <int N>
 struct HostScr {

@@ -44,22 +44,6 @@ def test_pose_sqp_4096_matches_oracle(gpu, oracle, tol, max_iter):
         assert oracle.pose_cost(pb, i, pose[i], HIPS, ORDER) <= oracle.pose_cost(pb, i, pb["pose"][i], HIPS, ORDER) + 1e-12
 
 
-def test_one_lane_kernel_still_matches_oracle(gpu, oracle, monkeypatch):
-    """The first, one-lane-per-problem kernel stays available as a second implementation (QLAMD_OPT_POSE_ONE_LANE)."""
-    capi, ctx, torch = gpu
-    pb = synth.make_pose_problems(512)
-    ctx.set_option(capi.OPT_POSE_ONE_LANE, 1)
-    try:
-        pose, it, st = capi.pose_sqp(ctx, pb)
-    finally:
-        ctx.set_option(capi.OPT_POSE_ONE_LANE, 0)
-    pose2, it2, st2 = capi.pose_sqp(ctx, pb)                      # the cooperative kernel on the same problems
-    assert (st == 0).all() and np.array_equal(it, it2) and np.abs(pose - pose2).max() < POSE_TOL
-    for i in range(0, 512, 9):
-        r = oracle.pose_sqp(pb, i, HIPS, ORDER)
-        assert r["iters"] == it[i] and np.abs(r["pose"] - pose[i]).max() < POSE_TOL
-
-
 def test_pose_sqp_host_memory_edge_cases(gpu, oracle):
     capi, ctx, torch = gpu
     # the reference's SquareUp case, a single problem through host buffers
@@ -125,21 +109,21 @@ def test_qp_batch_random_and_error_paths(gpu, oracle):
             assert r["status"] == st[i]
             if st[i] == 0:
                 assert np.abs(r["x"] - x[i]).max() < 1e-8 * max(1.0, np.abs(r["x"]).max())
-    # the one-lane kernel (second implementation) agrees with the cooperative one
-    import os
-    n, m, B = 12, 20, 64
+    # two genuine equality columns (projected out one after the other) against the pinned restatement
+    n, m, B = 8, 10, 48
     M = rng.normal(size=(B, n, n)); G = M @ M.transpose(0, 2, 1) + 1e-2 * np.eye(n); g0 = 10 * rng.normal(size=(B, n))
+    CE, ce0 = rng.normal(size=(B, n, 2)), rng.normal(size=(B, 2))
     CI, ci0 = rng.normal(size=(B, n, m)), rng.normal(size=(B, m)) + 1.0
-    zero_eq = (np.zeros((B, n, 1)), np.zeros((B, 1)))              # the reference's dummy column
-    xa, fa, sa = capi.qp_solve(ctx, G, g0, *zero_eq, CI, ci0)
-    ctx.set_option(capi.OPT_QP_ONE_LANE, 1)
-    try:
-        xb, fb, sb = capi.qp_solve(ctx, G, g0, *zero_eq, CI, ci0)
-    finally:
-        ctx.set_option(capi.OPT_QP_ONE_LANE, 0)
-    assert np.array_equal(sa, sb)
-    ok = sa == 0
-    assert ok.sum() > 10 and np.abs(xa[ok] - xb[ok]).max() < 1e-8 * max(1.0, np.abs(xb[ok]).max()) and np.allclose(fa[ok], fb[ok], rtol=1e-9)
+    x, f, st = capi.qp_solve(ctx, G, g0, CE, ce0, CI, ci0)
+    nok = 0
+    for i in range(B):
+        r = oracle.solve_quadprog(G[i], g0[i], CE[i], ce0[i], CI[i], ci0[i])
+        assert r["status"] == st[i]
+        if st[i] == 0:
+            nok += 1
+            assert np.abs(r["x"] - x[i]).max() < 1e-8 * max(1.0, np.abs(r["x"]).max())
+            assert np.abs(CE[i].T @ x[i] + ce0[i]).max() < 1e-9
+    assert nok > B // 2
     # not positive definite / infeasible
     x, f, st = capi.qp_solve(ctx, np.array([[[1.0, 2.0], [2.0, 1.0]]]), np.zeros((1, 2)), None, None, None, None)
     assert st[0] == capi.STATUS_NOT_PD

@@ -21,10 +21,6 @@ for it in (1, 5):
     prm.tolerance, prm.max_iterations = 0.0, it
     for _ in range(REPS):
         capi.pose_sqp(ctx, pb, prm)
-ctx.set_option(capi.OPT_POSE_ONE_LANE, 1)      # the one-lane-per-problem kernel, for comparison
-for _ in range(REPS):
-    capi.pose_sqp(ctx, pb, prm)
-ctx.set_option(capi.OPT_POSE_ONE_LANE, 0)
 for _ in range(REPS):
     capi.pose_qp(ctx, pb)
     capi.pose_check(ctx, pb, np.full((B, 4), 0.1), 0.0)
