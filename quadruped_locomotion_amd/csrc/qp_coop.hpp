@@ -120,6 +120,11 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_s_waitcnt(0xC07F);
 
+  // Active-set loop in the form of balance_coop.hpp (see the notes there): selection of the next violated constraint
+  // by 32-bit keys (slack in single precision, low six bits = lane and which of my KC rows) with one DPP max per
+  // level, its slack fetched from its lane, the feasibility sum only when the worst slack is inside the tolerance;
+  // the selection sits in the shadow of the rank-one update; passes in which every live row adds run in an inner
+  // loop without predication, everything else goes through the general tail.
   double Ns[N];
 #pragma unroll
   for (int j = 0; j < N; j++) Ns[j] = 0.0;
@@ -131,10 +136,14 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
   int q = 0, iters = 0, status = kStatusOk;
   const double psi_tol = (double)m * eps * c1 * c2 * 100.0;
   double rnorm2 = 1.0;
-  bool done = skip, need_select = true, fresh = true;
+  bool done = skip;
   int ip = 0;
-  double sp = 0.0, ucand = 0.0;
+  double sp = 0.0, ucand = 0.0, npj = 0.0;
   if (bad && !skip) { status = kStatusNotPd; done = true; }
+  const int neq = (has_eq ? 1 : 0) + (has_eq2 ? 1 : 0);
+  const unsigned lanebit = 1u << lr;
+  const int row_addr = ((int)threadIdx.x & 48) << 2;
+  const int vlane = lr < N ? lr : 0;
 
   const auto slacks = [&](double xx, double (&sl)[KC]) {
 #pragma unroll
@@ -146,124 +155,185 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
       for (int s = 1; s < KC; s++) fmac_bc<i>(sl[s], xx, a[s][i]);
     });
   };
-
-  for (int tick = 0; tick < 40 * kMaxOuter; tick++) {
-    if (__all(done)) break;
-    if (!done && need_select) {
-      if (fresh) { iters++; excl = 0; }
-      double sl[KC];
-      slacks(x, sl);
+  const auto umax_dpp = [](unsigned k, auto Ctrl) -> unsigned {
+    constexpr int ctrl = decltype(Ctrl)::value;
+    const unsigned o = (unsigned)__builtin_amdgcn_mov_dpp((int)k, ctrl, 0xF, 0xF, true);
+    return k > o ? k : o;
+  };
+  double vec = 0.0, hc = 0.0, nc = 0.0;
+  // kMode 0: before the first step (no update, every live row selects); 1: general (rows in `resel` select, `fresh`
+  // after an add); 2: every live row has just added a constraint
+  const auto update_and_select = [&](auto Mode, bool resel, bool fresh) {
+    constexpr int kMode = decltype(Mode)::value;
+    if constexpr (kMode == 1) {
+      iters += (resel && fresh) ? 1 : 0;
+      excl = (resel && fresh) ? (mask_t)0 : excl;
+    } else {
+      iters += 1;
+      excl = 0;
+    }
+    const mask_t avail = ~(act_mask | excl);
+    double sl[KC];
+    slacks(x, sl);
+    unsigned key = 0u;
+    double myv = sl[0];
+#pragma unroll
+    for (int s = 0; s < KC; s++) {
+      unsigned k = __float_as_uint((float)sl[s]);
+      k = (v[s] && ((avail >> (lr + 16 * s)) & 1u) && sl[s] < 0.0) ? ((k & ~63u) | (unsigned)(lr | (s << 4))) : 0u;
+      myv = k > key ? sl[s] : myv;
+      key = k > key ? k : key;
+    }
+    if constexpr (kMode != 0) {
+      static_for<N>([&](auto J) {
+        constexpr int j = J;
+        fmac_bc<j, j == 0>(H[j], vec, hc);
+        fmac_bc<j>(Ns[j], vec, nc);
+      });
+    }
+    key = umax_dpp(key, std::integral_constant<int, 0x128>{});
+    key = umax_dpp(key, std::integral_constant<int, 0x124>{});
+    key = umax_dpp(key, std::integral_constant<int, 0x122>{});
+    key = umax_dpp(key, std::integral_constant<int, 0x121>{});
+    const int wl = (int)key & 15;
+    const int addr = row_addr + (wl << 2);
+    const int vlo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(myv));
+    const int vhi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(myv));
+    const int key_ip = wl + 16 * (((int)key >> 4) & 3);
+    const double np_tab = ct[N * key_ip + vlane];
+    const double np_new = lr < N ? np_tab : 0.0;
+    const bool any = (int)key < 0;
+    const double vsel = __hiloint2double(vhi, vlo);
+    bool feasible = false;
+    const bool close = (kMode != 1 || (resel && fresh)) && any && !(vsel < -psi_tol);
+    if (__builtin_amdgcn_ballot_w64(close) != 0ull) { // QuadProg++.cc:246-250
       float viol = 0.0f;
 #pragma unroll
       for (int s = 0; s < KC; s++) viol += v[s] ? (float)vmin(0.0, sl[s]) : 0.0f;
       const double psi = (double)row_sum_f32(viol);
-      const mask_t blocked = act_mask | excl;
-      double vv = sel(v[0] && !((blocked >> lr) & 1u) && sl[0] < 0.0, sl[0], inf);
-      int which = 0;
-#pragma unroll
-      for (int s = 1; s < KC; s++) {
-        const bool better = v[s] && !((blocked >> (lr + 16 * s)) & 1u) && sl[s] < 0.0 && sl[s] < vv;
-        vv = sel(better, sl[s], vv);
-        which = better ? s : which;
-      }
-      const double vbest = row_min(vv);
-      const int wl = row_first(vv == vbest && vv < 0.0);
-      const int sh = (threadIdx.x & 48) + (wl & 15);
-      int wset = (int)((unsigned)(__ballot(which & 1) >> sh) & 1u);
-      if constexpr (KC > 2) wset |= (int)((unsigned)(__ballot((which & 2) != 0) >> sh) & 1u) << 1;
-      const bool feasible = fresh && (fabs(psi) <= psi_tol);     // QuadProg++.cc:246-250
-      const bool stop = feasible || !(vbest < 0.0) || iters > kMaxOuter; // :271-274
-      status = (stop && iters > kMaxOuter) ? kStatusMaxIter : status;
-      done = stop;
-      ip = stop ? ip : (wl + 16 * wset);
-      sp = sel(stop, sp, vbest);
-      ucand = sel(stop, ucand, 0.0);
-      need_select = stop;
+      feasible = close && (fabs(psi) <= psi_tol);
     }
-    if (!done) {
-      const double npj = lr < N ? ct[N * ip + (lr < N ? lr : 0)] : 0.0;
+    const bool stop = !any || feasible || iters > kMaxOuter; // :271-274
+    if constexpr (kMode == 1) {
+      status = (resel && stop && iters > kMaxOuter) ? kStatusMaxIter : status;
+      done = done || (resel && stop);
+      const bool take = resel && !stop;
+      ip = take ? key_ip : ip;
+      sp = sel(take, vsel, sp);
+      ucand = sel(take, 0.0, ucand);
+      npj = sel(take, np_new, npj);
+    } else {
+      status = (!done && stop && iters > kMaxOuter) ? kStatusMaxIter : status;
+      done = done || stop;
+      ip = key_ip; sp = vsel; ucand = 0.0; npj = np_new;
+    }
+  };
+  const auto drop_vectors = [&](int lpos) {
+    if (lr == lpos) {
+#pragma unroll
+      for (int j = 0; j < N; j++) nrow[j] = Ns[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const double nt_me = lr < N ? nrow[vlane] : 0.0;
+    const int drop_id = __shfl(idk, lpos, 16);
+    double Gn = 0.0;
+    static_for<N>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(Gn, nt_me, Gm[j]); });
+    const double einv = rcp_nr1(row_sum(nt_me * Gn));
+    double coef = 0.0;
+    static_for<N>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(coef, Gn, Ns[j]); });
+    vec = nt_me;
+    hc = nt_me * einv;
+    nc = -coef * einv;
+    return drop_id;
+  };
+
+  update_and_select(std::integral_constant<int, 0>{}, true, true);
+
+  for (;;) {
+    double z = 0.0, r = 0.0, zn = 0.0, zinv = 0.0, t = 0.0, tl1 = 0.0, tl2 = 0.0, ratio = 0.0;
+    bool is_add = false;
+    while (!done) {
       double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
       static_for<N>([&](auto J) {
         constexpr int j = J;
         fmac_bc<j, j == 0>(za[j % 3], npj, H[j]);
         fmac_bc<j>(ra[j % 3], npj, Ns[j]);
       });
-      const double z = (za[0] + za[1]) + za[2], r = (ra[0] + ra[1]) + ra[2];
-      const bool slot = (used >> lr) & 1u;
-      const double zn = row_sum(z * npj);
+      z = (za[0] + za[1]) + za[2];
+      r = (ra[0] + ra[1]) + ra[2];
+      const bool slot = (used & lanebit) != 0u;
+      zn = row_sum(z * npj);
       const float zf = (float)z;
       const double zz = (double)row_sum_f32(zf * zf);
-      const double ur = u * rcp_nr(r);
-      const double ratio = sel(slot && r > 0.0, ur, inf);
-      const double t1 = row_min(ratio);
-      const int lpos = row_first(ratio == t1 && ratio < inf);
-      const double t2v = -sp * rcp_nr(zn);
+      const double ur = u * rcp_nr1(r);
+      ratio = sel(slot && r > 0.0, ur, inf);
+      tl1 = row_min(ratio);
+      zinv = rcp_nr(zn);
+      const double t2v = -sp * zinv;
       // with n - (equality) constraints active the null space is empty and z is exactly 0 in the reference (J2 has
       // no columns); the explicit projector only leaves ~1e-7 of drift there, which must not pass for a direction
-      const bool exhausted = q + (has_eq ? 1 : 0) + (has_eq2 ? 1 : 0) >= n_free;
-      const double t2 = sel(!exhausted && fabs(zz) > eps && !(t2v < 0.0), t2v, inf);
-      const double t = vmin(t1, t2);
-      const bool infeasible = !(t < inf);                          // :339-344
-      const bool dual_only = (t2 >= inf);
-      const bool full = !infeasible && !dual_only && (t2 <= t1);   // :384
-      const bool degenerate = full && !(zn > eps * eps * rnorm2);  // add_constraint failure (:392)
-      const bool is_add = full && !degenerate;
+      const bool exhausted = q + neq >= n_free;
+      tl2 = sel((int)(!exhausted) & (int)(fabs(zz) > eps) & (int)(!(t2v < 0.0)), t2v, inf);
+      t = vmin(tl1, tl2);
+      is_add = (tl2 < inf) && (tl2 <= tl1) && (zn > eps * eps * rnorm2); // full step (:384), add_constraint succeeds (:392)
+      if (__builtin_amdgcn_ballot_w64(!is_add) != 0ull) break;
+      x += t * z;
+      u = fma(-t, r, u);
+      const int newlane = __ffs(~used & ((1u << N) - 1u)) - 1;
+      const bool newslot = lr == newlane;
+      vec = z * zinv;
+      hc = -z;
+      nc = sel(newslot, 1.0, -r);
+      u = sel(newslot, ucand + t, u);
+      idk = newslot ? ip : idk;
+      used |= 1u << newlane;
+      act_mask |= one << ip;
+      rnorm2 = vmax(rnorm2, zn);
+      q += 1;
+      update_and_select(std::integral_constant<int, 2>{}, true, true);
+    }
+    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+    if (!done) {
+      const bool infeasible = !(t < inf);                            // :339-344
+      const bool dual_only = (tl2 >= inf);
+      const bool full = !infeasible && !dual_only && (tl2 <= tl1);   // :384
+      const bool degenerate = full && !is_add;                       // add_constraint failure (:392)
       const bool is_drop = !infeasible && !full;
       if (infeasible) { status = kStatusInfeasible; done = true; }
       const double tp = (infeasible || dual_only || degenerate) ? 0.0 : t;
       const double td = (infeasible || degenerate) ? 0.0 : t;
       x += tp * z;
-      u -= sel(slot, td * r, 0.0);
+      u = fma(-td, r, u);
       ucand += td;
       sp += tp * zn;
       const int newlane = __ffs(~used & ((1u << N) - 1u)) - 1;
       const bool newslot = is_add && (lr == newlane);
-      double vec = is_add ? z * rcp_nr(zn) : 0.0;
-      double hc = is_add ? -z : 0.0;
-      double nc = sel(newslot, 1.0, sel(is_add && slot, -r, 0.0));
+      vec = is_add ? z * zinv : 0.0;
+      hc = is_add ? -z : 0.0;
+      nc = sel(newslot, 1.0, sel(is_add, -r, 0.0));
       u = newslot ? ucand : u;
       idk = newslot ? ip : idk;
       used |= is_add ? (1u << newlane) : 0u;
       act_mask |= is_add ? (one << ip) : (mask_t)0;
-      rnorm2 = is_add ? fmax(rnorm2, zn) : rnorm2;
+      rnorm2 = is_add ? vmax(rnorm2, zn) : rnorm2;
       q += is_add ? 1 : 0;
       excl |= degenerate ? (one << ip) : (mask_t)0;
-      need_select = need_select || full;
-      fresh = is_add ? true : (degenerate ? false : fresh);
+      int lpos = 16;
       if (is_drop) {
-        if (lr == lpos) {
-#pragma unroll
-          for (int j = 0; j < N; j++) nrow[j] = Ns[j];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        const double nt_me = lr < N ? nrow[lr < N ? lr : 0] : 0.0;
-        double Gn = 0.0;
-        static_for<N>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(Gn, nt_me, Gm[j]); });
-        const double einv = rcp_nr(row_sum(nt_me * Gn));
-        double coef = 0.0;
-        static_for<N>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(coef, Gn, Ns[j]); });
-        vec = nt_me;
-        hc = nt_me * einv;
-        nc = -coef * einv;
-        const int drop_id = __shfl(idk, lpos, 16);
+        lpos = row_first(ratio == tl1 && ratio < inf);
+        const int drop_id = drop_vectors(lpos);
         act_mask &= ~(one << drop_id);
         used &= ~(1u << lpos);
-        if (lr == lpos) u = 0.0;
         q--;
       }
-      static_for<N>([&](auto J) {
-        constexpr int j = J;
-        fmac_bc<j, j == 0>(H[j], vec, hc);
-        fmac_bc<j>(Ns[j], vec, nc);
-      });
+      update_and_select(std::integral_constant<int, 1>{}, full, is_add);
       if (is_drop && lr == lpos) {
 #pragma unroll
         for (int j = 0; j < N; j++) Ns[j] = 0.0;
       }
     }
   }
-  if (!done) status = kStatusMaxIter;
   // one refinement pass on the final working set (see balance_coop.hpp)
   if (status == kStatusOk && q > 0 && !skip) {
     if (lr < N) {
