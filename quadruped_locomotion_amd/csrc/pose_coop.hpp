@@ -96,6 +96,9 @@ __device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const 
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_s_waitcnt(0xC07F); // the normals are in LDS
 
+  // Active-set loop in the form of balance_coop.hpp (see the notes there): key selection on the constraint lanes,
+  // the chosen slack fetched from its lane, lazy feasibility sum, selection in the shadow of the rank-one update,
+  // unpredicated inner loop for the passes in which every live row adds.
   double Ns[6];
 #pragma unroll
   for (int j = 0; j < 6; j++) Ns[j] = 0.0;
@@ -105,117 +108,184 @@ __device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const 
   int q = 0, iters = 0, status = kStatusOk;
   const double psi_tol = (double)m * eps * c1 * c2 * 100.0;
   double rnorm2 = 1.0;
-  bool done = skip, need_select = true, fresh = true;
+  bool done = skip;
   int ip = 0;
-  double sp = 0.0, ucand = 0.0;
+  double sp = 0.0, ucand = 0.0, npj = 0.0;
   if (bad && !skip) { status = kStatusNotPd; done = true; }
+  const unsigned lanebit = 1u << lr;
+  const int row_addr = ((int)threadIdx.x & 48) << 2;
+  const int vlane = var ? lr : 0;
+  const bool mine = cvalid && lr >= 8;
+  const unsigned cbit = mine ? (1u << (cj & 7)) : 0u;
 
-  for (int tick = 0; tick < 40 * kMaxOuter; tick++) {
-    if (__all(done)) break;
-    if (!done && need_select) {
-      if (fresh) { iters++; excl = 0; }
-      // slacks on the constraint lanes: s_j = a_j'x + ci0_j
-      double s = bci0;
-      static_for<6>([&](auto I) { constexpr int i = I; fmac_bc<i, i == 0>(s, x, a[i]); });
-      const bool mine = cvalid && lr >= 8;
+  const auto umax_dpp = [](unsigned k, auto Ctrl) -> unsigned {
+    constexpr int ctrl = decltype(Ctrl)::value;
+    const unsigned o = (unsigned)__builtin_amdgcn_mov_dpp((int)k, ctrl, 0xF, 0xF, true);
+    return k > o ? k : o;
+  };
+  double vec = 0.0, hc = 0.0, nc = 0.0;
+  const auto update_and_select = [&](auto Mode, bool resel, bool fresh) {
+    constexpr int kMode = decltype(Mode)::value;
+    if constexpr (kMode == 1) {
+      iters += (resel && fresh) ? 1 : 0;
+      excl = (resel && fresh) ? 0u : excl;
+    } else {
+      iters += 1;
+      excl = 0u;
+    }
+    const unsigned avail = ~(act_mask | excl);
+    // slack of my constraint: s_j = a_j'x + ci0_j
+    double s = bci0;
+    static_for<6>([&](auto I) { constexpr int i = I; fmac_bc<i, i == 0>(s, x, a[i]); });
+    unsigned key = __float_as_uint((float)s);
+    key = ((avail & cbit) != 0u && s < 0.0) ? ((key & ~15u) | (unsigned)lr) : 0u;
+    if constexpr (kMode != 0) {
+      static_for<6>([&](auto J) {
+        constexpr int j = J;
+        fmac_bc<j, j == 0>(H[j], vec, hc);
+        fmac_bc<j>(Ns[j], vec, nc);
+      });
+    }
+    key = umax_dpp(key, std::integral_constant<int, 0x128>{});
+    key = umax_dpp(key, std::integral_constant<int, 0x124>{});
+    key = umax_dpp(key, std::integral_constant<int, 0x122>{});
+    key = umax_dpp(key, std::integral_constant<int, 0x121>{});
+    const int wl = (int)key & 15;
+    const int addr = row_addr + (wl << 2);
+    const int vlo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(s));
+    const int vhi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(s));
+    const int key_ip = (wl - 8) & 7;
+    const double np_tab = ct[6 * key_ip + vlane];
+    const double np_new = var ? np_tab : 0.0;
+    const bool any = (int)key < 0;
+    const double vsel = __hiloint2double(vhi, vlo);
+    bool feasible = false;
+    const bool close = (kMode != 1 || (resel && fresh)) && any && !(vsel < -psi_tol);
+    if (__builtin_amdgcn_ballot_w64(close) != 0ull) { // QuadProg++.cc:246-250
       const float viol = mine ? (float)vmin(0.0, s) : 0.0f;
       const double psi = (double)row_sum_f32(viol);
-      const unsigned blocked = act_mask | excl;
-      double v = sel(mine && !((blocked >> (cj & 7)) & 1u) && s < 0.0, s, inf);
-      const double vbest = row_min(v);
-      const int wl = row_first(v == vbest && v < 0.0);
-      const bool feasible = fresh && (fabs(psi) <= psi_tol);     // QuadProg++.cc:246-250
-      const bool stop = feasible || !(vbest < 0.0) || iters > kMaxOuter; // :271-274
-      status = (stop && iters > kMaxOuter) ? kStatusMaxIter : status;
-      done = stop;
-      ip = stop ? ip : (wl - 8);
-      sp = sel(stop, sp, vbest);
-      ucand = sel(stop, ucand, 0.0);
-      need_select = stop;
+      feasible = close && (fabs(psi) <= psi_tol);
     }
-    if (!done) {
-      const double npj = var ? ct[6 * ip + lr] : 0.0;
+    const bool stop = !any || feasible || iters > kMaxOuter; // :271-274
+    if constexpr (kMode == 1) {
+      status = (resel && stop && iters > kMaxOuter) ? kStatusMaxIter : status;
+      done = done || (resel && stop);
+      const bool take = resel && !stop;
+      ip = take ? key_ip : ip;
+      sp = sel(take, vsel, sp);
+      ucand = sel(take, 0.0, ucand);
+      npj = sel(take, np_new, npj);
+    } else {
+      status = (!done && stop && iters > kMaxOuter) ? kStatusMaxIter : status;
+      done = done || stop;
+      ip = key_ip; sp = vsel; ucand = 0.0; npj = np_new;
+    }
+  };
+  const auto drop_vectors = [&](int lpos) {
+    if (lr == lpos) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) nrow[j] = Ns[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const double nt_me = var ? nrow[vlane] : 0.0;
+    const int drop_id = __shfl(idk, lpos, 16);
+    double Gn = 0.0;
+    static_for<6>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(Gn, nt_me, Gm[j]); });
+    const double einv = rcp_nr1(row_sum(nt_me * Gn));
+    double coef = 0.0;
+    static_for<6>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(coef, Gn, Ns[j]); });
+    vec = nt_me;
+    hc = nt_me * einv;
+    nc = -coef * einv;
+    return drop_id;
+  };
+
+  update_and_select(std::integral_constant<int, 0>{}, true, true);
+
+  for (;;) {
+    double z = 0.0, r = 0.0, zn = 0.0, zinv = 0.0, t = 0.0, tl1 = 0.0, tl2 = 0.0, ratio = 0.0;
+    bool is_add = false;
+    while (!done) {
       double za[2] = {0.0, 0.0}, ra[2] = {0.0, 0.0};
       static_for<6>([&](auto J) {
         constexpr int j = J;
         fmac_bc<j, j == 0>(za[j & 1], npj, H[j]);
         fmac_bc<j>(ra[j & 1], npj, Ns[j]);
       });
-      const double z = za[0] + za[1], r = ra[0] + ra[1];
-      const bool slot = (used >> lr) & 1u;
-      const double zn = row_sum(z * npj);
+      z = za[0] + za[1];
+      r = ra[0] + ra[1];
+      const bool slot = (used & lanebit) != 0u;
+      zn = row_sum(z * npj);
       const float zf = (float)z;
       const double zz = (double)row_sum_f32(zf * zf);
       // step lengths, QuadProg++.cc:304-331
-      const double ur = u * rcp_nr(r);
-      const double ratio = sel(slot && r > 0.0, ur, inf);
-      const double t1 = row_min(ratio);
-      const int lpos = row_first(ratio == t1 && ratio < inf);
-      const double t2v = -sp * rcp_nr(zn);
+      const double ur = u * rcp_nr1(r);
+      ratio = sel(slot && r > 0.0, ur, inf);
+      tl1 = row_min(ratio);
+      zinv = rcp_nr(zn);
+      const double t2v = -sp * zinv;
       const bool exhausted = q + (dummy_eq ? 1 : 0) >= n; // empty null space: z is exactly 0 in the reference
-      const double t2 = sel(!exhausted && fabs(zz) > eps && !(t2v < 0.0), t2v, inf);
-      const double t = vmin(t1, t2);
-      const bool infeasible = !(t < inf);                          // :339-344
-      const bool dual_only = (t2 >= inf);
-      const bool full = !infeasible && !dual_only && (t2 <= t1);   // :384
-      const bool degenerate = full && !(zn > eps * eps * rnorm2);  // add_constraint failure (:392)
-      const bool is_add = full && !degenerate;
+      tl2 = sel((int)(!exhausted) & (int)(fabs(zz) > eps) & (int)(!(t2v < 0.0)), t2v, inf);
+      t = vmin(tl1, tl2);
+      is_add = (tl2 < inf) && (tl2 <= tl1) && (zn > eps * eps * rnorm2); // full step (:384), add_constraint succeeds (:392)
+      if (__builtin_amdgcn_ballot_w64(!is_add) != 0ull) break;
+      x += t * z;
+      u = fma(-t, r, u);
+      const int newlane = __ffs(~used & 0x3Fu) - 1;
+      const bool newslot = lr == newlane;
+      vec = z * zinv;
+      hc = -z;
+      nc = sel(newslot, 1.0, -r);
+      u = sel(newslot, ucand + t, u);
+      idk = newslot ? ip : idk;
+      used |= 1u << newlane;
+      act_mask |= 1u << ip;
+      rnorm2 = vmax(rnorm2, zn);
+      q += 1;
+      update_and_select(std::integral_constant<int, 2>{}, true, true);
+    }
+    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+    if (!done) {
+      const bool infeasible = !(t < inf);                            // :339-344
+      const bool dual_only = (tl2 >= inf);
+      const bool full = !infeasible && !dual_only && (tl2 <= tl1);   // :384
+      const bool degenerate = full && !is_add;                       // add_constraint failure (:392)
       const bool is_drop = !infeasible && !full;
       if (infeasible) { status = kStatusInfeasible; done = true; }
       const double tp = (infeasible || dual_only || degenerate) ? 0.0 : t;
       const double td = (infeasible || degenerate) ? 0.0 : t;
       x += tp * z;
-      u -= sel(slot, td * r, 0.0);
+      u = fma(-td, r, u);
       ucand += td;
       sp += tp * zn;
       const int newlane = __ffs(~used & 0x3Fu) - 1;
       const bool newslot = is_add && (lr == newlane);
-      double vec = is_add ? z * rcp_nr(zn) : 0.0;
-      double hc = is_add ? -z : 0.0;
-      double nc = sel(newslot, 1.0, sel(is_add && slot, -r, 0.0));
+      vec = is_add ? z * zinv : 0.0;
+      hc = is_add ? -z : 0.0;
+      nc = sel(newslot, 1.0, sel(is_add, -r, 0.0));
       u = newslot ? ucand : u;
       idk = newslot ? ip : idk;
       used |= is_add ? (1u << newlane) : 0u;
       act_mask |= is_add ? (1u << ip) : 0u;
-      rnorm2 = is_add ? fmax(rnorm2, zn) : rnorm2;
+      rnorm2 = is_add ? vmax(rnorm2, zn) : rnorm2;
       q += is_add ? 1 : 0;
       excl |= degenerate ? (1u << ip) : 0u;
-      need_select = need_select || full;
-      fresh = is_add ? true : (degenerate ? false : fresh);
+      int lpos = 16;
       if (is_drop) {
-        if (lr == lpos) {
-#pragma unroll
-          for (int j = 0; j < 6; j++) nrow[j] = Ns[j];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        const double nt_me = var ? nrow[lr] : 0.0;
-        double Gn = 0.0;
-        static_for<6>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(Gn, nt_me, Gm[j]); });
-        const double einv = rcp_nr(row_sum(nt_me * Gn));
-        double coef = 0.0;
-        static_for<6>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(coef, Gn, Ns[j]); });
-        vec = nt_me;
-        hc = nt_me * einv;
-        nc = -coef * einv;
-        const int drop_id = __shfl(idk, lpos, 16);
+        lpos = row_first(ratio == tl1 && ratio < inf);
+        const int drop_id = drop_vectors(lpos);
         act_mask &= ~(1u << drop_id);
         used &= ~(1u << lpos);
-        if (lr == lpos) u = 0.0;
         q--;
       }
-      static_for<6>([&](auto J) {
-        constexpr int j = J;
-        fmac_bc<j, j == 0>(H[j], vec, hc);
-        fmac_bc<j>(Ns[j], vec, nc);
-      });
+      update_and_select(std::integral_constant<int, 1>{}, full, is_add);
       if (is_drop && lr == lpos) {
 #pragma unroll
         for (int j = 0; j < 6; j++) Ns[j] = 0.0;
       }
     }
   }
-  if (!done) status = kStatusMaxIter;
   // one refinement pass on the final working set (see balance_coop.hpp)
   if (status == kStatusOk && q > 0 && !skip) {
     if (lr < 6) {
