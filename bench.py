@@ -333,7 +333,7 @@ def bench_full_tick(args):
                 limb_state=np.zeros((B, 4), np.int8), store_flag=np.zeros((B, 4), np.uint8), stored_joint_position=np.zeros((B, 12)),
                 leg_mode=np.zeros((B, 4), np.uint8), support=np.ones((B, 4), np.uint8), pid_error_last=np.zeros((B, 12)),
                 pid_error_integral=np.zeros((B, 12)), joint_effort=np.zeros((B, 12)), leg_state_code=np.zeros((B, 4), np.int8), status=np.full(B, -1, np.int32),
-                message_status=np.full(B, -1, np.int32))
+                message_status=np.full(B, -1, np.int32), command=np.zeros(capi.tick_command_bytes(B), np.uint8))
     dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to("cuda:0") for k, v in host.items()}
     ctx = capi.Context(device=0)
     stream = torch.cuda.current_stream().cuda_stream

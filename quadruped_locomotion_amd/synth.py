@@ -215,6 +215,8 @@ def make_messages(batch, ragged=False, seed=SEED + 21, mode_names=None):
                   foot_acceleration=rng.normal(size=(batch, 12)), surface_normal=rng.normal(size=(batch, 12)),
                   phase=rng.random((batch, 4)), support_leg=rng.integers(0, 2, (batch, 4)).astype(np.uint8))
     pick = rng.integers(0, len(names), (batch, 4))
+    if not ragged:  # one publisher, one layout: the mode names (strings) are the same for every robot
+        pick[:] = pick[0]
     fields["leg_mode"] = np.array([[wire.MODE_CODE.get(names[k], 0) for k in row] for row in pick], dtype=np.uint8)
     one = wire.random_layout(np.random.default_rng(seed + 1))
     msgs = []

@@ -1,5 +1,5 @@
 """The one-line JSON contract of bench.py: every key the driver reads, with the types and relations it relies on.
-CPU: the committed line of the last measured run (profiles/r1/final_bench_static_b4096.json).  GPU: a short live run."""
+CPU: the committed line of the last measured run (profiles/r2/bench_static_b4096.json).  GPU: a short live run."""
 import json
 import os
 import subprocess
@@ -38,9 +38,12 @@ def check(line, want_cpu=True):
 
 
 def test_committed_bench_line_follows_the_contract():
-    path = os.path.join(ROOT, "profiles", "r1", "final_bench_static_b4096.json")
+    path = os.path.join(ROOT, "profiles", "r2", "bench_static_b4096.json")
     d = check(open(path).read().strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["config"]["robots_per_gpu"] == 4096 and d["config"]["all_status_ok"] is True
+    # what round 2 added: the input is disclosed, the timed region is a median of samples, PMC numbers carry their source
+    assert d["config"]["tracking_error"] == [0.004, 0.005, 0.01] and len(d["config"]["samples_ms"]) >= 11
+    assert "traffic_source" in d["roofline"] and d["cpu_baseline"]["cpu_model"] and d["cpu_baseline"]["thread_sweep"]
 
 
 @pytest.mark.gpu

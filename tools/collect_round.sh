@@ -1,0 +1,38 @@
+#!/bin/bash
+# Everything a round commits under profiles/rN, in one GPU-box call:
+#   bash tools/collect_round.sh r2        -> gpurun_out/r2_final/ (copy the summaries into profiles/r2/ afterwards)
+# 1. rocprofv3 kernel statistics and PMC passes (tools/collect_profiles.py) -> pmc_index.json, kernel_stats_*.csv
+# 2. the bench lines of every workload (the PMC index is put where bench.py looks for it first)
+# 3. kernel durations of the auxiliary entries, the single-wavefront latency probe, host-buffer latencies
+set -u
+R=${1:-r2}
+OUT=gpurun_out/${R}_final
+mkdir -p $OUT profiles/$R
+python3 tools/collect_profiles.py $OUT > $OUT/collect_profiles.log 2>&1
+rm -rf $OUT/raw
+cp $OUT/pmc_index.json profiles/$R/pmc_index.json
+b() { name=$1; shift; python3 bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; }
+b static_b4096 --steps 200 --warmup 20
+b static_survey_b4096 --errors survey --steps 200 --warmup 20 --no-cpu-baseline
+b trot_b4096 --gait trot --steps 200 --warmup 20
+b trot_b8192 --gait trot --batch 8192 --steps 200 --warmup 20 --no-cpu-baseline
+b trot_b65536 --gait trot --batch 65536 --steps 100 --warmup 10 --no-cpu-baseline
+b static_b1048576 --gait static --batch 1048576 --steps 20 --warmup 5 --no-cpu-baseline
+b trot_b8192_force_collective --force-collective --gait trot --batch 8192 --steps 100 --warmup 10 --no-cpu-baseline
+b pose_sqp_b4096 --workload pose_sqp --steps 200 --warmup 20
+b full_tick_b4096 --workload full_tick --steps 100
+b full_tick_ragged_b4096 --workload full_tick --ragged --steps 100
+b full_tick_b65536 --workload full_tick --batch 65536 --steps 50
+b wholebody_static_b4096 --workload wholebody --gait static --steps 100
+b wholebody_trot_b4096 --workload wholebody --gait trot --steps 100
+b wholebody_dynamics_b4096 --workload wholebody_dynamics --steps 100
+b wholebody_dynamics_b65536 --workload wholebody_dynamics --batch 65536 --steps 50
+b wholebody_dynamics_b1048576 --workload wholebody_dynamics --batch 1048576 --steps 10
+( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/aux_raw -o aux -- python3 $GRAFT_REPO_ROOT/tools/aux_kernels.py > /dev/null 2>&1 )
+python3 tools/rocpd_kernels.py $(find $OUT/aux_raw -name "*_results.db" | head -1) $OUT/kernel_stats_aux_entries_b4096.csv > /dev/null 2>&1
+rm -rf $OUT/aux_raw
+python3 tools/tail_probe.py 2>&1 | grep -v amdgpu > $OUT/single_wavefront_latency.txt
+python3 tools/latency_b1.py 2>&1 | grep -v amdgpu > $OUT/host_buffer_latency.txt
+./tools/ubench/issue_model > $OUT/issue_model.txt 2>&1
+./tools/ubench/rcp_accuracy > $OUT/rcp_accuracy.txt 2>&1
+ls $OUT
