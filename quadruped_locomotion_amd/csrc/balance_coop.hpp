@@ -800,6 +800,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   };
   // dropping slot lpos (partial or dual-only step): n~ = row lpos of N* reaches the variable lanes through LDS,
   // then H += n~ n~'/e and N* -= (N* G n~) n~'/e with e = n~'G n~ (row lpos of N* becomes 0)
+  double drop_einv = 0.0;
   const auto drop_vectors = [&](int lpos) {
     if (lr == lpos) {
 #pragma unroll
@@ -812,6 +813,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     double Gn = 0.0;
     static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(Gn, nt_me, Gm[j]); });
     const double einv = rcp_nr1(row_sum(nt_me * Gn));
+    drop_einv = einv;
     double coef = 0.0;
     static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(coef, Gn, Ns[j]); });
     vec = nt_me;
@@ -829,22 +831,26 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   // (Alternative tails inside ONE loop cost 24 register copies of H and N* on its back edge; and the launch lasts as
   // long as its slowest robot, which is alone in its wavefront for most of its passes.)
   // Terminates: at most kMaxOuter adds, every drop undoes an earlier add, a failed add bans its row until the next add.
+  double z = 0.0, r = 0.0, zn = 0.0, zinv = 0.0, t = 0.0, tl1 = 0.0, tl2 = 0.0, ratio = 0.0;
+  bool have_dirs = false; // wave-uniform: the directions of the pass at hand follow from the drop just made
   for (;;) {
-    double z = 0.0, r = 0.0, zn = 0.0, zinv = 0.0, t = 0.0, tl1 = 0.0, tl2 = 0.0, ratio = 0.0;
     bool is_add = false;
     while (!done) {
-      // ---- directions: z = H n_p (lane i), r = N* n_p (slot lane k; 0 on free lanes, whose rows are 0)
-      // three partial sums per product: consecutive dependent FMAs are 6 instructions apart
-      double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
-      static_for<12>([&](auto J) {
-        constexpr int j = J;
-        fmac_bc<lane_of(j), j == 0>(za[j % 3], npj, H[j]);
-        fmac_bc<lane_of(j)>(ra[j % 3], npj, Ns[j]);
-      });
-      z = (za[0] + za[1]) + za[2];
-      r = (ra[0] + ra[1]) + ra[2];
+      if (!have_dirs) {
+        // ---- directions: z = H n_p (lane i), r = N* n_p (slot lane k; 0 on free lanes, whose rows are 0)
+        // three partial sums per product: consecutive dependent FMAs are 6 instructions apart
+        double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
+        static_for<12>([&](auto J) {
+          constexpr int j = J;
+          fmac_bc<lane_of(j), j == 0>(za[j % 3], npj, H[j]);
+          fmac_bc<lane_of(j)>(ra[j % 3], npj, Ns[j]);
+        });
+        z = (za[0] + za[1]) + za[2];
+        r = (ra[0] + ra[1]) + ra[2];
+        zn = row_sum(z * npj);
+      }
+      have_dirs = false;
       const bool slot = (used & lanebit) != 0u;
-      zn = row_sum(z * npj);
       const float zf = (float)z;
       const double zz = (double)row_sum_f32(zf * zf); // only compared with eps below
       // ---- step lengths, QuadProg++.cc:304-331
@@ -886,6 +892,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
         ucand += t;
         sp += tp * zn; // slack of ip after a partial step (:436-440, linear in t)
         const int lpos = row_first(ratio == tl1 && ratio < inf);
+        const double r_lpos = __shfl(r, lpos, 16);
         const int drop_id = drop_vectors(lpos);
         act_mask &= ~(1u << drop_id);
         used &= ~(1u << lpos);
@@ -895,7 +902,14 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
 #pragma unroll
           for (int j = 0; j < 12; j++) Ns[j] = 0.0;
         }
+        // the same candidate continues with the working set one smaller: with H' = H + n~ n~'/e and N*' = N* - c n~'/e
+        // its directions are z' = z + (n~/e) r_k, r' = r - (c/e) r_k, z'n = zn + r_k^2/e (r_k = n~'n_p = r of the
+        // dropped slot) -- no need for the 24 broadcasts of the next pass
+        z = fma(hc, r_lpos, z);
+        r = fma(nc, r_lpos, r);
+        zn = fma(r_lpos * r_lpos, drop_einv, zn);
       }
+      have_dirs = true;
     } else if (!done) {
       // ---- the pass of the live rows in general form (all row-uniform)
       const bool infeasible = !(t < inf);                          // :339-344
