@@ -284,6 +284,8 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   QL_STAMP(1);
   // ---------------------------------------------------------------- wrench (replicated)
   double Rm[9], gB[3], b[6];
+  double wr_d[3] = {0.0, 0.0, 0.0}, wr_dw = 1.0, wr_k = 2.0; // orientation error: vector part, scalar part, 2 alpha / sin(alpha)
+  bool wr_slow = false;
   quat_to_matrix(quat, Rm);
   {
     const double gW[3] = {0.0, 0.0, -P.grav};
@@ -296,12 +298,61 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) { in.quat[k] = quat[k]; in.dquat[k] = dquat[k]; }
-    if (s.wrench) {
+    // Computed unconditionally and without a branch, so that the leg kinematics below -- an independent chain of
+    // about the same length -- sits in the same basic block and the scheduler can weave the two (a lone wavefront
+    // issues a dependent instruction every 8.5 cycles, an independent one every 5.5).  The orientation error
+    // -log(q_d^-1 q_m) = -k d_vec with k = 2 acos(d_w) / sqrt(1 - d_w^2) is evaluated as the series of
+    // 2 asin(s) / s in s^2 = 1 - d_w^2 (ten terms, < 1e-16 below s^2 = 0.01, i.e. errors up to 0.2 rad); a row outside
+    // that range gets the libm form as a correction after the kinematics, and an externally supplied wrench
+    // (computeForceDistribution's arguments) replaces the result there as well.
+    in.has_wrench = false;
+    wr_dw = 0.0;
+    {
+      const double *qd = in.dquat, *qm = in.quat;
+      const double aw = qd[0], ax = -qd[1], ay = -qd[2], az = -qd[3];
+      wr_dw = aw * qm[0] - ax * qm[1] - ay * qm[2] - az * qm[3];
+      wr_d[0] = aw * qm[1] + ax * qm[0] + ay * qm[3] - az * qm[2];
+      wr_d[1] = aw * qm[2] - ax * qm[3] + ay * qm[0] + az * qm[1];
+      wr_d[2] = aw * qm[3] + ax * qm[2] - ay * qm[1] + az * qm[0];
+      const double s2 = 1.0 - wr_dw * wr_dw;
+      double p = 34459425.0 / 3530096640.0;
+      p = fma(p, s2, 2027025.0 / 175472640.0);
+      p = fma(p, s2, 135135.0 / 9676800.0);
+      p = fma(p, s2, 10395.0 / 599040.0);
+      p = fma(p, s2, 945.0 / 42240.0);
+      p = fma(p, s2, 105.0 / 3456.0);
+      p = fma(p, s2, 15.0 / 336.0);
+      p = fma(p, s2, 3.0 / 40.0);
+      p = fma(p, s2, 1.0 / 6.0);
+      p = fma(p, s2, 1.0);
+      wr_k = 2.0 * p;
+      wr_slow = !(s2 < 0.01) || !(wr_dw > 0.0);
+    }
+    {
+      double e_p[3], e_v[3], e_w[3];
 #pragma unroll
-      for (int k = 0; k < 6; k++) b[k] = wr[k];
-    } else {
-      in.has_wrench = false;
-      virtual_wrench(P, in, Rm, gB, b);
+      for (int k = 0; k < 3; k++) {
+        e_p[k] = in.dpos[k] - in.pos[k];
+        e_v[k] = in.dlinvel[k] - in.linvel[k];
+        e_w[k] = in.dangvel[k] - in.angvel[k];
+      }
+      // VirtualModelController.cpp:208-231 (vertical P and D enter twice), as virtual_wrench()
+      const double ff[3] = {in.dlinvel[0], in.dlinvel[1], 0.0};
+      const double gfb[3] = {0.0, 0.0, P.kp_t[2] * e_p[2]};
+      const double gdb[3] = {0.0, 0.0, P.kd_t[2] * e_v[2]};
+      double Rep[3], Rev[3], Rff[3], fbp[3], fbd[3];
+      irot(Rm, e_p, Rep); irot(Rm, e_v, Rev); irot(Rm, ff, Rff); irot(Rm, gfb, fbp); irot(Rm, gdb, fbd);
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        b[k] = P.kp_t[k] * Rep[k] + P.kd_t[k] * Rev[k] + P.kff_t[k] * Rff[k] - P.Fg_scale * gB[k] + fbp[k] + fbd[k];
+      // VirtualModelController.cpp:244-259
+      const double kdw[3] = {P.kd_r[0] * e_w[0], P.kd_r[1] * e_w[1], P.kd_r[2] * e_w[2]};
+      const double kfw[3] = {0.0, 0.0, P.kff_r[2] * in.dangvel[2]};
+      double Rd[3], Rf[3], Tg[3];
+      irot(Rm, kdw, Rd); irot(Rm, kfw, Rf);
+      cross3(P.Tg_arm, gB, Tg);
+#pragma unroll
+      for (int k = 0; k < 3; k++) b[3 + k] = P.kp_r[k] * (-wr_k * wr_d[k]) + Rd[k] + Rf[k] - Tg[k];
     }
   }
 
@@ -369,6 +420,18 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     }
   }
 
+  if (__builtin_amdgcn_ballot_w64(wr_slow) != 0ull) { // a large orientation error: the libm form of the factor
+    const double s2 = 1.0 - wr_dw * wr_dw;
+    double k = 2.0;
+    if (s2 >= 1e-12) k = 2.0 * acos(wr_dw) / sqrt(s2);
+    const double dk = wr_slow ? k - wr_k : 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) b[3 + a] -= P.kp_r[a] * dk * wr_d[a];
+  }
+  if (s.wrench) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) b[k] = wr[k];
+  }
   // Jacobian row and gravity torque are not needed before the torques at the very end: parked in LDS ([k][lane]) so
   // that the kernel stays within 256 registers without a spill to scratch memory
 #pragma unroll
