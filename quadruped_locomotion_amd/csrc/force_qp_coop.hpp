@@ -1,0 +1,544 @@
+// The contact-force QP of one robot on its 16 lanes: inverse of G, unconstrained minimiser, the active-set loop and
+// the refinement on the final working set -- the part of the balance step (balance_coop.hpp) and of the whole-body step
+// (wholebody_coop.hpp) that is the same.  Device-only (gfx950).
+//
+//   min 1/2 x'G x + g0'x   over the 12 contact-force components (lane 4 leg + c holds component c of leg `leg` and row
+//   3 leg + c of every matrix; c = 3 is a spare lane; rows of a swing leg are padding: unit diagonal, g0 = 0)
+//   s.t. per stance leg   n'f >= f_min,   mu n'f +- t1'f >= 0,   mu n'f +- t2'f >= 0          (kinds 0, 1..4)
+//   kTorque:              |tau0_k - J[:,k]'f| <= tau_max for the leg's joints k = 0..2           (kinds 5+2k upper, 6+2k lower)
+// Every row touches the three variables of ONE leg, which is what the loop is built on: lane (leg, c) watches friction
+// row c + 1 of its leg, the minimum-force row when c = 0 and, with kTorque, the two torque bounds of joint c.
+//
+// Method: Goldfarb-Idnani with the operators of the original paper kept explicitly (see balance_coop.hpp's header),
+// pivot rule, step lengths and termination test of QuadProg++ (QuadProg++.cc:216-445).
+#pragma once
+
+#include "coop_lanes.hpp"
+
+namespace qlamd {
+namespace coop {
+
+// LDS of one robot: N* export for the refinement, row export for drops
+constexpr int kCoopLdsDoubles = 12 * 12 + 12;
+// rows of the wavefront's table of constraint normals ([row kind][lane]) the QP uses: 5, and 3 more with kTorque
+constexpr int kForceQpNrmRows = 5, kForceQpNrmRowsTorque = 8;
+
+struct ForceQp {
+  double Gm[12];                 // my row of G
+  double g0;                     // my entry of g0
+  double nb[3], t1[3], t2[3];    // my leg's contact normal and tangents (base frame), whole vectors
+  double myn, myt1, myt2;        // their component c (0 on the spare lane)
+  double mu, f_min;
+  bool on, comp;                 // my leg supports; I carry a variable (c < 3)
+  int nS;                        // number of stance legs
+  int refine_passes;
+  // kTorque only.  tau = tau0 - J_leg' f:  J[c][k] and J[k][c] of my leg (0 unless on && comp)
+  double jrow[3], jcol[3];
+  double tq_up, tq_lo;           // tau_max - tau0_c, tau_max + tau0_c
+};
+
+// My row of G and my entry of g0 for the objective  |A f - F|^2_S + w_reg |f|^2  (A = [1 ... ; [r_leg]x ...], the
+// distribution of the target wrench F = [force ; moment] over the contact forces, ContactForceDistribution.cpp:184-252),
+// plus, when `jrow` is given, the torque term  w_tau |tau0 - J' f|^2  of the whole-body step on my own leg's block.
+// foot: component c of my leg's foot position; stance: bit per leg; row_on: my leg supports and I carry a variable.
+// S: the six weights; jrow[k] = J[c][k] of my leg, jt0 = sum_k J[c][k] tau0_k.
+__device__ __forceinline__ void force_qp_objective(const double S[6], double w_reg, double foot, unsigned stance, bool row_on,
+                                                   const double F[6], const double *jrow, double w_tau_jt0, double Gm[12],
+                                                   double &g0, double w_tau = 0.0) {
+  const int lr = threadIdx.x & 15, leg = lr >> 2, c = lr & 3;
+  const int myidx = 3 * leg + c;
+  // foot positions of all legs, replicated
+  double r[4][3];
+  static_for<12>([&](auto J) { constexpr int j = J; r[j / 3][j % 3] = bcv<j>(foot); });
+  const double rl[3] = {quad_bc<0>(foot), quad_bc<1>(foot), quad_bc<2>(foot)};
+  // a = r_leg x e_c  (column c of skew(r_leg))
+  const double a[3] = {sel(c == 1, -rl[2], sel(c == 2, rl[1], 0.0)), sel(c == 0, rl[2], sel(c == 2, -rl[0], 0.0)),
+                       sel(c == 0, -rl[1], sel(c == 1, rl[0], 0.0))};
+  const double sa[3] = {S[3] * a[0], S[4] * a[1], S[5] * a[2]};
+  const double Sfc = pick3(S, c);
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const bool both = row_on && ((stance >> m) & 1u);
+    const double xp = r[m][0], yp = r[m][1], zp = r[m][2];
+    // (r_m x e_b) for b = 0,1,2: (0,z',-y'), (-z',0,x'), (y',-x',0)
+    const double e0 = sa[1] * zp - sa[2] * yp;
+    const double e1 = -sa[0] * zp + sa[2] * xp;
+    const double e2 = sa[0] * yp - sa[1] * xp;
+    Gm[3 * m + 0] = both ? e0 + (c == 0 ? Sfc : 0.0) : 0.0;
+    Gm[3 * m + 1] = both ? e1 + (c == 1 ? Sfc : 0.0) : 0.0;
+    Gm[3 * m + 2] = both ? e2 + (c == 2 ? Sfc : 0.0) : 0.0;
+  }
+  if (jrow) { // w_tau J J' on my own leg's block: entry (c, b) = sum_k J[c][k] J[b][k]
+    double jj[3];
+    static_for<3>([&](auto Bq) {
+      constexpr int bq = Bq;
+      jj[bq] = jrow[0] * quad_bc<bq>(jrow[0]) + jrow[1] * quad_bc<bq>(jrow[1]) + jrow[2] * quad_bc<bq>(jrow[2]);
+    });
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const bool own = row_on && m == leg;
+#pragma unroll
+      for (int bq = 0; bq < 3; bq++) Gm[3 * m + bq] += own ? w_tau * jj[bq] : 0.0;
+    }
+  }
+  // rows of legs that do not support are padding: unit diagonal (they never meet a stance row)
+#pragma unroll
+  for (int j = 0; j < 12; j++)
+    if (c < 3 && j == myidx) Gm[j] += row_on ? w_reg : 1.0;
+  const double Fc = pick3(F, c);
+  const double ST[3] = {S[3] * F[3], S[4] * F[4], S[5] * F[5]};
+  const double g0v = -(Sfc * Fc + (a[0] * ST[0] + a[1] * ST[1] + a[2] * ST[2]) + w_tau_jt0);
+  g0 = sel(row_on, g0v, 0.0);
+}
+
+// Returns the status; x: my component of the minimiser (valid for kStatusOk).
+template <bool kTorque>
+__device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, double *lds_nrm, double &x) {
+  using mask_t = std::conditional_t<kTorque, unsigned long long, unsigned>;
+  constexpr int kKinds = kTorque ? 11 : 5;
+  const int lr = threadIdx.x & 15, leg = lr >> 2, c = lr & 3;
+  const bool comp = Q.comp, on = Q.on, row_on = comp && on;
+  const int myidx = 3 * leg + c, nS = Q.nS;
+  const double eps = 2.220446049250313e-16;
+  const double inf = INFINITY;
+  const double mu = Q.mu, f_min = Q.f_min, g0 = Q.g0;
+  const double myn = Q.myn, myt1 = Q.myt1, myt2 = Q.myt2;
+  const double *nb = Q.nb, *t1 = Q.t1, *t2 = Q.t2, *Gm = Q.Gm;
+  double H[12];
+  double c1 = 0.0, c2 = 0.0;
+  {
+#pragma unroll
+    for (int j = 0; j < 12; j++) H[j] = Gm[j];
+    // trace(G) over the stance block
+    {
+      double diag = 0.0;
+#pragma unroll
+      for (int j = 0; j < 12; j++) diag = (j == myidx) ? Gm[j] : diag;
+      c1 = row_sum(sel(row_on, diag, 0.0));
+    }
+    // in-place Gauss-Jordan inversion, row per lane; pivot k = L_kk^2 of the Cholesky factor.
+    // Row update H[j] -= f * H_k[j] is one v_fmac_f64_dpp (pivot row read through the DPP operand);
+    // on the pivot lane f = 1 - 1/d turns the same formula into H_k[j] / d.
+    bool bad = false;
+    double my_pivot = 1.0; // pivot of my own row, for c2 below
+    // The chain pivot -> reciprocal -> factor -> row updates -> next pivot is serial; the column of the NEXT pivot is
+    // updated first, so that its reciprocal (hardware seed + one Newton step, 2e-15: the final refinement works on
+    // G itself, not on this inverse) is under way while the other ten columns are still being updated.
+    double d = bcv<0>(H[0]);
+    static_for<12>([&](auto K) {
+      constexpr int k = K;
+      bad = bad || !(d > 0.0);
+      const double p = rcp_nr1(d);
+      const bool piv = comp && (myidx == k);
+      my_pivot = piv ? d : my_pivot;
+      const double f = piv ? (1.0 - p) : H[k] * p;
+      const double nf = -f;
+      if constexpr (k < 11) {
+        fmac_bc<lane_of(k), true>(H[k + 1], H[k + 1], nf);
+        d = bcv<k + 1>(H[k + 1]);
+      }
+      static_for<12>([&](auto J) {
+        constexpr int j = J;
+        if constexpr (j != k && j != k + 1) fmac_bc<lane_of(k), (k == 11 && j == 0)>(H[j], H[j], nf);
+      });
+      H[k] = piv ? p : nf;
+    });
+    // c2 = trace(J) = sum over the stance rows of 1/sqrt(pivot): one rsqrt per lane instead of one per pivot
+    // (it only feeds the termination tolerance psi_tol)
+    const double rp = rsqrt_nr(my_pivot);
+    c2 = row_sum(sel(row_on, rp, 0.0));
+    if (bad && nS > 0) return kStatusNotPd;
+  }
+
+  QL_STAMP(5);
+  // ---------------------------------------------------------------- x0 = -H g0
+  x = 0.0;
+  {
+    const double ng0 = -g0;
+    double xa[3] = {0.0, 0.0, 0.0};
+    static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(xa[j % 3], ng0, H[j]); });
+    x = (xa[0] + xa[1]) + xa[2];
+  }
+
+  QL_STAMP(6);
+  // ---------------------------------------------------------------- active-set loop
+  // One pass of the loop = one step of the dual method (an add or a drop) followed by the rank-one update of H and
+  // N*, with the selection of the next violated constraint (QuadProg++.cc:252-274) computed on the new x in the
+  // shadow of that update: the two are independent, so the broadcast chain of the update fills the wait states of
+  // the selection's cross-lane reduction and vice versa.  Slots are NOT compacted on a drop: a freed slot lane is
+  // reused by the next add (the order of the slots only breaks exact ties in the blocking-constraint search).
+  //
+  // A lone wavefront issues one instruction every ~4.5 cycles whatever its kind (tools/ubench/issue_model.hip), so a
+  // pass costs what it has instructions.  The four robots of a wavefront take different branches of the method, which
+  // makes every state update a predicated select; but the launch lasts as long as its slowest robot, which spends
+  // most of its passes as the only live row of its wavefront.  So the tail of a pass exists three times: all live
+  // rows add (no predication, selection follows), all live rows drop (no selection), and the general predicated form.
+  //
+  // Selection.  Lane (leg, c) watches friction row c + 1 of its leg and, when c = 0, the minimum-force row: with the
+  // three components of x_leg fetched through quad_perm each slack is a 3-term dot product with the lane's own row
+  // vector.  The most violated row is found as the maximum of a 32-bit key per lane: the bits of the slack rounded to
+  // single precision (negative floats order by magnitude as unsigned integers), low five bits replaced by lane and
+  // row kind -- one v_max_u32 with a DPP operand per level instead of two moves and a v_min_f64.  Rows whose slacks
+  // agree to 18 bits are ordered by lane; which of two almost equally violated rows enters first only changes the
+  // path, the minimiser is unique.  Everything that decides a result in double precision stays in double precision:
+  // whether a row is violated at all, the slack of the chosen row (fetched from its lane with ds_bpermute) and the
+  // feasibility test |psi| <= tol (:246), which is only evaluated when the chosen slack is above -tol (psi <= the
+  // most negative slack, so the test cannot pass otherwise).  Component c of the chosen row's normal comes from a
+  // table in LDS ([row kind][lane], written once before the loop), read in the same shadow.
+  double Ns[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) Ns[j] = 0.0;
+  double u = 0.0;            // multiplier of slot lr (free lanes: never read)
+  int idk = 0;               // constraint id of slot lr
+  unsigned used = 0;         // bit k set <=> slot lane k holds an active constraint
+  int q = 0, iters = 0, status = kStatusOk;
+  mask_t act_mask = 0, excl = 0;
+  const double psi_tol = (double)(kKinds * nS) * eps * c1 * c2 * 100.0;
+  double rnorm2 = 1.0; // R_norm^2
+  bool done = (nS == 0);
+  int ip = 0;
+  double sp = 0.0, ucand = 0.0, npj = 0.0;
+  // rows this lane evaluates
+  const double fa = c == 0 ? 1.0 : c == 1 ? -1.0 : 0.0, fb = c == 2 ? 1.0 : c == 3 ? -1.0 : 0.0;
+  const double Wf0 = mu * nb[0] + (fa * t1[0] + fb * t2[0]), Wf1 = mu * nb[1] + (fa * t1[1] + fb * t2[1]),
+               Wf2 = mu * nb[2] + (fa * t1[2] + fb * t2[2]);
+  const mask_t one = 1;
+  const mask_t maskf = on ? (one << (kKinds * leg + c + 1)) : 0, maskm = (on && c == 0) ? (one << (kKinds * leg)) : 0;
+  const mask_t masku = (kTorque && on && comp) ? (one << (kKinds * leg + 5 + 2 * c)) : 0, maskl = masku << 1;
+  // key tag: lane, then what the lane's row is -- kTagBits low bits: 0 friction, 1 minimum force, 2 / 3 upper / lower torque bound
+  constexpr int kTagBits = kTorque ? 2 : 1;
+  constexpr unsigned kTagMask = (1u << (4 + kTagBits)) - 1u;
+  const unsigned tagf = (unsigned)lr << kTagBits, tagm = tagf | 1u;
+  const int row_addr = ((int)threadIdx.x & 48) << 2; // ds_bpermute byte address of lane 0 of my row
+  const unsigned lanebit = 1u << lr;
+  // table of normals: entry [kind][lane] = component c of my leg's row of that kind (0 minimum force, 1..4 friction)
+  {
+    const double nrm[5] = {myn, mu * myn + myt1, mu * myn - myt1, mu * myn + myt2, mu * myn - myt2};
+#pragma unroll
+    for (int k = 0; k < 5; k++) lds_nrm[64 * k + ((int)threadIdx.x & 63)] = nrm[k];
+    if constexpr (kTorque) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) lds_nrm[64 * (5 + k) + ((int)threadIdx.x & 63)] = Q.jrow[k];
+    }
+  }
+  double s_up = 0.0, s_lo = 0.0; // kTorque: slacks of my joint's torque bounds, set by slacks()
+  const auto slacks = [&](double xx, double &s_min, double &s_fric) {
+    const double x0 = quad_bc<0>(xx), x1 = quad_bc<1>(xx), x2 = quad_bc<2>(xx);
+    s_fric = fma(Wf2, x2, fma(Wf1, x1, Wf0 * x0));
+    s_min = fma(nb[2], x2, fma(nb[1], x1, fma(nb[0], x0, -f_min)));
+    if constexpr (kTorque) {
+      const double d = fma(Q.jcol[2], x2, fma(Q.jcol[1], x1, Q.jcol[0] * x0));
+      s_up = Q.tq_up + d;
+      s_lo = Q.tq_lo - d;
+    }
+  };
+  // sum of the violations of the rows this lane watches (QuadProg++.cc:238-245), after slacks()
+  const auto violation = [&](double s_min, double s_fric) -> double {
+    double v = vmin(0.0, s_fric) + sel(c == 0, vmin(0.0, s_min), 0.0);
+    if constexpr (kTorque) v += sel(comp, vmin(0.0, s_up) + vmin(0.0, s_lo), 0.0);
+    return v;
+  };
+  const auto umax_dpp = [](unsigned k, auto Ctrl) -> unsigned {
+    constexpr int ctrl = decltype(Ctrl)::value;
+    const unsigned o = (unsigned)__builtin_amdgcn_mov_dpp((int)k, ctrl, 0xF, 0xF, true);
+    return k > o ? k : o;
+  };
+
+  // Update of H and N* with the vectors of the step just taken (H[j] += hc * vec_j, N*[j] += nc * vec_j) and
+  // selection of the next constraint at the new x, in one block so that the scheduler can weave the two (and the
+  // bookkeeping of the step in front of them) together.  kMode 0: before the first step (no update; every live row
+  // selects).  kMode 1: general -- rows in `resel` select (`fresh`: after an add, :252-262), the others keep their
+  // candidate.  kMode 2: every live row has just added a constraint.
+  double vec = 0.0, hc = 0.0, nc = 0.0;
+  const auto update_and_select = [&](auto Mode, bool resel, bool fresh) {
+    constexpr int kMode = decltype(Mode)::value;
+    constexpr bool kUpd = kMode != 0;
+    if constexpr (kMode == 1) {
+      iters += (resel && fresh) ? 1 : 0;
+      excl = (resel && fresh) ? 0 : excl;
+    } else {
+      iters += 1;
+      excl = 0;
+    }
+    const mask_t avail = ~(act_mask | excl);
+    double s_min, s_fric;
+    slacks(x, s_min, s_fric);
+    unsigned kf = __float_as_uint((float)s_fric), km = __float_as_uint((float)s_min);
+    kf = ((avail & maskf) != 0 && s_fric < 0.0) ? ((kf & ~kTagMask) | tagf) : 0u;
+    km = ((avail & maskm) != 0 && s_min < 0.0) ? ((km & ~kTagMask) | tagm) : 0u;
+    double myv = km > kf ? s_min : s_fric; // the slack behind this lane's key
+    unsigned key = km > kf ? km : kf;
+    if constexpr (kTorque) { // of the two bounds of a joint only the nearer one can be violated
+      const bool lower = s_lo < s_up;
+      const double s_t = lower ? s_lo : s_up;
+      unsigned kt = __float_as_uint((float)s_t);
+      kt = ((avail & (lower ? maskl : masku)) != 0 && s_t < 0.0) ? ((kt & ~kTagMask) | tagf | (lower ? 3u : 2u)) : 0u;
+      myv = kt > key ? s_t : myv;
+      key = kt > key ? kt : key;
+    }
+    if constexpr (kUpd) {
+      static_for<3>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(H[j], vec, hc); fmac_bc<lane_of(j)>(Ns[j], vec, nc); });
+    }
+    key = umax_dpp(key, std::integral_constant<int, 0x128>{});
+    if constexpr (kUpd) {
+      static_for<3>([&](auto J) { constexpr int j = J + 3; fmac_bc<lane_of(j)>(H[j], vec, hc); fmac_bc<lane_of(j)>(Ns[j], vec, nc); });
+    }
+    key = umax_dpp(key, std::integral_constant<int, 0x124>{});
+    if constexpr (kUpd) {
+      static_for<2>([&](auto J) { constexpr int j = J + 6; fmac_bc<lane_of(j)>(H[j], vec, hc); fmac_bc<lane_of(j)>(Ns[j], vec, nc); });
+    }
+    key = umax_dpp(key, std::integral_constant<int, 0x122>{});
+    if constexpr (kUpd) {
+      static_for<2>([&](auto J) { constexpr int j = J + 8; fmac_bc<lane_of(j)>(H[j], vec, hc); fmac_bc<lane_of(j)>(Ns[j], vec, nc); });
+    }
+    key = umax_dpp(key, std::integral_constant<int, 0x121>{});
+    // the chosen row: lane and kind from the low bits, its slack from its lane, its normal from the table
+    const int wl = (int)(key >> kTagBits) & 15;
+    const int addr = row_addr + (wl << 2);
+    const int vlo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(myv));
+    const int vhi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(myv));
+    int key_kind = (key & 1u) ? 0 : (wl & 3) + 1, tab_kind = key_kind;
+    if constexpr (kTorque) {
+      const bool tq = (key & 2u) != 0u;
+      tab_kind = tq ? 5 + (wl & 3) : key_kind;
+      key_kind = tq ? 5 + 2 * (wl & 3) + (int)(key & 1u) : key_kind;
+    }
+    const int key_ip = kKinds * (wl >> 2) + key_kind;
+    double np_tab = lds_nrm[64 * tab_kind + ((int)threadIdx.x & 63)];
+    if constexpr (kTorque) np_tab = ((key & 3u) == 3u) ? -np_tab : np_tab;
+    if constexpr (kUpd) {
+      static_for<2>([&](auto J) { constexpr int j = J + 10; fmac_bc<lane_of(j)>(H[j], vec, hc); fmac_bc<lane_of(j)>(Ns[j], vec, nc); });
+    }
+    const double np_new = sel((wl >> 2) == leg, np_tab, 0.0);
+    const bool any = (int)key < 0;                       // a violated row that may enter
+    const double v = __hiloint2double(vhi, vlo);
+    // feasibility, QuadProg++.cc:246-250: only when the worst slack is within the tolerance can the sum be
+    bool feasible = false;
+    const bool close = (kMode != 1 || (resel && fresh)) && any && !(v < -psi_tol);
+    if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
+      const double psi = (double)row_sum_f32((float)sel(on, violation(s_min, s_fric), 0.0));
+      feasible = close && (fabs(psi) <= psi_tol);
+    }
+    const bool stop = !any || feasible || iters > kMaxOuter; // :271-274
+    if constexpr (kMode == 1) {
+      status = (resel && stop && iters > kMaxOuter) ? kStatusMaxIter : status;
+      done = done || (resel && stop);
+      const bool take = resel && !stop;
+      ip = take ? key_ip : ip;
+      sp = sel(take, v, sp);
+      ucand = sel(take, 0.0, ucand);
+      npj = sel(take, np_new, npj);
+    } else { // every row here selects: what a stopping row is left with is never read
+      status = (stop && iters > kMaxOuter) ? kStatusMaxIter : status;
+      done = done || stop;
+      ip = key_ip; sp = v; ucand = 0.0; npj = np_new;
+    }
+  };
+  const auto update_only = [&]() {
+    static_for<12>([&](auto J) {
+      constexpr int j = J;
+      fmac_bc<lane_of(j), j == 0>(H[j], vec, hc);
+      fmac_bc<lane_of(j)>(Ns[j], vec, nc);
+    });
+  };
+  // dropping slot lpos (partial or dual-only step): n~ = row lpos of N* reaches the variable lanes through LDS,
+  // then H += n~ n~'/e and N* -= (N* G n~) n~'/e with e = n~'G n~ (row lpos of N* becomes 0)
+  double drop_einv = 0.0;
+  const auto drop_vectors = [&](int lpos) {
+    if (lr == lpos) {
+#pragma unroll
+      for (int j = 0; j < 12; j++) lds_row[144 + j] = Ns[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+    const double nt_me = comp ? lds_row[144 + myidx] : 0.0;
+    const int drop_id = __shfl(idk, lpos, 16);
+    double Gn = 0.0;
+    static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(Gn, nt_me, Gm[j]); });
+    const double einv = rcp_nr1(row_sum(nt_me * Gn));
+    drop_einv = einv;
+    double coef = 0.0;
+    static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(coef, Gn, Ns[j]); });
+    vec = nt_me;
+    hc = nt_me * einv;
+    nc = -coef * einv;
+    return drop_id;
+  };
+
+  update_and_select(std::integral_constant<int, 0>{}, true, true);
+
+  // Loop structure.  A pass = directions and step lengths, then what the step is.  Passes in which EVERY live row adds
+  // its constraint run in an inner loop that is one straight path: unpredicated bookkeeping, then update + selection.
+  // It is left as soon as some row drops, fails or is infeasible; that pass is finished by the tail below (all rows
+  // drop: unpredicated, no selection; otherwise the general predicated form) and the inner loop is entered again.
+  // (Alternative tails inside ONE loop cost 24 register copies of H and N* on its back edge; and the launch lasts as
+  // long as its slowest robot, which is alone in its wavefront for most of its passes.)
+  // Terminates: at most kMaxOuter adds, every drop undoes an earlier add, a failed add bans its row until the next add.
+  double z = 0.0, r = 0.0, zn = 0.0, zinv = 0.0, t = 0.0, tl1 = 0.0, tl2 = 0.0, ratio = 0.0;
+  bool have_dirs = false; // wave-uniform: the directions of the pass at hand follow from the drop just made
+  for (;;) {
+    bool is_add = false;
+    while (!done) {
+      if (!have_dirs) {
+        // ---- directions: z = H n_p (lane i), r = N* n_p (slot lane k; 0 on free lanes, whose rows are 0)
+        // three partial sums per product: consecutive dependent FMAs are 6 instructions apart
+        double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
+        static_for<12>([&](auto J) {
+          constexpr int j = J;
+          fmac_bc<lane_of(j), j == 0>(za[j % 3], npj, H[j]);
+          fmac_bc<lane_of(j)>(ra[j % 3], npj, Ns[j]);
+        });
+        z = (za[0] + za[1]) + za[2];
+        r = (ra[0] + ra[1]) + ra[2];
+        zn = row_sum(z * npj);
+      }
+      have_dirs = false;
+      const bool slot = (used & lanebit) != 0u;
+      const float zf = (float)z;
+      const double zz = (double)row_sum_f32(zf * zf); // only compared with eps below
+      // ---- step lengths, QuadProg++.cc:304-331
+      const double ur = u * rcp_nr1(r);
+      ratio = sel(slot && r > 0.0, ur, inf);
+      tl1 = row_min(ratio);
+      zinv = rcp_nr(zn);
+      const double t2v = -sp * zinv;
+      const bool exhausted = q >= 3 * nS; // empty null space: z is exactly 0 in the reference
+      tl2 = sel((int)(!exhausted) & (int)(fabs(zz) > eps) & (int)(!(t2v < 0.0)), t2v, inf);
+      t = vmin(tl1, tl2);
+      // a full step (:384) whose constraint can be added (:392: |R_qq| = sqrt(z'n_p) > eps * R_norm, compared squared)
+      is_add = (tl2 < inf) && (tl2 <= tl1) && (zn > eps * eps * rnorm2);
+      if (__builtin_amdgcn_ballot_w64(!is_add) != 0ull) break;
+      // ---- every live row takes a full step and adds its constraint: H -= z z'/d, N* <- [N* - r z'/d ; z'/d],
+      // the new row goes to the lowest free slot lane
+      x += t * z;
+      u = fma(-t, r, u);
+      const int newlane = __ffs(~used & 0xFFFu) - 1;
+      const bool newslot = lr == newlane;
+      vec = z * zinv;
+      hc = -z;
+      nc = sel(newslot, 1.0, -r);
+      u = sel(newslot, ucand + t, u);
+      idk = newslot ? ip : idk;
+      used |= 1u << newlane;
+      act_mask |= one << ip;
+      rnorm2 = vmax(rnorm2, zn);
+      q += 1;
+      update_and_select(std::integral_constant<int, 2>{}, true, true);
+    }
+    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+    if (__builtin_amdgcn_ballot_w64(!done && !(tl1 < tl2)) == 0ull) {
+      // ---- every live row drops a constraint (t1 < t2: partial step, or dual step only when t2 is infinite)
+      if (!done) {
+        const double tp = (tl2 >= inf) ? 0.0 : t;
+        x += tp * z;
+        u = fma(-t, r, u);
+        ucand += t;
+        sp += tp * zn; // slack of ip after a partial step (:436-440, linear in t)
+        const int lpos = row_first(ratio == tl1 && ratio < inf);
+        const double r_lpos = __shfl(r, lpos, 16);
+        const int drop_id = drop_vectors(lpos);
+        act_mask &= ~(one << drop_id);
+        used &= ~(1u << lpos);
+        q--;
+        update_only();
+        if (lr == lpos) {
+#pragma unroll
+          for (int j = 0; j < 12; j++) Ns[j] = 0.0;
+        }
+        // the same candidate continues with the working set one smaller: with H' = H + n~ n~'/e and N*' = N* - c n~'/e
+        // its directions are z' = z + (n~/e) r_k, r' = r - (c/e) r_k, z'n = zn + r_k^2/e (r_k = n~'n_p = r of the
+        // dropped slot) -- no need for the 24 broadcasts of the next pass
+        z = fma(hc, r_lpos, z);
+        r = fma(nc, r_lpos, r);
+        zn = fma(r_lpos * r_lpos, drop_einv, zn);
+      }
+      have_dirs = true;
+    } else if (!done) {
+      // ---- the pass of the live rows in general form (all row-uniform)
+      const bool infeasible = !(t < inf);                          // :339-344
+      const bool dual_only = (tl2 >= inf);
+      const bool full = !infeasible && !dual_only && (tl2 <= tl1);   // :384
+      const bool degenerate = full && !is_add;
+      const bool is_drop = !infeasible && !full;                   // partial or dual-only step
+      if (infeasible) { status = kStatusInfeasible; done = true; }
+      const double tp = (infeasible || dual_only || degenerate) ? 0.0 : t;
+      const double td = (infeasible || degenerate) ? 0.0 : t;
+      x += tp * z;
+      u = fma(-td, r, u);
+      ucand += td;
+      sp += tp * zn;
+      // add (predicated).  A numerically dependent normal is skipped and selection repeated.
+      const int newlane = __ffs(~used & 0xFFFu) - 1;
+      const bool newslot = is_add && (lr == newlane);
+      vec = is_add ? z * zinv : 0.0;
+      hc = is_add ? -z : 0.0;
+      nc = sel(newslot, 1.0, sel(is_add, -r, 0.0));
+      u = newslot ? ucand : u;
+      idk = newslot ? ip : idk;
+      used |= is_add ? (1u << newlane) : 0u;
+      act_mask |= is_add ? (one << ip) : 0;
+      rnorm2 = is_add ? vmax(rnorm2, zn) : rnorm2;
+      q += is_add ? 1 : 0;
+      excl |= degenerate ? (one << ip) : 0;
+      int lpos = 16;
+      if (is_drop) {
+        lpos = row_first(ratio == tl1 && ratio < inf);
+        const int drop_id = drop_vectors(lpos);
+        act_mask &= ~(one << drop_id);
+        used &= ~(1u << lpos);
+        q--;
+      }
+      update_and_select(std::integral_constant<int, 1>{}, full, is_add);
+      if (is_drop && lr == lpos) {
+#pragma unroll
+        for (int j = 0; j < 12; j++) Ns[j] = 0.0;
+      }
+    }
+  }
+
+  QL_STAMP(7);
+  // ---------------------------------------------------------------- refinement on the final working set
+  if (!done) status = kStatusMaxIter;
+  if (status == kStatusOk && q > 0) {
+    // export N* through LDS once: lane (leg,c) needs column myidx of N*
+    if (lr < 12) {
+#pragma unroll
+      for (int j = 0; j < 12; j++) lds_row[12 * lr + j] = Ns[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    double NsT[12]; // N*[k][myidx], k = 0..11
+#pragma unroll
+    for (int k = 0; k < 12; k++) NsT[k] = comp ? lds_row[12 * k + myidx] : 0.0;
+    // the row behind my slot: leg, kind, and the lane that watches it
+    const int lg = kTorque ? ((idk * 47) >> 9) : id_leg(idk), tt = idk - kKinds * lg;
+    const bool myslot = (used >> lr) & 1u;
+    const int src = myslot ? (4 * lg + (tt == 0 ? 0 : (tt < 5 ? tt - 1 : (tt - 5) >> 1))) : 0;
+    for (int pass = 0; pass < Q.refine_passes; pass++) {
+      // (1) reduced gradient: x -= H (G x + g0)
+      double grad = g0;
+      static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(grad, x, Gm[j]); });
+      double corr = 0.0;
+      static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(corr, grad, H[j]); });
+      x -= corr;
+      // (2) constraint residuals rho_k = b_k - n_k'x on slot lanes; x += N*' rho
+      double s_min, s_fric;
+      slacks(x, s_min, s_fric);
+      const double vm = __shfl(s_min, src, 16), vf = __shfl(s_fric, src, 16);
+      double res = sel(tt == 0, vm, vf);
+      if constexpr (kTorque) {
+        const double vu = __shfl(s_up, src, 16), vl = __shfl(s_lo, src, 16);
+        res = sel(tt < 5, res, sel(((tt - 5) & 1) != 0, vl, vu));
+      }
+      const double rho = sel(myslot, -res, 0.0);
+      double dx = 0.0;
+      static_for<12>([&](auto K) { constexpr int k = K; fmac_bc<k, k == 0>(dx, rho, NsT[k]); });
+      x += dx;
+    }
+  }
+
+  return status;
+}
+
+} // namespace coop
+} // namespace qlamd

@@ -15,7 +15,7 @@
 // Spatial vectors are [angular ; linear]; the interface order is [linear ; angular] like the reference's (F, T).
 #pragma once
 
-#include "qp_coop.hpp"
+#include "balance_coop.hpp"
 
 namespace qlamd {
 namespace coop {
@@ -233,10 +233,6 @@ __device__ __forceinline__ void wb_crba(const WbParamsDev &W, const WbLink &L, i
 // Layout of one robot's staging block in LDS for the dynamics kernel: M [18][18]; then h [18], Jc [12][18]
 // (the kernel stages M first and, after writing it out, h and Jc in the same block)
 constexpr int kWbM = 0, kWbStage = 324; // pass 2: h of the block's 4 robots [4][18], then Jc [4][216]
-
-// Layout of the exchange block of the whole-body solve (quad-lane results -> variable / constraint lanes)
-constexpr int kWxTau0 = 0, kWxJ = 12 /* [leg][a][k] */, kWxR = 48 /* [leg][3] */, kWxN = 60 /* [leg][n,t1,t2][3] */,
-              kWxB = 96, kWxX = 102, kWxDoubles = 114;
 
 } // namespace coop
 } // namespace qlamd

@@ -151,19 +151,19 @@ __global__ __launch_bounds__(64) void wholebody_dynamics_kernel(const DevicePara
 }
 
 // One whole-body control step per robot: inverse dynamics for the desired accelerations -> force/torque QP over the
-// stance legs (12 force variables, torques eliminated through the joint rows; 11 inequality rows per stance leg)
-// -> joint efforts.  Quad lanes (leg, body) do the dynamics, then lane i < 12 carries variable i = 3 leg + c and lane
-// j the inequalities j, j + 16, j + 32 with id = 11 leg + t: t = 0 minimal normal force, 1..4 friction pyramid,
-// 5 + 2k (+1) upper (lower) torque bound of joint k.
+// stance legs -> joint efforts.  The torques are eliminated through the joint rows (tau = tau0 - J_leg' f), which leaves
+// 12 force variables and 11 inequality rows per stance leg (minimal normal force, friction pyramid, upper and lower
+// bound of each joint torque), every one of them local to a leg: the QP runs on the quad layout the dynamics was
+// computed in (lane 4 leg + c: body c of the leg = force component c = joint c), force_qp_coop.hpp with its torque rows
+// -- no exchange through LDS, no general dense solver.
 template <bool kPerLeg>
 __global__ __launch_bounds__(64) void wholebody_solve_kernel(const DeviceParams *__restrict__ Pp, const coop::WbParamsDev W,
                                                              const WbPtrs s, int64_t B, double *__restrict__ tau_out,
                                                              double *__restrict__ grf_out, int32_t *__restrict__ status_out) {
   using namespace coop;
-  typedef QpCoopLds<12, 3> L3;
   __shared__ double tab[4 * kTabPerLeg];
-  __shared__ double xch[4 * kWxDoubles];
-  __shared__ double qpl[4 * L3::kTotal];
+  __shared__ double rows[4 * kCoopLdsDoubles];
+  __shared__ double nrm[kForceQpNrmRowsTorque * 64];
   const DeviceParams &P = *Pp;
   TabStage ts;
   ts.issue(P);
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void wholebody_solve_kernel(const DeviceParams 
                                   ((sm & 0xFF000000u) ? 8u : 0u))
                                : 0u;
   const int nS = __popc(stance);
-  double *xb = xch + kWxDoubles * row;
+  const bool comp = c < 3, on = ((stance >> leg) & 1u) != 0u, row_on = comp && on;
 
   // ---- dynamics on the quad lanes
   double Rm[9], gB[3], vB[3];
@@ -201,123 +201,56 @@ __global__ __launch_bounds__(64) void wholebody_solve_kernel(const DeviceParams 
   const double V0[6] = {in.angvel[0], in.angvel[1], in.angvel[2], vB[0], vB[1], vB[2]};
   const double A0[6] = {ades[3], ades[4], ades[5], ades[0] - gB[0], ades[1] - gB[1], ades[2] - gB[2]};
   double tau0, gb[6];
-  wb_inverse_dynamics(W, L, c, V0, A0, c < 3 ? in.qdj : 0.0, (c < 3 && s.qdd) ? qdd_raw : 0.0, tau0, gb);
+  wb_inverse_dynamics(W, L, c, V0, A0, comp ? in.qdj : 0.0, (comp && s.qdd) ? qdd_raw : 0.0, tau0, gb);
+  tau0 = comp ? tau0 : 0.0;
+
+  ForceQp Q;
   // friction pyramid of my leg (ContactForceDistribution.cpp:254-336, as in balance_coop.hpp)
-  double nb[3], t1[3], t2[3];
   {
     const double ey[3] = {0.0, 1.0, 0.0}, ez[3] = {0.0, 0.0, 1.0};
     double yB[3], nW[3];
     irot(Rm, ey, yB);
     if (kPerLeg) { nW[0] = nWl[0]; nW[1] = nWl[1]; nW[2] = nWl[2]; }
     else rot(Rm, ez, nW);
-    irot(Rm, nW, nb);
-    cross3(nb, yB, t1);
-    double nn = rsqrt_nr(dot3(t1, t1));
-    t1[0] *= nn; t1[1] *= nn; t1[2] *= nn;
-    cross3(nb, t1, t2);
-    nn = rsqrt_nr(dot3(t2, t2));
-    t2[0] *= nn; t2[1] *= nn; t2[2] *= nn;
+    irot(Rm, nW, Q.nb);
+    cross3(Q.nb, yB, Q.t1);
+    double nn = rsqrt_nr(dot3(Q.t1, Q.t1));
+    Q.t1[0] *= nn; Q.t1[1] *= nn; Q.t1[2] *= nn;
+    cross3(Q.nb, Q.t1, Q.t2);
+    nn = rsqrt_nr(dot3(Q.t2, Q.t2));
+    Q.t2[0] *= nn; Q.t2[1] *= nn; Q.t2[2] *= nn;
+    Q.myn = pick3(Q.nb, c); Q.myt1 = pick3(Q.t1, c); Q.myt2 = pick3(Q.t2, c);
   }
-  // ---- exchange through LDS: quad layout -> variable / constraint layout
-  if (c < 3) {
-    xb[kWxTau0 + 3 * leg + c] = tau0;
+  // contact Jacobian of my leg: my lane's joint gives COLUMN c, J[a][c] = (z_c x (p_foot - p_c))[a]; row c is what the
+  // lanes of the quad hold at index c
+  {
     const double d[3] = {L.pf[0] - L.p[0], L.pf[1] - L.p[1], L.pf[2] - L.p[2]};
     double col[3];
     cross3(L.z, d, col);
 #pragma unroll
-    for (int a = 0; a < 3; a++) xb[kWxJ + 9 * leg + 3 * a + c] = col[a];
-  } else {
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      xb[kWxR + 3 * leg + a] = L.pf[a];
-      xb[kWxN + 9 * leg + a] = nb[a]; xb[kWxN + 9 * leg + 3 + a] = t1[a]; xb[kWxN + 9 * leg + 6 + a] = t2[a];
-    }
+    for (int a = 0; a < 3; a++) Q.jcol[a] = row_on ? col[a] : 0.0;
+    static_for<3>([&](auto K) {
+      constexpr int k = K;
+      const double v[3] = {quad_bc<k>(Q.jcol[0]), quad_bc<k>(Q.jcol[1]), quad_bc<k>(Q.jcol[2])};
+      Q.jrow[k] = pick3(v, c);
+    });
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_s_waitcnt(0xC07F);
+  const double jt0 = Q.jrow[0] * quad_bc<0>(tau0) + Q.jrow[1] * quad_bc<1>(tau0) + Q.jrow[2] * quad_bc<2>(tau0);
+  const double foot = row_on ? pick3(L.pf, c) : 0.0;
+  force_qp_objective(P.S, P.w_reg, foot, stance, row_on, gb, Q.jrow, W.w_tau * jt0, Q.Gm, Q.g0, W.w_tau);
+  Q.mu = P.mu; Q.f_min = P.f_min;
+  Q.on = on; Q.comp = comp; Q.nS = nS; Q.refine_passes = P.refine_passes;
+  Q.tq_up = W.tau_max - tau0; Q.tq_lo = W.tau_max + tau0;
+  double x = 0.0;
+  const int st = force_qp_coop<true>(Q, rows + kCoopLdsDoubles * row, nrm, x);
 
-  // ---- QP data.  Variable lane i = 3 vl + vc.
-  const int vi = lr < 12 ? lr : 0, vl = (vi * 11) >> 5, vc = vi - 3 * vl; // vi / 3 for vi < 12
-  const bool von = lr < 12 && ((stance >> vl) & 1u);
-  double rl[3], Jl[9], tl[3];
-#pragma unroll
-  for (int a = 0; a < 3; a++) { rl[a] = xb[kWxR + 3 * vl + a]; tl[a] = xb[kWxTau0 + 3 * vl + a]; }
-#pragma unroll
-  for (int a = 0; a < 9; a++) Jl[a] = xb[kWxJ + 9 * vl + a];
-  // column vc of [r_l]x, weighted
-  const double av[3] = {sel(vc == 1, -rl[2], sel(vc == 2, rl[1], 0.0)), sel(vc == 0, rl[2], sel(vc == 2, -rl[0], 0.0)),
-                        sel(vc == 0, -rl[1], sel(vc == 1, rl[0], 0.0))};
-  const double sa[3] = {P.S[3] * av[0], P.S[4] * av[1], P.S[5] * av[2]};
-  const double Sfc = pick3(P.S, vc);
-  double jr[3]; // row vc of J_leg: J[vc][k]
-#pragma unroll
-  for (int k = 0; k < 3; k++) jr[k] = sel(vc == 0, Jl[k], sel(vc == 1, Jl[3 + k], Jl[6 + k]));
-  double Gm[12];
-#pragma unroll
-  for (int m = 0; m < 4; m++) {
-    const bool both = von && ((stance >> m) & 1u);
-    const double xp = xb[kWxR + 3 * m], yp = xb[kWxR + 3 * m + 1], zp = xb[kWxR + 3 * m + 2];
-    const double e0 = sa[1] * zp - sa[2] * yp;
-    const double e1 = -sa[0] * zp + sa[2] * xp;
-    const double e2 = sa[0] * yp - sa[1] * xp;
-    // torque regulariser w_tau J J' on my own leg's block
-    const bool own = m == vl;
-    const double jj0 = jr[0] * Jl[0] + jr[1] * Jl[1] + jr[2] * Jl[2];
-    const double jj1 = jr[0] * Jl[3] + jr[1] * Jl[4] + jr[2] * Jl[5];
-    const double jj2 = jr[0] * Jl[6] + jr[1] * Jl[7] + jr[2] * Jl[8];
-    Gm[3 * m + 0] = both ? e0 + (vc == 0 ? Sfc : 0.0) + (own ? W.w_tau * jj0 : 0.0) : 0.0;
-    Gm[3 * m + 1] = both ? e1 + (vc == 1 ? Sfc : 0.0) + (own ? W.w_tau * jj1 : 0.0) : 0.0;
-    Gm[3 * m + 2] = both ? e2 + (vc == 2 ? Sfc : 0.0) + (own ? W.w_tau * jj2 : 0.0) : 0.0;
-  }
-#pragma unroll
-  for (int j = 0; j < 12; j++) Gm[j] += (lr == j) ? (von ? P.w_reg : 1.0) : 0.0; // identity row for a swing-leg variable
-  const double ST[3] = {P.S[3] * gb[3], P.S[4] * gb[4], P.S[5] * gb[5]};
-  const double Fc = pick3(gb, vc);
-  const double g0 = von ? -(Sfc * Fc + (av[0] * ST[0] + av[1] * ST[1] + av[2] * ST[2]) +
-                            W.w_tau * (jr[0] * tl[0] + jr[1] * tl[1] + jr[2] * tl[2]))
-                        : 0.0;
-  // my three inequalities
-  double a[3][12], b[3];
-  bool v[3];
-#pragma unroll
-  for (int sidx = 0; sidx < 3; sidx++) {
-    const int id = lr + 16 * sidx;
-    const int cl = (id * 47) >> 9;                 // id / 11 for id < 48
-    const int t = id - 11 * cl;
-    const int cll = cl < 4 ? cl : 3;
-    v[sidx] = id < 44 && ((stance >> cll) & 1u);
-    const double *nrm = xb + kWxN + 9 * cll;
-    const int k = t >= 5 ? ((t - 5) >> 1) : 0;
-    const bool lower = t >= 5 && ((t - 5) & 1);
-    double nv[3];
-#pragma unroll
-    for (int e = 0; e < 3; e++) {
-      const double fr = P.mu * nrm[e] + ((t == 1) ? nrm[3 + e] : (t == 2) ? -nrm[3 + e] : (t == 3) ? nrm[6 + e] : -nrm[6 + e]);
-      const double jc = xb[kWxJ + 9 * cll + 3 * e + k];
-      nv[e] = t == 0 ? nrm[e] : (t < 5 ? fr : (lower ? -jc : jc));
-    }
-    const double t0k = xb[kWxTau0 + 3 * cll + k];
-    b[sidx] = !v[sidx] ? 0.0 : (t == 0 ? -P.f_min : (t < 5 ? 0.0 : (lower ? W.tau_max + t0k : W.tau_max - t0k)));
-#pragma unroll
-    for (int j = 0; j < 12; j++) a[sidx][j] = (v[sidx] && (j / 3) == cll) ? nv[j % 3] : 0.0;
-  }
-  double x, fobj;
-  const int st = qp_coop_impl<12, 3>(Gm, g0, 12, 3 * nS, 44, false, 0.0, 0.0, a, b, v, !live || nS == 0,
-                                      qpl + L3::kTotal * row, x, fobj);
-  (void)fobj;
   // ---- joint efforts: tau = tau0 - J_leg' f on the stance legs, tau0 elsewhere
   const bool ok = st == kStatusOk;
-  if (lr < 12) xb[kWxX + lr] = von && ok ? x : 0.0;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  if (lr < 12 && live) {
-    const double f0 = xb[kWxX + 3 * vl], f1 = xb[kWxX + 3 * vl + 1], f2 = xb[kWxX + 3 * vl + 2];
-    // joint vc of leg vl: column vc of J_leg
-    const double tq = pick3(tl, vc) - (sel(vc == 0, Jl[0], sel(vc == 1, Jl[1], Jl[2])) * f0 +
-                                       sel(vc == 0, Jl[3], sel(vc == 1, Jl[4], Jl[5])) * f1 +
-                                       sel(vc == 0, Jl[6], sel(vc == 1, Jl[7], Jl[8])) * f2);
-    tau_out[12 * i + lr] = ok ? tq : 0.0;
-    if (grf_out) grf_out[12 * i + lr] = xb[kWxX + lr];
+  const double f = (row_on && ok) ? x : 0.0;
+  const double tq = tau0 - (Q.jcol[0] * quad_bc<0>(f) + Q.jcol[1] * quad_bc<1>(f) + Q.jcol[2] * quad_bc<2>(f));
+  if (comp && live) {
+    tau_out[12 * i + 3 * leg + c] = ok ? tq : 0.0;
+    if (grf_out) grf_out[12 * i + 3 * leg + c] = f;
   }
   if (lr == 0 && live) status_out[i] = st;
 }
