@@ -82,6 +82,8 @@ def parse():
                     help="timed samples of exactly K steps each (barrier + synchronize on both sides); the median is reported")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU-only check of the multi-rank launcher, sharding and gather layout over gloo: no solve, no measurement")
+    ap.add_argument("--wholebody-form", default="auto", choices=["auto", "leg", "row"],
+                    help="wholebody_dynamics: one lane per leg, 16 lanes per robot, or the library's choice by batch size")
     ap.add_argument("--workload", default="balance", choices=["balance", "pose_sqp", "wholebody", "wholebody_dynamics", "full_tick"],
                     help="pose_sqp = BASELINE config 5; wholebody / wholebody_dynamics = SURVEY 8 row f4; full_tick = the "
                          "whole update() from a serialised message to 12 efforts (rows a1 + f1 + f2) "
@@ -246,6 +248,9 @@ def bench_wholebody(args):
     gait = "trot" if args.gait == "trot" else "static"
     s = synth.make_wholebody_states(B, gait)
     ctx = capi.Context(device=0)
+    form = {"auto": capi.DYNAMICS_AUTO, "leg": capi.DYNAMICS_LEG, "row": capi.DYNAMICS_ROW}[args.wholebody_form]
+    ctx.set_option(capi.OPT_DYNAMICS_FORM, form)
+    leg_form = form == capi.DYNAMICS_LEG or (form == capi.DYNAMICS_AUTO and B > 8192)
     d = capi.to_device(s)
     dev = dict(dtype=torch.float64, device="cuda:0")
     tau, grf, st = torch.zeros(B, 12, **dev), torch.zeros(B, 12, **dev), torch.zeros(B, dtype=torch.int32, device="cuda:0")
@@ -308,7 +313,8 @@ def bench_wholebody(args):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      # HBM bytes per launch from rocprofv3 --pmc (profiles/r1/pmc_dynamics_b65536.json), measured at 65536 robots
                      "traffic": int((10361.5 + 285696.0) * 1024) if (not solve and B == 65536) else None,
-                     "kernel": "wholebody_solve_kernel" if solve else "wholebody_dynamics_kernel",
+                     "kernel": "wholebody_solve_kernel" if solve else
+                     ("wholebody_dynamics_leg_kernel" if leg_form else "wholebody_dynamics_kernel"),
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": per * B},
         **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
 

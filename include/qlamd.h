@@ -145,12 +145,17 @@ int qlamd_set_robots_per_wave(qlamd_context *ctx, int robots_per_wave);
  *                          the reference's behaviour, whose update() logs "VMC compute failed" and commands the
  *                          efforts still held in State from the previous tick (ros_balance_controller.cpp:418-424,441-454).
  *   QLAMD_OPT_REFINE_PASSES  refinement passes of the lane-cooperative force QP on its final working set (default 1)
- *   QLAMD_OPT_WHOLEBODY_SPLIT  1 selects the two-launch form of the whole-body dynamics (diagnostics). */
+ *   QLAMD_OPT_DYNAMICS_FORM  layout of qlamd_wholebody_dynamics_batch's kernel: QLAMD_DYNAMICS_AUTO (default) picks by batch
+ *                          size; _LEG = one lane per leg, 16 robots per wavefront (throughput: large batches); _ROW = 16
+ *                          lanes per robot (latency: small batches).  Same results to rounding. */
 #define QLAMD_OPT_ON_FAILURE 1
 #define QLAMD_OPT_REFINE_PASSES 2
-#define QLAMD_OPT_WHOLEBODY_SPLIT 5
+#define QLAMD_OPT_DYNAMICS_FORM 5
 #define QLAMD_ON_FAILURE_ZERO 0
 #define QLAMD_ON_FAILURE_KEEP 1
+#define QLAMD_DYNAMICS_AUTO 0
+#define QLAMD_DYNAMICS_LEG 1
+#define QLAMD_DYNAMICS_ROW 2
 int qlamd_set_option(qlamd_context *ctx, int option, int value);
 
 /* One control step for `batch` robots: virtual-model wrench -> leg FK ->

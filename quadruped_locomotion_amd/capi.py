@@ -706,7 +706,8 @@ def wholebody_dynamics_device(ctx, dstate, M, h, Jc, gravity=9.81, stream=None):
         raise QlamdError(rc, "qlamd_wholebody_dynamics_batch")
 
 
-OPT_ON_FAILURE, OPT_REFINE_PASSES, OPT_WHOLEBODY_SPLIT = 1, 2, 5
+OPT_ON_FAILURE, OPT_REFINE_PASSES, OPT_DYNAMICS_FORM = 1, 2, 5
+DYNAMICS_AUTO, DYNAMICS_LEG, DYNAMICS_ROW = 0, 1, 2
 ON_FAILURE_ZERO, ON_FAILURE_KEEP = 0, 1
 STATUS_NO_COMMAND = 4
 

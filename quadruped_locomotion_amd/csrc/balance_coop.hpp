@@ -138,7 +138,11 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       wr_d[0] = aw * qm[1] + ax * qm[0] + ay * qm[3] - az * qm[2];
       wr_d[1] = aw * qm[2] - ax * qm[3] + ay * qm[0] + az * qm[1];
       wr_d[2] = aw * qm[3] + ax * qm[2] - ay * qm[1] + az * qm[0];
-      const double s2 = 1.0 - wr_dw * wr_dw;
+      const double s2r = 1.0 - wr_dw * wr_dw;
+      // the series is evaluated inside its range only: a quaternion that is not of unit length (|d_w| > 1: the
+      // reference's factor is then 2, its branch for s^2 < 1e-12) gives s^2 = 0 here, anything above the range is
+      // corrected below from a bounded value
+      const double s2 = vmin(vmax(s2r, 0.0), 0.01);
       double p = 34459425.0 / 3530096640.0;
       p = fma(p, s2, 2027025.0 / 175472640.0);
       p = fma(p, s2, 135135.0 / 9676800.0);
@@ -150,7 +154,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       p = fma(p, s2, 1.0 / 6.0);
       p = fma(p, s2, 1.0);
       wr_k = 2.0 * p;
-      wr_slow = !(s2 < 0.01) || !(wr_dw > 0.0);
+      wr_slow = !(s2r < 0.01) || !(wr_dw > 0.0);
     }
     {
       double e_p[3], e_v[3], e_w[3];

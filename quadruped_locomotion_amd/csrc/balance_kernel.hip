@@ -306,7 +306,7 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
   ctx->tick_ws = nullptr;
   ctx->tick_ws_bytes = 0;
   ctx->on_failure = QLAMD_ON_FAILURE_ZERO;
-  ctx->wb_split = 0;
+  ctx->dynamics_form = QLAMD_DYNAMICS_AUTO;
   ctx->depth = 0;
   ctx->has_last_stream = false;
   ctx->last_stream = nullptr;
@@ -363,7 +363,10 @@ int qlamd_set_option(qlamd_context *ctx, int option, int value) {
       if (value < 0 || value > 4) return QLAMD_ERR_INVALID_ARGUMENT;
       ctx->params.refine_passes = value;
       break;
-    case QLAMD_OPT_WHOLEBODY_SPLIT: ctx->wb_split = value != 0; return QLAMD_OK;
+    case QLAMD_OPT_DYNAMICS_FORM:
+      if (value < QLAMD_DYNAMICS_AUTO || value > QLAMD_DYNAMICS_ROW) return QLAMD_ERR_INVALID_ARGUMENT;
+      ctx->dynamics_form = (int)value;
+      return QLAMD_OK;
     default: return QLAMD_ERR_INVALID_ARGUMENT;
   }
   // the device copy of the parameters: after everything already queued on the context has read the old one

@@ -32,7 +32,7 @@ struct qlamd_context {
   void *pinned;        // page-locked mirror of the head of ws, for small host-buffer calls (one copy each way)
   size_t pinned_bytes;
   // options (qlamd_set_option): never read from the environment
-  int on_failure, wb_split;
+  int on_failure, dynamics_form;
   // one call at a time (include/qlamd.h, "Threads and streams"): owner thread and nesting depth of the call in
   // progress, and the stream of the previous call
   std::mutex gate;

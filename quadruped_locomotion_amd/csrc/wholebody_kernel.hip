@@ -150,6 +150,157 @@ __global__ __launch_bounds__(64) void wholebody_dynamics_kernel(const DevicePara
   }
 }
 
+// The dynamics entry in its throughput form: ONE LANE PER LEG, 16 robots per wavefront (wholebody_coop.hpp, wb_leg_*).
+// All arithmetic first; then the outputs go through a staging block in LDS to contiguous 16-byte stores, eight robots
+// (one half of the wavefront) at a time so that the block is 20 KB: M of robots 0-7, M of robots 8-15, then h and Jc
+// likewise.  (270 registers: one wavefront per SIMD.  Capped at 256 it spills ten values and is no faster; what bounds
+// it at 1 M robots is the store stream, 84 % of what a plain fill of the same bytes reaches.)  Every row of M and Jc a lane is responsible for is written in full (zeros
+// included): no fill pass.
+template <bool kM, bool kHJ>
+__global__ __launch_bounds__(64) void wholebody_dynamics_leg_kernel(const DeviceParams *__restrict__ Pp, const coop::WbParamsDev W,
+                                                                       const WbPtrs s, int64_t B, double *__restrict__ Mo,
+                                                                       double *__restrict__ ho, double *__restrict__ Jo) {
+  using namespace coop;
+  __shared__ double tab[4 * kTabPerLeg];
+  __shared__ __attribute__((aligned(16))) double outb[8 * kWbStage];
+  const DeviceParams &P = *Pp;
+  TabStage ts;
+  ts.issue(P);
+  const int rb = threadIdx.x >> 2, leg = threadIdx.x & 3;
+  const int64_t r0 = (int64_t)blockIdx.x * 16;
+  const int64_t i = (r0 + rb) < B ? (r0 + rb) : B - 1;
+  double quat[4], linvel[3], angvel[3], q[3], qd[3];
+  {
+    const double2 *a2 = reinterpret_cast<const double2 *>(s.quat + 4 * i);
+    double2 v = a2[0]; quat[0] = v.x; quat[1] = v.y;
+    v = a2[1]; quat[2] = v.x; quat[3] = v.y;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      linvel[k] = s.linvel[3 * i + k]; angvel[k] = s.angvel[3 * i + k];
+      q[k] = s.q[12 * i + 3 * leg + k]; qd[k] = s.qd[12 * i + 3 * leg + k];
+    }
+  }
+  ts.commit(tab);
+  const bool wantM = kM && Mo, wantHJ = kHJ && (ho || Jo);
+  const int nrob = (int)((B - r0) < 16 ? (B - r0) : 16);
+  const double2 zero2 = {0.0, 0.0};
+  const int j0 = 6 + 3 * leg; // my first joint's row / column
+  const int half = rb >> 3, rh = rb & 7;
+
+  WbInertia T;                  // composite inertia of the robot
+  double Fcol[3][6], Mj[3][3];  // my joints' columns of M, my leg's joint block
+  WbLeg G;
+  double gB[3], vB[3];
+  {
+    double Rm[9];
+    quat_to_matrix(quat, Rm);
+    const double gW[3] = {0.0, 0.0, -W.grav};
+    irot(Rm, gW, gB);
+    irot(Rm, linvel, vB);
+    double sj[3], cj[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) sincos_reduced(q[k], sj[k], cj[k]);
+    wb_leg_chain(CoopTab{tab + kTabPerLeg * leg}, sj, cj, G);
+  }
+
+  // ---- the mass matrix
+  if (wantM) {
+    wb_leg_crba(W, G, T, Fcol, Mj);
+#pragma unroll 1
+    for (int hf = 0; hf < 2; hf++) {
+      if (half == hf) {
+        double *ob = outb + kWbStage * rh;
+        // the base block (the same on the four lanes of the robot), interface order [linear ; angular]:
+        // [[m 1, -[h]x], [[h]x, I]], two entries per store
+        {
+          double2 *o2 = reinterpret_cast<double2 *>(ob);
+          const double m = T.m, hx = T.h[0], hy = T.h[1], hz = T.h[2];
+          const double2 r0a = {m, 0.0}, r0b = {0.0, 0.0}, r0c = {hz, -hy};
+          const double2 r1a = {0.0, m}, r1b = {0.0, -hz}, r1c = {0.0, hx};
+          const double2 r2a = {0.0, 0.0}, r2b = {m, hy}, r2c = {-hx, 0.0};
+          const double2 r3a = {0.0, -hz}, r3b = {hy, T.I[0]}, r3c = {T.I[1], T.I[2]};
+          const double2 r4a = {hz, 0.0}, r4b = {-hx, T.I[1]}, r4c = {T.I[3], T.I[4]};
+          const double2 r5a = {-hy, hx}, r5b = {0.0, T.I[2]}, r5c = {T.I[4], T.I[5]};
+          o2[0] = r0a; o2[1] = r0b; o2[2] = r0c;
+          o2[9] = r1a; o2[10] = r1b; o2[11] = r1c;
+          o2[18] = r2a; o2[19] = r2b; o2[20] = r2c;
+          o2[27] = r3a; o2[28] = r3b; o2[29] = r3c;
+          o2[36] = r4a; o2[37] = r4b; o2[38] = r4c;
+          o2[45] = r5a; o2[46] = r5b; o2[47] = r5c;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const int j = j0 + k;
+          // my joint's column in the base rows, and its whole row: [force ; moment | zeros except my leg's block]
+#pragma unroll
+          for (int a = 0; a < 3; a++) { ob[18 * a + j] = Fcol[k][3 + a]; ob[18 * (3 + a) + j] = Fcol[k][a]; }
+          double2 *rowp = reinterpret_cast<double2 *>(ob + 18 * j);
+          const double2 f01 = {Fcol[k][3], Fcol[k][4]}, f2n0 = {Fcol[k][5], Fcol[k][0]}, n12 = {Fcol[k][1], Fcol[k][2]};
+          rowp[0] = f01; rowp[1] = f2n0; rowp[2] = n12;
+#pragma unroll
+          for (int e = 3; e < 9; e++) rowp[e] = zero2;
+#pragma unroll
+          for (int k2 = 0; k2 < 3; k2++) ob[18 * j + j0 + k2] = k2 <= k ? Mj[k2][k] : Mj[k][k2];
+        }
+      }
+      __syncthreads();
+      const int n = nrob - 8 * hf;
+      if (n > 0) copy_out(Mo + (r0 + 8 * hf) * 324, outb, 324 * (n < 8 ? n : 8));
+      __syncthreads();
+    }
+  }
+  // ---- bias forces and the contact Jacobian: h of eight robots, then their Jc
+  if (wantHJ) {
+    double tau[3], gb[6], Jl[3][3], pf[3];
+    const double V0[6] = {angvel[0], angvel[1], angvel[2], vB[0], vB[1], vB[2]};
+    const double A0[6] = {0.0, 0.0, 0.0, -gB[0], -gB[1], -gB[2]};
+    const double qdd[3] = {0.0, 0.0, 0.0};
+    wb_leg_inverse_dynamics(W, G, V0, A0, qd, qdd, tau, gb);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { // J[a][k] = (z_k x (p_foot - p_k))[a]
+      const double d[3] = {G.pf[0] - G.p[k][0], G.pf[1] - G.p[k][1], G.pf[2] - G.p[k][2]};
+      double col[3];
+      cross3(G.z[k], d, col);
+#pragma unroll
+      for (int a = 0; a < 3; a++) Jl[a][k] = col[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) pf[a] = G.pf[a];
+#pragma unroll 1
+    for (int hf = 0; hf < 2; hf++) {
+      if (half == hf) {
+        double *hb = outb + 18 * rh, *jb = outb + 8 * 18 + 216 * rh;
+        double2 *h2 = reinterpret_cast<double2 *>(hb);
+        const double2 g01 = {gb[0], gb[1]}, g23 = {gb[2], gb[3]}, g45 = {gb[4], gb[5]};
+        h2[0] = g01; h2[1] = g23; h2[2] = g45;
+#pragma unroll
+        for (int k = 0; k < 3; k++) hb[j0 + k] = tau[k];
+        // my leg's three rows of Jc: [1 , -[r]x | zeros except my leg's block]
+        const double sk[3][3] = {{0.0, pf[2], -pf[1]}, {-pf[2], 0.0, pf[0]}, {pf[1], -pf[0], 0.0}};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          double *jr = jb + 18 * (3 * leg + a);
+          double2 *jr2 = reinterpret_cast<double2 *>(jr);
+          const double2 e01 = {a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0}, e2s0 = {a == 2 ? 1.0 : 0.0, sk[a][0]}, s12 = {sk[a][1], sk[a][2]};
+          jr2[0] = e01; jr2[1] = e2s0; jr2[2] = s12;
+#pragma unroll
+          for (int e = 3; e < 9; e++) jr2[e] = zero2;
+#pragma unroll
+          for (int k = 0; k < 3; k++) jr[j0 + k] = Jl[a][k];
+        }
+      }
+      __syncthreads();
+      const int n = nrob - 8 * hf;
+      if (n > 0) {
+        const int nn = n < 8 ? n : 8;
+        if (ho) copy_out(ho + (r0 + 8 * hf) * 18, outb, 18 * nn);
+        if (Jo) copy_out(Jo + (r0 + 8 * hf) * 216, outb + 8 * 18, 216 * nn);
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // One whole-body control step per robot: inverse dynamics for the desired accelerations -> force/torque QP over the
 // stance legs -> joint efforts.  The torques are eliminated through the joint rows (tau = tau0 - J_leg' f), which leaves
 // 12 force variables and 11 inequality rows per stance leg (minimal normal force, friction pyramid, upper and lower
@@ -308,20 +459,33 @@ int qlamd_wholebody_dynamics_batch(qlamd_context *ctx, const qlamd_wholebody_bat
     dM = sg.dev<double>(5); dh = sg.dev<double>(6); dJ = sg.dev<double>(7);
   }
   const coop::WbParamsDev W = wb_params_of(ctx, 0.0, 0.0, gravity);
-  const dim3 grid((unsigned)((batch + 3) / 4));
-  // One launch for everything.  Two launches (M; h and Jc) need 140 / 158 instead of 204 registers, i.e. three waves
-  // per SIMD instead of two, but repeat the link kinematics: measured 9 % slower at 65 536 robots, 30 % at 4096
-  // (QLAMD_WB_SPLIT=1 selects them, for measurement).
-  const bool fused = !ctx->wb_split;
-  if (fused && dM && (dh || dJ)) {
-    hipLaunchKernelGGL((wholebody_dynamics_kernel<true, true>), grid, dim3(64), 0, st, ctx->d_params, W, s, batch, dM, dh, dJ);
-  } else {
-    if (dM)
-      hipLaunchKernelGGL((wholebody_dynamics_kernel<true, false>), grid, dim3(64), 0, st, ctx->d_params, W, s, batch, dM,
+  // Two layouts of the same arithmetic.  Measured (profiles/r2): the row form 9.8 / 13.9 / 22.5 us at 4096 / 8192 / 16 384
+  // robots against 13.1 / 14.3 / 19.8 for the leg form, which then pulls away (1 M robots: 0.92 ms against 1.22 ms).
+  const bool leg_form = ctx->dynamics_form == QLAMD_DYNAMICS_LEG || (ctx->dynamics_form == QLAMD_DYNAMICS_AUTO && batch > 8192);
+  if (leg_form) {
+    // one lane per leg, 16 robots per wavefront; M, then h and Jc, from one launch
+    const dim3 grid((unsigned)((batch + 15) / 16));
+    if (dM && (dh || dJ))
+      hipLaunchKernelGGL((wholebody_dynamics_leg_kernel<true, true>), grid, dim3(64), 0, st, ctx->d_params, W, s, batch, dM, dh, dJ);
+    else if (dM)
+      hipLaunchKernelGGL((wholebody_dynamics_leg_kernel<true, false>), grid, dim3(64), 0, st, ctx->d_params, W, s, batch, dM,
                          (double *)nullptr, (double *)nullptr);
-    if (dh || dJ)
-      hipLaunchKernelGGL((wholebody_dynamics_kernel<false, true>), grid, dim3(64), 0, st, ctx->d_params, W, s, batch,
+    else
+      hipLaunchKernelGGL((wholebody_dynamics_leg_kernel<false, true>), grid, dim3(64), 0, st, ctx->d_params, W, s, batch,
                          (double *)nullptr, dh, dJ);
+  } else {
+    // 16 lanes per robot, 4 robots per wavefront
+    const dim3 grid((unsigned)((batch + 3) / 4));
+    if (dM && (dh || dJ)) {
+      hipLaunchKernelGGL((wholebody_dynamics_kernel<true, true>), grid, dim3(64), 0, st, ctx->d_params, W, s, batch, dM, dh, dJ);
+    } else {
+      if (dM)
+        hipLaunchKernelGGL((wholebody_dynamics_kernel<true, false>), grid, dim3(64), 0, st, ctx->d_params, W, s, batch, dM,
+                           (double *)nullptr, (double *)nullptr);
+      if (dh || dJ)
+        hipLaunchKernelGGL((wholebody_dynamics_kernel<false, true>), grid, dim3(64), 0, st, ctx->d_params, W, s, batch,
+                           (double *)nullptr, dh, dJ);
+    }
   }
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   if (memory == QLAMD_MEM_HOST) return sg.finish(st);

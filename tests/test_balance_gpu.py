@@ -223,6 +223,38 @@ def test_survey_literal_tracking_errors_match_oracle(gpu, oracle):
     assert ((fxy > 0.59 * fz).any(axis=1)).mean() > 0.3   # the input really loads the pyramid
 
 
+def test_orientation_error_of_any_size_and_quaternions_off_the_unit_sphere(gpu, oracle):
+    """The kernel evaluates the orientation-error factor 2 acos(d_w) / sqrt(1 - d_w^2) (VirtualModelController.cpp:
+    120-124) as a series for small errors and corrects larger ones with the libm form; the reference takes the factor 2
+    whenever 1 - d_w^2 < 1e-12, which includes |d_w| > 1 for quaternions that are not of unit length.  Every regime
+    against the oracle: random desired attitudes (errors up to pi, both signs of d_w), scaled quaternions on either
+    side, exactly equal attitudes, errors at the series' switch-over."""
+    B = 1024
+    s = synth.make_states(B, "static", errors="survey")
+    rng = np.random.default_rng(12)
+    q = rng.normal(size=(B, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    s["des_quat"][:256] = q[:256]                                             # arbitrary rotation between the two
+    s["des_quat"][256:384] = s["base_quat"][256:384] * rng.uniform(1.5, 40.0, (128, 1))   # |d_w| > 1
+    s["des_quat"][384:512] = s["base_quat"][384:512] * rng.uniform(0.05, 0.9, (128, 1))   # shrunk
+    s["base_quat"][512:640] = s["base_quat"][512:640] * rng.uniform(1.01, 3.0, (128, 1))
+    s["des_quat"][640:704] = s["base_quat"][640:704]                           # no error at all
+    s["des_quat"][704:768] = -s["base_quat"][704:768]                          # the same attitude, other sign
+    ang = np.linspace(0.19, 0.21, 128)                                        # around s^2 = 0.01
+    for k in range(128):
+        a = ang[k] / 2
+        w0, x0, y0, z0 = s["base_quat"][768 + k]
+        dw, dz = np.cos(a), np.sin(a)                                         # base * rot_z(angle)
+        s["des_quat"][768 + k] = [w0 * dw - z0 * dz, x0 * dw + y0 * dz, y0 * dw - x0 * dz, z0 * dw + w0 * dz]
+    tau, grf, st = solve_device(gpu, s)
+    t_ref, g_ref, s_ref = oracle.balance_batch(s, nthreads=8)
+    assert np.array_equal(st, s_ref)
+    ok = st == 0
+    assert ok.sum() > B // 2
+    scale = np.maximum(1.0, np.abs(t_ref[ok]).max(axis=1, keepdims=True) / 300.0)  # efforts are clamped at 300
+    assert (np.abs(tau[ok] - t_ref[ok]) / scale).max() < TAU_TOL
+
+
 def test_one_context_refuses_a_second_thread(gpu, oracle):
     """A context is single-threaded (include/qlamd.h): a call entering while another thread is inside gets
     QLAMD_ERR_BUSY instead of sharing the staging slab; every call that was admitted returns correct torques."""
