@@ -34,6 +34,7 @@ struct CoopPtrs {
   const double *normals;
   const double *wrench; // [B][6] or NULL: externally supplied (F_B, T_B)
   const uint8_t *live;  // [B] or NULL: 0 = leave this robot alone (whole tick: no command in force), nothing is written
+  int support_only;     // whole tick: write the efforts of the support legs only (the swing branch owns the others)
 };
 
 // One robot per 16-lane row.  lds_tab: 256-double model table; lds_row: this robot's private
@@ -309,7 +310,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   const int status = force_qp_coop<false>(Q, lds_row, lds_nrm, x);
   if (status == kStatusNotPd) {
     if (lr == 0 && robot_live) status_out[i] = kStatusNotPd;
-    if (comp && robot_live && !P.keep_on_failure) { tau_out[12 * i + myidx] = 0.0; if (grf_out) grf_out[12 * i + myidx] = 0.0; }
+    if (comp && robot_live && !P.keep_on_failure && (on || !s.support_only)) { tau_out[12 * i + myidx] = 0.0; if (grf_out) grf_out[12 * i + myidx] = 0.0; }
     return;
   }
 
@@ -330,7 +331,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     double t = sel(c == 0, t0, sel(c == 1, t1, t2));
     t = t > P.tau_max ? P.tau_max : t;
     t = t < -P.tau_max ? -P.tau_max : t;
-    if (comp && robot_live && !(P.keep_on_failure && status != kStatusOk)) {
+    if (comp && robot_live && !(P.keep_on_failure && status != kStatusOk) && (on || !s.support_only)) {
       tau_out[12 * i + myidx] = live ? t : 0.0;
       if (grf_out) grf_out[12 * i + myidx] = live ? x : 0.0;
     }

@@ -15,6 +15,8 @@ struct StatePtrs {
   const double *normals;
   const double *wrench; // [B][6] or NULL
   const uint8_t *live;  // [B] or NULL: 0 = robot left alone (nothing written)
+  int support_only;     // whole tick: only the support legs' efforts are written (the swing branch, which writes the
+                        // others, runs beside this kernel on another stream)
 };
 
 __device__ __forceinline__ void load_robot(const StatePtrs &s, int64_t i, RobotIn &in) {
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(64) void balance_step_kernel(const DeviceParams *__
     if (i < B && (!s.live || s.live[i])) {
       LdsScratch scr{scratch + rb, RPW};
       if (P.keep_on_failure && scr.at(kScrStatus) != 0.0) continue;
+      if (s.support_only && s.stance[4 * i + leg] == 0) continue;
       const bool live = (s.stance[4 * i + leg] != 0) && (scr.at(kScrStatus) == 0.0);
       double t[3], f[3];
       phase_c_leg(leg, live, P.tau_max, scr, t, f);
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(64 * kCoopWaves, 2) void balance_coop_kernel(const 
   const bool live = i < B;
   if (!live) i = B - 1;
   const coop::CoopPtrs cp{s.q, s.pos, s.quat, s.linvel, s.angvel, s.dpos, s.dquat, s.dlinvel, s.dangvel, s.stance,
-                          s.normals, s.wrench, s.live};
+                          s.normals, s.wrench, s.live, s.support_only};
 #ifdef QLAMD_STAMPS
 #pragma unroll 1
   for (int rep = 0; rep < 2; rep++) // second pass runs with a warm instruction cache
@@ -223,13 +226,6 @@ __global__ __launch_bounds__(64) void leg_kinematics_kernel(const DeviceParams *
 }
 
 
-int pick_rpw(const qlamd_context *ctx, int64_t batch) {
-  // The lane-cooperative kernel wins at every batch size measured (1 K ... 1 M robots, static and
-  // trot: tools/batch_sweep.py); the one-lane-per-robot kernels stay selectable as an independent
-  // second implementation (different QP linear algebra) for cross-checks.
-  (void)batch;
-  return ctx->rpw_override ? ctx->rpw_override : 4;
-}
 
 template <int RPW>
 hipError_t launch_balance(const qlamd_context *ctx, const StatePtrs &s, int64_t B, double *tau, double *grf,
@@ -379,7 +375,7 @@ int qlamd_set_option(qlamd_context *ctx, int option, int value) {
 } // extern "C"
 
 // live: device pointer [B] or NULL (whole tick, QLAMD_MEM_DEVICE only): robots with 0 are left alone
-int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, const double *wrench, const uint8_t *live,
+int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, const double *wrench, const uint8_t *live, int support_only,
                             int64_t batch, double *joint_effort, double *contact_force, int32_t *status, int memory,
                             void *stream) {
   if (!ctx || !in_user || batch < 0 || !joint_effort || !status) return QLAMD_ERR_INVALID_ARGUMENT;
@@ -445,7 +441,7 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
                   (const double *)(w + off[3]), (const double *)(w + off[4]), (const double *)(w + off[5]),
                   (const double *)(w + off[6]), (const double *)(w + off[7]), (const double *)(w + off[8]),
                   (const uint8_t *)(w + off[9]), in->surface_normal ? (const double *)(w + off[10]) : nullptr,
-                  wrench ? (const double *)(w + off[11]) : nullptr, nullptr};
+                  wrench ? (const double *)(w + off[11]) : nullptr, nullptr, 0};
     d_tau = (double *)(w + off[12]);
     d_grf = contact_force ? (double *)(w + off[13]) : nullptr;
     d_status = (int32_t *)(w + off[14]);
@@ -453,7 +449,7 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
     s = StatePtrs{in->joint_position, in->base_position, in->base_orientation, in->base_linear_velocity,
                   in->base_angular_velocity, in->desired_position, in->desired_orientation,
                   in->desired_linear_velocity, in->desired_angular_velocity, in->support_leg,
-                  in->surface_normal, wrench, live};
+                  in->surface_normal, wrench, live, support_only};
   }
 
   hipError_t e;
@@ -496,7 +492,7 @@ extern "C" {
 
 int qlamd_balance_solve_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch, double *joint_effort,
                               double *contact_force, int32_t *status, int memory, void *stream) {
-  return balance_impl(ctx, in, nullptr, nullptr, batch, joint_effort, contact_force, status, memory, stream);
+  return balance_impl(ctx, in, nullptr, nullptr, 0, batch, joint_effort, contact_force, status, memory, stream);
 }
 
 int qlamd_force_distribution_batch(qlamd_context *ctx, const double *joint_position, const double *base_orientation,
@@ -510,7 +506,7 @@ int qlamd_force_distribution_batch(qlamd_context *ctx, const double *joint_posit
   in.base_orientation = base_orientation;
   in.support_leg = support_leg;
   in.surface_normal = surface_normal;
-  return balance_impl(ctx, &in, virtual_wrench, nullptr, batch, joint_effort, contact_force, status, memory, stream);
+  return balance_impl(ctx, &in, virtual_wrench, nullptr, 0, batch, joint_effort, contact_force, status, memory, stream);
 }
 
 int qlamd_virtual_wrench_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch, double *wrench,

@@ -125,7 +125,14 @@ struct CallGuard {
 
 // balance_kernel.hip: the control step behind qlamd_balance_solve_batch / qlamd_force_distribution_batch, with the
 // whole tick's per-robot `live` flags (device pointer or NULL)
-int balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, const double *wrench, const uint8_t *live,
+// Robots per wavefront of the balance kernel.  The lane-cooperative kernel (4) wins at every batch size measured
+// (1 K ... 1 M robots, static and trot: tools/batch_sweep.py); the one-lane-per-robot kernels stay selectable as an
+// independent second implementation (different QP linear algebra) for cross-checks.
+inline int pick_rpw(const qlamd_context *ctx, int64_t batch) {
+  (void)batch;
+  return ctx->rpw_override ? ctx->rpw_override : 4;
+}
+int balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, const double *wrench, const uint8_t *live, int support_only,
                  int64_t batch, double *joint_effort, double *contact_force, int32_t *status, int memory, void *stream);
 
 inline int ensure_ws(qlamd_context *ctx, size_t bytes) {

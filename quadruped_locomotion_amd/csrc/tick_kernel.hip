@@ -79,15 +79,13 @@ struct SwingBranchPtrs {
   const uint8_t *live; // [B] or NULL (whole tick): 0 = robot left alone
 };
 
-__global__ __launch_bounds__(64) void swing_branch_kernel(const DeviceParams *__restrict__ Pp, const SwingParamsDev SP,
-                                                          const PidParamsDev pid, const SwingPtrs s,
-                                                          const SwingBranchPtrs b, double period, int64_t B,
-                                                          double *__restrict__ effort) {
-  __shared__ double tab[4 * kTabPerLeg];
-  const DeviceParams &P = *Pp;
+// One (robot, leg) per lane; `block`: index of the 64-lane block among the swing blocks; tab: 4 * kTabPerLeg doubles of LDS.
+__device__ __forceinline__ void swing_branch_block(const DeviceParams &P, const SwingParamsDev &SP, const PidParamsDev &pid,
+                                                   const SwingPtrs &s, const SwingBranchPtrs &b, double period, int64_t B,
+                                                   double *__restrict__ effort, int64_t block, double *tab) {
   TabStage ts;
   ts.issue(P);
-  const int64_t t0 = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t t0 = block * 64 + threadIdx.x;
   const bool live = t0 < 4 * B;
   const int64_t t = live ? t0 : 4 * B - 1;
   const int64_t i = t >> 2;
@@ -108,6 +106,43 @@ __global__ __launch_bounds__(64) void swing_branch_kernel(const DeviceParams *__
                    ei, out);
 #pragma unroll
   for (int k = 0; k < 3; k++) { effort[3 * t + k] = out[k]; b.e_last[3 * t + k] = el[k]; b.e_int[3 * t + k] = ei[k]; }
+}
+
+__global__ __launch_bounds__(64) void swing_branch_kernel(const DeviceParams *__restrict__ Pp, const SwingParamsDev SP,
+                                                          const PidParamsDev pid, const SwingPtrs s,
+                                                          const SwingBranchPtrs b, double period, int64_t B,
+                                                          double *__restrict__ effort) {
+  __shared__ double tab[4 * kTabPerLeg];
+  swing_branch_block(*Pp, SP, pid, s, b, period, B, effort, (int64_t)blockIdx.x, tab);
+}
+
+// The whole tick's two solvers in ONE launch: blocks [0, nbal) are the balance step (balance_coop.hpp: 4 robots per
+// block, the efforts of the support legs), the blocks behind them the swing branch (64 (robot, leg) pairs per block,
+// the efforts of the other legs).  Neither reads what the other writes.  The balance blocks are dispatched first and
+// occupy one wavefront per SIMD for as long as their slowest robot needs; the swing blocks run in that shadow, so
+// their 8 us and a launch gap disappear from the tick.  (Two streams joined by events cost as much as they saved.)
+struct TickSwingArgs {
+  SwingParamsDev SP;
+  PidParamsDev pid;
+  SwingPtrs s;
+  SwingBranchPtrs b;
+  double period;
+};
+__global__ __launch_bounds__(64, 2) void tick_solve_kernel(const DeviceParams *__restrict__ Pp, const coop::CoopPtrs cp, int64_t B,
+                                                           double *__restrict__ effort, int32_t *__restrict__ status,
+                                                           unsigned nbal, const TickSwingArgs sw) {
+  __shared__ double tab[4 * kTabPerLeg];
+  __shared__ double rows[4 * coop::kCoopLdsDoubles];
+  __shared__ double nrm[coop::kCoopNrmDoubles];
+  if (blockIdx.x < nbal) {
+    const int row = threadIdx.x >> 4;
+    int64_t i = (int64_t)blockIdx.x * 4 + row;
+    const bool live = i < B;
+    if (!live) i = B - 1;
+    coop::coop_robot<false, 64>(*Pp, cp, i, live, tab, rows + row * coop::kCoopLdsDoubles, nrm, effort, nullptr, status);
+  } else {
+    swing_branch_block(*Pp, sw.SP, sw.pid, sw.s, sw.b, sw.period, B, effort, (int64_t)(blockIdx.x - nbal), tab);
+  }
 }
 
 // ---- leg state machine (row f2): one robot per lane, flags and a few doubles in, flags out ----------
@@ -244,21 +279,31 @@ struct LdsBytes {
 // sits; pass 2 reads the payload at those anchors with independent loads.  Same results as robot_state_unpack
 // (wire_core.hpp), which stays the reference implementation for the host build and the global-memory fallback.
 constexpr int kTplMaxFields = 128; // length fields a layout template can hold (a reference message has ~95)
+// The chain pos -> length field -> pos is what the walk costs (one LDS round trip and a handful of dependent
+// instructions per field, one lane), so a step is kept to the minimum: `field(pre)` steps over `pre` fixed bytes, reads
+// the uint32 there and leaves pos behind it; `over(n, post)` steps over n variable and `post` fixed bytes.  Only the
+// read position and the result of `over` are clamped to cap = len + 1 (the staging window reaches 16 bytes past the last
+// message, so a read at cap is harmless): once a field points past the end pos sticks at cap ("bad"), the status is
+// decided by pos >= cap at the very end, and anchors noted on the way are only used for a message that ended well.
+// kLog: this message's (position, value) pairs become the next launch's layout template.
+template <bool kLog>
 struct WireSkeleton {
   const LdsBytes &p;
-  uint32_t pos, cap; // cap = len + 1; pos saturates there ("bad")
-  uint32_t *log;     // global (position, value) pairs of the layout template, or NULL: only block 0's first message logs
+  uint32_t pos, cap;
+  uint32_t *log;
   uint32_t nf;
-  __device__ __forceinline__ void skip(uint32_t n) { pos = min(pos + min(n, cap), cap); }
-  __device__ __forceinline__ uint32_t len_field() { // read a uint32 at pos, step over it
-    const uint32_t at = min(pos, cap - 1);
+  __device__ __forceinline__ uint32_t field(uint32_t pre) {
+    const uint32_t at = min(pos + pre, cap);
     const uint32_t v = p.u32(at);
-    if (log && nf < (uint32_t)kTplMaxFields) { log[2 * nf] = at; log[2 * nf + 1] = v; }
+    if (kLog) {
+      if (nf < (uint32_t)kTplMaxFields) { log[2 * nf] = at; log[2 * nf + 1] = v; }
+    }
     nf++;
-    skip(4);
+    pos = at + 4u;
     return v;
   }
-  __device__ __forceinline__ void header() { skip(12); skip(len_field()); }
+  __device__ __forceinline__ void over(uint32_t n, uint32_t post) { pos = min(pos + min(n, cap) + post, cap); }
+  __device__ __forceinline__ bool bad() const { return pos >= cap; }
 };
 
 enum WireAnchor : int { // uint32 slots per message
@@ -274,64 +319,61 @@ enum WireAnchor : int { // uint32 slots per message
 };
 
 // Pass 1.  Returns the status; nf = number of length fields met, end_pos = position after the last field.
+template <bool kLog>
 __device__ __forceinline__ int wire_lds_skeleton(const LdsBytes &src, int64_t len64, uint32_t *an, uint32_t *log, uint32_t &nf,
                                                  uint32_t &end_pos) {
   nf = 0u; end_pos = 0u;
   if (len64 < 0 || len64 > 0x7FFFFFF0ll) return kWireTruncated;
   const uint32_t len = (uint32_t)len64;
-  WireSkeleton c{src, 0u, len + 1u, log, 0u};
+  WireSkeleton<kLog> c{src, 0u, len + 1u, log, 0u};
   bool missing = false;
-  // ---- pass 1: skeleton
+  const auto times8 = [](uint32_t n) { return n > 0x0FFFFFFFu ? 0xFFFFFFFFu : 8u * n; };
 #pragma nounroll
   for (int l = 0; l < 4; l++) { // sensor_msgs/JointState
-    c.header();
-    uint32_t nn = c.len_field();
+    c.over(c.field(12), 0);                       // header: seq, stamp, frame_id
+    uint32_t nn = c.field(0);
 #pragma nounroll
-    for (; nn > 0 && c.pos < c.cap; nn--) c.skip(c.len_field());
-    const uint32_t np = c.len_field();
+    for (; nn > 0 && !c.bad(); nn--) c.over(c.field(0), 0);
+    const uint32_t np = c.field(0);
     missing = missing || np < 3;
     an[kAnJointPos + l] = c.pos;
     an[kAnJointCnt + l] = np;
-    c.skip(np > 0x0FFFFFFFu ? 0xFFFFFFFFu : 8u * np);
-    const uint32_t nv = c.len_field(); c.skip(nv > 0x0FFFFFFFu ? 0xFFFFFFFFu : 8u * nv);
-    const uint32_t ne = c.len_field(); c.skip(ne > 0x0FFFFFFFu ? 0xFFFFFFFFu : 8u * ne);
+    c.over(times8(np), 0);
+    c.over(times8(c.field(0)), 0);
+    c.over(times8(c.field(0)), 0);
   }
-  c.header();                       // nav_msgs/Odometry
-  c.skip(c.len_field());            // child_frame_id
+  c.over(c.field(12), 0);                         // nav_msgs/Odometry: header
+  c.over(c.field(0), 0);                          // child_frame_id
   an[kAnOdomPose] = c.pos;
-  c.skip(56 + 288 + 48 + 288);
+  c.over(0, 56 + 288 + 48 + 288);
 #pragma nounroll
-  for (int l = 0; l < 4; l++) {     // free_gait_msgs/LegMode
-    const uint32_t n = c.len_field();
+  for (int l = 0; l < 4; l++) {                   // free_gait_msgs/LegMode
+    const uint32_t n = c.field(0);
     an[kAnModeName + l] = c.pos;
     an[kAnModeLen + l] = n;
-    c.skip(n);
+    c.over(n, 0);
     an[kAnModeFlag + l] = c.pos;
-    c.skip(1 + 8 + 8);              // support_leg, duration, phase
-    c.header();
+    c.over(c.field(1 + 8 + 8 + 12), 0);           // support_leg, duration, phase; header
     an[kAnModeNormal + l] = c.pos;
-    c.skip(24 + 1);
+    c.over(0, 24 + 1);
   }
 #pragma nounroll
-  for (int l = 0; l < 4; l++) {     // free_gait_msgs/EndEffectorTarget
-    c.skip(c.len_field());          // name
+  for (int l = 0; l < 4; l++) {                   // free_gait_msgs/EndEffectorTarget
+    c.over(c.field(0), 0);                        // name
 #pragma nounroll
     for (int arr = 0; arr < 4; arr++) {
-      uint32_t n = c.len_field();
+      const uint32_t n = c.field(0);
       if (arr < 3) missing = missing || n == 0;
 #pragma nounroll
-      for (uint32_t k = 0; k < n && c.pos < c.cap; k++) {
-        c.header();
-        if (k == 0 && arr < 3) an[kAnTarget + 3 * l + arr] = c.pos;
-        c.skip(24);
+      for (uint32_t k = 0; k < n && !c.bad(); k++) {
+        c.over(c.field(12), 24);                  // header; the 24 payload bytes
+        if (k == 0 && arr < 3) an[kAnTarget + 3 * l + arr] = c.pos - 24u;
       }
     }
-    c.skip(8);                      // average_velocity
-    c.header();
-    c.skip(24 + 2);                 // surface_normal.vector, ignore_contact, ignore_for_pose_adaptation
+    c.over(c.field(8 + 12), 24 + 2);              // average_velocity; header; surface_normal.vector, two flags
   }
   nf = c.nf; end_pos = c.pos;
-  if (c.pos >= c.cap) return kWireTruncated; // some field ran past the end: the record stays cleared
+  if (c.bad()) return kWireTruncated; // some field ran past the end: the record stays cleared
   return missing ? kWireMissingField : kWireOk;
 }
 
@@ -496,7 +538,8 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   if (lr == 0 && mine) {
     if (!sane) st = kWireTruncated;
     else if (hit) st = tpl[kTplMissing] ? kWireMissingField : kWireOk;
-    else if (staged) st = wire_lds_skeleton(msg, mb - ma, anchors[row], logger ? tpl_out + kTplPairs : nullptr, nf, end_pos);
+    else if (staged && logger) st = wire_lds_skeleton<true>(msg, mb - ma, anchors[row], tpl_out + kTplPairs, nf, end_pos);
+    else if (staged) st = wire_lds_skeleton<false>(msg, mb - ma, anchors[row], nullptr, nf, end_pos);
     else st = robot_state_unpack(PlainBytes{messages + ma}, mb - ma, rec[row]);
     status[i0 + row] = st;
     okm[row] = (st == kWireOk || !valid) ? 1 : 0;
@@ -937,18 +980,41 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
                         d.leg_state_code ? d.leg_state_code : (int8_t *)ctx->tick_ws, U(kCmdMode), d.leg_mode, live, d.status};
   hipLaunchKernelGGL(leg_state_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, ls, index_quirk, batch);
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
-  // 3. balance solve for the support legs (all 12 efforts written: 0 for the others)
-  qlamd_state_batch sb{d.joint_position, d.base_position, d.base_orientation, d.base_linear_velocity, d.base_angular_velocity,
-                       D(kCmdPos), D(kCmdQuat), D(kCmdLin), D(kCmdAng), d.support, nullptr};
-  rc = balance_impl(ctx, &sb, nullptr, live, batch, d.joint_effort, nullptr, d.status, QLAMD_MEM_DEVICE, stream);
-  if (rc != QLAMD_OK) return rc;
-  // 4. swing branch for the legs that do not support
+  // 3. + 4. the balance solve for the support legs and the swing branch for the others
   qlamd_swing_params sp = *swing;
   sp.period = period;
-  const qlamd_swing_batch sw{d.joint_position, d.joint_velocity, d.joint_velocity_oldest, D(kCmdFootP), D(kCmdFootV), d.support, nullptr};
-  const qlamd_swing_branch_extra ex{d.base_orientation, D(kCmdJoint), d.leg_mode, d.pid_error_last, d.pid_error_integral};
-  rc = swing_branch_impl(ctx, &sp, pid, &sw, &ex, live, period, batch, d.joint_effort, QLAMD_MEM_DEVICE, stream);
-  if (rc != QLAMD_OK) return rc;
+  if (pick_rpw(ctx, batch) == 4) {
+    // one launch (tick_solve_kernel)
+    if (!(sp.period > 0.0) || !(sp.accel_window > 0.0)) return QLAMD_ERR_INVALID_ARGUMENT;
+    TickSwingArgs ta;
+    for (int k = 0; k < 3; k++) { ta.SP.kp[k] = sp.kp[k]; ta.SP.kd[k] = sp.kd[k]; }
+    ta.SP.period = sp.period; ta.SP.accel_window = sp.accel_window; ta.SP.accel_scale = sp.accel_scale;
+    ta.SP.gravity = sp.gravity;
+    memcpy(ta.pid.p, pid->p, sizeof(ta.pid.p)); memcpy(ta.pid.i, pid->i, sizeof(ta.pid.i)); memcpy(ta.pid.d, pid->d, sizeof(ta.pid.d));
+    memcpy(ta.pid.i_max, pid->i_max, sizeof(ta.pid.i_max)); memcpy(ta.pid.i_min, pid->i_min, sizeof(ta.pid.i_min));
+    memcpy(ta.pid.lower, pid->lower, sizeof(ta.pid.lower)); memcpy(ta.pid.upper, pid->upper, sizeof(ta.pid.upper));
+    ta.pid.antiwindup = pid->antiwindup;
+    ta.s = SwingPtrs{d.joint_position, d.joint_velocity, d.joint_velocity_oldest, D(kCmdFootP), D(kCmdFootV), nullptr, d.support};
+    ta.b = SwingBranchPtrs{d.base_orientation, D(kCmdJoint), d.leg_mode, d.pid_error_last, d.pid_error_integral, live};
+    ta.period = period;
+    const coop::CoopPtrs cp{d.joint_position, d.base_position, d.base_orientation, d.base_linear_velocity,
+                            d.base_angular_velocity, D(kCmdPos), D(kCmdQuat), D(kCmdLin), D(kCmdAng), d.support,
+                            nullptr, nullptr, live, 1};
+    const unsigned nbal = (unsigned)((batch + 3) / 4), nsw = (unsigned)((4 * batch + 63) / 64);
+    hipLaunchKernelGGL(tick_solve_kernel, dim3(nbal + nsw), dim3(64), 0, st, ctx->d_params, cp, batch, d.joint_effort, d.status,
+                       nbal, ta);
+    if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  } else {
+    // the one-lane balance kernels (qlamd_set_robots_per_wave, cross-checks): two launches
+    qlamd_state_batch sb{d.joint_position, d.base_position, d.base_orientation, d.base_linear_velocity, d.base_angular_velocity,
+                         D(kCmdPos), D(kCmdQuat), D(kCmdLin), D(kCmdAng), d.support, nullptr};
+    rc = balance_impl(ctx, &sb, nullptr, live, 1, batch, d.joint_effort, nullptr, d.status, QLAMD_MEM_DEVICE, stream);
+    if (rc != QLAMD_OK) return rc;
+    const qlamd_swing_batch sw{d.joint_position, d.joint_velocity, d.joint_velocity_oldest, D(kCmdFootP), D(kCmdFootV), d.support, nullptr};
+    const qlamd_swing_branch_extra ex{d.base_orientation, D(kCmdJoint), d.leg_mode, d.pid_error_last, d.pid_error_integral};
+    rc = swing_branch_impl(ctx, &sp, pid, &sw, &ex, live, period, batch, d.joint_effort, QLAMD_MEM_DEVICE, stream);
+    if (rc != QLAMD_OK) return rc;
+  }
   if (memory == QLAMD_MEM_HOST) return sg.finish(st);
   return QLAMD_OK;
 }

@@ -209,6 +209,39 @@ def test_device_unpack_layout_template(oracle):
     assert (st[:9] == 2).all() and (st[9:] == 0).all()
 
 
+@pytest.mark.gpu
+def test_device_unpack_truncated_and_corrupted_length_fields(oracle):
+    """The layout walk clamps positions only where it reads and where it finishes a step: every way a message can end
+    early or a length field can point outside it must give the oracle's status (and the oracle's fields where the
+    message is still delivered).  Every prefix class of a ragged message, and length fields overwritten by small,
+    large and huge counts."""
+    from quadruped_locomotion_amd import capi
+    ctx = capi.Context()
+    rng = np.random.default_rng(5)
+    base, _ = random_message(np.random.default_rng(78), ragged=True)
+    raws = [base[:n] for n in sorted(set(rng.integers(0, len(base), 150).tolist() + [0, 1, 3, 4, 11, 12, 15, 16, len(base) - 1]))]
+    # positions of uint32 words that look like length fields: overwrite with other counts
+    words = [at for at in range(0, len(base) - 4) if int.from_bytes(base[at:at + 4], "little") in range(0, 40)]
+    for at in rng.choice(words, min(150, len(words)), replace=False):
+        for v in (0, 1, int(rng.integers(2, 60)), len(base), 0x0FFFFFFF, 0x10000000, 0x7FFFFFFF, 0xFFFFFFFF)[int(rng.integers(0, 3))::3]:
+            b = bytearray(base)
+            b[at:at + 4] = int(v).to_bytes(4, "little")
+            raws.append(bytes(b))
+    off = np.zeros(len(raws) + 1, np.int64)
+    off[1:] = np.cumsum([len(r) for r in raws])
+    out, st = capi.robot_state_unpack(ctx, b"".join(raws), off)
+    seen = set()
+    for i, r in enumerate(raws):
+        want, wst = oracle.robot_state_unpack(r)
+        assert st[i] == wst, (i, len(r))
+        seen.add(int(wst))
+        if wst != 1:
+            same({k: v[i] for k, v in out.items()}, want)
+        else:
+            assert all(not np.asarray(v[i]).any() for v in out.values())
+    assert {0, 1} <= seen
+
+
 def test_package_writer_matches_the_schema_serialiser(oracle):
     """quadruped_locomotion_amd/wire.py writes the stream front to back; tests/ros1_wire.py walks the .msg schema.
     Same content and layout -> same bytes, and the oracle parser reads the fields back."""
