@@ -163,9 +163,8 @@ struct LegStatePtrs {
   int32_t *status;
 };
 
-__global__ __launch_bounds__(256) void leg_state_kernel(const LegStatePtrs s, int index_quirk, int64_t B) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= B) return;
+// the state machine of robot i, by one lane
+__device__ __forceinline__ void leg_state_robot(const LegStatePtrs &s, int index_quirk, int64_t i) {
   LegStateRobot r;
   // four flags per robot travel as one 32-bit word
   const uint32_t sup = *reinterpret_cast<const uint32_t *>(s.support_leg + 4 * i);
@@ -243,6 +242,11 @@ __global__ __launch_bounds__(256) void leg_state_kernel(const LegStatePtrs s, in
   *reinterpret_cast<uint32_t *>(s.support + 4 * i) = sup_o;
   *reinterpret_cast<uint32_t *>(s.code + 4 * i) = code_o;
   if (s.msg_mode) *reinterpret_cast<uint32_t *>(s.leg_mode + 4 * i) = merged;
+}
+
+__global__ __launch_bounds__(256) void leg_state_kernel(const LegStatePtrs s, int index_quirk, int64_t B) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < B) leg_state_robot(s, index_quirk, i);
 }
 
 // ---- free_gait_msgs/RobotState wire format -> SoA (row f2): one message per lane ---------------------
@@ -444,7 +448,10 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
                                                                 const RobotStateOutPtrs o, int32_t *__restrict__ status,
                                                                 const uint32_t *__restrict__ tpl_in,
                                                                 uint32_t *__restrict__ tpl_out,
-                                                                uint8_t *__restrict__ valid) {
+                                                                uint8_t *__restrict__ valid, const LegStatePtrs ls,
+                                                                int leg_state_mode) {
+  // leg_state_mode (whole tick): 0 = parse only; 1 / 2 = the block also runs the leg state machine of its robots on the
+  // command now in force (without / with the reference's index quirk): one launch and one memory round trip less per tick
   // valid != NULL (whole tick): the outputs are the per-robot command in force -- only a well-formed message
   // replaces a robot's record and sets valid[robot]; a malformed one leaves both as they are.
   extern __shared__ uint32_t wire_lds[];
@@ -594,6 +601,10 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
     if (o.leg_mode && okm[m]) o.leg_mode[4 * i0 + tid] = rec[m].leg_mode[l];
   }
   QL_STAMP(25);
+  if (leg_state_mode) {
+    __syncthreads(); // the block's records (and valid flags) are in memory
+    if (tid < n) leg_state_robot(ls, leg_state_mode == 2, i0 + tid);
+  }
 }
 
 } // namespace
@@ -776,7 +787,8 @@ int qlamd_leg_state_machine_batch(qlamd_context *ctx, const qlamd_leg_state_batc
 
 // valid: device pointer [B] or NULL (whole tick, QLAMD_MEM_DEVICE only), see robot_state_unpack_kernel
 static int unpack_impl(qlamd_context *ctx, const uint8_t *messages, const int64_t *offsets, int64_t batch,
-                       const qlamd_robot_state_fields *out, int32_t *status, uint8_t *valid, int memory, void *stream) {
+                       const qlamd_robot_state_fields *out, int32_t *status, uint8_t *valid, int memory, void *stream,
+                       const LegStatePtrs *ls = nullptr, int leg_state_mode = 0) {
   if (!ctx || !messages || !offsets || !out || !status || batch < 0) return QLAMD_ERR_INVALID_ARGUMENT;
   if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
   if (batch == 0) return QLAMD_OK;
@@ -824,7 +836,8 @@ static int unpack_impl(qlamd_context *ctx, const uint8_t *messages, const int64_
   uint32_t *tpl_out = ctx->wire_tpl + kTplWords * (ctx->wire_flip ^ 1);
   ctx->wire_flip ^= 1;
   hipLaunchKernelGGL(robot_state_unpack_kernel, dim3((unsigned)((batch + kWireMsgsPerBlock - 1) / kWireMsgsPerBlock)),
-                     dim3(64), kWireLdsBytes, st, d_msg, d_off, batch, o, d_st, tpl_in, tpl_out, valid);
+                     dim3(64), kWireLdsBytes, st, d_msg, d_off, batch, o, d_st, tpl_in, tpl_out, valid,
+                     ls ? *ls : LegStatePtrs{}, ls ? leg_state_mode : 0);
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   if (memory == QLAMD_MEM_HOST) return sg.finish(st);
   return QLAMD_OK;
@@ -970,21 +983,29 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
   f.joint_command = D(kCmdJoint); f.foot_position = D(kCmdFootP); f.foot_velocity = D(kCmdFootV); f.phase = D(kCmdPhase);
   f.support_leg = U(kCmdSup); f.leg_mode = U(kCmdMode);
   const uint8_t *live = U(kCmdValid);
-  rc = unpack_impl(ctx, d.messages, d.offsets, batch, &f, d.message_status, U(kCmdValid), QLAMD_MEM_DEVICE, stream);
-  if (rc != QLAMD_OK) return rc;
-  // 2. leg modes in force, footContactsCallback + the switch of update(): support legs, held joint commands, nudged
-  //    foot targets (one launch: the kernel of qlamd_leg_state_machine_batch with the mode merge in front); robots
-  //    without a command get their status here and are left alone by every kernel of the tick
+  // 2. (same launch) leg modes in force, footContactsCallback + the switch of update(): support legs, held joint
+  //    commands, nudged foot targets -- the state machine of qlamd_leg_state_machine_batch with the mode merge in front,
+  //    run by the parser's blocks on the command they have just put in force; robots without a command get their status
+  //    here and are left alone by every kernel of the tick
   const LegStatePtrs ls{U(kCmdSup), nullptr, d.contact, D(kCmdPhase), d.joint_position, d.limb_state, d.store_flag,
                         d.stored_joint_position, D(kCmdJoint), D(kCmdFootP), d.support,
                         d.leg_state_code ? d.leg_state_code : (int8_t *)ctx->tick_ws, U(kCmdMode), d.leg_mode, live, d.status};
-  hipLaunchKernelGGL(leg_state_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, ls, index_quirk, batch);
-  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  // (large batches: its own launch, one robot per lane, 256 per block -- the parser is bandwidth-bound there and four
+  // busy lanes at the tail of every block cost more than a launch: 402 against 365 us at 65 536 robots)
+  const bool one_launch = batch <= 16384;
+  rc = unpack_impl(ctx, d.messages, d.offsets, batch, &f, d.message_status, U(kCmdValid), QLAMD_MEM_DEVICE, stream,
+                   one_launch ? &ls : nullptr, index_quirk ? 2 : 1);
+  if (rc != QLAMD_OK) return rc;
+  if (!one_launch) {
+    hipLaunchKernelGGL(leg_state_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, ls, index_quirk, batch);
+    if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  }
   // 3. + 4. the balance solve for the support legs and the swing branch for the others
   qlamd_swing_params sp = *swing;
   sp.period = period;
-  if (pick_rpw(ctx, batch) == 4) {
-    // one launch (tick_solve_kernel)
+  if (pick_rpw(ctx, batch) == 4 && batch <= 16384) {
+    // one launch (tick_solve_kernel); beyond a few wavefronts per SIMD the swing blocks no longer find idle issue slots
+    // and pay for the balance kernel's registers and LDS instead (65 536 robots: 381 us fused, 365 us apart)
     if (!(sp.period > 0.0) || !(sp.accel_window > 0.0)) return QLAMD_ERR_INVALID_ARGUMENT;
     TickSwingArgs ta;
     for (int k = 0; k < 3; k++) { ta.SP.kp[k] = sp.kp[k]; ta.SP.kd[k] = sp.kd[k]; }
@@ -1005,7 +1026,7 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
                        nbal, ta);
     if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   } else {
-    // the one-lane balance kernels (qlamd_set_robots_per_wave, cross-checks): two launches
+    // two launches (large batches; the one-lane balance kernels of qlamd_set_robots_per_wave, cross-checks)
     qlamd_state_batch sb{d.joint_position, d.base_position, d.base_orientation, d.base_linear_velocity, d.base_angular_velocity,
                          D(kCmdPos), D(kCmdQuat), D(kCmdLin), D(kCmdAng), d.support, nullptr};
     rc = balance_impl(ctx, &sb, nullptr, live, 1, batch, d.joint_effort, nullptr, d.status, QLAMD_MEM_DEVICE, stream);

@@ -122,6 +122,30 @@ def test_full_tick_without_a_command_block_skips_malformed_messages(oracle):
     assert io["status"][5] == 4 and io["message_status"][5] != 0
 
 
+def test_full_tick_large_batches_take_the_same_results_through_separate_launches():
+    """Up to 16 384 robots the tick is two launches (parser + state machine, balance + swing branch); above, four.  The
+    arithmetic is the same: 33 001 robots in one call against the same robots in two calls of half the size, bit for bit
+    (the small form is the one the oracle chain is compared with above)."""
+    from quadruped_locomotion_amd import capi
+    B, period = 33001, 0.0025
+    msgs, tin = make_tick_inputs(B, 0, truncated=(7, 20000))
+    whole = dict(tin, **fresh_state(B, capi))
+    whole["command"] = None
+    capi.full_tick(capi.Context(), whole, period)
+    assert (whole["status"] == 4).sum() == 2 and (whole["status"] == 0).sum() > B // 2
+    off = tin["offsets"]
+    for lo, hi in ((0, 16500), (16500, B)):
+        n = hi - lo
+        part = {k: np.ascontiguousarray(v[lo:hi]) for k, v in tin.items() if k not in ("messages", "offsets")}
+        part["messages"] = np.ascontiguousarray(tin["messages"][off[lo]:off[hi]])
+        part["offsets"] = np.ascontiguousarray(off[lo:hi + 1] - off[lo])
+        io = dict(part, **fresh_state(n, capi))
+        io["command"] = None
+        capi.full_tick(capi.Context(), io, period)
+        for k in PERSIST + ("joint_effort", "status", "message_status", "leg_state_code"):
+            assert np.array_equal(io[k], whole[k][lo:hi]), (k, lo)
+
+
 def test_full_tick_keeps_the_previous_efforts_of_a_failed_solve(oracle):
     """QLAMD_ON_FAILURE_KEEP = the reference's 'VMC compute failed' branch (ros_balance_controller.cpp:418-424,441-454):
     the support legs of a robot whose solve fails are commanded the efforts of the tick before.  The force QP is always
