@@ -279,6 +279,9 @@ def bench_wholebody(args):
     # forces 96 + status 4 out; dynamics: M 2592 + h 144 + Jc 1728 out
     per = (272 + 52 + 196) if solve else (272 + 4464)
     achieved = per * B / (kernel_ms * 1e-3) / 1e9
+    kname = "wholebody_solve_kernel" if solve else ("wholebody_dynamics_leg_kernel" if leg_form else "wholebody_dynamics_kernel")
+    rec, traffic_src = pmc_record(kname, B, ("wholebody-" + gait) if solve else "wholebody_dynamics")
+    traffic = int(rec["fetch_bytes"] + rec["write_bytes"]) if rec and "fetch_bytes" in rec and "write_bytes" in rec else None
     cpu = None
     if solve and not args.no_cpu_baseline:
         from oracle import oracle as O
@@ -311,10 +314,8 @@ def bench_wholebody(args):
                                 "batch=%d robots, %s, 18x18 mass matrix + bias forces + 12x18 contact Jacobian") % (B, gait),
                    **({"all_status_ok": bool((st == 0).all().item())} if solve else {})},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     # HBM bytes per launch from rocprofv3 --pmc (profiles/r1/pmc_dynamics_b65536.json), measured at 65536 robots
-                     "traffic": int((10361.5 + 285696.0) * 1024) if (not solve and B == 65536) else None,
-                     "kernel": "wholebody_solve_kernel" if solve else
-                     ("wholebody_dynamics_leg_kernel" if leg_form else "wholebody_dynamics_kernel"),
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": kname,
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": per * B},
         **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
 

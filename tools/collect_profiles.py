@@ -32,6 +32,9 @@ WORKLOADS = [
     ("trot", "balance_coop_kernel", 65536, ["--gait", "trot", "--batch", "65536"]),
     ("trot", "balance_coop_kernel", 8192, ["--gait", "trot", "--batch", "8192"]),
     ("pose_sqp", "pose_sqp_coop_kernel", 4096, ["--workload", "pose_sqp"]),
+    ("wholebody-trot", "wholebody_solve_kernel", 4096, ["--workload", "wholebody", "--gait", "trot"]),
+    ("wholebody_dynamics", "wholebody_dynamics_leg_kernel", 1048576, ["--workload", "wholebody_dynamics", "--batch", "1048576"]),
+    ("wholebody_dynamics", "wholebody_dynamics_kernel", 4096, ["--workload", "wholebody_dynamics", "--batch", "4096"]),
 ]
 SQ_GROUP = "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"
 

@@ -28,11 +28,14 @@ b wholebody_trot_b4096 --workload wholebody --gait trot --steps 100
 b wholebody_dynamics_b4096 --workload wholebody_dynamics --steps 100
 b wholebody_dynamics_b65536 --workload wholebody_dynamics --batch 65536 --steps 50
 b wholebody_dynamics_b1048576 --workload wholebody_dynamics --batch 1048576 --steps 10
+b wholebody_dynamics_row_b1048576 --workload wholebody_dynamics --wholebody-form row --batch 1048576 --steps 10
+b full_tick_b16384 --workload full_tick --batch 16384 --steps 50
 ( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/aux_raw -o aux -- python3 $GRAFT_REPO_ROOT/tools/aux_kernels.py > /dev/null 2>&1 )
 python3 tools/rocpd_kernels.py $(find $OUT/aux_raw -name "*_results.db" | head -1) $OUT/kernel_stats_aux_entries_b4096.csv > /dev/null 2>&1
 rm -rf $OUT/aux_raw
 python3 tools/tail_probe.py 2>&1 | grep -v amdgpu > $OUT/single_wavefront_latency.txt
 python3 tools/latency_b1.py 2>&1 | grep -v amdgpu > $OUT/host_buffer_latency.txt
+python3 tools/write_bw.py 2>&1 | grep -v amdgpu > $OUT/write_bandwidth.txt
 ./tools/ubench/issue_model > $OUT/issue_model.txt 2>&1
 ./tools/ubench/rcp_accuracy > $OUT/rcp_accuracy.txt 2>&1
 ls $OUT
