@@ -436,7 +436,14 @@ def main():
     dev = "cuda:%d" % local_rank
     collective = world > 1 or args.force_collective
     ranks_seen = 1
+    json_fd = 1
     if collective:
+        # RCCL writes a version banner to file descriptor 1 when it shuts down; the contract is ONE JSON line on stdout.
+        # Everything this process and its libraries write to fd 1 from here on goes to stderr; the line itself is
+        # written to the saved descriptor.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
@@ -646,7 +653,7 @@ def main():
                                   "note": "SQ_INSTS_VALU (rocprofv3 --pmc) x 4 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz)"}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(state, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
 
     if collective:
         dist.destroy_process_group()

@@ -156,27 +156,22 @@ __device__ __forceinline__ void load_row_problem(const PoseParamsDev &P, const P
   for (int k = 0; k < 4; k++) io[19 + k] = min_len ? min_len[4 * i + P.leg_order[k]] : 0.0;
 }
 
-__global__ __launch_bounds__(64) void pose_geometric_coop_kernel(const PoseParamsDev P, const PosePtrs s,
-                                                                 const double *__restrict__ sfo_in, int64_t B,
-                                                                 double *__restrict__ pose_out) {
-  __shared__ PoseProblem pbs[coop::kPoseCoopRows];
-  __shared__ double io[coop::kPoseCoopRows][24];
-  const int row = threadIdx.x >> 4, lr = threadIdx.x & 15;
-  int64_t i = (int64_t)blockIdx.x * coop::kPoseCoopRows + row;
-  const bool live = i < B;
-  if (!live) i = B - 1;
-  if (lr == 0) load_row_problem(P, s, sfo_in, nullptr, i, pbs[row], io[row]);
-  __syncthreads();
+// PoseOptimizationGeometric on its own: one problem per lane (pose_core.hpp's serial form: Kabsch matrix, cyclic Jacobi,
+// heading and roll / pitch).  No QP is involved and nothing is shared between the lanes of a row, so the row layout has
+// nothing to offer here: the 16-lane form of the same arithmetic (coop::pose_geometric_coop, the first stage of
+// base_auto_coop_kernel) measured 37 us as its own launch against 14 us for this one at 4096 problems.
+__global__ __launch_bounds__(64) void pose_geometric_kernel(const PoseParamsDev P, const PosePtrs s,
+                                                            const double *__restrict__ sfo_in, int64_t B,
+                                                            double *__restrict__ pose_out) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= B) return;
+  PoseProblem pb;
   double pose[7], sfo[4][3];
+  load_pose_problem(P, s, i, pb, pose);
+  load_sfo(s, sfo_in, i, sfo);
+  pose_geometric(pb, sfo, pose);
 #pragma unroll
-  for (int l = 0; l < 4; l++)
-#pragma unroll
-    for (int a = 0; a < 3; a++) sfo[l][a] = io[row][7 + 3 * l + a];
-  coop::pose_geometric_coop(pbs[row], sfo, pose);
-  if (lr == 0 && live) {
-#pragma unroll
-    for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
-  }
+  for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
 }
 
 // BaseAuto::optimizePose: geometric -> QP -> check -> SQP for the problems the check rejects
@@ -378,7 +373,7 @@ static int pose_impl(const PoseCall &call, qlamd_context *ctx, const qlamd_pose_
                          call.leg_tol, batch, d_ok);
       break;
     case kPoseGeometric:
-      hipLaunchKernelGGL(pose_geometric_coop_kernel, dim3(rgrid), dim3(64), 0, st, P, s, d_sfo, batch, d_out);
+      hipLaunchKernelGGL(pose_geometric_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, P, s, d_sfo, batch, d_out);
       break;
     case kPoseBaseAuto:
       hipLaunchKernelGGL(base_auto_coop_kernel, dim3(rgrid), dim3(64), 0, st, P, s, d_sfo, d_min, call.leg_tol, batch, d_out,
