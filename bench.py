@@ -372,7 +372,10 @@ def bench_full_tick(args):
                                (B, nbytes // B, "ragged layouts" if args.ragged else "one layout"),
                    "messages_ok": int((dev["message_status"] == 0).sum().item()), "solves_ok": int((dev["status"] == 0).sum().item())},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "four kernels per tick (unpack, leg state, balance, swing branch)",
+                     "traffic": None,
+                     "kernel": ("two launches per tick (robot_state_unpack_kernel incl. the leg state machine; tick_solve_kernel = "
+                                "balance blocks + swing-branch blocks)") if B <= 16384 else
+                               "four launches per tick (unpack, leg state, balance, swing branch)",
                      "kernel_ms": tick_ms, "algorithmic_bytes_per_launch": algo}}), flush=True)
 
 
