@@ -128,6 +128,51 @@ def test_solve_with_binding_torque_limits_subsets_and_normals(gpu, oracle):
     print("non-OK:", int((~ok).sum()), "robots with a torque row active:", int(bound.any(axis=1).sum()))
 
 
+def test_solve_full_size_properties(gpu, oracle):
+    """65 536 trot robots with tight torque limits: what holds at any size.  Every solved robot's forces lie in the
+    friction pyramid with at least the minimal normal force, every stance torque within the limit, efforts of stance
+    legs equal tau0 - J'f of the returned forces (through the dynamics entry's contact Jacobian and bias forces), swing
+    legs carry the inverse-dynamics torque alone; a 512-robot sample agrees with the oracle."""
+    capi, ctx, torch = gpu
+    B = 65536
+    s = synth.make_wholebody_states(B, "trot")
+    prm, oprm = capi.default_wholebody_params(), oracle.default_wb_params()
+    prm.torque_limit = oprm.torque_limit = 60.0
+    d = capi.to_device(s)
+    tau = torch.zeros(B, 12, dtype=torch.float64, device="cuda:0")
+    grf = torch.zeros(B, 12, dtype=torch.float64, device="cuda:0")
+    st = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+    capi.wholebody_solve_device(ctx, d, tau, grf, st, prm)
+    Jc = torch.zeros(B, 12, 18, dtype=torch.float64, device="cuda:0")
+    capi.wholebody_dynamics_device(ctx, d, None, None, Jc)
+    torch.cuda.synchronize()
+    tau, grf, st, Jc = tau.cpu().numpy(), grf.cpu().numpy(), st.cpu().numpy(), Jc.cpu().numpy()
+    ok = st == 0
+    assert ok.mean() > 0.99
+    stance = s["stance"].astype(bool)
+    f = grf.reshape(B, 4, 3)
+    mu, fmin = oprm.friction, oprm.min_normal_force
+    on = stance & ok[:, None]
+    assert (f[on][:, 2] >= fmin - 1e-6).all()                              # flat ground: the normal is the base z axis
+    # the pyramid's tangents follow the base yaw, so in base axes the forces lie in the cone that contains every such pyramid
+    assert (np.hypot(f[on][:, 0], f[on][:, 1]) <= np.sqrt(2.0) * mu * f[on][:, 2] + 1e-6).all()
+    assert (f[~stance] == 0).all()
+    on_j = np.repeat(on, 3, axis=1)
+    assert np.abs(tau[on_j]).max() <= 60.0 + 1e-6 and np.isclose(np.abs(tau[on_j]), 60.0, atol=1e-6).sum() > 50
+    # tau = tau0 - J_leg' f: with f = 0 the solve returns tau0, so the difference of two solves isolates -J'f
+    sw = {k: v.copy() for k, v in s.items()}
+    sw["stance"][:] = 0
+    tau0 = capi.wholebody_solve(ctx, {k: v[:4096] for k, v in sw.items()}, prm)[0]
+    for b in np.nonzero(ok[:4096])[0][::16]:
+        Jleg = Jc[b][:, 6:]                                               # 12 x 12, block diagonal by leg
+        assert np.abs(tau[b] - (tau0[b] - Jleg.T @ grf[b])).max() < 1e-8
+    idx = np.arange(0, B, B // 512)
+    t0, g0, s0 = oracle.wb_step_batch({k: v[idx] for k, v in s.items()}, oprm, nthreads=8)
+    assert np.array_equal(st[idx], s0)
+    good = s0 == 0
+    assert np.abs(tau[idx][good] - t0[good]).max() < TAU_TOL
+
+
 def test_device_buffers_ragged_and_non_finite(gpu, oracle):
     capi, ctx, torch = gpu
     s = synth.make_wholebody_states(67, "trot")
