@@ -55,3 +55,23 @@ def test_live_bench_line_follows_the_contract():
     assert len(lines) == 1, "bench.py must print exactly one line"
     d = check(lines[0])
     assert d["steps"] == 20 and d["warmup"] == 3 and d["config"]["all_status_ok"] is True
+
+
+def test_profile_collection_names_exist_in_the_sources():
+    """tools/collect_profiles.py keys its PMC records by kernel name and bench.py looks them up by the same strings: every
+    kernel named there must be a __global__ function of the library, and the committed index must carry one record per
+    workload of the list."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("collect_profiles", os.path.join(ROOT, "tools", "collect_profiles.py"))
+    cp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cp)
+    csrc = os.path.join(ROOT, "quadruped_locomotion_amd", "csrc")
+    text = "".join(open(os.path.join(csrc, f)).read() for f in os.listdir(csrc) if f.endswith(".hip"))
+    kernels = set(re.findall(r"__global__[^;{]*?\bvoid\s+(\w+)\s*\(", text))
+    for name, kernel, batch, args in cp.WORKLOADS:
+        assert kernel in kernels, kernel
+    idx = json.load(open(os.path.join(ROOT, "profiles", "r2", "pmc_index.json")))
+    have = {(r["kernel"], r["batch"], r["workload"]) for r in idx["records"]}
+    assert have == {(k, b, n) for n, k, b, _ in cp.WORKLOADS}
+    assert all("fetch_bytes" in r and "write_bytes" in r and "valu_insts" in r for r in idx["records"])
