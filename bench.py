@@ -558,9 +558,7 @@ def main():
         fence()
         t0 = time.perf_counter()
         if graph is not None:
-            e0.record()
-            graph.replay()
-            e1.record()
+            graph.replay()  # nothing else inside the timed region: the event pair is taken on a replay of its own below
         else:
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
             for k in range(args.steps):
@@ -574,9 +572,13 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         if graph is not None:
-            # HIP events around the replay: K kernels back to back, so this average includes the ~1.5 us
+            # HIP events around an untimed replay: K kernels back to back, so this average includes the
             # kernel-to-kernel boundary (an upper bound of the pure kernel duration; the rocprofv3 summary under
             # profiles/ has the exact figure)
+            e0.record()
+            graph.replay()
+            e1.record()
+            fence()
             kernel_ms = e0.elapsed_time(e1) / args.steps
         else:
             kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
