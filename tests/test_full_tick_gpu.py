@@ -146,6 +146,27 @@ def test_full_tick_large_batches_take_the_same_results_through_separate_launches
             assert np.array_equal(io[k], whole[k][lo:hi]), (k, lo)
 
 
+def test_full_tick_on_the_one_lane_balance_kernels():
+    """qlamd_set_robots_per_wave(16 | 64) swaps the tick's balance stage onto the one-lane-per-robot kernels (an
+    independent second implementation of the QP): same statuses and state, efforts to the torque tolerance."""
+    from quadruped_locomotion_amd import capi
+    B, period = 512, 0.0025
+    msgs, tin = make_tick_inputs(B, 1, truncated=(9,))
+    ref = dict(tin, **fresh_state(B, capi))
+    capi.full_tick(capi.Context(), ref, period)
+    for rpw in (16, 64):
+        ctx = capi.Context()
+        ctx.set_robots_per_wave(rpw)
+        io = dict(tin, **fresh_state(B, capi))
+        capi.full_tick(ctx, io, period)
+        for k in PERSIST + ("status", "message_status", "leg_state_code"):
+            if k in ("pid_error_last", "pid_error_integral"):
+                assert np.abs(io[k] - ref[k]).max() < 1e-12, k
+            else:
+                assert np.array_equal(io[k], ref[k]), k
+        assert np.abs(io["joint_effort"] - ref["joint_effort"]).max() < TAU_TOL
+
+
 def test_full_tick_keeps_the_previous_efforts_of_a_failed_solve(oracle):
     """QLAMD_ON_FAILURE_KEEP = the reference's 'VMC compute failed' branch (ros_balance_controller.cpp:418-424,441-454):
     the support legs of a robot whose solve fails are commanded the efforts of the tick before.  The force QP is always
