@@ -27,15 +27,17 @@ static void rpy_to_mat(const double rpy[3], double *R) {
 }
 
 /* Recursive Newton-Euler in base coordinates for a fixed-base chain; the fixed foot link rides on
- * link 3 (RBDL merges fixed bodies into their movable parent). */
-void oracle_leg_rnea(int leg, const double q[3], const double qd[3], const double qdd[3], const double g[3],
-                     double tau[3]) {
+ * link 3 (RBDL merges fixed bodies into their movable parent).  The chain is given segment by segment as the URDF
+ * gives it (joint origin xyz / rpy, link mass, centre of mass and inertia about it in the link frame). */
+void oracle_chain_rnea(const double joint_xyz[4][3], const double joint_rpy[4][3], const double link_mass[4],
+                       const double link_com[4][3], const double link_inertia[4][6], const double q[3],
+                       const double qd[3], const double qdd[3], const double g[3], double tau[3]) {
   double R[4][9], p[4][3];
   {
     double Rc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pc[3] = {0, 0, 0};
     for (int k = 0; k < 4; k++) {
       double R0[9], Rs[9], Rn[9], rp[3];
-      rpy_to_mat(QLAMD_JOINT_RPY[leg][k], R0);
+      rpy_to_mat(joint_rpy[k], R0);
       if (k < 3) {
         const double c = cos(q[k]), s = sin(q[k]);
         const double Rz[9] = {c, -s, 0, s, c, 0, 0, 0, 1};
@@ -43,7 +45,7 @@ void oracle_leg_rnea(int leg, const double q[3], const double qd[3], const doubl
       } else {
         memcpy(Rs, R0, sizeof(Rs));
       }
-      mat3_vec(Rc, QLAMD_JOINT_XYZ[leg][k], rp);
+      mat3_vec(Rc, joint_xyz[k], rp);
       for (int i = 0; i < 3; i++) pc[i] += rp[i];
       mat3_mul(Rc, Rs, Rn);
       memcpy(Rc, Rn, sizeof(Rc));
@@ -78,13 +80,13 @@ void oracle_leg_rnea(int leg, const double q[3], const double qd[3], const doubl
   for (int b = 0; b < 4; b++) {
     const int i = b < 3 ? b : 2;
     double rc[3], dc[3], axd[3], wxd[3], wxwxd[3], acc[3];
-    mat3_vec(R[b], QLAMD_LINK_COM[leg][b], rc);
+    mat3_vec(R[b], link_com[b], rc);
     for (int k = 0; k < 3; k++) { c[b][k] = p[b][k] + rc[k]; dc[k] = c[b][k] - p[i][k]; }
     cross3(al[i], dc, axd);
     cross3(w[i], dc, wxd);
     cross3(w[i], wxd, wxwxd);
-    for (int k = 0; k < 3; k++) { acc[k] = a[i][k] + axd[k] + wxwxd[k]; F[b][k] = QLAMD_LINK_MASS[leg][b] * acc[k]; }
-    const double *I6 = QLAMD_LINK_INERTIA[leg][b]; /* ixx ixy ixz iyy iyz izz */
+    for (int k = 0; k < 3; k++) { acc[k] = a[i][k] + axd[k] + wxwxd[k]; F[b][k] = link_mass[b] * acc[k]; }
+    const double *I6 = link_inertia[b]; /* ixx ixy ixz iyy iyz izz */
     const double Il[9] = {I6[0], I6[1], I6[2], I6[1], I6[3], I6[4], I6[2], I6[4], I6[5]};
     double T[9], Rt[9], Ib[9], Ia[3], Iw[3], wIw[3];
     for (int r = 0; r < 3; r++) for (int s = 0; s < 3; s++) Rt[3 * r + s] = R[b][3 * s + r];
@@ -104,6 +106,20 @@ void oracle_leg_rnea(int leg, const double q[3], const double qd[3], const doubl
     }
     tau[i] = acc;
   }
+}
+
+void oracle_chain_rnea_rows(long rows, const double joint_xyz[4][3], const double joint_rpy[4][3],
+                            const double link_mass[4], const double link_com[4][3], const double link_inertia[4][6],
+                            const double *q, const double *qd, const double *qdd, const double g[3], double *tau) {
+  for (long i = 0; i < rows; i++)
+    oracle_chain_rnea(joint_xyz, joint_rpy, link_mass, link_com, link_inertia, q + 3 * i, qd + 3 * i, qdd + 3 * i, g,
+                      tau + 3 * i);
+}
+
+void oracle_leg_rnea(int leg, const double q[3], const double qd[3], const double qdd[3], const double g[3],
+                     double tau[3]) {
+  oracle_chain_rnea(QLAMD_JOINT_XYZ[leg], QLAMD_JOINT_RPY[leg], QLAMD_LINK_MASS[leg], QLAMD_LINK_COM[leg],
+                    QLAMD_LINK_INERTIA[leg], q, qd, qdd, g, tau);
 }
 
 void oracle_swing_default_params(oracle_swing_params *p) {

@@ -26,6 +26,20 @@ extern "C" {
 void oracle_leg_rnea(int leg, const double q[3], const double qd[3], const double qdd[3], const double g[3],
                      double tau[3]);
 
+/* The same recursion on any 3-joint chain (+ fixed end link), segment k given as the URDF gives it.  This is the
+ * entry that PINS the recursion: on the 3-link model of MyRobotSolver::model_initialization
+ * (model_test_header.cpp:183-222) it reproduces the 10 001 torques RBDL's InverseDynamics wrote into
+ * single_leg_test/DataFloder/TauofInversedynamics.txt (IDynamicsCalculation, :277-301) to their print precision
+ * (tests/golden/rbdl_leg_id.npz, tests/test_rbdl_pin.py). */
+void oracle_chain_rnea(const double joint_xyz[4][3], const double joint_rpy[4][3], const double link_mass[4],
+                       const double link_com[4][3], const double link_inertia[4][6], const double q[3],
+                       const double qd[3], const double qdd[3], const double g[3], double tau[3]);
+
+/* rows of (q, qd, qdd) [rows][3] -> tau [rows][3] */
+void oracle_chain_rnea_rows(long rows, const double joint_xyz[4][3], const double joint_rpy[4][3],
+                            const double link_mass[4], const double link_com[4][3], const double link_inertia[4][6],
+                            const double *q, const double *qd, const double *qdd, const double g[3], double *tau);
+
 typedef struct {
   double kp[3], kd[3];    /* 300 / 20 each, controller_gains.yaml:42-51 */
   double period;          /* control period (0.0025 s, balance_controller_manager.cpp:48) */

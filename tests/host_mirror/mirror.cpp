@@ -220,6 +220,17 @@ extern "C" void mirror_swing_leg(int leg, const SwingParamsDev *SP, const double
   swing_leg_torque(P.legtab + kTabPerLeg * leg, *SP, q_id, q, qd, qd_old, tp, tv, tau);
 }
 
+// the same arithmetic on a caller-given robot model (tests/test_rbdl_pin.py: the reference's RBDL test model)
+extern "C" void mirror_swing_leg_model(const qlamd_robot_model *model, int leg, const SwingParamsDev *SP, const double *q_id,
+                                       const double *q, const double *qd, const double *qd_old, const double *tp,
+                                       const double *tv, double *tau) {
+  qlamd_balance_params prm;
+  default_balance_params(&prm);
+  DeviceParams P;
+  build_device_params(prm, *model, &P);
+  swing_leg_torque(P.legtab + kTabPerLeg * leg, *SP, q_id, q, qd, qd_old, tp, tv, tau);
+}
+
 extern "C" void mirror_swing_branch_leg(int leg, int leg_mode, const SwingParamsDev *SP, const PidParamsDev *pid,
                                         const double *quat, const double *q_id, const double *q, const double *qd,
                                         const double *qd_old, const double *tp, const double *tv, const double *cmd,
