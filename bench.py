@@ -8,7 +8,9 @@ outputs resident in HBM.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--gait static|trot] [--batch B]
 
-N = 1: BASELINE configs[1], batch = 4096 robots, static 4-contact stance.
+N = 1: BASELINE configs[1], batch = 4096 robots, static 4-contact stance with SURVEY.md 8(d)'s literal tracking errors
+       (0.02 m / 0.05 rad / 0.1); the same line carries an `also` object with the other presets measured in the same
+       process (static-calm, trot), each with its kernel time, roofline fraction and PMC provenance.
 N > 1: BASELINE configs[3], 8192 trot robots per GPU (65 536 on 8 GPUs), one rank per GPU; every rank
 solves its own contiguous shard (weak scaling: robots are independent, no data-path collective) and the
 joint torques are all-gathered over RCCL/xGMI for result collection, as the north star asks.  Started
@@ -75,9 +77,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=None, help="robots per GPU (default 4096 with one GPU, 8192 with several)")
     ap.add_argument("--gait", default=None, choices=["static", "trot"], help="default static with one GPU, trot with several")
-    ap.add_argument("--errors", default="calm", choices=["calm", "survey"],
-                    help="static stance tracking errors: calm = 0.004 m / 0.005 rad / 0.01 m/s (default, DESIGN.md 2), "
-                         "survey = SURVEY.md 8(d)'s literal 0.02 / 0.05 / 0.1")
+    ap.add_argument("--errors", default="survey", choices=["calm", "survey"],
+                    help="static stance tracking errors: survey = SURVEY.md 8(d)'s literal 0.02 m / 0.05 rad / 0.1 (default), "
+                         "calm = 0.004 / 0.005 / 0.01 (a robot holding its pose: constraints mostly inactive, DESIGN.md 2)")
+    ap.add_argument("--no-also", action="store_true", help="skip the `also` object (the other presets of the headline workload)")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--replays", type=int, default=11,
                     help="timed samples of exactly K steps each (barrier + synchronize on both sides); the median is reported")
     ap.add_argument("--selftest-launcher", action="store_true",
@@ -110,13 +114,11 @@ def parse():
 def launch_ranks(args):
     """`python bench.py --gpus N` from a bare shell: start the N ranks as a child torch.distributed.run and exit with
     its code.  This parent process must not touch any GPU API (it only counts on the child for that)."""
-    import socket
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the c10d rendezvous picks a free port itself and hands it to the ranks (nothing bound and released
+    # here for another process to take in between)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
@@ -132,20 +134,41 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(state, seconds):
-    """The oracle (plain-C restatement of the reference path) on the host cores of this box, same workload, bounded
-    sample.  Reported next to the GPU number; not the target.  Every pass count runs inside ONE OpenMP region (threads
-    keep their block of robots, no fork / join between passes, active waiting), timed in C between two barriers; all
-    visible cores are tried as well as smaller counts (a container's CPU quota can be below the visible count) and the
-    fastest is `value`; the single-thread and all-core rates are stated beside it."""
-    os.environ.setdefault("OMP_WAIT_POLICY", "active")
-    os.environ.setdefault("OMP_PROC_BIND", "false")
+def cpu_quota_cores():
+    """Cores the container's CPU quota serves (cgroup v2 cpu.max, v1 cpu.cfs_quota_us), or None without a quota."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+CPU_PROBE_SECONDS = 1.5
+
+
+def cpu_baseline_measure(gait, errors, batch, seconds):
+    """Runs in the child process started by cpu_baseline() (numpy + the oracle only, threads pinned by the environment
+    it was started with).  Every thread count is measured for at least CPU_PROBE_SECONDS -- long enough for a CPU quota
+    to throttle an oversubscribed count -- inside ONE OpenMP region (threads keep their block of robots, no fork / join
+    between passes), timed in C between two barriers.  `value` is the best SUSTAINED rate: the fastest count of the
+    sweep is run again for `seconds`, and if that falls more than 10 % short of its probe the runner-up is given the
+    same chance; the larger of the long runs is reported."""
     from oracle import oracle as O
+    from quadruped_locomotion_amd import synth
+    state = synth.make_states(batch, gait, errors=errors)
     visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    B = state["q"].shape[0]
-    # at least 64 robots per thread and pass: tile the batch for many-core hosts (same robots, same work per robot)
-    tile = max(1, -(-64 * visible // B))
-    big = {k: (np_tile(v, tile)) for k, v in state.items()}
+    quota = cpu_quota_cores()
+    # thread counts beyond twice what the quota serves only measure the throttle
+    limit = visible if quota is None else max(1, min(visible, int(2 * quota + 0.5)))
+    B = batch
+    tile = max(1, -(-64 * limit // B))       # at least 64 robots per thread and pass (same robots, same work per robot)
+    big = {k: np_tile(v, tile) for k, v in state.items()}
     Bb = B * tile
 
     def rate(threads, budget):
@@ -155,17 +178,43 @@ def cpu_baseline(state, seconds):
         dt = O.balance_batch_repeat(big, passes, threads)
         return passes * Bb / dt, passes, dt
 
-    cands = sorted({1, 2, 4, 8, 16, 32, 64, 128, visible} | ({visible // 2} if visible >= 4 else set()))
-    cands = [c for c in cands if 1 <= c <= visible]
-    probe = {c: rate(c, 0.3)[0] for c in cands}
-    best = max(probe, key=probe.get)
-    value, n, dt = rate(best, seconds)
+    cands = sorted({1, 2, 4, 8, 16, 32, 64, 128, limit} | ({limit // 2} if limit >= 4 else set()) |
+                   ({int(quota)} if quota and quota >= 1 else set()))
+    cands = [c for c in cands if 1 <= c <= limit]
+    probe = {c: rate(c, CPU_PROBE_SECONDS)[0] for c in cands}
+    order = sorted(cands, key=lambda c: -probe[c])
+    sustained = {}
+    value, best, n, dt = 0.0, order[0], 0, 0.0
+    for c in order[:2]:
+        v, nn, d = rate(c, seconds if c == order[0] else 0.5 * seconds)
+        sustained[str(c)] = v
+        if v > value:
+            value, best, n, dt = v, c, nn, d
+        if value >= 0.9 * max(probe.values()):
+            break
     return {"value": value, "unit": "control-step QP solves/s", "cores": best, "kind": "port",
-            "single_thread_value": probe.get(1), "all_visible_cores_value": probe.get(visible),
-            "per_core_value": value / best, "visible_cores": visible, "cpu_model": cpu_model(),
-            "thread_sweep": {str(c): probe[c] for c in cands},
+            "single_thread_value": probe.get(1), "per_core_value": value / best, "visible_cores": visible,
+            "quota_cores": quota, "cpu_model": cpu_model(),
+            "thread_sweep": {str(c): probe[c] for c in cands}, "thread_sweep_seconds_each": CPU_PROBE_SECONDS,
+            "sustained": sustained,
+            "threads": "OMP_PLACES=%s OMP_PROC_BIND=%s OMP_WAIT_POLICY=%s" % tuple(
+                os.environ.get(k, "-") for k in ("OMP_PLACES", "OMP_PROC_BIND", "OMP_WAIT_POLICY")),
             "sample": "%d passes over the same %d-robot batch%s (%.1f s) inside one OpenMP region, robots blocked over "
-                      "%d threads (fastest of %s)" % (n, B, " tiled x%d" % tile if tile > 1 else "", dt, best, cands)}
+                      "%d pinned threads; best sustained rate of %s" % (n, B, " tiled x%d" % tile if tile > 1 else "", dt,
+                                                                        best, cands)}
+
+
+def cpu_baseline(gait, errors, batch, seconds):
+    """The oracle (plain-C restatement of the reference path, kind "port") on the host cores of this box, same workload,
+    bounded sample.  Reported next to the GPU number; not the target.  Measured in a child process of its own, started
+    before this process touches the GPU: libgomp reads OMP_PLACES / OMP_PROC_BIND once, when it is loaded, and `import
+    torch` loads it -- so the pinning has to be in the environment of a fresh process."""
+    import subprocess
+    env = dict(os.environ, OMP_PLACES="cores", OMP_PROC_BIND="close", OMP_WAIT_POLICY="passive", OMP_DYNAMIC="false")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--gait", gait, "--errors", errors,
+           "--batch", str(batch), "--cpu-seconds", str(seconds)]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, check=True).stdout.decode()
+    return json.loads(out.strip().splitlines()[-1])
 
 
 def np_tile(v, tile):
@@ -232,7 +281,8 @@ def bench_pose_sqp(args):
         "config": {"workload": "batch=%d pose optimisations, 5 SQP iterations x inner Goldfarb-Idnani QP "
                                "(n=6, m=8, dummy equality)" % B, "all_status_ok": bool((out[2] == 0).all().item())},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": int(rec["fetch_bytes"] + rec["write_bytes"]) if rec else None,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": int(rec["fetch_bytes"] + rec["write_bytes"]) if rec and "fetch_bytes" in rec and "write_bytes" in rec else None,
                      "traffic_source": prov, "kernel": "pose_sqp_coop_kernel", "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": algo},
         **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
@@ -411,6 +461,9 @@ def selftest_launcher(args):
 
 def main():
     args = parse()
+    if args.cpu_baseline_child:
+        print(json.dumps(cpu_baseline_measure(args.gait, args.errors, args.batch, args.cpu_seconds)), flush=True)
+        return None
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare shell: this process stays off the GPU and starts the ranks as a child
         sys.exit(launch_ranks(args))
@@ -422,17 +475,23 @@ def main():
         return bench_pose_sqp(args)
     if args.workload in ("wholebody", "wholebody_dynamics"):
         return bench_wholebody(args)
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-
-    from quadruped_locomotion_amd import capi, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # rank 0 at N = 1 only: the CPU baseline, in a pinned child process, BEFORE this process touches the GPU
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline(args.gait, args.errors, args.batch, args.cpu_seconds)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from quadruped_locomotion_amd import capi, synth
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback in the product path)")
     torch.cuda.set_device(local_rank)
@@ -456,29 +515,11 @@ def main():
         assert ranks_seen == world == dist.get_world_size(), "RCCL saw %d ranks, expected %d" % (ranks_seen, world)
 
     B = args.batch
-    # rank r owns robots [r*B, (r+1)*B) of the global batch (contiguous shards)
-    state = synth.make_states(B, args.gait, offset=rank * B, errors=args.errors)
     ctx = capi.Context(device=local_rank)
     if args.rpw:
         ctx.set_robots_per_wave(args.rpw)
-    d = capi.to_device(state, dev)
-    tau = [torch.zeros(B, 12, dtype=torch.float64, device=dev) for _ in range(2)]
-    status = torch.full((B,), -1, dtype=torch.int32, device=dev)
     gather = collective and not args.no_gather
-    gathered = [torch.zeros(world * B, 12, dtype=torch.float64, device=dev) for _ in range(2)] if gather else None
     stream = torch.cuda.current_stream().cuda_stream
-
-    def step(k, with_gather, events=None):
-        buf = k & 1
-        if events is not None:
-            events[0].record()
-        ctx.balance_solve_device(d, tau[buf], None, status, stream=stream)
-        if events is not None:
-            events[1].record()
-        if with_gather:
-            # result collection only; overlaps with the next step's solve (double-buffered)
-            return dist.all_gather_into_tensor(gathered[buf], tau[buf], async_op=True)
-        return None
 
     def fence():
         torch.cuda.synchronize()
@@ -486,144 +527,198 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        w = step(k, gather)
-        if w is not None:
-            w.wait()
-    fence()
+    def run_preset(gait, errors, with_gather, replays, second_without_gather):
+        """One workload preset on this rank's shard: warm-up, K steps captured as one hipGraph, `replays` timed samples."""
+        # rank r owns robots [r*B, (r+1)*B) of the global batch (contiguous shards, SURVEY.md 8e)
+        state = synth.make_states(B, gait, offset=rank * B, errors=errors)
+        d = capi.to_device(state, dev)
+        tau = [torch.zeros(B, 12, dtype=torch.float64, device=dev) for _ in range(2)]
+        status = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        gathered = [torch.zeros(world * B, 12, dtype=torch.float64, device=dev) for _ in range(2)] if with_gather else None
 
-    # ---- K steps as one hipGraph ----------------------------------------------------------------
-    # The K steps (solve, plus the all-gather of the torques when there are several ranks) are captured once into a
-    # hipGraph (solves on one stream, gathers on a second one) and replayed: a step is a few tens of microseconds,
-    # comparable to one eager launch from Python.  If capture fails the steps are launched eagerly, the all-gather of
-    # step k then overlapping the solve of step k+1.
-    def capture(with_gather):
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                cap = torch.cuda.current_stream().cuda_stream
-                # The gathers go to a second captured stream: gather k (reads tau[k & 1]) overlaps solve k+1 (writes
-                # the other buffer); solve k+2 waits for gather k before it reuses the buffer.  (With a single rank
-                # the "gather" is a local copy and the extra graph edges cost more than they hide -- measured 27.8 vs
-                # 22.6 us per step -- so the self-test keeps everything on one stream.)
-                overlap = with_gather and (world > 1 or args.overlap_gather)
-                comm = torch.cuda.Stream() if overlap else None
-                gathered_ev = [None, None]
-                for k in range(args.steps):
-                    buf = k & 1
-                    if overlap and gathered_ev[buf] is not None:
-                        side.wait_event(gathered_ev[buf])
-                    ctx.balance_solve_device(d, tau[buf], None, status, stream=cap)
-                    if overlap:  # RCCL collectives are capturable; they replay from the graph
-                        solved = torch.cuda.Event()
-                        solved.record(side)
-                        comm.wait_event(solved)
-                        with torch.cuda.stream(comm):
-                            dist.all_gather_into_tensor(gathered[buf], tau[buf])
-                            gathered_ev[buf] = torch.cuda.Event()
-                            gathered_ev[buf].record(comm)
-                    elif with_gather:
-                        dist.all_gather_into_tensor(gathered[buf], tau[buf])
-                if overlap:
-                    side.wait_stream(comm)  # join before the capture ends
-        torch.cuda.current_stream().wait_stream(side)
-        return graph
+        def step(k, wg, events=None):
+            buf = k & 1
+            if events is not None:
+                events[0].record()
+            ctx.balance_solve_device(d, tau[buf], None, status, stream=stream)
+            if events is not None:
+                events[1].record()
+            if wg:
+                # result collection only; overlaps with the next step's solve (double-buffered)
+                return dist.all_gather_into_tensor(gathered[buf], tau[buf], async_op=True)
+            return None
 
-    def build_graph(with_gather):
-        graph = None
-        if not args.no_graph:
-            try:
-                graph = capture(with_gather)
-            except Exception as e:  # pragma: no cover - fall back to eager launches
-                sys.stderr.write("hipGraph capture failed (%s); eager launches\n" % e)
-                graph = None
-            if collective:
-                # every rank must take the same path, or the collectives would not match up
-                okflag = torch.tensor([1 if graph is not None else 0], dtype=torch.int32, device=dev)
-                dist.all_reduce(okflag, op=dist.ReduceOp.MIN)
-                if int(okflag.item()) == 0:
-                    graph = None
-            if graph is not None:
-                graph.replay()  # one untimed replay (instantiation / upload)
-                fence()
-        return graph
-
-    def sample(graph, with_gather):
-        """One timed region: exactly K steps between barrier + synchronize on both sides.  Returns (wall seconds,
-        mean solve-kernel ms from HIP events on the launch stream)."""
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev, pending = [], []
-        fence()
-        t0 = time.perf_counter()
-        if graph is not None:
-            graph.replay()  # nothing else inside the timed region: the event pair is taken on a replay of its own below
-        else:
-            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-            for k in range(args.steps):
-                w = step(k, with_gather, ev[k])
-                if w is not None:
-                    pending.append(w)
-                    if len(pending) > 1:
-                        pending.pop(0).wait()
-            for w in pending:
+        for k in range(args.warmup):
+            w = step(k, with_gather)
+            if w is not None:
                 w.wait()
         fence()
-        elapsed = time.perf_counter() - t0
-        if graph is not None:
-            # HIP events around an untimed replay: K kernels back to back, so this average includes the
-            # kernel-to-kernel boundary (an upper bound of the pure kernel duration; the rocprofv3 summary under
-            # profiles/ has the exact figure)
-            e0.record()
-            graph.replay()
-            e1.record()
+
+        # ---- K steps as one hipGraph ------------------------------------------------------------
+        # The K steps (solve, plus the all-gather of the torques when there are several ranks) are captured once into a
+        # hipGraph (solves on one stream, gathers on a second one) and replayed: a step is a few tens of microseconds,
+        # comparable to one eager launch from Python.  If capture fails the steps are launched eagerly, the all-gather
+        # of step k then overlapping the solve of step k+1.
+        def capture(wg):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    cap = torch.cuda.current_stream().cuda_stream
+                    # The gathers go to a second captured stream: gather k (reads tau[k & 1]) overlaps solve k+1 (writes
+                    # the other buffer); solve k+2 waits for gather k before it reuses the buffer.  (With a single rank
+                    # the "gather" is a local copy and the extra graph edges cost more than they hide -- measured 27.8
+                    # vs 22.6 us per step -- so the self-test keeps everything on one stream unless asked.)
+                    overlap = wg and (world > 1 or args.overlap_gather)
+                    comm = torch.cuda.Stream() if overlap else None
+                    gathered_ev = [None, None]
+                    for k in range(args.steps):
+                        buf = k & 1
+                        if overlap and gathered_ev[buf] is not None:
+                            side.wait_event(gathered_ev[buf])
+                        ctx.balance_solve_device(d, tau[buf], None, status, stream=cap)
+                        if overlap:  # RCCL collectives are capturable; they replay from the graph
+                            solved = torch.cuda.Event()
+                            solved.record(side)
+                            comm.wait_event(solved)
+                            with torch.cuda.stream(comm):
+                                dist.all_gather_into_tensor(gathered[buf], tau[buf])
+                                gathered_ev[buf] = torch.cuda.Event()
+                                gathered_ev[buf].record(comm)
+                        elif wg:
+                            dist.all_gather_into_tensor(gathered[buf], tau[buf])
+                    if overlap:
+                        side.wait_stream(comm)  # join before the capture ends
+            torch.cuda.current_stream().wait_stream(side)
+            return graph, overlap
+
+        def build_graph(wg):
+            graph, overlap = None, False
+            if not args.no_graph:
+                try:
+                    graph, overlap = capture(wg)
+                except Exception as e:  # pragma: no cover - fall back to eager launches
+                    sys.stderr.write("hipGraph capture failed (%s); eager launches\n" % e)
+                    graph = None
+                if collective:
+                    # every rank must take the same path, or the collectives would not match up
+                    okflag = torch.tensor([1 if graph is not None else 0], dtype=torch.int32, device=dev)
+                    dist.all_reduce(okflag, op=dist.ReduceOp.MIN)
+                    if int(okflag.item()) == 0:
+                        graph = None
+                if graph is not None:
+                    graph.replay()  # one untimed replay (instantiation / upload)
+                    fence()
+            return graph, overlap
+
+        def sample(graph, wg):
+            """One timed region: exactly K steps between barrier + synchronize on both sides.  Returns (wall seconds,
+            mean solve-kernel ms from HIP events on the launch stream)."""
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev, pending = [], []
             fence()
-            kernel_ms = e0.elapsed_time(e1) / args.steps
-        else:
-            kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-        return elapsed, kernel_ms
+            t0 = time.perf_counter()
+            if graph is not None:
+                graph.replay()  # nothing else inside the timed region: the event pair is taken on a replay of its own below
+            else:
+                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+                for k in range(args.steps):
+                    w = step(k, wg, ev[k])
+                    if w is not None:
+                        pending.append(w)
+                        if len(pending) > 1:
+                            pending.pop(0).wait()
+                for w in pending:
+                    w.wait()
+            fence()
+            elapsed = time.perf_counter() - t0
+            if graph is not None:
+                # HIP events around an untimed replay: K kernels back to back, so this average includes the
+                # kernel-to-kernel boundary (an upper bound of the pure kernel duration; the rocprofv3 summary under
+                # profiles/ has the exact figure)
+                e0.record()
+                graph.replay()
+                e1.record()
+                fence()
+                kernel_ms = e0.elapsed_time(e1) / args.steps
+            else:
+                kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+            return elapsed, kernel_ms
 
-    def measure(with_gather):
-        graph = build_graph(with_gather)
-        n = max(1, args.replays)
-        el = np.zeros(n)
-        km = np.zeros(n)
-        for r in range(n):
-            el[r], km[r] = sample(graph, with_gather)
-        if collective:  # a sample lasts as long as its slowest rank
-            t = torch.from_numpy(el).to(dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = t.cpu().numpy()
-        pick = int(np.argsort(el)[n // 2])  # the median sample is the timed region reported
-        return dict(elapsed=float(el[pick]), kernel_ms=float(np.median(km)), samples_ms=[float(x * 1e3) for x in el],
-                    graph=graph is not None)
+        def measure(wg):
+            graph, overlap = build_graph(wg)
+            n = max(1, replays)
+            el = np.zeros(n)
+            km = np.zeros(n)
+            for r in range(n):
+                el[r], km[r] = sample(graph, wg)
+            if collective:  # a sample lasts as long as its slowest rank
+                t = torch.from_numpy(el).to(dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = t.cpu().numpy()
+            pick = int(np.argsort(el)[n // 2])  # the median sample is the timed region reported
+            return dict(elapsed=float(el[pick]), kernel_ms=float(np.median(km)), samples_ms=[float(x * 1e3) for x in el],
+                        graph=graph is not None, overlap=overlap)
 
-    res = measure(gather)
-    res_plain = measure(False) if (gather and world > 1) else None
+        res = measure(with_gather)
+        res["plain"] = measure(False) if (with_gather and second_without_gather) else None
+        if collective and rank == 0 and args.steps > 0 and with_gather:
+            # the gathered buffer holds every rank's torques in rank order
+            last = (args.steps - 1) & 1
+            assert torch.equal(gathered[last][rank * B:(rank + 1) * B], tau[last]), "all-gather layout"
+            res["gather_layout_ok"] = True
+        ok = bool((status.cpu().numpy() == 0).all())
+        if collective:
+            okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            ok = bool(okt.item())
+        res["ok"] = ok
+        return res
 
-    if collective and rank == 0 and args.steps > 0 and gather:  # the gathered buffer holds every rank's torques in rank order
-        last = (args.steps - 1) & 1
-        assert torch.equal(gathered[last][:B], tau[last]), "all-gather layout"
-
-    st = status.cpu().numpy()
-    ok = bool((st == 0).all())
-    if collective:
-        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        ok = bool(okt.item())
-
-    if rank == 0:
-        elapsed, kernel_ms = res["elapsed"], res["kernel_ms"]
-        total = world * B * args.steps
-        value = total / elapsed
+    def roofline_of(res, gait, errors):
+        """roofline and valu_issue objects of one preset from its kernel time and the committed PMC record."""
+        kernel_ms = res["kernel_ms"]
         algo_bytes = ALGO_BYTES_PER_STEP * B
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        wl = "static-%s" % args.errors if args.gait == "static" else "trot"
+        wl = "static-%s" % errors if gait == "static" else "trot"
         rec, prov = pmc_record("balance_coop_kernel", B, wl)
+        have = rec is not None and "fetch_bytes" in rec and "write_bytes" in rec
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": int(rec["fetch_bytes"] + rec["write_bytes"]) if have else None, "traffic_source": prov,
+                "traffic_rule": rec.get("fetch_size_rule") if have else None,
+                "kernel": "balance_coop_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes}
+        valu = None
+        if rec and rec.get("valu_insts"):
+            insts = rec["valu_insts"]
+            valu = {"insts_per_launch": insts, "frac": insts * 4.0 / (N_SIMD * kernel_ms * 1e-3 * SHADER_CLOCK_HZ), "source": prov,
+                    "note": "SQ_INSTS_VALU (rocprofv3 --pmc) x 4 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz)"}
+        return roof, valu
+
+    res = run_preset(args.gait, args.errors, gather, args.replays, world > 1)
+
+    # the other presets of the headline workload, same process, same batch (one GPU only; fewer samples each)
+    also = None
+    if world == 1 and not collective and not args.no_also:
+        also = {}
+        for gait, errors in (("static", "calm"), ("static", "survey"), ("trot", "survey")):
+            if gait == args.gait and (gait == "trot" or errors == args.errors):
+                continue
+            r = run_preset(gait, errors, False, min(args.replays, 5), False)
+            roof, valu = roofline_of(r, gait, errors)
+            also["static-%s" % errors if gait == "static" else "trot"] = {
+                "value": B * args.steps / r["elapsed"], "ms_per_step": r["elapsed"] / args.steps * 1e3,
+                "kernel_ms": r["kernel_ms"], "tracking_error": list(synth.tracking_error(gait, errors)),
+                "all_status_ok": r["ok"], "roofline_frac": roof["frac"], "traffic": roof["traffic"],
+                "valu_issue_frac": valu["frac"] if valu else None, "pmc_source": roof["traffic_source"]}
+
+    if rank == 0:
+        elapsed = res["elapsed"]
+        total = world * B * args.steps
+        roof, valu = roofline_of(res, args.gait, args.errors)
         line = {
             "metric": "control-step QP solves/sec (18-DoF, 4-contact) at 1/2/4/8 MI355X",
-            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": total / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "batch=%d robots per GPU, %s, one balance-controller control step "
@@ -632,32 +727,29 @@ def main():
                                       else "trot gait (2<->4 contacts)"),
                        "robots_per_gpu": B, "global_batch": world * B, "gait": args.gait, "seed": synth.SEED,
                        "tracking_error": list(synth.tracking_error(args.gait, args.errors)),
-                       "tracking_error_note": "half-widths of the uniform position (m) / rotation-vector (rad) / twist errors; "
-                                              "SURVEY.md 8(d) lists 0.02 / 0.05 / 0.1 (--errors survey), the static default is "
-                                              "smaller so that constraints are mostly inactive (DESIGN.md 2)",
+                       "tracking_error_note": "half-widths of the uniform position (m) / rotation-vector (rad) / twist errors: "
+                                              "SURVEY.md 8(d)'s 0.02 / 0.05 / 0.1 unless --errors calm (static only; `also` "
+                                              "carries the other presets)",
                        "result_collection": "rccl all_gather of torques" if gather else
                        ("none (--no-gather)" if collective else "none (single GPU)"),
                        "rccl_ranks": ranks_seen if collective else None,
                        "launch": "hipGraph of K steps" if res["graph"] else "eager",
+                       "gather_stream": ("second captured stream" if res["overlap"] else "solve stream") if gather else None,
+                       "gather_layout_ok": res.get("gather_layout_ok"),
                        "timed_region": "median of %d samples of exactly K steps, each between barrier + synchronize" % len(res["samples_ms"]),
                        "samples_ms": res["samples_ms"],
-                       "all_status_ok": ok},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": int(rec["fetch_bytes"] + rec["write_bytes"]) if rec else None, "traffic_source": prov,
-                         "kernel": "balance_coop_kernel", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": algo_bytes},
+                       "all_status_ok": res["ok"]},
+            "roofline": roof,
         }
-        if res_plain is not None:
-            line["without_gather"] = {"value": total / res_plain["elapsed"], "ms_per_step": res_plain["elapsed"] / args.steps * 1e3,
-                                      "samples_ms": res_plain["samples_ms"]}
-        if rec and rec.get("valu_insts"):
-            insts = rec["valu_insts"]
-            line["valu_issue"] = {"insts_per_launch": insts, "frac": insts * 4.0 / (N_SIMD * kernel_ms * 1e-3 * SHADER_CLOCK_HZ),
-                                  "source": prov,
-                                  "note": "SQ_INSTS_VALU (rocprofv3 --pmc) x 4 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz)"}
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(state, args.cpu_seconds)
+        if res["plain"] is not None:
+            line["without_gather"] = {"value": total / res["plain"]["elapsed"], "ms_per_step": res["plain"]["elapsed"] / args.steps * 1e3,
+                                      "samples_ms": res["plain"]["samples_ms"]}
+        if valu:
+            line["valu_issue"] = valu
+        if also is not None:
+            line["also"] = also
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
         os.write(json_fd, (json.dumps(line) + "\n").encode())
 
     if collective:

@@ -49,6 +49,11 @@ extern "C" {
 #define QLAMD_STATUS_NO_COMMAND 4     /* whole tick only: no well-formed command message has reached this robot yet;
                                          nothing of the robot was read or written (the reference's update() runs on
                                          the last command baseCommandCallback stored, ros_balance_controller.cpp:761) */
+#define QLAMD_STATUS_DEPENDENT_EQUALITY 5 /* qlamd_qp_solve_batch with p = 2 only: the second equality column is all-zero
+                                         or linearly dependent on the first and was left out; x is the solution of the
+                                         problem without it.  (solve_quadprog ignores add_constraint's result there,
+                                         QuadProg++.cc:203-209, and carries on with R_qq ~ 0: that artefact is not
+                                         reproduced, it is reported.) */
 
 /* ---- where caller buffers live ------------------------------------------ */
 #define QLAMD_MEM_DEVICE 0            /* device pointers, used in place, async on `stream` */
@@ -245,7 +250,8 @@ int qlamd_leg_kinematics_batch(qlamd_context *ctx, const double *joint_position,
  * (qp_solver/src/quadraticproblemsolver.cpp:65-97; its wrapper passes CI = -A', ci0 = b for A x <= b,
  * :164).  The Goldfarb-Idnani iteration is the reference's, including its treatment of an all-zero
  * equality column when p = 1 (with p = 2 both columns have to be genuine, linearly independent normals: an
- * all-zero or dependent second column is ignored).  G is not modified.
+ * all-zero or dependent second column is left out and the problem's status is QLAMD_STATUS_DEPENDENT_EQUALITY).
+ * G is not modified.
  *   G [B][n][n], g0 [B][n], CE [B][n][p] (NULL if p = 0), ce0 [B][p], CI [B][n][m], ci0 [B][m]
  *   x [B][n] out, objective [B] out or NULL (+inf when infeasible), status [B] out (QLAMD_STATUS_*)
  */

@@ -291,7 +291,9 @@ class Context:
             raise QlamdError(rc, "qlamd_set_robots_per_wave")
 
     # ---- host (numpy) buffers -------------------------------------------------
-    def balance_solve_host(self, state, normals=None, want_forces=True):
+    def balance_solve_host(self, state, normals=None, want_forces=True, tau=None, grf=None):
+        """tau / grf: C-contiguous float64 [B,12] arrays to write into (what QLAMD_ON_FAILURE_KEEP leaves alone is the
+        caller's), fresh zeros otherwise."""
         B = int(np.asarray(state["q"]).reshape(-1, 12).shape[0])
         sb, keep = StateBatch(), []
         for key, field, k in FIELD_OF_KEY:
@@ -304,8 +306,10 @@ class Context:
             nw = np.ascontiguousarray(np.asarray(normals, dtype=np.float64).reshape(B, 12))
             keep.append(nw)
             sb.surface_normal = nw.ctypes.data
-        tau = np.zeros((B, 12))
-        grf = np.zeros((B, 12)) if want_forces else None
+        tau = np.zeros((B, 12)) if tau is None else tau
+        grf = (np.zeros((B, 12)) if grf is None else grf) if want_forces else None
+        for a in (tau, grf):
+            assert a is None or (a.dtype == np.float64 and a.flags["C_CONTIGUOUS"] and a.shape == (B, 12))
         status = np.full(B, -1, dtype=np.int32)
         rc = lib().qlamd_balance_solve_batch(self._h, C.byref(sb), B, tau.ctypes.data,
                                              grf.ctypes.data if want_forces else None, status.ctypes.data,
@@ -386,13 +390,15 @@ def _ptr(a):
     return a.data_ptr() if hasattr(a, "data_ptr") else a.ctypes.data
 
 
-def force_distribution(ctx, q, quat, support, wrench, normals=None, memory=MEM_HOST):
+def force_distribution(ctx, q, quat, support, wrench, normals=None, memory=MEM_HOST, tau=None, grf=None):
     """qlamd_force_distribution_batch with host (numpy) buffers -> (tau, grf, status)."""
     q = np.ascontiguousarray(q, dtype=np.float64); quat = np.ascontiguousarray(quat, dtype=np.float64)
     support = np.ascontiguousarray(support, dtype=np.uint8); wrench = np.ascontiguousarray(wrench, dtype=np.float64)
     normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float64)
     B = q.shape[0]
-    tau = np.zeros((B, 12)); grf = np.zeros((B, 12)); st = np.full(B, -1, dtype=np.int32)
+    tau = np.zeros((B, 12)) if tau is None else tau
+    grf = np.zeros((B, 12)) if grf is None else grf
+    st = np.full(B, -1, dtype=np.int32)
     rc = lib().qlamd_force_distribution_batch(ctx._h, _ptr(q), _ptr(quat), _ptr(support), _ptr(normals), _ptr(wrench), B,
                                               _ptr(tau), _ptr(grf), _ptr(st), memory, None)
     if rc != OK:
@@ -672,13 +678,15 @@ def wholebody_dynamics(ctx, state, gravity=9.81, want=("M", "h", "Jc")):
     return out
 
 
-def wholebody_solve(ctx, state, params=None):
+def wholebody_solve(ctx, state, params=None, tau=None, grf=None):
     """qlamd_wholebody_solve_batch on host buffers -> (tau [B,12], grf [B,12], status [B])."""
     prm = params if params is not None else default_wholebody_params()
     keep = []
     wb = _wholebody_batch(state, keep)
     B = state["q"].shape[0]
-    tau = np.zeros((B, 12)); grf = np.zeros((B, 12)); st = np.full(B, -1, np.int32)
+    tau = np.zeros((B, 12)) if tau is None else tau
+    grf = np.zeros((B, 12)) if grf is None else grf
+    st = np.full(B, -1, np.int32)
     rc = lib().qlamd_wholebody_solve_batch(ctx._h, C.byref(prm), C.byref(wb), B, _ptr(tau), _ptr(grf), _ptr(st), MEM_HOST, None)
     if rc != OK:
         raise QlamdError(rc, "qlamd_wholebody_solve_batch")
@@ -710,6 +718,7 @@ OPT_ON_FAILURE, OPT_REFINE_PASSES, OPT_DYNAMICS_FORM = 1, 2, 5
 DYNAMICS_AUTO, DYNAMICS_LEG, DYNAMICS_ROW = 0, 1, 2
 ON_FAILURE_ZERO, ON_FAILURE_KEEP = 0, 1
 STATUS_NO_COMMAND = 4
+STATUS_DEPENDENT_EQUALITY = 5
 
 
 def tick_command_bytes(batch):

@@ -52,7 +52,7 @@
 
 namespace qlamd {
 
-constexpr int kStatusOk = 0, kStatusInfeasible = 1, kStatusNotPd = 2, kStatusMaxIter = 3;
+constexpr int kStatusOk = 0, kStatusInfeasible = 1, kStatusNotPd = 2, kStatusMaxIter = 3, kStatusDependentEquality = 5;
 constexpr int kMaxOuter = 200; // guard; the reference has none
 
 // Batch-invariant data, resident in device memory, read through scalar loads.

@@ -304,8 +304,9 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
   ctx->on_failure = QLAMD_ON_FAILURE_ZERO;
   ctx->dynamics_form = QLAMD_DYNAMICS_AUTO;
   ctx->depth = 0;
-  ctx->has_last_stream = false;
   ctx->last_stream = nullptr;
+  ctx->done_event = nullptr;
+  ctx->done_recorded = false;
   qlamd_robot_model m;
   if (model) m = *model; else default_robot_model(&m);
   build_device_params(*params, m, &ctx->params);
@@ -337,6 +338,7 @@ void qlamd_context_destroy(qlamd_context *ctx) {
   if (ctx->wire_tpl) (void)hipFree(ctx->wire_tpl);
   if (ctx->tick_ws) (void)hipFree(ctx->tick_ws);
   if (ctx->d_params) (void)hipFree(ctx->d_params);
+  if (ctx->done_event) (void)hipEventDestroy(ctx->done_event);
   delete ctx;
 }
 
@@ -348,7 +350,7 @@ int qlamd_set_robots_per_wave(qlamd_context *ctx, int rpw) {
 
 int qlamd_set_option(qlamd_context *ctx, int option, int value) {
   if (!ctx) return QLAMD_ERR_INVALID_ARGUMENT;
-  QL_ENTER(ctx, ctx->has_last_stream ? ctx->last_stream : nullptr);
+  QL_ENTER_NO_STREAM(ctx);
   switch (option) {
     case QLAMD_OPT_ON_FAILURE:
       if (value != QLAMD_ON_FAILURE_ZERO && value != QLAMD_ON_FAILURE_KEEP) return QLAMD_ERR_INVALID_ARGUMENT;
@@ -426,16 +428,29 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
     small_host = total <= kSmallHostCall && ensure_pinned(ctx, kSmallHostCall) == QLAMD_OK;
     out_off = off[12];
     out_bytes = total - off[12];
+    // QLAMD_ON_FAILURE_KEEP: a failed robot's entries are not written by the kernel, and the whole output region is
+    // copied back below -- so the caller's efforts / forces go up with the inputs and come back untouched
+    const bool keep = ctx->params.keep_on_failure != 0;
+    const size_t up_bytes = keep ? off[14] : off[12];
     if (small_host) {
       // a single robot or a few: a dozen separate pageable copies cost ~10 us each; pack, copy once
       char *h = (char *)ctx->pinned;
       for (int k = 0; k < 12; k++)
         if (sz[k]) memcpy(h + off[k], src[k], sz[k]);
-      if (hipMemcpyAsync(w, h, off[12], hipMemcpyHostToDevice, st) != hipSuccess) return QLAMD_ERR_HIP;
+      if (keep) {
+        memcpy(h + off[12], joint_effort, B * 96);
+        if (contact_force) memcpy(h + off[13], contact_force, B * 96);
+      }
+      if (hipMemcpyAsync(w, h, up_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return QLAMD_ERR_HIP;
     } else {
       for (int k = 0; k < 12; k++)
         if (sz[k] && hipMemcpyAsync(w + off[k], src[k], sz[k], hipMemcpyHostToDevice, st) != hipSuccess)
           return QLAMD_ERR_HIP;
+      if (keep) {
+        if (hipMemcpyAsync(w + off[12], joint_effort, B * 96, hipMemcpyHostToDevice, st) != hipSuccess) return QLAMD_ERR_HIP;
+        if (contact_force && hipMemcpyAsync(w + off[13], contact_force, B * 96, hipMemcpyHostToDevice, st) != hipSuccess)
+          return QLAMD_ERR_HIP;
+      }
     }
     s = StatePtrs{(const double *)(w + off[0]), (const double *)(w + off[1]), (const double *)(w + off[2]),
                   (const double *)(w + off[3]), (const double *)(w + off[4]), (const double *)(w + off[5]),

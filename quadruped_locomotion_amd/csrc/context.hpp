@@ -38,8 +38,9 @@ struct qlamd_context {
   std::mutex gate;
   std::thread::id owner;
   int depth;
-  hipStream_t last_stream;
-  bool has_last_stream;
+  hipStream_t last_stream;   // compared only, never passed to a HIP call after its own call returned
+  hipEvent_t done_event;     // recorded behind the work of every outermost call (created on first use)
+  bool done_recorded;
 };
 
 
@@ -88,39 +89,61 @@ __device__ __forceinline__ void load3(const double *p, int64_t t, double o[3]) {
 
 
 // Entry guard of every call that uses the context.  A second thread entering while a call is in progress gets
-// QLAMD_ERR_BUSY (the whole tick nests calls on its own thread: allowed).  A call on another stream than the previous
-// one first waits for that stream, so that the scratch memory both calls use is never shared by work in flight;
-// while either stream is being captured into a graph the wait is skipped (it would invalidate the capture): the
-// capturing caller orders the graph.
+// QLAMD_ERR_BUSY (the whole tick nests calls on its own thread: allowed).  Calls on one stream are ordered by the
+// stream.  When the stream changes, the new call's work must not overtake the previous call's (both use the context's
+// scratch memory): every outermost call records the context's own event behind its work, and a call on another stream
+// makes its stream wait for that event -- asynchronous, and no handle of the caller's is kept beyond the call (only its
+// value, to see that the stream changed).  While a stream is being captured into a graph neither is done (an event
+// recorded inside a capture cannot be waited for outside it, and the reverse): the capturing caller orders the graph.
 struct CallGuard {
   qlamd_context *c;
   int rc;
-  CallGuard(qlamd_context *ctx, hipStream_t st) : c(ctx), rc(QLAMD_OK) {
+  hipStream_t st;
+  bool uses_stream;
+  static bool capturing(hipStream_t s) {
+    hipStreamCaptureStatus a = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &a) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a != hipStreamCaptureStatusNone;
+  }
+  CallGuard(qlamd_context *ctx, hipStream_t stream, bool uses = true) : c(ctx), rc(QLAMD_OK), st(stream), uses_stream(uses) {
     const std::thread::id me = std::this_thread::get_id();
     {
       std::lock_guard<std::mutex> lk(c->gate);
       if (c->depth > 0 && c->owner != me) { rc = QLAMD_ERR_BUSY; c = nullptr; return; }
       c->owner = me;
-      if (c->depth++ > 0) return;
+      if (c->depth++ > 0) { uses_stream = false; return; } // nested: the outermost call records
     }
-    if (c->has_last_stream && c->last_stream != st) {
-      hipStreamCaptureStatus a = hipStreamCaptureStatusNone, b = hipStreamCaptureStatusNone;
-      (void)hipStreamIsCapturing(st, &a);
-      (void)hipStreamIsCapturing(c->last_stream, &b);
-      if (a == hipStreamCaptureStatusNone && b == hipStreamCaptureStatusNone) (void)hipStreamSynchronize(c->last_stream);
-      (void)hipGetLastError(); // a stream the caller has destroyed since is not an error of this call
+    if (!uses_stream) return;
+    if (c->done_recorded && c->last_stream != st && !capturing(st)) {
+      if (hipStreamWaitEvent(st, c->done_event, 0) != hipSuccess) (void)hipGetLastError();
     }
-    c->last_stream = st;
-    c->has_last_stream = true;
   }
   ~CallGuard() {
     if (!c) return;
+    if (uses_stream) {
+      // outermost call: mark the end of its work for a later call on another stream
+      if (!capturing(st)) {
+        if (!c->done_event && hipEventCreateWithFlags(&c->done_event, hipEventDisableTiming) != hipSuccess) {
+          (void)hipGetLastError();
+          c->done_event = nullptr;
+        }
+        c->done_recorded = c->done_event && hipEventRecord(c->done_event, st) == hipSuccess;
+        if (!c->done_recorded) (void)hipGetLastError();
+      } else {
+        c->done_recorded = false;
+      }
+      c->last_stream = st;
+    }
     std::lock_guard<std::mutex> lk(c->gate);
     c->depth--;
   }
 };
 #define QL_ENTER(ctx, st)                         \
   ::qlamd::rt::CallGuard ql_guard_((ctx), (st));  \
+  if (ql_guard_.rc != QLAMD_OK) return ql_guard_.rc
+// a call that queues nothing on a stream (options)
+#define QL_ENTER_NO_STREAM(ctx)                            \
+  ::qlamd::rt::CallGuard ql_guard_((ctx), nullptr, false); \
   if (ql_guard_.rc != QLAMD_OK) return ql_guard_.rc
 
 // balance_kernel.hip: the control step behind qlamd_balance_solve_batch / qlamd_force_distribution_batch, with the

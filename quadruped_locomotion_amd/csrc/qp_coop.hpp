@@ -106,12 +106,14 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
     const double g11 = bc<0>(Gm[0]);
     H[0] = sel(dummy && lr == 0, H[0] - rcp_nr(g11), H[0]);
   }
+  bool eq2_dependent = false;
   if (has_eq2) { // the second equality column: stepped onto and projected out of what the first has left
     double za[3] = {0.0, 0.0, 0.0};
     static_for<N>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(za[j % 3], ne2, H[j]); });
     const double z = (za[0] + za[1]) + za[2];
     const double zn = row_sum(z * ne2), zz = row_sum(z * z), nx = row_sum(ne2 * x);
     const bool indep = fabs(zz) > eps && zn > 0.0;
+    eq2_dependent = !indep; // all-zero or in the span of the first: left out, reported through the status
     const double dinv = rcp_nr(indep ? zn : 1.0);
     x += sel(indep, (-nx - ce02) * dinv * z, 0.0);
     const double vec = sel(indep, z * dinv, 0.0), hc = sel(indep, -z, 0.0);
@@ -140,7 +142,7 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
   int ip = 0;
   double sp = 0.0, ucand = 0.0, npj = 0.0;
   if (bad && !skip) { status = kStatusNotPd; done = true; }
-  const int neq = (has_eq ? 1 : 0) + (has_eq2 ? 1 : 0);
+  const int neq = (has_eq ? 1 : 0) + ((has_eq2 && !eq2_dependent) ? 1 : 0); // columns that took a dimension
   const unsigned lanebit = 1u << lr;
   const int row_addr = ((int)threadIdx.x & 48) << 2;
   const int vlane = lr < N ? lr : 0;
@@ -373,7 +375,7 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
     f_out = status == kStatusInfeasible ? inf : fv;
   }
   x_out = x;
-  return status;
+  return (status == kStatusOk && eq2_dependent) ? kStatusDependentEquality : status;
 }
 
 // two inequalities per lane (m <= 24): the shape qlamd_qp_solve_batch uses

@@ -399,7 +399,8 @@ __global__ __launch_bounds__(64) void wholebody_solve_kernel(const DeviceParams 
   const bool ok = st == kStatusOk;
   const double f = (row_on && ok) ? x : 0.0;
   const double tq = tau0 - (Q.jcol[0] * quad_bc<0>(f) + Q.jcol[1] * quad_bc<1>(f) + Q.jcol[2] * quad_bc<2>(f));
-  if (comp && live) {
+  // a failed robot: zeros, or (QLAMD_ON_FAILURE_KEEP) its entries stay as the caller left them
+  if (comp && live && !(P.keep_on_failure && !ok)) {
     tau_out[12 * i + 3 * leg + c] = ok ? tq : 0.0;
     if (grf_out) grf_out[12 * i + 3 * leg + c] = f;
   }
@@ -523,8 +524,9 @@ int qlamd_wholebody_solve_batch(qlamd_context *ctx, const qlamd_wholebody_params
     sg.add(in->desired_joint_acceleration, B * 96, true, false);
     sg.add(in->support_leg, B * 4, true, false);
     sg.add(in->surface_normal, B * 96, true, false);
-    sg.add(joint_effort, B * 96, false, true);
-    sg.add(contact_force, B * 96, false, true);
+    const bool keep = ctx->params.keep_on_failure != 0; // entries the kernel leaves alone come back as they went up
+    sg.add(joint_effort, B * 96, keep, true);
+    sg.add(contact_force, B * 96, keep, true);
     sg.add(status, B * 4, false, true);
     const int rc = sg.upload(ctx, st);
     if (rc != QLAMD_OK) return rc;

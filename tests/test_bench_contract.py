@@ -48,13 +48,63 @@ def test_committed_bench_line_follows_the_contract():
 
 @pytest.mark.gpu
 def test_live_bench_line_follows_the_contract():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--cpu-seconds", "1"],
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--cpu-seconds", "2",
+                          "--no-also"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, "bench.py must print exactly one line"
     d = check(lines[0])
     assert d["steps"] == 20 and d["warmup"] == 3 and d["config"]["all_status_ok"] is True
+    # the CPU baseline is a sustained rate: within 10 % of the best count of its own sweep (every count measured >= 1.5 s)
+    c = d["cpu_baseline"]
+    assert c["value"] >= 0.9 * max(c["thread_sweep"].values()) and c["thread_sweep_seconds_each"] >= 1.5
+    assert "OMP_PLACES=cores" in c["threads"] and "OMP_PROC_BIND=close" in c["threads"]
+
+
+def _bench(*argv):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=900,
+                         cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "bench.py must print exactly one line (RCCL's shutdown banner included): %r" % lines
+    return lines[0]
+
+
+@pytest.mark.gpu
+def test_live_default_line_is_the_contract_workload_and_carries_the_other_presets():
+    """`python bench.py` with no workload flags: BASELINE configs[1] on SURVEY.md 8(d)'s literal tracking errors, and an
+    `also` object with static-calm and trot measured in the same process."""
+    d = check(_bench("--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--replays", "3"), want_cpu=False)
+    assert d["config"]["gait"] == "static" and d["config"]["tracking_error"] == [0.02, 0.05, 0.1]
+    assert set(d["also"]) == {"static-calm", "trot"}
+    for name, a in d["also"].items():
+        assert a["all_status_ok"] is True and a["value"] > 0 and a["kernel_ms"] > 0 and 0 < a["roofline_frac"] < 1, name
+        assert "pmc_source" in a and "valu_issue_frac" in a
+    assert d["also"]["static-calm"]["tracking_error"] == [0.004, 0.005, 0.01]
+    assert d["also"]["static-calm"]["kernel_ms"] < d["roofline"]["kernel_ms"]     # the calm preset is the lighter one
+
+
+@pytest.mark.gpu
+def test_collective_path_with_one_rank():
+    """The code path the N > 1 runs take -- RCCL process group, the K steps with their all-gathers captured into one
+    hipGraph, gathers on a second captured stream -- exercised with a single rank, then without the gather, then with
+    eager launches (what the ranks fall back to when a capture fails)."""
+    common = ("--force-collective", "--gait", "trot", "--batch", "8192", "--steps", "20", "--warmup", "3",
+              "--no-cpu-baseline", "--replays", "3")
+    d = check(_bench(*common, "--overlap-gather"), want_cpu=False)
+    c = d["config"]
+    assert c["rccl_ranks"] == 1 and d["n_gpus"] == 1 and c["robots_per_gpu"] == 8192 and c["all_status_ok"] is True
+    assert c["launch"] == "hipGraph of K steps" and c["gather_stream"] == "second captured stream"
+    assert c["result_collection"] == "rccl all_gather of torques" and c["gather_layout_ok"] is True
+    assert "also" not in d and "cpu_baseline" not in d
+    with_gather = d["value"]
+    d = check(_bench(*common, "--no-gather"), want_cpu=False)
+    assert d["config"]["result_collection"] == "none (--no-gather)" and d["config"]["rccl_ranks"] == 1
+    assert d["config"]["launch"] == "hipGraph of K steps" and d["config"]["gather_stream"] is None
+    assert d["value"] > 0.8 * with_gather
+    d = check(_bench(*common, "--overlap-gather", "--no-graph"), want_cpu=False)
+    assert d["config"]["launch"] == "eager" and d["config"]["gather_layout_ok"] is True and d["config"]["all_status_ok"] is True
 
 
 def test_profile_collection_names_exist_in_the_sources():

@@ -124,6 +124,16 @@ def test_qp_batch_random_and_error_paths(gpu, oracle):
             assert np.abs(r["x"] - x[i]).max() < 1e-8 * max(1.0, np.abs(r["x"]).max())
             assert np.abs(CE[i].T @ x[i] + ce0[i]).max() < 1e-9
     assert nok > B // 2
+    # p = 2 with a second column that carries nothing new -- all-zero, or a multiple of the first: left out and
+    # reported (QLAMD_STATUS_DEPENDENT_EQUALITY); x is the solution with the first column alone
+    x1, f1, st1 = capi.qp_solve(ctx, G, g0, CE[:, :, :1], ce0[:, :1], CI, ci0)
+    for second, off in ((np.zeros((B, n, 1)), np.zeros((B, 1))), (-2.5 * CE[:, :, :1], -2.5 * ce0[:, :1])):
+        xd, fd, std = capi.qp_solve(ctx, G, g0, np.concatenate([CE[:, :, :1], second], axis=2),
+                                    np.concatenate([ce0[:, :1], off], axis=1), CI, ci0)
+        ok = st1 == 0
+        assert ok.sum() > B // 2
+        assert (std[ok] == capi.STATUS_DEPENDENT_EQUALITY).all() and np.array_equal(std[~ok], st1[~ok])
+        assert np.abs(xd[ok] - x1[ok]).max() < 1e-11 and np.allclose(fd[ok], f1[ok], rtol=1e-12, atol=1e-12)
     # not positive definite / infeasible
     x, f, st = capi.qp_solve(ctx, np.array([[[1.0, 2.0], [2.0, 1.0]]]), np.zeros((1, 2)), None, None, None, None)
     assert st[0] == capi.STATUS_NOT_PD

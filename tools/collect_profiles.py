@@ -10,9 +10,12 @@ Writes <out>/kernel_stats_<workload>.csv and <out>/pmc_index.json, whose records
 (kernel, batch, workload) and by the hash of the kernel sources they were taken on.
 
 This driver never touches the GPU itself: every measured program is a child `rocprofv3 ... -- python3 bench.py ...`.
-FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB.  FETCH_SIZE is taken as it reads: for this path's 8-byte-per-lane
-record loads the raw counter matched the known input byte count to 1 % (profiles/r1/hbm_traffic_pmc_bench_static_b4096.json);
-the x2 of the guide applies to 16-byte-per-lane streams.
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB.  Which correction of MI355X_MICROARCH.md's HBM section a record's
+FETCH_SIZE got is WRITTEN INTO THE RECORD (`fetch_size_rule`), per kernel (FETCH_RULES below): "as read" for kernels whose
+loads are 8-byte-per-lane record loads (the raw counter matched the known input byte count to 1 %,
+profiles/r1/hbm_traffic_pmc_bench_static_b4096.json), "x2" for kernels that stream 16 bytes per lane (the guide's gfx950
+correction).  WRITE_SIZE is taken as read everywhere (it matched the algorithmic output of the dynamics kernel exactly).
+A rocprofv3 pass that exits non-zero or yields no counter rows marks the record `incomplete` and this script exits non-zero.
 """
 import glob
 import json
@@ -26,8 +29,8 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = [
     # name, kernel substring, batch, bench.py arguments
-    ("static-calm", "balance_coop_kernel", 4096, ["--gait", "static"]),
     ("static-survey", "balance_coop_kernel", 4096, ["--gait", "static", "--errors", "survey"]),
+    ("static-calm", "balance_coop_kernel", 4096, ["--gait", "static", "--errors", "calm"]),
     ("trot", "balance_coop_kernel", 4096, ["--gait", "trot"]),
     ("trot", "balance_coop_kernel", 65536, ["--gait", "trot", "--batch", "65536"]),
     ("trot", "balance_coop_kernel", 8192, ["--gait", "trot", "--batch", "8192"]),
@@ -36,6 +39,10 @@ WORKLOADS = [
     ("wholebody_dynamics", "wholebody_dynamics_leg_kernel", 1048576, ["--workload", "wholebody_dynamics", "--batch", "1048576"]),
     ("wholebody_dynamics", "wholebody_dynamics_kernel", 4096, ["--workload", "wholebody_dynamics", "--batch", "4096"]),
 ]
+# FETCH_SIZE correction per kernel (see the docstring): every kernel here reads its inputs with 8-byte-per-lane loads
+# (24-/32-byte records and the 12 joint angles coalesced over 12 lanes; the whole-body kernels read q, qd the same way)
+FETCH_RULES = {"balance_coop_kernel": "as read", "pose_sqp_coop_kernel": "as read", "wholebody_solve_kernel": "as read",
+               "wholebody_dynamics_leg_kernel": "as read", "wholebody_dynamics_kernel": "as read"}
 SQ_GROUP = "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"
 
 
@@ -67,11 +74,12 @@ def main():
     bench_py = os.path.join(ROOT, "bench.py")
     for name, kernel, batch, args in WORKLOADS:
         tag = "%s_b%d" % (name.replace("-", "_"), batch)
-        rec = dict(kernel=kernel, batch=batch, workload=name, source_hash=bench.source_hash(), files=[])
+        rec = dict(kernel=kernel, batch=batch, workload=name, source_hash=bench.source_hash(), files=[], failed_passes=[])
         # kernel durations (the K steps as one hipGraph, as the bench line is measured)
         d = os.path.join(out, "raw", tag + "_stats")
-        run(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "s", "--", "python3", bench_py, *args, "--steps", "50",
-             "--warmup", "10", "--no-cpu-baseline", "--replays", "5"], os.path.join(out, tag + "_stats.log"))
+        if run(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "s", "--", "python3", bench_py, *args, "--steps", "50",
+                "--warmup", "10", "--no-cpu-baseline", "--no-also", "--replays", "5"], os.path.join(out, tag + "_stats.log")) != 0:
+            rec["failed_passes"].append("kernel-trace --stats")
         dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
         if dbs:
             rows = kernel_rows(dbs[0])
@@ -87,23 +95,33 @@ def main():
         # counters: eager launches, one counter group per pass
         for group in ("FETCH_SIZE", "WRITE_SIZE", SQ_GROUP):
             d = os.path.join(out, "raw", tag + "_pmc_" + group.split()[0])
-            run(["rocprofv3", "--kernel-trace", "--pmc", *group.split(), "-d", d, "-o", "p", "--", "python3", bench_py, *args,
-                 "--no-graph", "--steps", "25", "--warmup", "5", "--no-cpu-baseline", "--replays", "1"],
-                os.path.join(out, tag + "_pmc_" + group.split()[0] + ".log"))
+            rc = run(["rocprofv3", "--kernel-trace", "--pmc", *group.split(), "-d", d, "-o", "p", "--", "python3", bench_py, *args,
+                      "--no-graph", "--steps", "25", "--warmup", "5", "--no-cpu-baseline", "--no-also", "--replays", "1"],
+                     os.path.join(out, tag + "_pmc_" + group.split()[0] + ".log"))
+            got = 0
             for db in glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True):
                 for c, v in counters(db, kernel).items():
                     rec.setdefault("counters", {})[c] = v
+                    got += 1
+            if rc != 0 or got == 0:
+                rec["failed_passes"].append("pmc " + group.split()[0])
         c = rec.get("counters", {})
         if "FETCH_SIZE" in c:
-            rec["fetch_bytes"] = c["FETCH_SIZE"] * 1024.0
+            rule = FETCH_RULES[kernel]
+            rec["fetch_size_rule"] = "FETCH_SIZE %s (KB -> bytes), WRITE_SIZE as read" % rule
+            rec["fetch_bytes"] = c["FETCH_SIZE"] * 1024.0 * (2.0 if rule == "x2" else 1.0)
         if "WRITE_SIZE" in c:
             rec["write_bytes"] = c["WRITE_SIZE"] * 1024.0
         if "SQ_INSTS_VALU" in c:
             rec["valu_insts"] = c["SQ_INSTS_VALU"]
+        rec["incomplete"] = bool(rec["failed_passes"]) or not all(k in rec for k in ("fetch_bytes", "write_bytes", "valu_insts", "kernel_avg_us"))
         records.append(rec)
         print(json.dumps(rec))
     json.dump({"records": records, "collected_with": "tools/collect_profiles.py (rocprofv3 --kernel-trace [--stats | --pmc <one group>])"},
               open(os.path.join(out, "pmc_index.json"), "w"), indent=1, sort_keys=True)
+    bad = [(r["workload"], r["batch"], r["failed_passes"]) for r in records if r["incomplete"]]
+    if bad:
+        sys.exit("incomplete records: %s" % bad)
 
 
 if __name__ == "__main__":

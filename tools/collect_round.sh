@@ -1,11 +1,11 @@
 #!/bin/bash
 # Everything a round commits under profiles/rN, in one GPU-box call:
-#   bash tools/collect_round.sh r2        -> gpurun_out/r2_final/ (copy the summaries into profiles/r2/ afterwards)
+#   bash tools/collect_round.sh r3        -> gpurun_out/r3_final/ (copy the summaries into profiles/r3/ afterwards)
 # 1. rocprofv3 kernel statistics and PMC passes (tools/collect_profiles.py) -> pmc_index.json, kernel_stats_*.csv
 # 2. the bench lines of every workload (the PMC index is put where bench.py looks for it first)
 # 3. kernel durations of the auxiliary entries, the single-wavefront latency probe, host-buffer latencies
 set -u
-R=${1:-r2}
+R=${1:-r3}
 OUT=gpurun_out/${R}_final
 mkdir -p $OUT profiles/$R
 python3 tools/collect_profiles.py $OUT > $OUT/collect_profiles.log 2>&1
@@ -13,12 +13,13 @@ rm -rf $OUT/raw
 cp $OUT/pmc_index.json profiles/$R/pmc_index.json
 b() { name=$1; shift; python3 bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; }
 b static_b4096 --steps 200 --warmup 20
-b static_survey_b4096 --errors survey --steps 200 --warmup 20 --no-cpu-baseline
-b trot_b4096 --gait trot --steps 200 --warmup 20
-b trot_b8192 --gait trot --batch 8192 --steps 200 --warmup 20 --no-cpu-baseline
-b trot_b65536 --gait trot --batch 65536 --steps 100 --warmup 10 --no-cpu-baseline
-b static_b1048576 --gait static --batch 1048576 --steps 20 --warmup 5 --no-cpu-baseline
-b trot_b8192_force_collective --force-collective --gait trot --batch 8192 --steps 100 --warmup 10 --no-cpu-baseline
+b static_calm_b4096 --errors calm --steps 200 --warmup 20 --no-cpu-baseline --no-also
+b trot_b4096 --gait trot --steps 200 --warmup 20 --no-also
+b trot_b8192 --gait trot --batch 8192 --steps 200 --warmup 20 --no-cpu-baseline --no-also
+b trot_b65536 --gait trot --batch 65536 --steps 100 --warmup 10 --no-cpu-baseline --no-also
+b static_calm_b1048576 --gait static --errors calm --batch 1048576 --steps 20 --warmup 5 --no-cpu-baseline --no-also
+b trot_b8192_force_collective --force-collective --overlap-gather --gait trot --batch 8192 --steps 100 --warmup 10 --no-cpu-baseline
+b trot_b8192_force_collective_no_gather --force-collective --no-gather --gait trot --batch 8192 --steps 100 --warmup 10 --no-cpu-baseline
 b pose_sqp_b4096 --workload pose_sqp --steps 200 --warmup 20
 b full_tick_b4096 --workload full_tick --steps 100
 b full_tick_ragged_b4096 --workload full_tick --ragged --steps 100
