@@ -260,6 +260,31 @@ int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *
                          int64_t batch, double *x, double *objective, int32_t *status, int memory,
                          void *stream);
 
+/* ---- weighted least squares with equality and two-sided inequality rows (the OOQP seam of row a8) -------------
+ * min (Ax - b)'S(Ax - b) + x'Wx   s.t.  Cx = c,  d <= Dx <= f,   one problem per batch entry, all of one shape.
+ * Replaces, argument for argument,
+ *     static bool ooqpei::QuadraticProblemFormulation::solve(A, S, b, W, C, c, D, d, f, x)
+ * (third-party ooqp_eigen_interface, un-vendored; call sites balance_controller/src/contact_force_distribution/
+ * ContactForceDistribution.cpp:367 and :490, matrices declared ContactForceDistribution.hpp:172-188, problem stated
+ * at .cpp:388): the narrowest seam at which the reference keeps its own assembly (prepareOptimization,
+ * addMinimalForceConstraints, addFrictionConstraints, addDesiredLegLoadConstraints) and swaps only the solver.
+ *   A [B][k][n] row-major (k <= 12, n <= 12), S [B][k] and W [B][n]: the DIAGONALS (the reference holds
+ *   Eigen::DiagonalMatrix for both), b [B][k];
+ *   C [B][p][n], c [B][p] (p <= 12; NULL when p = 0).  A row that is all-zero or in the span of the rows before it is
+ *   skipped when consistent (the reference's first pass hands over 3 nS zero rows with c = 0, .cpp:364-366), and makes
+ *   the problem QLAMD_STATUS_INFEASIBLE when not;
+ *   D [B][m][n], d [B][m], f [B][m] (m <= 24; NULL when m = 0).  A bound of +-DBL_MAX (what the reference writes for
+ *   "none", .cpp:246,329: std::numeric_limits<double>::max()) or +-infinity is no bound and never enters arithmetic.
+ *   x [B][n] out; status [B] out: QLAMD_STATUS_OK / _INFEASIBLE / _NOT_PD (A'SA + W not positive definite) / _MAX_ITER.
+ * ooqpei returns false when OOQP fails; here that is status != QLAMD_STATUS_OK (host/ooqp_eigen_interface/
+ * QuadraticProblemFormulation.hpp maps it back to the bool).  OOQP is an interior-point method that stops at its
+ * complementarity tolerance; this entry returns the exact minimiser of the same strictly convex problem (active-set
+ * method of qlamd_qp_solve_batch, equality rows projected out one by one). */
+int qlamd_weighted_lsq_qp_batch(qlamd_context *ctx, int n, int k, int p, int m, const double *A, const double *S,
+                                const double *b, const double *W, const double *C, const double *c, const double *D,
+                                const double *d, const double *f, int64_t batch, double *x, int32_t *status, int memory,
+                                void *stream);
+
 /* ---- pose optimisation batch (BASELINE config 5) ----------------------
  * Replaces free_gait::PoseOptimizationSQP::optimize(Pose&) with its setters
  * (free_gait_core/include/free_gait_core/pose_optimization/PoseOptimizationSQP.hpp:36-54,

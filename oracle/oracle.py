@@ -258,6 +258,34 @@ def force_qp_assemble(r_feet, wrench, n_B, t1, t2, params=None):
     return G, g0, CI, ci0
 
 
+def force_lsq_assemble(r_feet, wrench, n_B, t1, t2, params=None):
+    """The force problem in the reference's own (A, S, b, W, D, d, f) form (ContactForceDistribution.cpp:168-336)."""
+    prm = params or default_params()
+    r_feet = np.ascontiguousarray(r_feet, dtype=np.float64).reshape(-1, 3)
+    nS = r_feet.shape[0]
+    n, m = 3 * nS, 5 * nS
+    A, S, b, W = np.zeros((6, n)), np.zeros(6), np.zeros(6), np.zeros(n)
+    D, d, f = np.zeros((m, n)), np.zeros(m), np.zeros(m)
+    a = [_d(v) for v in (r_feet, wrench, np.reshape(n_B, (nS, 3)), np.reshape(t1, (nS, 3)), np.reshape(t2, (nS, 3)))]
+    lib().oracle_force_lsq_assemble(C.byref(prm), nS, a[0][1], a[1][1], a[2][1], a[3][1], a[4][1],
+                                    *[v.ctypes.data_as(_dp) for v in (A, S, b, W, D, d, f)])
+    return A, S, b, W, D, d, f
+
+
+def weighted_lsq_qp(A, S, b, W, Ceq=None, ceq=None, D=None, d=None, f=None):
+    """oracle_weighted_lsq_qp on one problem -> (x, status)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    k, n = A.shape
+    p = 0 if Ceq is None else int(np.asarray(Ceq).shape[0])
+    m = 0 if D is None else int(np.asarray(D).shape[0])
+    arrs = [_d(v) if v is not None else (None, None) for v in (A, S, b, W, Ceq, ceq, D, d, f)]
+    x = np.zeros(n)
+    fn = lib().oracle_weighted_lsq_qp
+    fn.restype = C.c_int
+    st = fn(n, k, p, m, *[a[1] for a in arrs], x.ctypes.data_as(_dp))
+    return x, int(st)
+
+
 # ---- pose optimisation (config 5) ---------------------------------------------------------------
 class PoseProblem(C.Structure):
     _fields_ = [("n_legs", C.c_int), ("leg_order", C.c_int * 4), ("stance", (C.c_double * 3) * 4),

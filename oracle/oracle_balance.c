@@ -1,6 +1,7 @@
 /* ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle_balance.h). */
 #include "oracle_balance.h"
 
+#include <float.h>
 #include <math.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -347,4 +348,168 @@ double oracle_balance_batch_repeat(const oracle_balance_params *prm, int64_t B,
 #endif
   }
   return t1 - t0;
+}
+
+/* ---- the reference's own problem statement, as handed to ooqpei::QuadraticProblemFormulation::solve ----------
+ * prepareOptimization (ContactForceDistribution.cpp:168-206): b = [F ; T], S = diag(virtualForceWeights_),
+ * A = [I ... I ; skew(r_1) ... skew(r_nS)], W = groundForceWeight_ I;
+ * addMinimalForceConstraints (:210-252): nS rows n_B' f_i, d = minimalNormalGroundForce_, f = DBL_MAX;
+ * addFrictionConstraints (:254-336): per leg (mu n + t1)', (mu n - t1)', (mu n + t2)', (mu n - t2)', d = 0, f = DBL_MAX.
+ * A is [6][n], D is [5 nS][n], row-major; S and W are the diagonals. */
+void oracle_force_lsq_assemble(const oracle_balance_params *prm, int nS, const double *r_feet, const double wrench[6],
+                               const double *n_B, const double *t1, const double *t2, double *A, double *S, double *b,
+                               double *W, double *D, double *d, double *f) {
+  const int n = 3 * nS, m = 5 * nS;
+  memset(A, 0, sizeof(double) * 6 * (size_t)n);
+  memset(D, 0, sizeof(double) * (size_t)m * (size_t)n);
+  for (int l = 0; l < nS; l++) {
+    const double *r = r_feet + 3 * l;
+    for (int i = 0; i < 3; i++) A[i * n + 3 * l + i] = 1.0;
+    A[3 * n + 3 * l + 1] = -r[2]; A[3 * n + 3 * l + 2] = r[1];
+    A[4 * n + 3 * l + 0] = r[2];  A[4 * n + 3 * l + 2] = -r[0];
+    A[5 * n + 3 * l + 0] = -r[1]; A[5 * n + 3 * l + 1] = r[0];
+  }
+  for (int kk = 0; kk < 6; kk++) { S[kk] = prm->force_weights[kk]; b[kk] = wrench[kk]; }
+  for (int i = 0; i < n; i++) W[i] = prm->regularizer;
+  for (int l = 0; l < nS; l++) {
+    const double *nb = n_B + 3 * l, *a = t1 + 3 * l, *c = t2 + 3 * l;
+    for (int i = 0; i < 3; i++) {
+      D[l * n + 3 * l + i] = nb[i];
+      D[(nS + 4 * l + 0) * n + 3 * l + i] = prm->friction * nb[i] + a[i];
+      D[(nS + 4 * l + 1) * n + 3 * l + i] = prm->friction * nb[i] - a[i];
+      D[(nS + 4 * l + 2) * n + 3 * l + i] = prm->friction * nb[i] + c[i];
+      D[(nS + 4 * l + 3) * n + 3 * l + i] = prm->friction * nb[i] - c[i];
+    }
+    d[l] = prm->min_normal_force;
+    f[l] = DBL_MAX;                                      /* std::numeric_limits<double>::max(), :246 */
+    for (int kk = 0; kk < 4; kk++) { d[nS + 4 * l + kk] = 0.0; f[nS + 4 * l + kk] = DBL_MAX; } /* :328-329 */
+  }
+}
+
+/* min (Ax - b)'S(Ax - b) + x'Wx  s.t. Cx = c, d <= Dx <= f -- the contract of ooqpei::QuadraticProblemFormulation::solve
+ * (third-party, absent: PARITY UNPINNED at this boundary; the problem is strictly convex, the target is its unique
+ * minimiser).  Route, deliberately different from the device's (which projects the rows out of an explicit inverse one
+ * by one): the equality rows are eliminated with a rank-revealing, pivoted Gram-Schmidt into x = x_p + Z y, the reduced
+ * problem in y is solved by the pinned Goldfarb-Idnani restatement without equalities, bounds of +-DBL_MAX / inf dropped.
+ * Returns ORACLE_QP_OK / ORACLE_QP_INFEASIBLE (inconsistent equalities or empty feasible set) / ORACLE_QP_NOT_PD. */
+int oracle_weighted_lsq_qp(int n, int k, int p, int m, const double *A, const double *S, const double *b, const double *W,
+                           const double *C, const double *c, const double *D, const double *d, const double *f, double *x) {
+  double G[12 * 12], g0[12], Q[12][12], xp[12];
+  int rank = 0;
+  if (n < 1 || n > 12 || k < 1 || k > 12 || p < 0 || p > 12 || m < 0 || m > 24) return ORACLE_QP_INFEASIBLE;
+  for (int i = 0; i < n; i++) {
+    for (int j = 0; j < n; j++) {
+      double acc = 0.0;
+      for (int r = 0; r < k; r++) acc += A[r * n + i] * S[r] * A[r * n + j];
+      G[i * n + j] = 2.0 * (acc + (i == j ? W[i] : 0.0));
+    }
+    double acc = 0.0;
+    for (int r = 0; r < k; r++) acc += A[r * n + i] * S[r] * b[r];
+    g0[i] = -2.0 * acc;
+    xp[i] = 0.0;
+  }
+  /* orthonormal basis Q[0..rank) of the row space of C (modified Gram-Schmidt, twice), particular solution xp */
+  for (int r = 0; r < p; r++) {
+    double v[12], nrm0 = 0.0, nrm = 0.0;
+    for (int i = 0; i < n; i++) { v[i] = C[r * n + i]; nrm0 += v[i] * v[i]; }
+    for (int pass = 0; pass < 2; pass++)
+      for (int q = 0; q < rank; q++) {
+        double dot = 0.0;
+        for (int i = 0; i < n; i++) dot += Q[q][i] * v[i];
+        for (int i = 0; i < n; i++) v[i] -= dot * Q[q][i];
+      }
+    for (int i = 0; i < n; i++) nrm += v[i] * v[i];
+    double cx = 0.0;
+    for (int i = 0; i < n; i++) cx += C[r * n + i] * xp[i];
+    if (nrm0 == 0.0 || nrm <= 1e-24 * nrm0) {            /* zero row or in the span of the rows before it */
+      if (fabs(c[r] - cx) > 1e-9 * (1.0 + fabs(c[r]))) return ORACLE_QP_INFEASIBLE;
+      continue;
+    }
+    nrm = sqrt(nrm);
+    for (int i = 0; i < n; i++) Q[rank][i] = v[i] / nrm;
+    /* move xp along the new direction until row r holds: C_r (xp + t q) = c_r, and C_r q = |v| by construction */
+    const double t = (c[r] - cx) / nrm;
+    for (int i = 0; i < n; i++) xp[i] += t * Q[rank][i];
+    rank++;
+  }
+  /* null-space basis Z: complete Q to an orthonormal basis of R^n with the unit vectors */
+  double Z[12][12];
+  int nz = 0;
+  for (int e = 0; e < n && rank + nz < n; e++) {
+    double v[12], nrm = 0.0;
+    for (int i = 0; i < n; i++) v[i] = (i == e) ? 1.0 : 0.0;
+    for (int pass = 0; pass < 2; pass++) {
+      for (int q = 0; q < rank; q++) {
+        double dot = 0.0;
+        for (int i = 0; i < n; i++) dot += Q[q][i] * v[i];
+        for (int i = 0; i < n; i++) v[i] -= dot * Q[q][i];
+      }
+      for (int q = 0; q < nz; q++) {
+        double dot = 0.0;
+        for (int i = 0; i < n; i++) dot += Z[q][i] * v[i];
+        for (int i = 0; i < n; i++) v[i] -= dot * Z[q][i];
+      }
+    }
+    for (int i = 0; i < n; i++) nrm += v[i] * v[i];
+    if (nrm < 1e-6) continue;
+    nrm = sqrt(nrm);
+    for (int i = 0; i < n; i++) Z[nz][i] = v[i] / nrm;
+    nz++;
+  }
+  /* one-sided rows CI'x + ci0 >= 0 in x, then reduced to y */
+  double CIx[48][12], ci0x[48];
+  int mi = 0;
+  for (int r = 0; r < m; r++) {
+    if (d[r] > -DBL_MAX) { for (int i = 0; i < n; i++) CIx[mi][i] = D[r * n + i]; ci0x[mi++] = -d[r]; }
+    if (f[r] < DBL_MAX) { for (int i = 0; i < n; i++) CIx[mi][i] = -D[r * n + i]; ci0x[mi++] = f[r]; }
+  }
+  if (nz == 0) { /* the equalities pin x: feasible or not */
+    for (int r = 0; r < mi; r++) {
+      double s = ci0x[r];
+      for (int i = 0; i < n; i++) s += CIx[r][i] * xp[i];
+      if (s < -1e-9 * (1.0 + fabs(ci0x[r]))) return ORACLE_QP_INFEASIBLE;
+    }
+    memcpy(x, xp, sizeof(double) * (size_t)n);
+    return ORACLE_QP_OK;
+  }
+  double Gy[12 * 12], gy[12], CIy[12 * 48], ciy[48], GZ[12][12], y[12], fval;
+  for (int a = 0; a < nz; a++)
+    for (int i = 0; i < n; i++) {
+      double acc = 0.0;
+      for (int j = 0; j < n; j++) acc += G[i * n + j] * Z[a][j];
+      GZ[a][i] = acc;
+    }
+  for (int a = 0; a < nz; a++) {
+    for (int bb = 0; bb < nz; bb++) {
+      double acc = 0.0;
+      for (int i = 0; i < n; i++) acc += Z[a][i] * GZ[bb][i];
+      Gy[a * nz + bb] = acc;
+    }
+    double acc = 0.0;
+    for (int i = 0; i < n; i++) {
+      double gxp = g0[i];
+      for (int j = 0; j < n; j++) gxp += G[i * n + j] * xp[j];
+      acc += Z[a][i] * gxp;
+    }
+    gy[a] = acc;
+  }
+  for (int r = 0; r < mi; r++) {
+    double s = ci0x[r];
+    for (int i = 0; i < n; i++) s += CIx[r][i] * xp[i];
+    ciy[r] = s;
+    for (int a = 0; a < nz; a++) {
+      double acc = 0.0;
+      for (int i = 0; i < n; i++) acc += CIx[r][i] * Z[a][i];
+      CIy[a * mi + r] = acc;
+    }
+  }
+  int active[64], nact = 0, iters = 0;
+  const int st = oracle_solve_quadprog(nz, 0, mi, Gy, gy, NULL, NULL, CIy, ciy, y, &fval, active, &nact, &iters);
+  if (st != ORACLE_QP_OK) return st;
+  for (int i = 0; i < n; i++) {
+    double acc = xp[i];
+    for (int a = 0; a < nz; a++) acc += Z[a][i] * y[a];
+    x[i] = acc;
+  }
+  return ORACLE_QP_OK;
 }

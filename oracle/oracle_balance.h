@@ -87,6 +87,19 @@ void oracle_force_qp_assemble(const oracle_balance_params *prm, int nS,
                               const double *n_B, const double *t1, const double *t2,
                               double *G, double *g0, double *CI, double *ci0);
 
+/* The same problem as the reference states it for ooqpei::QuadraticProblemFormulation::solve
+ * (ContactForceDistribution.cpp:168-336): A [6][n], S [6] and W [n] (diagonals), b [6], D [5 nS][n], d, f [5 nS] with
+ * f = DBL_MAX ("no bound", :246,329). */
+void oracle_force_lsq_assemble(const oracle_balance_params *prm, int nS, const double *r_feet, const double wrench[6],
+                               const double *n_B, const double *t1, const double *t2, double *A, double *S, double *b,
+                               double *W, double *D, double *d, double *f);
+
+/* min (Ax - b)'S(Ax - b) + x'Wx  s.t. Cx = c, d <= Dx <= f: the contract of ooqpei's solve (call sites
+ * ContactForceDistribution.cpp:367,490).  Equalities eliminated by a null-space basis, then the pinned Goldfarb-Idnani
+ * restatement; +-DBL_MAX / inf bounds dropped.  n, k, p <= 12, m <= 24.  Returns ORACLE_QP_*. */
+int oracle_weighted_lsq_qp(int n, int k, int p, int m, const double *A, const double *S, const double *b, const double *W,
+                           const double *C, const double *c, const double *D, const double *d, const double *f, double *x);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,7 @@ EXPORTS = (
     "qlamd_ik_default_params", "qlamd_leg_inverse_kinematics_batch",
     "qlamd_joint_pid_default_params", "qlamd_swing_branch_batch",
     "qlamd_wholebody_default_params", "qlamd_wholebody_dynamics_batch", "qlamd_wholebody_solve_batch",
-    "qlamd_full_tick_batch", "qlamd_set_option", "qlamd_tick_command_bytes",
+    "qlamd_full_tick_batch", "qlamd_set_option", "qlamd_tick_command_bytes", "qlamd_weighted_lsq_qp_batch",
 )
 
 
@@ -230,6 +230,8 @@ def lib():
                                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_wholebody_solve_batch.argtypes = [C.c_void_p, C.POINTER(WholebodyParams), C.POINTER(WholebodyBatch), C.c_int64,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.qlamd_weighted_lsq_qp_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9 + [
+            C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -633,6 +635,31 @@ def qp_solve(ctx, G, g0, CE, ce0, CI, ci0):
     if rc != OK:
         raise QlamdError(rc, "qlamd_qp_solve_batch")
     return x, f, st
+
+
+NO_BOUND = 1.7976931348623157e308   # std::numeric_limits<double>::max(): what the reference writes for "no bound"
+
+
+def weighted_lsq_qp(ctx, A, S, b, W, Ceq=None, ceq=None, D=None, d=None, f=None, memory=MEM_HOST, out=None, stream=None):
+    """qlamd_weighted_lsq_qp_batch: min (Ax-b)'S(Ax-b) + x'Wx  s.t. Cx = c, d <= Dx <= f  (the argument list of
+    ooqpei::QuadraticProblemFormulation::solve).  A [B,k,n], S [B,k], b [B,k], W [B,n] (diagonals), Ceq [B,p,n],
+    ceq [B,p], D [B,m,n], d / f [B,m].  Host: numpy in, (x, status) out; device: torch tensors and out = (x, status)."""
+    arrs = [A, S, b, W, Ceq, ceq, D, d, f]
+    if memory == MEM_HOST:
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in arrs]
+    A = arrs[0]
+    B, k, n = int(A.shape[0]), int(A.shape[1]), int(A.shape[2])
+    p = 0 if arrs[4] is None else int(arrs[4].shape[1])
+    m = 0 if arrs[6] is None else int(arrs[6].shape[1])
+    if memory == MEM_HOST:
+        x, st = np.zeros((B, n)), np.full(B, -1, dtype=np.int32)
+    else:
+        x, st = out
+    rc = lib().qlamd_weighted_lsq_qp_batch(ctx._h, n, k, p, m, *[_ptr(a) for a in arrs], B, _ptr(x), _ptr(st), memory,
+                                           C.c_void_p(stream) if stream else None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_weighted_lsq_qp_batch")
+    return x, st
 
 
 def to_device(state, device="cuda:0"):

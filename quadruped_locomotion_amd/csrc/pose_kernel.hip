@@ -268,6 +268,79 @@ __global__ __launch_bounds__(64) void qp_coop_kernel(int n, int p, int m, const 
   }
 }
 
+// Weighted least squares with equality rows and two-sided inequality rows, the form
+// ooqpei::QuadraticProblemFormulation::solve(A, S, b, W, C, c, D, d, f, x) takes (call sites
+// ContactForceDistribution.cpp:367,490):   min (Ax - b)'S(Ax - b) + x'Wx   s.t.  Cx = c,  d <= Dx <= f.
+// Lane i < n assembles row i of A'SA + W and entry i of -A'Sb (the objective halved: same minimiser); row r of D
+// gives the one-sided rows r (lower bound) and r + 24 (upper bound), a bound of +-DBL_MAX or +-inf being none;
+// the equality rows are projected out one by one inside qp_coop_impl.
+template <int N>
+__global__ __launch_bounds__(64) void weighted_lsq_qp_kernel(int n, int k, int p, int m, const double *__restrict__ A,
+                                                             const double *__restrict__ S, const double *__restrict__ bb,
+                                                             const double *__restrict__ W, const double *__restrict__ C,
+                                                             const double *__restrict__ cc, const double *__restrict__ D,
+                                                             const double *__restrict__ dlo, const double *__restrict__ fup,
+                                                             int64_t B, double *__restrict__ x, int32_t *__restrict__ status) {
+  typedef coop::QpCoopLds<N, 3> L;
+  __shared__ double rows[coop::kQpCoopRows * L::kTotal];
+  __shared__ double eq_dirs[coop::kQpCoopRows * 12 * N]; // step directions of the equality rows (refinement sweep)
+  const int row = threadIdx.x >> 4, lr = threadIdx.x & 15;
+  int64_t i = (int64_t)blockIdx.x * coop::kQpCoopRows + row;
+  const bool live = i < B;
+  if (!live) i = B - 1;
+  const bool var = lr < n;
+  const int rv = var ? lr : 0;
+  double Gm[N], gl = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; j++) Gm[j] = 0.0;
+  const double *Ap = A + (size_t)i * k * n;
+  for (int r = 0; r < k; r++) {
+    const double sr = S[(size_t)i * k + r], br = bb[(size_t)i * k + r];
+    const double ai = Ap[(size_t)r * n + rv] * sr;
+#pragma unroll
+    for (int j = 0; j < N; j++) Gm[j] = fma(ai, Ap[(size_t)r * n + (j < n ? j : 0)], Gm[j]);
+    gl = fma(-ai, br, gl);
+  }
+  const double wi = W[(size_t)i * n + rv];
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    const bool in = var && j < n;
+    Gm[j] = in ? Gm[j] + (j == lr ? wi : 0.0) : ((lr == j && lr < N) ? 1.0 : 0.0); // identity padding for rows n..N-1
+  }
+  gl = var ? gl : 0.0;
+  // one-sided rows of this lane: slots lr, lr + 16, lr + 32; slot j < 24 = lower bound of row j, else upper bound of row j - 24
+  double a[3][N], b[3];
+  bool v[3];
+  const double big = 1.7976931348623157e308;
+  int mine = 0;
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    const int slot = lr + 16 * s, r = slot < 24 ? slot : slot - 24;
+    const bool upper = slot >= 24, have = r < m;
+    const int rr = have ? r : 0;
+    const double bound = m > 0 ? (upper ? fup[(size_t)i * m + rr] : dlo[(size_t)i * m + rr]) : 0.0;
+    v[s] = have && (upper ? bound < big : bound > -big);      // DBL_MAX / inf = no bound; NaN = no row
+    b[s] = v[s] ? (upper ? bound : -bound) : 0.0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const double dj = (m > 0 && j < n) ? D[((size_t)i * m + rr) * n + j] : 0.0;
+      a[s][j] = v[s] ? (upper ? -dj : dj) : 0.0;
+    }
+    mine += v[s] ? 1 : 0;
+  }
+  // rows that exist, for the termination tolerance (QuadProg++.cc:246 counts its m)
+  int cnt = mine;
+  cnt += __shfl_xor(cnt, 8, 16); cnt += __shfl_xor(cnt, 4, 16); cnt += __shfl_xor(cnt, 2, 16); cnt += __shfl_xor(cnt, 1, 16);
+  double xo, fo;
+  const int st = coop::qp_coop_impl<N, 3>(Gm, gl, n, n, 48, false, 0.0, 0.0, a, b, v, !live, rows + row * L::kTotal, xo, fo, false,
+                                          0.0, 0.0, C ? C + (size_t)i * p * n : nullptr, cc ? cc + (size_t)i * p : nullptr,
+                                          C ? p : 0, cnt, eq_dirs + row * 12 * N);
+  if (live) {
+    if (var) x[(size_t)i * n + lr] = xo;
+    if (lr == 0) status[i] = st;
+  }
+}
+
 } // namespace
 
 extern "C" {
@@ -491,6 +564,44 @@ int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *
     if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
   }
   return QLAMD_OK;
+}
+
+int qlamd_weighted_lsq_qp_batch(qlamd_context *ctx, int n, int k, int p, int m, const double *A, const double *S,
+                                const double *b, const double *W, const double *C, const double *c, const double *D,
+                                const double *d, const double *f, int64_t batch, double *x, int32_t *status, int memory,
+                                void *stream) {
+  if (!ctx || batch < 0 || !A || !S || !b || !W || !x || !status) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (n < 1 || n > 12 || k < 1 || k > 12 || p < 0 || p > 12 || m < 0 || m > 24) return QLAMD_ERR_INVALID_ARGUMENT;
+  if ((p > 0 && (!C || !c)) || (m > 0 && (!D || !d || !f))) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  QL_ENTER(ctx, st);
+  const size_t B = (size_t)batch;
+  const double *dA = A, *dS = S, *db = b, *dW = W, *dC = p ? C : nullptr, *dc = p ? c : nullptr, *dD = m ? D : nullptr,
+               *dd = m ? d : nullptr, *df = m ? f : nullptr;
+  double *dx = x;
+  int32_t *dst = status;
+  Staged sg;
+  if (memory == QLAMD_MEM_HOST) {
+    const int iA = sg.add(A, B * k * n * 8, true, false), iS = sg.add(S, B * k * 8, true, false), ib = sg.add(b, B * k * 8, true, false);
+    const int iW = sg.add(W, B * n * 8, true, false), iC = sg.add(dC, B * p * n * 8, true, false), ic = sg.add(dc, B * p * 8, true, false);
+    const int iD = sg.add(dD, B * m * n * 8, true, false), id = sg.add(dd, B * m * 8, true, false), iF = sg.add(df, B * m * 8, true, false);
+    const int ox = sg.add(x, B * n * 8, false, true), os = sg.add(status, B * 4, false, true);
+    const int rc = sg.upload(ctx, st);
+    if (rc != QLAMD_OK) return rc;
+    dA = sg.dev<const double>(iA); dS = sg.dev<const double>(iS); db = sg.dev<const double>(ib); dW = sg.dev<const double>(iW);
+    dC = sg.dev<const double>(iC); dc = sg.dev<const double>(ic); dD = sg.dev<const double>(iD); dd = sg.dev<const double>(id);
+    df = sg.dev<const double>(iF); dx = sg.dev<double>(ox); dst = sg.dev<int32_t>(os);
+  }
+  const unsigned grid = (unsigned)((batch + coop::kQpCoopRows - 1) / coop::kQpCoopRows);
+  if (n <= 6)
+    hipLaunchKernelGGL(weighted_lsq_qp_kernel<6>, dim3(grid), dim3(64), 0, st, n, k, p, m, dA, dS, db, dW, dC, dc, dD, dd, df, batch, dx, dst);
+  else
+    hipLaunchKernelGGL(weighted_lsq_qp_kernel<12>, dim3(grid), dim3(64), 0, st, n, k, p, m, dA, dS, db, dW, dC, dc, dD, dd, df, batch, dx, dst);
+  if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  return memory == QLAMD_MEM_HOST ? sg.finish(st) : QLAMD_OK;
 }
 
 } // extern "C"

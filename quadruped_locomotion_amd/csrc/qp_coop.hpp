@@ -40,7 +40,9 @@ template <int N, int KC>
 __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, int n, int n_free, int m, bool has_eq, double ne,
                                             double ce0, const double (&a)[KC][N], const double (&b)[KC], const bool (&v)[KC],
                                             bool skip, double *lds_row, double &x_out, double &f_out, bool has_eq2 = false,
-                                            double ne2 = 0.0, double ce02 = 0.0) {
+                                            double ne2 = 0.0, double ce02 = 0.0, const double *eq_rows = nullptr,
+                                            const double *eq_rhs = nullptr, int p_rows = 0, int m_tol = -1,
+                                            double *eq_store = nullptr) {
   typedef QpCoopLds<N, KC> L;
   typedef typename std::conditional<(KC > 2), unsigned long long, unsigned>::type mask_t;
   const int lr = threadIdx.x & 15;
@@ -119,6 +121,43 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
     const double vec = sel(indep, z * dinv, 0.0), hc = sel(indep, -z, 0.0);
     static_for<N>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(H[j], vec, hc); });
   }
+  // Any number of equality ROWS  c_r'x = rhs_r  (eq_rows: this problem's [p_rows][n], row-major; the form
+  // ooqpei::QuadraticProblemFormulation::solve takes its C, c in): each is stepped onto and projected out of what the
+  // rows before it have left, exactly as the columns above.  A row that leaves nothing -- all-zero, or in the span of
+  // the earlier ones -- is skipped when the point already satisfies it (the reference's first pass hands over 3 nS
+  // zero rows with zero right-hand sides, ContactForceDistribution.cpp:364-366) and makes the problem infeasible otherwise.
+  int neq_rows = 0;
+  bool eq_inconsistent = false;
+  for (int r = 0; r < p_rows; r++) {
+    const double ner = var ? eq_rows[(size_t)r * n + lr] : 0.0;
+    const double rhs = eq_rhs[r];
+    double za[3] = {0.0, 0.0, 0.0};
+    static_for<N>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(za[j % 3], ner, H[j]); });
+    const double z = (za[0] + za[1]) + za[2];
+    const double zn = row_sum(z * ner), zz = row_sum(z * z), nx = row_sum(ner * x), ax = row_sum(fabs(ner * x));
+    const bool indep = fabs(zz) > eps && zn > 0.0 && neq_rows + (has_eq ? 1 : 0) + ((has_eq2 && !eq2_dependent) ? 1 : 0) < n_free;
+    const double resid = rhs - nx;
+    eq_inconsistent = eq_inconsistent || (!indep && fabs(resid) > 1e-9 * (1.0 + fabs(rhs) + ax));
+    neq_rows += indep ? 1 : 0;
+    const double dinv = rcp_nr(indep ? zn : 1.0);
+    x += sel(indep, resid * dinv * z, 0.0);
+    const double vec = sel(indep, z * dinv, 0.0), hc = sel(indep, -z, 0.0);
+    static_for<N>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(H[j], vec, hc); });
+    if (eq_store && lr < N) eq_store[r * N + lr] = vec; // the step direction of row r per unit of its residual
+  }
+  if (eq_store && p_rows > 0) {
+    // One sweep of refinement over the rows just projected out.  Direction r lies in the null space of rows 0..r-1 only up
+    // to the rounding of an explicit projector (times the conditioning of G: 3e5 for the force problem), so the rows
+    // taken first have drifted by the time the last one is in; stepping again along the stored directions, in the same
+    // order, puts every row back on its right-hand side (row r's step leaves rows 0..r-1 where the sweep has put them).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    for (int r = 0; r < p_rows; r++) {
+      const double ner = var ? eq_rows[(size_t)r * n + lr] : 0.0;
+      const double resid = eq_rhs[r] - row_sum(ner * x);
+      x += lr < N ? resid * eq_store[r * N + lr] : 0.0;
+    }
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_s_waitcnt(0xC07F);
 
@@ -136,13 +175,14 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
   mask_t act_mask = 0, excl = 0;
   const mask_t one = 1;
   int q = 0, iters = 0, status = kStatusOk;
-  const double psi_tol = (double)m * eps * c1 * c2 * 100.0;
+  const double psi_tol = (double)(m_tol >= 0 ? m_tol : m) * eps * c1 * c2 * 100.0; // m_tol: rows that exist, when m counts slots
   double rnorm2 = 1.0;
   bool done = skip;
   int ip = 0;
   double sp = 0.0, ucand = 0.0, npj = 0.0;
   if (bad && !skip) { status = kStatusNotPd; done = true; }
-  const int neq = (has_eq ? 1 : 0) + ((has_eq2 && !eq2_dependent) ? 1 : 0); // columns that took a dimension
+  if (eq_inconsistent && !bad && !skip) { status = kStatusInfeasible; done = true; }
+  const int neq = (has_eq ? 1 : 0) + ((has_eq2 && !eq2_dependent) ? 1 : 0) + neq_rows; // equalities that took a dimension
   const unsigned lanebit = 1u << lr;
   const int row_addr = ((int)threadIdx.x & 48) << 2;
   const int vlane = lr < N ? lr : 0;

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <limits>
 #include <vector>
 
 #include "balance_controller/RosBalanceController.hpp"
@@ -19,6 +20,7 @@
 #include "free_gait_core/PoseOptimizationGeometric.hpp"
 #include "free_gait_core/PoseOptimizationQP.hpp"
 #include "free_gait_core/PoseOptimizationSQP.hpp"
+#include "ooqp_eigen_interface/QuadraticProblemFormulation.hpp"
 #include "qp_solver/quadraticproblemsolver.hpp"
 
 int main(int argc, char **argv) {
@@ -60,6 +62,52 @@ int main(int argc, char **argv) {
   std::printf("cfd_effort"); for (double v : state->getAllJointEfforts()) std::printf(" %.17g", v); std::printf("\n");
   qlamd::Force f_lf; cfd.getForceForLeg(qlamd::LimbEnum::LF_LEG, f_lf);
   std::printf("cfd_force_lf %.17g %.17g %.17g\n", f_lf(0), f_lf(1), f_lf(2));
+
+  // ---- 1c. the OOQP seam: the reference's own assembly (ContactForceDistribution.cpp:168-336) and its literal two-pass
+  // sequence (addDesiredLegLoadConstraints :364-381: solve with 3 nS zero equality rows, then C = I, c = x1; :490 solve
+  // again) through ooqpei::QuadraticProblemFormulation::solve, on the wrench just given to computeForceDistribution
+  {
+    ooqpei::QuadraticProblemFormulation::setContext(ctx);
+    const int nS = 4, n = 3 * nS;
+    double foot[12];
+    if (qlamd_leg_kinematics_batch(ctx->get(), q, orientation, 1, foot, nullptr, nullptr, QLAMD_MEM_HOST, nullptr) != QLAMD_OK) return 22;
+    ooqpei::Matrix A_(6, n), C_(n, n), D_(5 * nS, n);
+    ooqpei::Vector S_(params.force_weights, params.force_weights + 6), b_{120.0, -40.0, 520.0, 10.0, -20.0, 5.0};
+    ooqpei::Vector W_(n, params.regularizer), c_(n, 0.0), d_(5 * nS, 0.0), f_(5 * nS, std::numeric_limits<double>::max()), x1, x2;
+    for (int l = 0; l < nS; ++l) {
+      const double *r = foot + 3 * l;
+      for (int i = 0; i < 3; ++i) A_(i, 3 * l + i) = 1.0;
+      A_(3, 3 * l + 1) = -r[2]; A_(3, 3 * l + 2) = r[1];               // kindr::getSkewMatrixFromVector(r), :197
+      A_(4, 3 * l + 0) = r[2];  A_(4, 3 * l + 2) = -r[0];
+      A_(5, 3 * l + 0) = -r[1]; A_(5, 3 * l + 1) = r[0];
+      // update() forces the surface normal to q.rotate(z) (ros_balance_controller.cpp:378): n_B = z.  The first tangential is
+      // n_B x (world y in the base frame) (:301-305); with the yaw-only attitude of this scenario world y reads
+      // (sin yaw, cos yaw, 0) in the base, so t1 = (-cos yaw, sin yaw, 0) and t2 = n_B x t1 = (-sin yaw, -cos yaw, 0)
+      const double nb[3] = {0, 0, 1}, t1[3] = {-std::cos(yaw), std::sin(yaw), 0}, t2[3] = {-std::sin(yaw), -std::cos(yaw), 0};
+      const double mu = params.friction;
+      for (int i = 0; i < 3; ++i) {
+        D_(l, 3 * l + i) = nb[i];
+        D_(nS + 4 * l + 0, 3 * l + i) = mu * nb[i] + t1[i];
+        D_(nS + 4 * l + 1, 3 * l + i) = mu * nb[i] - t1[i];
+        D_(nS + 4 * l + 2, 3 * l + i) = mu * nb[i] + t2[i];
+        D_(nS + 4 * l + 3, 3 * l + i) = mu * nb[i] - t2[i];
+      }
+      d_[l] = params.min_normal_force;
+    }
+    if (!ooqpei::QuadraticProblemFormulation::solve(A_, S_, b_, W_, C_, c_, D_, d_, f_, x1)) return 23;   // C = 0, c = 0
+    for (int i = 0; i < n; ++i) { C_(i, i) = 1.0; c_[i] = x1[i]; }
+    if (!ooqpei::QuadraticProblemFormulation::solve(A_, S_, b_, W_, C_, c_, D_, d_, f_, x2)) return 24;   // C = I, c = x1
+    std::printf("ooqpei_x1"); for (double v : x1) std::printf(" %.17g", v); std::printf("\n");
+    std::printf("ooqpei_x2"); for (double v : x2) std::printf(" %.17g", v); std::printf("\n");
+    std::printf("cfd_grf");
+    for (int l = 0; l < 4; ++l) { qlamd::Force fl; cfd.getForceForLeg(static_cast<qlamd::LimbEnum>(l), fl); for (int i = 0; i < 3; ++i) std::printf(" %.17g", -fl(i)); }
+    std::printf("\n");
+    // an inconsistent pair of equality rows is refused (OOQP reports failure; solve() returns false)
+    ooqpei::Matrix Cbad(2, n); Cbad(0, 0) = 1.0; Cbad(1, 0) = 1.0;
+    ooqpei::Vector xb;
+    if (ooqpei::QuadraticProblemFormulation::solve(A_, S_, b_, W_, Cbad, {1.0, 2.0}, D_, d_, f_, xb)) return 25;
+    std::printf("ooqpei_inconsistent_status %d\n", (int)ooqpei::QuadraticProblemFormulation::lastStatus());
+  }
 
   // ---- 1a. the whole-body controller on the same stance scenario (an extension, no reference counterpart)
   {

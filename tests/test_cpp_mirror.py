@@ -67,6 +67,14 @@ def test_mirror_matches_oracle(oracle):
                           + oracle.leg_gravity(l, out["state"][3 * l:3 * l + 3], gB) for l in range(4)])
     assert np.abs(out["cfd_effort"] - np.clip(tau, -300, 300)).max() < 1e-6
     assert np.abs(out["cfd_force_lf"] + x[:3]).max() < 1e-6      # desiredContactForce_ = -x
+    # 1c. the OOQP seam: the reference's assembly + its literal two-pass sequence through ooqpei::...::solve
+    A, S, b, W, D, d, f = oracle.force_lsq_assemble(feet, w, np.tile(nB, (4, 1)), np.tile(t1, (4, 1)), np.tile(t2, (4, 1)))
+    xo, sto = oracle.weighted_lsq_qp(A, S, b, W, None, None, D, d, f)
+    assert sto == 0 and np.abs(xo - x).max() < 1e-8
+    assert np.abs(out["ooqpei_x1"] - xo).max() < 1e-7                   # first pass: 12 zero equality rows
+    assert np.abs(out["ooqpei_x2"] - out["ooqpei_x1"]).max() < 1e-9     # second pass pinned to the first: x2 = x1
+    assert np.abs(out["cfd_grf"] - out["ooqpei_x1"]).max() < 1e-7       # = what the balance kernel's one solve distributes
+    assert out["ooqpei_inconsistent_status"][0] == 1                    # QLAMD_STATUS_INFEASIBLE
     # 1a. WholeBodyController::compute against the whole-body oracle on the same scenario
     wb = dict(q=out["state"][None], qd=out["wbc_qd"][None], base_quat=quat, base_linvel=np.array([[0.01, -0.02, 0.0]]),
               base_angvel=np.array([[0.0, 0.01, 0.02]]), a_des=np.array([[0.5, -0.3, 0.8, 0.2, -0.1, 0.4]]),
