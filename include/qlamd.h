@@ -13,9 +13,11 @@
  * slab, the intermediates of the whole tick, the layout template of the message parser) that every call
  * reuses.  Two calls on one context must not overlap: a second thread entering while a call is in progress
  * gets QLAMD_ERR_BUSY.  QLAMD_MEM_DEVICE calls are asynchronous on `stream`; work queued on one context must
- * stay ordered, so when a call arrives on another stream than the previous call the library first waits for
- * the previous stream to drain (not possible while the new stream is being captured into a hipGraph: the
- * capturing caller orders the graph itself).  Use one context per thread / per concurrent stream.
+ * stay ordered (calls share its scratch memory), so every call records an event of the context's own behind its
+ * work and a call that arrives on another stream makes that stream wait for the event -- on the device, the host
+ * does not block, and no stream handle is kept once its call has returned.  While a stream is being captured into
+ * a hipGraph neither happens: the capturing caller orders the graph itself.  Use one context per thread / per
+ * concurrent stream.
  */
 #ifndef QLAMD_H
 #define QLAMD_H
@@ -149,6 +151,9 @@ int qlamd_set_robots_per_wave(qlamd_context *ctx, int robots_per_wave);
  *                          leaves the robot's entries untouched: with one effort array reused tick after tick that is
  *                          the reference's behaviour, whose update() logs "VMC compute failed" and commands the
  *                          efforts still held in State from the previous tick (ros_balance_controller.cpp:418-424,441-454).
+ *                          Applies to qlamd_balance_solve_batch, qlamd_force_distribution_batch,
+ *                          qlamd_wholebody_solve_batch and qlamd_full_tick_batch, with QLAMD_MEM_HOST (the caller's
+ *                          arrays are read as well as written then) and QLAMD_MEM_DEVICE alike.
  *   QLAMD_OPT_REFINE_PASSES  refinement passes of the lane-cooperative force QP on its final working set (default 1)
  *   QLAMD_OPT_DYNAMICS_FORM  layout of qlamd_wholebody_dynamics_batch's kernel: QLAMD_DYNAMICS_AUTO (default) picks by batch
  *                          size; _LEG = one lane per leg, 16 robots per wavefront (throughput: large batches); _ROW = 16
@@ -525,7 +530,7 @@ int qlamd_wholebody_dynamics_batch(qlamd_context *ctx, const qlamd_wholebody_bat
  *          (ContactForceDistribution.cpp:210-336),  |tau| <= tau_max
  * i.e. 6 nS variables, 3 nS equalities and 11 nS inequalities; the torques are eliminated on the device.
  * joint_effort [B][12] (swing legs: tau0), contact_force [B][12] or NULL, status [B] (QLAMD_STATUS_*; on failure the
- * robot's efforts and forces are 0). */
+ * robot's efforts and forces are 0, or untouched with QLAMD_ON_FAILURE_KEEP). */
 int qlamd_wholebody_solve_batch(qlamd_context *ctx, const qlamd_wholebody_params *params,
                                 const qlamd_wholebody_batch *in, int64_t batch, double *joint_effort,
                                 double *contact_force, int32_t *status, int memory, void *stream);

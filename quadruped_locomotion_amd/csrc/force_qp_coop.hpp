@@ -361,7 +361,9 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(coef, Gn, Ns[j]); });
     vec = nt_me;
     hc = nt_me * einv;
-    nc = -coef * einv;
+    // the dropped slot's own coefficient is n~'G n~ / e = 1: with exactly -1 its row N*[lpos][j] - n~_j is exactly 0
+    // (n~ IS that row), which frees the slot without a pass of masked moves
+    nc = sel(lr == lpos, -1.0, -coef * einv);
     return drop_id;
   };
 
@@ -441,10 +443,6 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
         used &= ~(1u << lpos);
         q--;
         update_only();
-        if (lr == lpos) {
-#pragma unroll
-          for (int j = 0; j < 12; j++) Ns[j] = 0.0;
-        }
         // the same candidate continues with the working set one smaller: with H' = H + n~ n~'/e and N*' = N* - c n~'/e
         // its directions are z' = z + (n~/e) r_k, r' = r - (c/e) r_k, z'n = zn + r_k^2/e (r_k = n~'n_p = r of the
         // dropped slot) -- no need for the 24 broadcasts of the next pass
@@ -489,10 +487,6 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
         q--;
       }
       update_and_select(std::integral_constant<int, 1>{}, full, is_add);
-      if (is_drop && lr == lpos) {
-#pragma unroll
-        for (int j = 0; j < 12; j++) Ns[j] = 0.0;
-      }
     }
   }
 

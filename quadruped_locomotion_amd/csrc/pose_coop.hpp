@@ -197,7 +197,7 @@ __device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const 
     static_for<6>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(coef, Gn, Ns[j]); });
     vec = nt_me;
     hc = nt_me * einv;
-    nc = -coef * einv;
+    nc = sel(lr == lpos, -1.0, -coef * einv); // exactly -1 on the dropped slot: its row becomes exactly 0 (force_qp_coop.hpp)
     return drop_id;
   };
 
@@ -280,10 +280,6 @@ __device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const 
         q--;
       }
       update_and_select(std::integral_constant<int, 1>{}, full, is_add);
-      if (is_drop && lr == lpos) {
-#pragma unroll
-        for (int j = 0; j < 6; j++) Ns[j] = 0.0;
-      }
     }
   }
   // one refinement pass on the final working set (see balance_coop.hpp)

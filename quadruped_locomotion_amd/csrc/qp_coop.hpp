@@ -286,7 +286,7 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
     static_for<N>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(coef, Gn, Ns[j]); });
     vec = nt_me;
     hc = nt_me * einv;
-    nc = -coef * einv;
+    nc = sel(lr == lpos, -1.0, -coef * einv); // exactly -1 on the dropped slot: its row becomes exactly 0 (force_qp_coop.hpp)
     return drop_id;
   };
 
@@ -370,10 +370,6 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
         q--;
       }
       update_and_select(std::integral_constant<int, 1>{}, full, is_add);
-      if (is_drop && lr == lpos) {
-#pragma unroll
-        for (int j = 0; j < N; j++) Ns[j] = 0.0;
-      }
     }
   }
   // one refinement pass on the final working set (see balance_coop.hpp)

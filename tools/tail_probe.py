@@ -5,10 +5,9 @@ The 4096-robot step lasts as long as its slowest wavefront; this probe launches 
 robot four times) for robots of the bench batches with known iteration counts and prints microseconds per launch
 (hipGraph of launches; the constant launch gap is in every line, differences are pure kernel time).
 usage: tail_probe.py [--lib path/to/libqlamd_variant.so] [--gait static|trot] [--errors calm|survey]
-The iteration counts come from tests/golden-free oracle runs done in the build container and are passed in as a
-JSON file (tools/tail_probe_cases.json: {"static-calm": [[robot, iters, n_active], ...], ...})."""
+The robots and their iteration counts (CASES: workload -> [robot, outer iterations, final active rows]) come from oracle
+runs over the bench batches done in the build container."""
 import argparse
-import json
 import os
 import sys
 
@@ -16,6 +15,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+CASES = {
+    "static-calm": [[0, 1, 0], [35, 2, 1], [10, 3, 2], [209, 4, 3], [4, 6, 5], [1805, 8, 6], [1225, 10, 7], [923, 11, 6]],
+    "static-survey": [[8, 1, 0], [38, 2, 1], [9, 3, 2], [15, 4, 3], [46, 6, 5], [3, 8, 7], [1, 10, 7], [14, 11, 6], [10, 12, 9], [0, 14, 8], [4, 16, 10], [128, 18, 9], [973, 20, 12]],
+    "trot-survey": [[3, 1, 0], [7, 2, 1], [1, 3, 2], [0, 4, 3], [53, 6, 4], [147, 8, 6], [10, 10, 8], [35, 11, 8], [17, 12, 7], [33, 14, 9], [652, 16, 9], [973, 18, 12], [2998, 20, 10], [2748, 21, 10]],
+}
 
 
 def main():
@@ -27,7 +32,7 @@ def main():
     from quadruped_locomotion_amd import capi, synth
     if args.lib:
         capi.LIB_PATH = os.path.abspath(args.lib)
-    cases = json.load(open(os.path.join(ROOT, "tools", "tail_probe_cases.json")))
+    cases = CASES
     ctx = capi.Context(device=0)
     for name, rows in cases.items():
         gait, err = name.split("-")
