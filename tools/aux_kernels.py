@@ -64,6 +64,18 @@ for tag in ("n12", "n6"):                      # the golden force QPs (n = 12, m
     for _ in range(REPS):
         capi.qp_solve(ctx, Gq, g0q, None, None, CIq, ci0q)
 
+# the same 4096 force problems in the (A, S, b, W, D, d, f) form of the ooqpei seam: any A with A'A = G - W and
+# A'b = -g0 states the same problem (S = 1, W = 1e-4 I, the reference's regulariser): take it from the eigenvectors of G - W
+lam, V = np.linalg.eigh(g["n12_G"] - 1e-4 * np.eye(12))
+A128 = np.sqrt(np.clip(lam, 0.0, None))[:, :, None] * np.transpose(V, (0, 2, 1))          # [128][12][12], six rows ~ 0
+b128 = np.stack([-np.linalg.lstsq(A128[i].T, g["n12_g0"][i], rcond=None)[0] for i in range(128)])
+Aq, bq = np.tile(A128, (B // 128, 1, 1)), np.tile(b128, (B // 128, 1))
+Dq = np.tile(np.transpose(g["n12_CI"], (0, 2, 1)), (B // 128, 1, 1))
+dq = np.tile(-g["n12_ci0"], (B // 128, 1))
+for _ in range(REPS):
+    xw, stw = capi.weighted_lsq_qp(ctx, Aq, np.ones((B, 12)), bq, np.full((B, 12), 1e-4), None, None, Dq, dq, np.full(dq.shape, capi.NO_BOUND))
+print("weighted lsq vs golden x: %.2e" % np.abs(xw[:128] - g["n12_x"]).max())
+
 for _ in range(REPS):
     ctx.balance_solve_host(st)
     ctx.balance_solve_host(synth.make_states(B, "static"))
