@@ -13,11 +13,12 @@
  * slab, the intermediates of the whole tick, the layout template of the message parser) that every call
  * reuses.  Two calls on one context must not overlap: a second thread entering while a call is in progress
  * gets QLAMD_ERR_BUSY.  QLAMD_MEM_DEVICE calls are asynchronous on `stream`; work queued on one context must
- * stay ordered (calls share its scratch memory), so every call records an event of the context's own behind its
- * work and a call that arrives on another stream makes that stream wait for the event -- on the device, the host
- * does not block, and no stream handle is kept once its call has returned.  While a stream is being captured into
- * a hipGraph neither happens: the capturing caller orders the graph itself.  Use one context per thread / per
- * concurrent stream.
+ * stay ordered (calls share its scratch memory).  Calls on one stream are ordered by the stream.  The first call that
+ * arrives on another stream drains the device once; from then on every call records an event of the context's own
+ * behind its work and a call on another stream makes that stream wait for the event -- on the device, the host does not
+ * block, and no stream handle is kept once its call has returned.  While a stream is being captured into a hipGraph
+ * none of this happens: the capturing caller orders the graph itself.  Use one context per thread / per concurrent
+ * stream.
  */
 #ifndef QLAMD_H
 #define QLAMD_H

@@ -307,6 +307,8 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
   ctx->last_stream = nullptr;
   ctx->done_event = nullptr;
   ctx->done_recorded = false;
+  ctx->had_work = false;
+  ctx->multi_stream = false;
   qlamd_robot_model m;
   if (model) m = *model; else default_robot_model(&m);
   build_device_params(*params, m, &ctx->params);

@@ -39,8 +39,9 @@ struct qlamd_context {
   std::thread::id owner;
   int depth;
   hipStream_t last_stream;   // compared only, never passed to a HIP call after its own call returned
-  hipEvent_t done_event;     // recorded behind the work of every outermost call (created on first use)
+  hipEvent_t done_event;     // recorded behind the work of every outermost call once two streams have been seen
   bool done_recorded;
+  bool had_work, multi_stream;
 };
 
 
@@ -90,11 +91,14 @@ __device__ __forceinline__ void load3(const double *p, int64_t t, double o[3]) {
 
 // Entry guard of every call that uses the context.  A second thread entering while a call is in progress gets
 // QLAMD_ERR_BUSY (the whole tick nests calls on its own thread: allowed).  Calls on one stream are ordered by the
-// stream.  When the stream changes, the new call's work must not overtake the previous call's (both use the context's
-// scratch memory): every outermost call records the context's own event behind its work, and a call on another stream
-// makes its stream wait for that event -- asynchronous, and no handle of the caller's is kept beyond the call (only its
-// value, to see that the stream changed).  While a stream is being captured into a graph neither is done (an event
-// recorded inside a capture cannot be waited for outside it, and the reverse): the capturing caller orders the graph.
+// stream and cost nothing here.  When the stream changes, the new call's work must not overtake the previous call's
+// (both use the context's scratch memory).  No handle of the caller's is kept beyond its call -- only its value, to see
+// that the stream changed.  The first time that happens the device is drained once (the earlier stream cannot be named
+// any more) and the context turns to event ordering: from then on every outermost call records the context's own event
+// behind its work and a call on another stream makes its stream wait for it -- asynchronous, on the device.  A context
+// that stays on one stream never records anything (an event record costs an eager launch loop ~3 us per call,
+// measured).  While a stream is being captured into a graph neither is done (an event recorded inside a capture
+// cannot be waited for outside it, and the reverse): the capturing caller orders the graph.
 struct CallGuard {
   qlamd_context *c;
   int rc;
@@ -111,28 +115,38 @@ struct CallGuard {
       std::lock_guard<std::mutex> lk(c->gate);
       if (c->depth > 0 && c->owner != me) { rc = QLAMD_ERR_BUSY; c = nullptr; return; }
       c->owner = me;
-      if (c->depth++ > 0) { uses_stream = false; return; } // nested: the outermost call records
+      if (c->depth++ > 0) { uses_stream = false; return; } // nested: the outermost call does the ordering
     }
-    if (!uses_stream) return;
-    if (c->done_recorded && c->last_stream != st && !capturing(st)) {
+    if (!uses_stream || !c->had_work || c->last_stream == st || capturing(st)) return;
+    if (!c->multi_stream) {
+      // first change of stream: drain the device once (legal whatever another thread is capturing), then order by events
+      c->multi_stream = true;
+      hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+      (void)hipThreadExchangeStreamCaptureMode(&mode);
+      if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+      (void)hipThreadExchangeStreamCaptureMode(&mode);
+    } else if (c->done_recorded) {
       if (hipStreamWaitEvent(st, c->done_event, 0) != hipSuccess) (void)hipGetLastError();
     }
   }
   ~CallGuard() {
     if (!c) return;
     if (uses_stream) {
-      // outermost call: mark the end of its work for a later call on another stream
-      if (!capturing(st)) {
-        if (!c->done_event && hipEventCreateWithFlags(&c->done_event, hipEventDisableTiming) != hipSuccess) {
-          (void)hipGetLastError();
-          c->done_event = nullptr;
+      if (c->multi_stream) {
+        // mark the end of this call's work for a later call on another stream
+        if (!capturing(st)) {
+          if (!c->done_event && hipEventCreateWithFlags(&c->done_event, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            c->done_event = nullptr;
+          }
+          c->done_recorded = c->done_event && hipEventRecord(c->done_event, st) == hipSuccess;
+          if (!c->done_recorded) (void)hipGetLastError();
+        } else {
+          c->done_recorded = false;
         }
-        c->done_recorded = c->done_event && hipEventRecord(c->done_event, st) == hipSuccess;
-        if (!c->done_recorded) (void)hipGetLastError();
-      } else {
-        c->done_recorded = false;
       }
       c->last_stream = st;
+      c->had_work = true;
     }
     std::lock_guard<std::mutex> lk(c->gate);
     c->depth--;

@@ -29,6 +29,18 @@ struct BaseCommand { // what baseCommandCallback stores, ros_balance_controller.
   bool support[4] = {true, true, true, true};
 };
 
+// One record of the plugin's in-memory log (ros_balance_controller.cpp:606-716: leg_states_, joint_command_, joint_actual_,
+// foot_desired_contact_, leg_phases_, up to log_length_ = 10 000 ticks, :17; replayed on /log/* when /capture_log_data is
+// called, :1173-1191).  The ROS message types are absent; the fields are the numbers those messages carry.
+struct TickLogEntry {
+  int8_t leg_state[4];                 // leg_state.data (the state codes of the four limbs)
+  double joint_command[12];            // joint_command.effort: what joints[i].setCommand received
+  double joint_actual[12];             // joint_actual.position
+  double desired_contact_force[12];    // foot_desired_contact_: desiredContactForce_ (= -x) rotated to the WORLD frame (:656-661)
+  uint8_t is_contact[4];               // real_contact_ (:670)
+  double leg_phase[8];                 // leg_phase.data[2 i] = stance phase, [2 i + 1] = swing phase (:672-673)
+};
+
 class RosBalanceController {
  public:
   // init: false aborts the controller load (ros_balance_controller.cpp:98-141)
@@ -123,8 +135,13 @@ class RosBalanceController {
     if (qlamd_swing_branch_batch(ctx_->get(), &sp, &pid, &sw, &ex, period, 1, hw_.joint_effort_write, QLAMD_MEM_HOST, nullptr) !=
         QLAMD_OK)
       return false;
+    appendLog();
     return solved;
   }
+  // the tail of update() (:606-716): one record per tick while fewer than log_length_ are held
+  const std::vector<TickLogEntry> &log() const { return log_; }
+  void clearLog() { log_.clear(); }
+  void setLogLength(size_t n) { log_length_ = n; }
   // The same tick through ONE call of the C-ABI (qlamd_full_tick_batch, batch 1): message bytes in, 12 efforts out.
   // Equivalent to baseCommandCallback(msg) + footContactsCallback + updateFullTick(period); a message that cannot be
   // deserialised leaves the command of the last good one in force, as in the reference where it never reaches the
@@ -152,6 +169,27 @@ class RosBalanceController {
   const VirtualModelController &vmc() const { return *virtual_model_controller_; }
 
  private:
+  void appendLog() {
+    if (log_.size() >= log_length_) return;                                          // :607
+    TickLogEntry e{};
+    const double w = hw_.orientation[0], x = hw_.orientation[1], y = hw_.orientation[2], z = hw_.orientation[3];
+    const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                         2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+    const auto &grf = virtual_model_controller_->getContactForces();                 // x: ground reaction, base frame
+    for (int l = 0; l < 4; ++l) {
+      e.leg_state[l] = leg_state_code_[l];
+      e.is_contact[l] = contact_[l];
+      e.leg_phase[2 * l] = support_leg_[l] ? phase_[l] : 0.0;
+      e.leg_phase[2 * l + 1] = support_leg_[l] ? 0.0 : phase_[l];
+      for (int r = 0; r < 3; ++r)                                                    // orientation.rotate(-x_leg)
+        e.desired_contact_force[3 * l + r] = -(R[3 * r] * grf[3 * l] + R[3 * r + 1] * grf[3 * l + 1] + R[3 * r + 2] * grf[3 * l + 2]);
+    }
+    for (int i = 0; i < 12; ++i) { e.joint_command[i] = hw_.joint_effort_write[i]; e.joint_actual[i] = hw_.joint_position_read[i]; }
+    log_.push_back(e);
+  }
+  std::vector<TickLogEntry> log_;
+  size_t log_length_ = 10000;                                                        // log_length_, :17
   RobotStateHandleData hw_;
   BaseCommand cmd_;
   std::shared_ptr<qlamd::Context> ctx_;

@@ -158,6 +158,16 @@ int main(int argc, char **argv) {
     }
     std::sort(us.begin() + 50, us.end());
     std::printf("tick_latency_us %.1f %.1f\n", us[50 + 125], us[50 + 225]); // median and p90 after 50 warm-up ticks
+    // the in-memory log of update() (:606-716): one record per tick, capped at log_length_
+    const auto &log = tick.log();
+    std::printf("tick_log_size %zu\n", log.size());
+    std::printf("tick_log0_contact_force"); for (double v : log.front().desired_contact_force) std::printf(" %.17g", v); std::printf("\n");
+    std::printf("tick_log0_effort"); for (double v : log.front().joint_command) std::printf(" %.17g", v); std::printf("\n");
+    std::printf("tick_log0_leg_state"); for (int l = 0; l < 4; ++l) std::printf(" %d", log.front().leg_state[l]); std::printf("\n");
+    std::printf("tick_log0_phase"); for (double v : log.front().leg_phase) std::printf(" %.17g", v); std::printf("\n");
+    tick.setLogLength(log.size() + 2);
+    for (int rep = 0; rep < 5; ++rep) tick.updateFullTick(0.0025);
+    std::printf("tick_log_capped %zu\n", tick.log().size());
     // the same first tick through the one-call entry on a fresh controller: identical efforts; then its latency
     double effort1[12] = {0};
     balance_controller::RobotStateHandleData hw1 = hw;

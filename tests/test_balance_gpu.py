@@ -350,3 +350,39 @@ def test_keep_on_failure_leaves_failed_robots_untouched(oracle, B):
         assert np.array_equal(dt.cpu().numpy()[failed], pre_tau[failed]) and np.array_equal(dg.cpu().numpy()[failed], pre_grf[failed])
         assert np.array_equal(dt.cpu().numpy()[~failed], ref_tau[~failed])
         ctx.close()
+
+
+def test_calls_on_alternating_streams_stay_ordered(oracle):
+    """One context, calls alternating between two streams (and host-buffer calls on the default stream in between): every
+    call's work is ordered behind the previous call's -- they share the context's scratch memory -- without the library
+    holding on to a stream handle: a stream destroyed after its call is never touched again."""
+    import torch
+    from quadruped_locomotion_amd import capi
+    ctx = capi.Context()
+    B = 2048
+    states = [synth.make_states(B, "trot", offset=k * B) for k in range(6)]
+    refs = [oracle.balance_batch(s)[0] for s in states[:3]]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for k, s in enumerate(states):
+        st = streams[k & 1]
+        with torch.cuda.stream(st):
+            d = capi.to_device(s)
+            tau = torch.zeros(B, 12, dtype=torch.float64, device="cuda:0")
+            status = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+            ctx.balance_solve_device(d, tau, None, status, stream=st.cuda_stream)
+            outs.append((d, tau, status))
+        if k == 2:
+            host_tau, _, host_st = ctx.balance_solve_host(states[0])       # default stream, staging slab of the context
+            assert np.abs(host_tau - refs[0]).max() < TAU_TOL
+        if k == 3:
+            torch.cuda.synchronize()
+            streams[1] = None                                              # the stream of calls 1 and 3 is gone
+            streams[1] = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert (outs[k][2].cpu().numpy() == 0).all()
+        assert np.abs(outs[k][1].cpu().numpy() - refs[k]).max() < TAU_TOL
+    for k in range(3, 6):
+        assert (outs[k][2].cpu().numpy() == 0).all()
+    ctx.close()

@@ -130,6 +130,14 @@ def test_mirror_full_tick_matches_oracle(oracle, tmp_path):
     el, ei = np.zeros(3), np.zeros(3)
     swing = oracle.swing_branch_leg(0, 4, quat, q[:3], q[:3], qd[:3], np.zeros(3), foot_t[0], foot_v[0], cmd_q[:3], 0.0025, el, ei)
     assert np.abs(out["tick_effort"][:3] - swing).max() < 1e-8
+    # the in-memory log (ros_balance_controller.cpp:606-716): 301 ticks so far, the first record holds the first tick's
+    # efforts, state codes, phases, and the desired contact forces (-x) rotated into the world frame (:656-661)
+    assert out["tick_log_size"][0] == 301 and out["tick_log_capped"][0] == 303      # stops at log_length_
+    assert np.array_equal(out["tick_log0_effort"], out["tick_effort"]) and list(out["tick_log0_leg_state"]) == [0, 2, 2, 2]
+    Rm = oracle.quat_to_matrix(quat)
+    want = np.concatenate([Rm @ (-r["grf"][3 * l:3 * l + 3]) for l in range(4)])
+    assert np.abs(out["tick_log0_contact_force"] - want).max() < 1e-6 and np.abs(want[:3]).max() == 0.0   # LF swings
+    assert np.allclose(out["tick_log0_phase"], [0, 0.3, 0.3, 0, 0.3, 0, 0.3, 0])
     # the whole tick (message -> 12 efforts, host buffers, batch 1) fits the reference's 400 Hz loop many times over
     # the one-call tick (qlamd_full_tick_batch) gives the same efforts as the four-call tick
     assert np.array_equal(out["tick1_effort"], out["tick_effort"])
