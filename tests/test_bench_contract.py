@@ -1,5 +1,5 @@
 """The one-line JSON contract of bench.py: every key the driver reads, with the types and relations it relies on.
-CPU: the committed line of the last measured run (profiles/r2/bench_static_b4096.json).  GPU: a short live run."""
+CPU: the committed line of the last measured run (profiles/r3/bench_static_b4096.json).  GPU: short live runs."""
 import json
 import os
 import subprocess
@@ -38,12 +38,20 @@ def check(line, want_cpu=True):
 
 
 def test_committed_bench_line_follows_the_contract():
-    path = os.path.join(ROOT, "profiles", "r2", "bench_static_b4096.json")
+    path = os.path.join(ROOT, "profiles", "r3", "bench_static_b4096.json")
     d = check(open(path).read().strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["config"]["robots_per_gpu"] == 4096 and d["config"]["all_status_ok"] is True
-    # what round 2 added: the input is disclosed, the timed region is a median of samples, PMC numbers carry their source
-    assert d["config"]["tracking_error"] == [0.004, 0.005, 0.01] and len(d["config"]["samples_ms"]) >= 11
-    assert "traffic_source" in d["roofline"] and d["cpu_baseline"]["cpu_model"] and d["cpu_baseline"]["thread_sweep"]
+    # round 2: the input is disclosed, the timed region is a median of samples, PMC numbers carry their source
+    assert len(d["config"]["samples_ms"]) >= 11 and "traffic_source" in d["roofline"]
+    # round 3: the driver-timed workload is SURVEY 8(d)'s literal one, the other presets ride along, the CPU baseline is a
+    # sustained rate of pinned threads, every PMC record says which FETCH_SIZE rule it got
+    assert d["config"]["gait"] == "static" and d["config"]["tracking_error"] == [0.02, 0.05, 0.1]
+    assert set(d["also"]) == {"static-calm", "trot"} and all(a["all_status_ok"] for a in d["also"].values())
+    assert d["also"]["static-calm"]["tracking_error"] == [0.004, 0.005, 0.01]
+    c = d["cpu_baseline"]
+    assert c["cpu_model"] and c["value"] >= 0.9 * max(c["thread_sweep"].values()) and c["thread_sweep_seconds_each"] >= 1.5
+    assert d["roofline"]["traffic"] and "FETCH_SIZE" in d["roofline"]["traffic_rule"]
+    assert d["valu_issue"]["frac"] >= 0.25
 
 
 @pytest.mark.gpu
@@ -121,7 +129,8 @@ def test_profile_collection_names_exist_in_the_sources():
     kernels = set(re.findall(r"__global__[^;{]*?\bvoid\s+(\w+)\s*\(", text))
     for name, kernel, batch, args in cp.WORKLOADS:
         assert kernel in kernels, kernel
-    idx = json.load(open(os.path.join(ROOT, "profiles", "r2", "pmc_index.json")))
+    idx = json.load(open(os.path.join(ROOT, "profiles", "r3", "pmc_index.json")))
     have = {(r["kernel"], r["batch"], r["workload"]) for r in idx["records"]}
     assert have == {(k, b, n) for n, k, b, _ in cp.WORKLOADS}
     assert all("fetch_bytes" in r and "write_bytes" in r and "valu_insts" in r for r in idx["records"])
+    assert all(r["incomplete"] is False and r["fetch_size_rule"].startswith("FETCH_SIZE") for r in idx["records"])
