@@ -332,9 +332,21 @@ __global__ __launch_bounds__(64) void weighted_lsq_qp_kernel(int n, int k, int p
   int cnt = mine;
   cnt += __shfl_xor(cnt, 8, 16); cnt += __shfl_xor(cnt, 4, 16); cnt += __shfl_xor(cnt, 2, 16); cnt += __shfl_xor(cnt, 1, 16);
   double xo, fo;
-  const int st = coop::qp_coop_impl<N, 3>(Gm, gl, n, n, 48, false, 0.0, 0.0, a, b, v, !live, rows + row * L::kTotal, xo, fo, false,
-                                          0.0, 0.0, C ? C + (size_t)i * p * n : nullptr, cc ? cc + (size_t)i * p : nullptr,
-                                          C ? p : 0, cnt, eq_dirs + row * 12 * N);
+  int st;
+  const double *Ci = C ? C + (size_t)i * p * n : nullptr, *ci = cc ? cc + (size_t)i * p : nullptr;
+  // Slots 24..47 hold the upper bounds.  The reference's problem has none at all (f = DBL_MAX throughout,
+  // ContactForceDistribution.cpp:246,329): when no problem of this wavefront has one, the two-rows-per-lane form of the
+  // solver does with its 24 slots (the LDS block is laid out for the three-row form, the larger one).
+  if (__builtin_amdgcn_ballot_w64(v[2] || (v[1] && lr >= 8)) == 0ull) {
+    const double(&a2)[2][N] = reinterpret_cast<const double(&)[2][N]>(a);
+    const double(&b2)[2] = reinterpret_cast<const double(&)[2]>(b);
+    const bool(&v2)[2] = reinterpret_cast<const bool(&)[2]>(v);
+    st = coop::qp_coop_impl<N, 2>(Gm, gl, n, n, 24, false, 0.0, 0.0, a2, b2, v2, !live, rows + row * L::kTotal, xo, fo, false, 0.0,
+                                  0.0, Ci, ci, C ? p : 0, cnt, eq_dirs + row * 12 * N);
+  } else {
+    st = coop::qp_coop_impl<N, 3>(Gm, gl, n, n, 48, false, 0.0, 0.0, a, b, v, !live, rows + row * L::kTotal, xo, fo, false, 0.0,
+                                  0.0, Ci, ci, C ? p : 0, cnt, eq_dirs + row * 12 * N);
+  }
   if (live) {
     if (var) x[(size_t)i * n + lr] = xo;
     if (lr == 0) status[i] = st;
