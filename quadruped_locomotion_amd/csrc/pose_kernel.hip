@@ -294,12 +294,24 @@ __global__ __launch_bounds__(64) void weighted_lsq_qp_kernel(int n, int k, int p
 #pragma unroll
   for (int j = 0; j < N; j++) Gm[j] = 0.0;
   const double *Ap = A + (size_t)i * k * n;
-  for (int r = 0; r < k; r++) {
-    const double sr = S[(size_t)i * k + r], br = bb[(size_t)i * k + r];
-    const double ai = Ap[(size_t)r * n + rv] * sr;
+  {
+    // lane i holds column i of A (one load per row of A); entry (i, j) of A'SA is the sum over the rows r of
+    // A[r][i] S[r] (mine) times A[r][j] (lane j's, through the DPP operand): k x N broadcast-FMAs, no further loads
+    double acol[12], sa[12];
 #pragma unroll
-    for (int j = 0; j < N; j++) Gm[j] = fma(ai, Ap[(size_t)r * n + (j < n ? j : 0)], Gm[j]);
-    gl = fma(-ai, br, gl);
+    for (int r = 0; r < 12; r++) {
+      const bool in = r < k;
+      const int rr = in ? r : 0;
+      const double sr = S[(size_t)i * k + rr], br = bb[(size_t)i * k + rr];
+      const double av = Ap[(size_t)rr * n + rv];
+      acol[r] = (in && var) ? av : 0.0;
+      sa[r] = acol[r] * sr;
+      gl = fma(-sa[r], br, gl);
+    }
+    coop::static_for<12>([&](auto R) {
+      constexpr int r = R;
+      coop::static_for<N>([&](auto J) { constexpr int j = J; coop::fmac_bc<j, j == 0>(Gm[j], acol[r], sa[r]); });
+    });
   }
   const double wi = W[(size_t)i * n + rv];
 #pragma unroll
