@@ -171,8 +171,10 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
   // A lone wavefront issues one instruction every ~4.5 cycles whatever its kind (tools/ubench/issue_model.hip), so a
   // pass costs what it has instructions.  The four robots of a wavefront take different branches of the method, which
   // makes every state update a predicated select; but the launch lasts as long as its slowest robot, which spends
-  // most of its passes as the only live row of its wavefront.  So the tail of a pass exists three times: all live
-  // rows add (no predication, selection follows), all live rows drop (no selection), and the general predicated form.
+  // most of its passes as the only live row of its wavefront.  So the tail of a pass exists as two straight paths -- a
+  // row adds (no predication, selection follows), a row drops (no selection) -- which the rows of a wavefront take one
+  // after the other under their execution masks when they disagree, and as the general predicated form for what is left
+  // (a degenerate add, an infeasible problem).
   //
   // Selection.  Lane (leg, c) watches friction row c + 1 of its leg and, when c = 0, the minimum-force row: with the
   // three components of x_leg fetched through quad_perm each slack is a 3-term dot product with the lane's own row
@@ -371,13 +373,54 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
 
   // Loop structure.  A pass = directions and step lengths, then what the step is.  Passes in which EVERY live row adds
   // its constraint run in an inner loop that is one straight path: unpredicated bookkeeping, then update + selection.
-  // It is left as soon as some row drops, fails or is infeasible; that pass is finished by the tail below (all rows
-  // drop: unpredicated, no selection; otherwise the general predicated form) and the inner loop is entered again.
+  // It is left as soon as some row drops, fails or is infeasible; that pass is finished by the tail below (rows that
+  // drop: unpredicated, no selection; rows that add: the same straight path as in the inner loop; a row that does
+  // neither sends the whole pass through the general predicated form) and the inner loop is entered again.
   // (Alternative tails inside ONE loop cost 24 register copies of H and N* on its back edge; and the launch lasts as
   // long as its slowest robot, which is alone in its wavefront for most of its passes.)
   // Terminates: at most kMaxOuter adds, every drop undoes an earlier add, a failed add bans its row until the next add.
   double z = 0.0, r = 0.0, zn = 0.0, zinv = 0.0, t = 0.0, tl1 = 0.0, tl2 = 0.0, ratio = 0.0;
-  bool have_dirs = false; // wave-uniform: the directions of the pass at hand follow from the drop just made
+  bool have_dirs = false; // wave-uniform: the directions of the pass at hand follow from the drops just made
+  // ---- a full step that adds the candidate: H -= z z'/d, N* <- [N* - r z'/d ; z'/d], the new row goes to the lowest
+  // free slot lane; then the selection of the next candidate in the shadow of the update
+  const auto add_step = [&]() {
+    x += t * z;
+    u = fma(-t, r, u);
+    const int newlane = __ffs(~used & 0xFFFu) - 1;
+    const bool newslot = lr == newlane;
+    vec = z * zinv;
+    hc = -z;
+    nc = sel(newslot, 1.0, -r);
+    u = sel(newslot, ucand + t, u);
+    idk = newslot ? ip : idk;
+    used |= 1u << newlane;
+    act_mask |= one << ip;
+    rnorm2 = vmax(rnorm2, zn);
+    q += 1;
+    update_and_select(std::integral_constant<int, 2>{}, true, true);
+  };
+  // ---- a partial step (t1 < t2), or a dual step only when t2 is infinite: the blocking constraint leaves the working set
+  // and the same candidate continues
+  const auto drop_step = [&]() {
+    const double tp = (tl2 >= inf) ? 0.0 : t;
+    x += tp * z;
+    u = fma(-t, r, u);
+    ucand += t;
+    sp += tp * zn; // slack of ip after a partial step (:436-440, linear in t)
+    const int lpos = row_first(ratio == tl1 && ratio < inf);
+    const double r_lpos = __shfl(r, lpos, 16);
+    const int drop_id = drop_vectors(lpos);
+    act_mask &= ~(one << drop_id);
+    used &= ~(1u << lpos);
+    q--;
+    update_only();
+    // the same candidate continues with the working set one smaller: with H' = H + n~ n~'/e and N*' = N* - c n~'/e
+    // its directions are z' = z + (n~/e) r_k, r' = r - (c/e) r_k, z'n = zn + r_k^2/e (r_k = n~'n_p = r of the
+    // dropped slot) -- no need for the 24 broadcasts of the next pass when every live row has dropped
+    z = fma(hc, r_lpos, z);
+    r = fma(nc, r_lpos, r);
+    zn = fma(r_lpos * r_lpos, drop_einv, zn);
+  };
   for (;;) {
     bool is_add = false;
     while (!done) {
@@ -410,47 +453,20 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
       // a full step (:384) whose constraint can be added (:392: |R_qq| = sqrt(z'n_p) > eps * R_norm, compared squared)
       is_add = (tl2 < inf) && (tl2 <= tl1) && (zn > eps * eps * rnorm2);
       if (__builtin_amdgcn_ballot_w64(!is_add) != 0ull) break;
-      // ---- every live row takes a full step and adds its constraint: H -= z z'/d, N* <- [N* - r z'/d ; z'/d],
-      // the new row goes to the lowest free slot lane
-      x += t * z;
-      u = fma(-t, r, u);
-      const int newlane = __ffs(~used & 0xFFFu) - 1;
-      const bool newslot = lr == newlane;
-      vec = z * zinv;
-      hc = -z;
-      nc = sel(newslot, 1.0, -r);
-      u = sel(newslot, ucand + t, u);
-      idk = newslot ? ip : idk;
-      used |= 1u << newlane;
-      act_mask |= one << ip;
-      rnorm2 = vmax(rnorm2, zn);
-      q += 1;
-      update_and_select(std::integral_constant<int, 2>{}, true, true);
+      add_step(); // every live row adds
     }
     if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
-    if (__builtin_amdgcn_ballot_w64(!done && !(tl1 < tl2)) == 0ull) {
-      // ---- every live row drops a constraint (t1 < t2: partial step, or dual step only when t2 is infinite)
-      if (!done) {
-        const double tp = (tl2 >= inf) ? 0.0 : t;
-        x += tp * z;
-        u = fma(-t, r, u);
-        ucand += t;
-        sp += tp * zn; // slack of ip after a partial step (:436-440, linear in t)
-        const int lpos = row_first(ratio == tl1 && ratio < inf);
-        const double r_lpos = __shfl(r, lpos, 16);
-        const int drop_id = drop_vectors(lpos);
-        act_mask &= ~(one << drop_id);
-        used &= ~(1u << lpos);
-        q--;
-        update_only();
-        // the same candidate continues with the working set one smaller: with H' = H + n~ n~'/e and N*' = N* - c n~'/e
-        // its directions are z' = z + (n~/e) r_k, r' = r - (c/e) r_k, z'n = zn + r_k^2/e (r_k = n~'n_p = r of the
-        // dropped slot) -- no need for the 24 broadcasts of the next pass
-        z = fma(hc, r_lpos, z);
-        r = fma(nc, r_lpos, r);
-        zn = fma(r_lpos * r_lpos, drop_einv, zn);
-      }
-      have_dirs = true;
+    const bool drops = !done && (tl1 < tl2);
+    if (__builtin_amdgcn_ballot_w64(!done && !is_add && !drops) == 0ull) {
+      // ---- every live row either drops a constraint or adds one.  The rows that drop take the straight drop path, then
+      // the rows that add the straight add path, each under its rows' execution mask: a pass in which the robots of a
+      // wavefront disagree (a quarter of the passes of the survey-literal batch) costs one of each.  Through the
+      // predicated general form below, which such a pass took until round 3, it cost more than both together: 1.28 us
+      // (tools/experiments/mixed_pass_probe.py).  When every live row has dropped, the next pass starts from the
+      // continued directions; otherwise all rows compute theirs afresh (they are due for the rows that added anyway).
+      if (drops) drop_step();
+      if (!done && is_add) add_step();
+      have_dirs = __builtin_amdgcn_ballot_w64(!done && is_add) == 0ull;
     } else if (!done) {
       // ---- the pass of the live rows in general form (all row-uniform)
       const bool infeasible = !(t < inf);                          // :339-344
