@@ -484,7 +484,10 @@ def main():
     # rank 0 at N = 1 only: the CPU baseline, in a pinned child process, BEFORE this process touches the GPU
     cpu = None
     if not args.no_cpu_baseline and world == 1:
-        cpu = cpu_baseline(args.gait, args.errors, args.batch, args.cpu_seconds)
+        try:
+            cpu = cpu_baseline(args.gait, args.errors, args.batch, args.cpu_seconds)
+        except Exception as e:  # the GPU measurement must not be lost to a failing host-side probe
+            sys.stderr.write("cpu_baseline failed (%s: %s); the line is printed without it\n" % (type(e).__name__, e))
 
     import numpy as np
     import torch
