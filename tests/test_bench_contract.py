@@ -56,16 +56,17 @@ def test_committed_bench_line_follows_the_contract():
 
 @pytest.mark.gpu
 def test_live_bench_line_follows_the_contract():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--cpu-seconds", "2",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--cpu-seconds", "4",
                           "--no-also"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, "bench.py must print exactly one line"
     d = check(lines[0])
     assert d["steps"] == 20 and d["warmup"] == 3 and d["config"]["all_status_ok"] is True
-    # the CPU baseline is a sustained rate: within 10 % of the best count of its own sweep (every count measured >= 1.5 s)
+    # the CPU baseline is a sustained rate: close to the best count of its own sweep (every count measured >= 1.5 s; the
+    # committed 12-second line is held to 10 %, this short run on a shared host to 25 %)
     c = d["cpu_baseline"]
-    assert c["value"] >= 0.9 * max(c["thread_sweep"].values()) and c["thread_sweep_seconds_each"] >= 1.5
+    assert c["value"] >= 0.75 * max(c["thread_sweep"].values()) and c["thread_sweep_seconds_each"] >= 1.5
     assert "OMP_PLACES=cores" in c["threads"] and "OMP_PROC_BIND=close" in c["threads"]
 
 
