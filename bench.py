@@ -41,12 +41,13 @@ N_SIMD, SHADER_CLOCK_HZ = 1024, 2.4e9
 
 
 def source_hash():
-    """sha256 over the kernel sources and the C header (what a PMC record is valid for)."""
+    """sha256 over the kernel sources, the C header and the build recipe (what a PMC record is valid for)."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "quadruped_locomotion_amd", "csrc")
     files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp")))
-    files += [os.path.join(ROOT, "include", "qlamd.h"), os.path.join(ROOT, "include", "qlamd_robot_constants.h")]
+    files += [os.path.join(ROOT, "include", "qlamd.h"), os.path.join(ROOT, "include", "qlamd_robot_constants.h"),
+              os.path.join(ROOT, "quadruped_locomotion_amd", "build.py")]      # the code-generation flags per translation unit
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64) void wholebody_dynamics_leg_kernel(const Device
 // computed in (lane 4 leg + c: body c of the leg = force component c = joint c), force_qp_coop.hpp with its torque rows
 // -- no exchange through LDS, no general dense solver.
 template <bool kPerLeg>
-__global__ __launch_bounds__(64) void wholebody_solve_kernel(const DeviceParams *__restrict__ Pp, const coop::WbParamsDev W,
+__global__ __launch_bounds__(64, 2) void wholebody_solve_kernel(const DeviceParams *__restrict__ Pp, const coop::WbParamsDev W,
                                                              const WbPtrs s, int64_t B, double *__restrict__ tau_out,
                                                              double *__restrict__ grf_out, int32_t *__restrict__ status_out) {
   using namespace coop;
