@@ -18,11 +18,10 @@
 namespace qlamd {
 namespace coop {
 
-// LDS of one robot: N* export for the refinement, row export for drops
-constexpr int kCoopLdsDoubles = 12 * 12 + 12;
+// LDS of one robot: N* export for the refinement, row export for drops (slots 144..155)
+constexpr int kCoopLdsDoubles = 12 * 12 + 12 + 2; // ... and a zero (slot 156) for lanes that have no component to read
 // rows of the wavefront's table of constraint normals ([row kind][lane]) the QP uses: 5, and 3 more with kTorque
 constexpr int kForceQpNrmRows = 5, kForceQpNrmRowsTorque = 8;
-
 struct ForceQp {
   double Gm[12];                 // my row of G
   double g0;                     // my entry of g0
@@ -170,11 +169,10 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
   //
   // A lone wavefront issues one instruction every ~4.5 cycles whatever its kind (tools/ubench/issue_model.hip), so a
   // pass costs what it has instructions.  The four robots of a wavefront take different branches of the method, which
-  // makes every state update a predicated select; but the launch lasts as long as its slowest robot, which spends
-  // most of its passes as the only live row of its wavefront.  So the tail of a pass exists as two straight paths -- a
-  // row adds (no predication, selection follows), a row drops (no selection) -- which the rows of a wavefront take one
-  // after the other under their execution masks when they disagree, and as the general predicated form for what is left
-  // (a degenerate add, an infeasible problem).
+  // would make every state update a predicated select; so the tail of a pass exists as two straight paths -- a row adds
+  // (no predication, selection follows), a row drops (no selection) -- which the rows of a wavefront take one after the
+  // other under their execution masks when they disagree, and as the general predicated form for what is left (a
+  // degenerate add, an infeasible problem).  A row that has finished stays in the loop as a ghost (below).
   //
   // Selection.  Lane (leg, c) watches friction row c + 1 of its leg and, when c = 0, the minimum-force row: with the
   // three components of x_leg fetched through quad_perm each slack is a 3-term dot product with the lane's own row
@@ -197,7 +195,9 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
   mask_t act_mask = 0, excl = 0;
   const double psi_tol = (double)(kKinds * nS) * eps * c1 * c2 * 100.0;
   double rnorm2 = 1.0; // R_norm^2
-  bool done = (nS == 0);
+  // the rows that have finished, as a scalar mask: only ever assigned from a ballot taken where control is uniform (the
+  // compiler has to know it for uniform, or every branch of the loop turns into execution-mask bookkeeping)
+  unsigned long long done_m = 0ull;
   int ip = 0;
   double sp = 0.0, ucand = 0.0, npj = 0.0;
   // rows this lane evaluates
@@ -218,11 +218,25 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     const double nrm[5] = {myn, mu * myn + myt1, mu * myn - myt1, mu * myn + myt2, mu * myn - myt2};
 #pragma unroll
     for (int k = 0; k < 5; k++) lds_nrm[64 * k + ((int)threadIdx.x & 63)] = nrm[k];
+    lds_row[156] = 0.0;
     if constexpr (kTorque) {
 #pragma unroll
       for (int k = 0; k < 3; k++) lds_nrm[64 * (5 + k) + ((int)threadIdx.x & 63)] = Q.jrow[k];
     }
   }
+  // Ghost rows.  A row that has finished is not masked out of the loop: it runs along as a no-op.  Its
+  // candidate normal is zero from then on (its entries of the normals table, which a finished row's keys always point at,
+  // and its slots of the drop export are zeroed when it finishes), so z = r = n~ = 0 and both rank-one updates add exact
+  // zeros to its H and N*; the two divisors of a pass are biased to 1 (zb: 1/16 per lane into the row sums of z'n_p and
+  // n~'G n~); and what the epilogue needs of it (x, working set, status) is latched in its own LDS block at the moment it
+  // finishes -- whatever else it computes afterwards (x, u, bookkeeping) is garbage nobody reads.  Why:
+  // (1) EXEC stays full.  A lone wavefront issues the same instructions 7 % slower per pass when only one or two of its
+  //     four 16-lane rows are enabled (tools/ubench/exec_mask_model.hip: dependent v_fma_f64 8.4 -> 10.6 cycles with two
+  //     rows, independent ones 5.5 -> 6.7 with one; tools/experiments/row_mix_probe.py on this kernel), and the slowest
+  //     robot of a small batch spends most of its passes as the only live row of its wavefront;
+  // (2) every branch of the loop compares scalar masks: no execution-mask bookkeeping per pass.
+  const int nt_slot = comp ? 144 + myidx : 156; // where a drop reads its component of n~ (a zero on spare lanes)
+  double zb = 0.0;                              // 1/16 on ghost rows
   double s_up = 0.0, s_lo = 0.0; // kTorque: slacks of my joint's torque bounds, set by slacks()
   const auto slacks = [&](double xx, double &s_min, double &s_fric) {
     const double x0 = quad_bc<0>(xx), x1 = quad_bc<1>(xx), x2 = quad_bc<2>(xx);
@@ -246,13 +260,25 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     return k > o ? k : o;
   };
 
+  // rows that have just finished latch their results (slots 0..47 of their LDS block: free until the refinement) and
+  // turn into ghosts
+  const auto latch = [&](bool newly) {
+    if (newly) {
+      lds_row[lr] = x;
+      reinterpret_cast<int2 *>(lds_row + 16)[lr] = make_int2((int)used, idk);
+      reinterpret_cast<int2 *>(lds_row + 32)[lr] = make_int2(q, status);
+      lds_row[nt_slot] = 0.0;
+      lds_nrm[64 * 1 + ((int)threadIdx.x & 63)] = 0.0; // a finished row's key is 0: lane 0, friction row 1
+      zb = 0.0625; npj = 0.0;
+    }
+  };
   // Update of H and N* with the vectors of the step just taken (H[j] += hc * vec_j, N*[j] += nc * vec_j) and
   // selection of the next constraint at the new x, in one block so that the scheduler can weave the two (and the
   // bookkeeping of the step in front of them) together.  kMode 0: before the first step (no update; every live row
   // selects).  kMode 1: general -- rows in `resel` select (`fresh`: after an add, :252-262), the others keep their
   // candidate.  kMode 2: every live row has just added a constraint.
   double vec = 0.0, hc = 0.0, nc = 0.0;
-  const auto update_and_select = [&](auto Mode, bool resel, bool fresh) {
+  const auto update_and_select = [&](auto Mode, bool resel, bool fresh, bool finished = false) -> bool {
     constexpr int kMode = decltype(Mode)::value;
     constexpr bool kUpd = kMode != 0;
     if constexpr (kMode == 1) {
@@ -322,9 +348,10 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
       feasible = close && (fabs(psi) <= psi_tol);
     }
     const bool stop = !any || feasible || iters > kMaxOuter; // :271-274
+    bool fin = stop; // this row finishes here
     if constexpr (kMode == 1) {
       status = (resel && stop && iters > kMaxOuter) ? kStatusMaxIter : status;
-      done = done || (resel && stop);
+      fin = (resel && stop) || finished;
       const bool take = resel && !stop;
       ip = take ? key_ip : ip;
       sp = sel(take, v, sp);
@@ -332,9 +359,16 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
       npj = sel(take, np_new, npj);
     } else { // every row here selects: what a stopping row is left with is never read
       status = (stop && iters > kMaxOuter) ? kStatusMaxIter : status;
-      done = done || stop;
       ip = key_ip; sp = v; ucand = 0.0; npj = np_new;
     }
+    return fin;
+  };
+  // called where control is uniform, with the rows that have just finished (ghost rows report again: ignored)
+  const auto note_finished = [&](bool fin) {
+    const unsigned long long fin_m = __builtin_amdgcn_ballot_w64(fin);
+    const unsigned long long newly_m = fin_m & ~done_m;
+    done_m |= fin_m;
+    if (newly_m != 0ull) latch(__builtin_amdgcn_inverse_ballot_w64(newly_m));
   };
   const auto update_only = [&]() {
     static_for<12>([&](auto J) {
@@ -353,11 +387,11 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
-    const double nt_me = comp ? lds_row[144 + myidx] : 0.0;
+    const double nt_me = lds_row[nt_slot];
     const int drop_id = __shfl(idk, lpos, 16);
     double Gn = 0.0;
     static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(Gn, nt_me, Gm[j]); });
-    const double einv = rcp_nr1(row_sum(nt_me * Gn));
+    const double einv = rcp_nr1(row_sum(fma(nt_me, Gn, zb)));
     drop_einv = einv;
     double coef = 0.0;
     static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(coef, Gn, Ns[j]); });
@@ -369,21 +403,29 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     return drop_id;
   };
 
-  update_and_select(std::integral_constant<int, 0>{}, true, true);
+  {
+    // lanes that are not here (rows that have left with kStatusNotPd) count as finished: ballots never see them
+    done_m = ~__builtin_amdgcn_ballot_w64(true);
+    const bool fin0 = update_and_select(std::integral_constant<int, 0>{}, true, true);
+    note_finished(fin0);
+  }
 
   // Loop structure.  A pass = directions and step lengths, then what the step is.  Passes in which EVERY live row adds
   // its constraint run in an inner loop that is one straight path: unpredicated bookkeeping, then update + selection.
   // It is left as soon as some row drops, fails or is infeasible; that pass is finished by the tail below (rows that
   // drop: unpredicated, no selection; rows that add: the same straight path as in the inner loop; a row that does
   // neither sends the whole pass through the general predicated form) and the inner loop is entered again.
-  // (Alternative tails inside ONE loop cost 24 register copies of H and N* on its back edge; and the launch lasts as
-  // long as its slowest robot, which is alone in its wavefront for most of its passes.)
+  // What the register allocator needs of this shape (found the hard way, tools/kernel_isa.py shows it at once): nothing
+  // a pass computes may be live across a back edge, and the flags the branches test must be scalar masks assigned where
+  // control is uniform -- a lane-mask boolean that lives across the loops, a second site that updates the finished mask
+  // inside one branch of the tail, or an exit out of both loops at once each cost 24 register copies of H and N* per pass
+  // or turn every branch into execution-mask bookkeeping.
   // Terminates: at most kMaxOuter adds, every drop undoes an earlier add, a failed add bans its row until the next add.
   double z = 0.0, r = 0.0, zn = 0.0, zinv = 0.0, t = 0.0, tl1 = 0.0, tl2 = 0.0, ratio = 0.0;
   bool have_dirs = false; // wave-uniform: the directions of the pass at hand follow from the drops just made
   // ---- a full step that adds the candidate: H -= z z'/d, N* <- [N* - r z'/d ; z'/d], the new row goes to the lowest
   // free slot lane; then the selection of the next candidate in the shadow of the update
-  const auto add_step = [&]() {
+  const auto add_step = [&]() -> bool {
     x += t * z;
     u = fma(-t, r, u);
     const int newlane = __ffs(~used & 0xFFFu) - 1;
@@ -397,7 +439,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     act_mask |= one << ip;
     rnorm2 = vmax(rnorm2, zn);
     q += 1;
-    update_and_select(std::integral_constant<int, 2>{}, true, true);
+    return update_and_select(std::integral_constant<int, 2>{}, true, true);
   };
   // ---- a partial step (t1 < t2), or a dual step only when t2 is infinite: the blocking constraint leaves the working set
   // and the same candidate continues
@@ -421,94 +463,118 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     r = fma(nc, r_lpos, r);
     zn = fma(r_lpos * r_lpos, drop_einv, zn);
   };
-  for (;;) {
-    bool is_add = false;
-    while (!done) {
-      if (!have_dirs) {
-        // ---- directions: z = H n_p (lane i), r = N* n_p (slot lane k; 0 on free lanes, whose rows are 0)
-        // three partial sums per product: consecutive dependent FMAs are 6 instructions apart
-        double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
-        static_for<12>([&](auto J) {
-          constexpr int j = J;
-          fmac_bc<lane_of(j), j == 0>(za[j % 3], npj, H[j]);
-          fmac_bc<lane_of(j)>(ra[j % 3], npj, Ns[j]);
-        });
-        z = (za[0] + za[1]) + za[2];
-        r = (ra[0] + ra[1]) + ra[2];
-        zn = row_sum(z * npj);
-      }
-      have_dirs = false;
-      const bool slot = (used & lanebit) != 0u;
-      const float zf = (float)z;
-      const double zz = (double)row_sum_f32(zf * zf); // only compared with eps below
-      // ---- step lengths, QuadProg++.cc:304-331
-      const double ur = u * rcp_nr1(r);
-      ratio = sel(slot && r > 0.0, ur, inf);
-      tl1 = row_min(ratio);
-      zinv = rcp_nr(zn);
-      const double t2v = -sp * zinv;
-      const bool exhausted = q >= 3 * nS; // empty null space: z is exactly 0 in the reference
-      tl2 = sel((int)(!exhausted) & (int)(fabs(zz) > eps) & (int)(!(t2v < 0.0)), t2v, inf);
-      t = vmin(tl1, tl2);
-      // a full step (:384) whose constraint can be added (:392: |R_qq| = sqrt(z'n_p) > eps * R_norm, compared squared)
-      is_add = (tl2 < inf) && (tl2 <= tl1) && (zn > eps * eps * rnorm2);
-      if (__builtin_amdgcn_ballot_w64(!is_add) != 0ull) break;
-      add_step(); // every live row adds
+  // ---- directions of a pass: z = H n_p (lane i), r = N* n_p (slot lane k; 0 on free lanes, whose rows are 0), z'n_p
+  // three partial sums per product (z and r alternate: consecutive dependent FMAs are 6 instructions apart)
+  const auto general_dirs = [&]() {
+    double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
+    static_for<12>([&](auto J) {
+      constexpr int j = J;
+      fmac_bc<lane_of(j), j == 0>(za[j % 3], npj, H[j]);
+      fmac_bc<lane_of(j)>(ra[j % 3], npj, Ns[j]);
+    });
+    z = (za[0] + za[1]) + za[2];
+    r = (ra[0] + ra[1]) + ra[2];
+    zn = row_sum(fma(z, npj, zb));
+  };
+  // ---- step lengths, QuadProg++.cc:304-331; returns whether the pass is a full step that adds the candidate
+  const auto step_lengths = [&]() -> bool {
+    const bool slot = (used & lanebit) != 0u;
+    const float zf = (float)z;
+    const double zz = (double)row_sum_f32(zf * zf); // only compared with eps below
+    const double ur = u * rcp_nr1(r);
+    ratio = sel(slot && r > 0.0, ur, inf);
+    tl1 = row_min(ratio);
+    zinv = rcp_nr(zn);
+    const double t2v = -sp * zinv;
+    const bool exhausted = q >= 3 * nS; // empty null space: z is exactly 0 in the reference
+    tl2 = sel((int)(!exhausted) & (int)(fabs(zz) > eps) & (int)(!(t2v < 0.0)), t2v, inf);
+    t = vmin(tl1, tl2);
+    // a full step (:384) whose constraint can be added (:392: |R_qq| = sqrt(z'n_p) > eps * R_norm, compared squared)
+    return (tl2 < inf) && (tl2 <= tl1) && (zn > eps * eps * rnorm2);
+  };
+  // ---- the pass of a live row in general form (all row-uniform): a degenerate add, a dual step only, an infeasible problem
+  const auto general_pass = [&](bool is_add) -> bool {
+    // ---- the pass of the live rows in general form (all row-uniform)
+    const bool infeasible = !(t < inf);                          // :339-344
+    const bool dual_only = (tl2 >= inf);
+    const bool full = !infeasible && !dual_only && (tl2 <= tl1);   // :384
+    const bool degenerate = full && !is_add;
+    const bool is_drop = !infeasible && !full;                   // partial or dual-only step
+    if (infeasible) status = kStatusInfeasible;
+    const double tp = (infeasible || dual_only || degenerate) ? 0.0 : t;
+    const double td = (infeasible || degenerate) ? 0.0 : t;
+    x += tp * z;
+    u = fma(-td, r, u);
+    ucand += td;
+    sp += tp * zn;
+    // add (predicated).  A numerically dependent normal is skipped and selection repeated.
+    const int newlane = __ffs(~used & 0xFFFu) - 1;
+    const bool newslot = is_add && (lr == newlane);
+    vec = is_add ? z * zinv : 0.0;
+    hc = is_add ? -z : 0.0;
+    nc = sel(newslot, 1.0, sel(is_add, -r, 0.0));
+    u = newslot ? ucand : u;
+    idk = newslot ? ip : idk;
+    used |= is_add ? (1u << newlane) : 0u;
+    act_mask |= is_add ? (one << ip) : 0;
+    rnorm2 = is_add ? vmax(rnorm2, zn) : rnorm2;
+    q += is_add ? 1 : 0;
+    excl |= degenerate ? (one << ip) : 0;
+    int lpos = 16;
+    if (is_drop) {
+      lpos = row_first(ratio == tl1 && ratio < inf);
+      const int drop_id = drop_vectors(lpos);
+      act_mask &= ~(one << drop_id);
+      used &= ~(1u << lpos);
+      q--;
     }
-    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
-    const bool drops = !done && (tl1 < tl2);
-    if (__builtin_amdgcn_ballot_w64(!done && !is_add && !drops) == 0ull) {
-      // ---- every live row either drops a constraint or adds one.  The rows that drop take the straight drop path, then
-      // the rows that add the straight add path, each under its rows' execution mask: a pass in which the robots of a
-      // wavefront disagree (a quarter of the passes of the survey-literal batch) costs one of each.  Through the
-      // predicated general form below, which such a pass took until round 3, it cost more than both together: 1.28 us
-      // (tools/experiments/mixed_pass_probe.py).  When every live row has dropped, the next pass starts from the
-      // continued directions; otherwise all rows compute theirs afresh (they are due for the rows that added anyway).
-      if (drops) drop_step();
-      if (!done && is_add) add_step();
-      have_dirs = __builtin_amdgcn_ballot_w64(!done && is_add) == 0ull;
-    } else if (!done) {
-      // ---- the pass of the live rows in general form (all row-uniform)
-      const bool infeasible = !(t < inf);                          // :339-344
-      const bool dual_only = (tl2 >= inf);
-      const bool full = !infeasible && !dual_only && (tl2 <= tl1);   // :384
-      const bool degenerate = full && !is_add;
-      const bool is_drop = !infeasible && !full;                   // partial or dual-only step
-      if (infeasible) { status = kStatusInfeasible; done = true; }
-      const double tp = (infeasible || dual_only || degenerate) ? 0.0 : t;
-      const double td = (infeasible || degenerate) ? 0.0 : t;
-      x += tp * z;
-      u = fma(-td, r, u);
-      ucand += td;
-      sp += tp * zn;
-      // add (predicated).  A numerically dependent normal is skipped and selection repeated.
-      const int newlane = __ffs(~used & 0xFFFu) - 1;
-      const bool newslot = is_add && (lr == newlane);
-      vec = is_add ? z * zinv : 0.0;
-      hc = is_add ? -z : 0.0;
-      nc = sel(newslot, 1.0, sel(is_add, -r, 0.0));
-      u = newslot ? ucand : u;
-      idk = newslot ? ip : idk;
-      used |= is_add ? (1u << newlane) : 0u;
-      act_mask |= is_add ? (one << ip) : 0;
-      rnorm2 = is_add ? vmax(rnorm2, zn) : rnorm2;
-      q += is_add ? 1 : 0;
-      excl |= degenerate ? (one << ip) : 0;
-      int lpos = 16;
-      if (is_drop) {
-        lpos = row_first(ratio == tl1 && ratio < inf);
-        const int drop_id = drop_vectors(lpos);
-        act_mask &= ~(one << drop_id);
-        used &= ~(1u << lpos);
-        q--;
+    return update_and_select(std::integral_constant<int, 1>{}, full, is_add, infeasible);
+  };
+  // Which rows have finished (done_m), add (add_m) or drop (drop_m) in the pass at hand are scalar 64-bit masks and the
+  // branches compare them; the finished rows ride along on every path (ghost rows, above).
+  const auto in = [](unsigned long long m) -> bool { return __builtin_amdgcn_inverse_ballot_w64(m); };
+  if (~done_m != 0ull) {
+    for (;;) {
+      unsigned long long add_m = 0ull;
+      for (;;) { // passes in which every live row adds
+        if (!have_dirs) general_dirs();
+        have_dirs = false;
+        add_m = __builtin_amdgcn_ballot_w64(step_lengths());
+        if (~(add_m | done_m) != 0ull) break;
+        note_finished(add_step());
+        if (~done_m == 0ull) break;
       }
-      update_and_select(std::integral_constant<int, 1>{}, full, is_add);
+      const unsigned long long live_m = ~done_m;
+      if (live_m == 0ull) break;
+      const unsigned long long drop_m = __builtin_amdgcn_ballot_w64(tl1 < tl2) & live_m & ~add_m;
+      bool fin = false;
+      if ((live_m & ~add_m & ~drop_m) == 0ull) {
+        // ---- every live row either drops a constraint or adds one: the rows that drop take the straight drop path, then
+        // the rows that add the straight add path (ghost rows ride along on both).  When every live row has dropped, the
+        // next pass starts from the continued directions.
+        const bool any_add = (add_m & live_m) != 0ull;
+        if (in(drop_m | done_m)) drop_step();
+        if (any_add) {
+          if (in(add_m | done_m)) fin = add_step();
+        }
+        have_dirs = !any_add;
+      } else {
+        if (in(live_m)) fin = general_pass(in(add_m));
+      }
+      note_finished(fin);
+      if (~done_m == 0ull) break;
     }
+  }
+  {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    x = lds_row[lr];
+    const int2 a = reinterpret_cast<const int2 *>(lds_row + 16)[lr], b = reinterpret_cast<const int2 *>(lds_row + 32)[lr];
+    used = (unsigned)a.x; idk = a.y; q = b.x; status = b.y;
   }
 
   QL_STAMP(7);
   // ---------------------------------------------------------------- refinement on the final working set
-  if (!done) status = kStatusMaxIter;
   if (status == kStatusOk && q > 0) {
     // export N* through LDS once: lane (leg,c) needs column myidx of N*
     if (lr < 12) {
