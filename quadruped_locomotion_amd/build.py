@@ -58,13 +58,7 @@ def build(force=False, verbose=False, defines=(), lib=None, extra_flags=()):
     os.makedirs(obj_dir, exist_ok=True)
     common = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(_ROOT, "include"),
               "-I" + os.path.join(_PKG, "csrc")] + ["-D" + d for d in defines] + list(extra_flags)
-    sources = SOURCES
-    if "QLAMD_STAMPS" in defines:
-        # the diagnostic build keeps its stamp buffer in one device variable: one translation unit
-        unity = os.path.join(obj_dir, "unity.hip")
-        with open(unity, "w") as f:
-            f.write("".join('#include "%s"\n' % src for src in SOURCES))
-        sources = [unity]
+    sources = SOURCES  # the diagnostic build (QLAMD_STAMPS) keeps the units and their flags: one stamp buffer per unit
     objs = [os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o") for src in sources]
 
     def compile_one(pair):

@@ -258,11 +258,6 @@ void qlamd_balance_default_params(qlamd_balance_params *p) { if (p) default_bala
 void qlamd_default_robot_model(qlamd_robot_model *m) { if (m) default_robot_model(m); }
 int qlamd_version(void) { return QLAMD_VERSION_MAJOR * 1000 + QLAMD_VERSION_MINOR; }
 
-#ifdef QLAMD_STAMPS
-int qlamd_debug_stamps(unsigned long long *out, int n) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(qlamd::coop::g_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
-}
-#endif
 
 const char *qlamd_strerror(int code) {
   switch (code) {
@@ -591,3 +586,5 @@ int qlamd_leg_kinematics_batch(qlamd_context *ctx, const double *joint_position,
 }
 
 } // extern "C"
+
+QLAMD_STAMPS_ACCESSOR(qlamd_debug_stamps)

@@ -11,10 +11,16 @@
 namespace qlamd {
 namespace coop {
 
-// Diagnostic build only (-DQLAMD_STAMPS): s_memtime at segment boundaries of wave 0, read back
-// through qlamd_debug_stamps.  Never compiled into the shipped library.
+// Diagnostic build only (-DQLAMD_STAMPS): s_memtime at segment boundaries of wave 0, read back through
+// qlamd_debug_stamps (balance unit) / qlamd_debug_stamps_pose / _tick / _wholebody: every translation unit keeps a stamp
+// buffer of its own, so that the diagnostic build compiles the units exactly as the shipped library does (same flags per
+// unit, build.py).  Never compiled into the shipped library.
 #ifdef QLAMD_STAMPS
-__device__ unsigned long long g_stamps[64];
+static __device__ unsigned long long g_stamps[64];
+#define QLAMD_STAMPS_ACCESSOR(name)                                                                                      \
+  extern "C" int name(unsigned long long *out, int n) {                                                                  \
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(::qlamd::coop::g_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1; \
+  }
 #define QL_STAMP(k)                                                                         \
   do {                                                                                      \
     unsigned long long t_;                                                                  \
@@ -46,6 +52,7 @@ __device__ unsigned long long g_stamps[64];
       for (int k_ = 0; k_ < 8; k_++) ::qlamd::coop::g_stamps[16 + k_] = ql_acc_[k_];        \
   } while (0)
 #else
+#define QLAMD_STAMPS_ACCESSOR(name)
 #define QL_STAMP(k)
 #define QL_SEG_DECL
 #define QL_SEG_START

@@ -64,21 +64,28 @@ __device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const 
   for (int j = 0; j < 6; j++) H[j] = Gm[j];
   bool bad = false;
   double my_pivot = 1.0;
+  // as in force_qp_coop.hpp: the column of the NEXT pivot is updated first, so that its reciprocal (seed + one Newton
+  // step: the refinement and the next SQP iteration work on G itself) is under way while the other columns are updated
+  double d = bc<0>(H[0]);
   static_for<6>([&](auto K) {
     constexpr int k = K;
-    const double d = bc<k>(H[k]);
     bad = bad || !(d > 0.0);
-    const double p = rcp_nr(d);
+    const double p = rcp_nr1(d);
     const bool piv = lr == k;
     my_pivot = piv ? d : my_pivot;
     const double f = piv ? (1.0 - p) : H[k] * p;
     const double nf = -f;
+    if constexpr (k < 5) {
+      fmac_bc<k, true>(H[k + 1], H[k + 1], nf);
+      d = bc<k + 1>(H[k + 1]);
+    }
     static_for<6>([&](auto J) {
       constexpr int j = J;
-      if constexpr (j != k) fmac_bc<k, (j == (k == 0 ? 1 : 0))>(H[j], H[j], nf);
+      if constexpr (j != k && j != k + 1) fmac_bc<k, (k == 5 && j == 0)>(H[j], H[j], nf);
     });
     H[k] = piv ? p : nf;
   });
+  QL_STAMP(23);
   const double rp = rsqrt_nr(my_pivot);
   const double c2 = row_sum(sel(real, rp, 0.0));
   // x0 = -G^-1 g0 (the equality below holds there by construction)
@@ -135,8 +142,9 @@ __device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const 
     }
     const unsigned avail = ~(act_mask | excl);
     // slack of my constraint: s_j = a_j'x + ci0_j
-    double s = bci0;
-    static_for<6>([&](auto I) { constexpr int i = I; fmac_bc<i, i == 0>(s, x, a[i]); });
+    double s = bci0, s1 = 0.0;
+    static_for<3>([&](auto I) { constexpr int i = I; fmac_bc<2 * i, i == 0>(s, x, a[2 * i]); fmac_bc<2 * i + 1>(s1, x, a[2 * i + 1]); });
+    s += s1;
     unsigned key = __float_as_uint((float)s);
     key = ((avail & cbit) != 0u && s < 0.0) ? ((key & ~15u) | (unsigned)lr) : 0u;
     if constexpr (kMode != 0) {
@@ -202,6 +210,7 @@ __device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const 
   };
 
   update_and_select(std::integral_constant<int, 0>{}, true, true);
+  QL_STAMP(24);
 
   for (;;) {
     double z = 0.0, r = 0.0, zn = 0.0, zinv = 0.0, t = 0.0, tl1 = 0.0, tl2 = 0.0, ratio = 0.0;
@@ -282,6 +291,7 @@ __device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const 
       update_and_select(std::integral_constant<int, 1>{}, full, is_add);
     }
   }
+  QL_STAMP(25);
   // one refinement pass on the final working set (see balance_coop.hpp)
   if (status == kStatusOk && q > 0 && !skip) {
     if (lr < 6) {
@@ -307,6 +317,7 @@ __device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const 
     static_for<6>([&](auto K) { constexpr int k = K; fmac_bc<k, k == 0>(dx, rho, NsT[k]); });
     x += dx;
   }
+  QL_STAMP(26);
   x_out = x;
   return status;
 }
@@ -337,13 +348,55 @@ __device__ __forceinline__ int pose_sqp_coop(const PoseParamsDev &P, const PoseP
                                              double pose[7], int &iters_out) {
   const int lr = threadIdx.x & 15;
   const int cj = lr - 8;
-  double centroid[2], GA[4][2], gb[4];
-  polygon_centroid(pb.n_vertices, pb.polygon, centroid);
-  const int nsp = polygon_halfspaces(pb.n_vertices, pb.polygon, GA, gb);
-  // my constraint's fixed data: half-space row (cj < 4) or leg slot (cj >= 4)
-  double ga0 = 0.0, ga1 = 0.0, gbj = 0.0;
+  // Support polygon (grid_map::Polygon: getCentroid and convertToInequalityConstraints, as polygon_centroid /
+  // polygon_halfspaces of pose_core.hpp): the centroid replicated and branch-free (vertices beyond n_vertices contribute
+  // nothing), and of the half-spaces only MY edge -- constraint lane 8 + e holds edge e (a degenerate edge is a constraint
+  // that is not present; the reference compacts the rows, which keeps their order and changes nothing else).  Reciprocals
+  // instead of the twelve divisions of the general form: the prologue of the kernel took 1.3 us with them.
+  const int nv = pb.n_vertices;
+  double centroid[2];
+  {
+    double sc = 0.0, cx = 0.0, cy = 0.0;
 #pragma unroll
-  for (int j = 0; j < 4; j++) { ga0 = sel(cj == j, GA[j][0], ga0); ga1 = sel(cj == j, GA[j][1], ga1); gbj = sel(cj == j, gb[j], gbj); }
+    for (int i = 0; i < 4; i++) {
+      const bool wrap = (i + 1 >= nv) || i == 3;
+      const double nx = wrap ? pb.polygon[0][0] : pb.polygon[i < 3 ? i + 1 : 0][0];
+      const double ny = wrap ? pb.polygon[0][1] : pb.polygon[i < 3 ? i + 1 : 0][1];
+      const double cr = i < nv ? pb.polygon[i][0] * ny - nx * pb.polygon[i][1] : 0.0;
+      sc += cr;
+      cx = fma(cr, pb.polygon[i][0] + nx, cx);
+      cy = fma(cr, pb.polygon[i][1] + ny, cy);
+    }
+    const double r3 = rcp_nr(3.0 * sc); // c / (6 area), area = sc / 2
+    centroid[0] = cx * r3; centroid[1] = cy * r3;
+  }
+  double ga0 = 0.0, ga1 = 0.0, gbj = 0.0;
+  bool edge_ok = false;
+  {
+    const int e = cj & 3;
+    double mx = 0.0, my = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { mx += i < nv ? pb.polygon[i][0] : 0.0; my += i < nv ? pb.polygon[i][1] : 0.0; }
+    const double rn = rcp_nr((double)nv);
+    mx *= rn; my *= rn;
+    double px = 0.0, py = 0.0, qx = 0.0, qy = 0.0; // my edge: vertex e and its successor
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      px = sel(e == i, pb.polygon[i][0], px); py = sel(e == i, pb.polygon[i][1], py);
+      const bool wrap = (i + 1 >= nv) || i == 3;
+      qx = sel(e == i, wrap ? pb.polygon[0][0] : pb.polygon[i < 3 ? i + 1 : 0][0], qx);
+      qy = sel(e == i, wrap ? pb.polygon[0][1] : pb.polygon[i < 3 ? i + 1 : 0][1], qy);
+    }
+    const double x1 = px - mx, y1 = py - my, x2 = qx - mx, y2 = qy - my;
+    const double det = x1 * y2 - x2 * y1;
+    edge_ok = e < nv && !(fabs(det) <= 1e-12 * (fabs(x1 * y2) + fabs(x2 * y1) + 1e-300));
+    const double rd = rcp_nr(edge_ok ? det : 1.0);
+    ga0 = (y2 - y1) * rd; ga1 = (x1 - x2) * rd;
+    gbj = 1.0 + (ga0 * mx + ga1 * my);
+  }
+  // number of half-spaces of my problem: the valid edges on lanes 8..11 of my row
+  const unsigned long long okm = __builtin_amdgcn_ballot_w64(edge_ok && lr >= 8 && lr < 12);
+  const int nsp = __popc((unsigned)(okm >> (threadIdx.x & 48)) & 0xF00u);
   const int kleg = cj - 4;
   double lf[3] = {0, 0, 0}, lh[3] = {0, 0, 0}, lmax = 0.0;
 #pragma unroll
@@ -354,64 +407,108 @@ __device__ __forceinline__ int pose_sqp_coop(const PoseParamsDev &P, const PoseP
   }
   const unsigned present = pb.present;
   const int nl = __popc(present & 0xFu);
-  const bool cvalid = lr >= 8 && (cj < 4 ? cj < nsp : ((present >> (kleg & 3)) & 1u) != 0);
+  const bool cvalid = lr >= 8 && (cj < 4 ? edge_ok : ((present >> (kleg & 3)) & 1u) != 0);
   const int m = nsp + nl;
+
+  // The objective's sums over the stance legs are linear in the rotation: with the per-problem constants
+  //   Sd = sum d_k,  Sf = sum f_k,  M = sum d_k f_k'   (d_k the nominal stance in base coordinates, f_k the foothold)
+  // and Pd_k = R d_k, e_k = p - f_k every one of them follows from R Sd (a rotation) and R M (a 3x3 product):
+  //   sum Pd_k = R Sd                      sum (e_k + Pd_k) = nl p - Sf + R Sd
+  //   sum Pd_k x e_k = (R Sd) x p - vee(R M)        (vee(A) = (A12 - A21, A20 - A02, A01 - A10))
+  //   sum e_k.Pd_k = p.(R Sd) - trace(R M)        sum Pd_k e_k' = (R Sd) p' - R M
+  // -- 36 multiply-adds per iteration where a loop over the legs takes four rotations, four cross products and 60 sums.
+  double Sd[3] = {0, 0, 0}, Sf[3] = {0, 0, 0}, Mm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) {
+    const bool on = ((present >> kk) & 1u) != 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const double d = on ? pb.nominal[kk][c] : 0.0, f = on ? pb.stance[kk][c] : 0.0;
+      Sd[c] += d;
+      Sf[c] += f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const double d = on ? pb.nominal[kk][c] : 0.0;
+#pragma unroll
+      for (int e = 0; e < 3; e++) Mm[c][e] = fma(d, pb.stance[kk][e], Mm[c][e]);
+    }
+  }
+  const double w = P.com_weight;
+  const double n0 = 2.0 * ((double)nl + w), n2 = 2.0 * (double)nl;
+  const int c3 = lr < 3 ? lr : (lr < 6 ? lr - 3 : 3); // my row inside its 3x3 block; 3: no row
+  const bool top = lr < 3;
 
   int k = 0, status = kStatusOk;
   bool sqp_done = !live;
+  QL_STAMP(18);
   for (int outer = 0; outer < P.max_iter; outer++) {
     if (__all(sqp_done)) break;
+    QL_STAMP(20);
     const double *p = pose;
     double R[9];
     quat_to_matrix(pose + 3, R);
-    // ---- objective: sums over the stance legs (replicated)
-    double sPd[3] = {0, 0, 0}, sg[3] = {0, 0, 0}, sx[3] = {0, 0, 0}, sB[6] = {0, 0, 0, 0, 0, 0}, sdot = 0.0;
+    // ---- objective (replicated)
+    double sPd[3], RM[3][3];
+    rot(R, Sd, sPd);
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      if (!((present >> kk) & 1u)) continue;
-      double Pd[3];
-      rot(R, pb.nominal[kk], Pd);
-      const double e[3] = {p[0] - pb.stance[kk][0], p[1] - pb.stance[kk][1], p[2] - pb.stance[kk][2]};
-      double cr[3];
-      cross3(Pd, e, cr); // D (p - f) = Pd x e
+    for (int i = 0; i < 3; i++) {
 #pragma unroll
-      for (int c = 0; c < 3; c++) { sPd[c] += Pd[c]; sg[c] += e[c] + Pd[c]; sx[c] += cr[c]; }
-      sdot += dot3(e, Pd);
-      sB[0] += Pd[0] * e[0]; sB[1] += 0.5 * (Pd[0] * e[1] + e[0] * Pd[1]); sB[2] += 0.5 * (Pd[0] * e[2] + e[0] * Pd[2]);
-      sB[3] += Pd[1] * e[1]; sB[4] += 0.5 * (Pd[1] * e[2] + e[1] * Pd[2]); sB[5] += Pd[2] * e[2];
+      for (int e = 0; e < 3; e++) RM[i][e] = R[3 * i] * Mm[0][e] + R[3 * i + 1] * Mm[1][e] + R[3 * i + 2] * Mm[2][e];
     }
+    const double fnl = (double)nl;
+    const double sg[3] = {fnl * p[0] - Sf[0] + sPd[0], fnl * p[1] - Sf[1] + sPd[1], fnl * p[2] - Sf[2] + sPd[2]};
+    double sx[3];
+    cross3(sPd, p, sx);
+    sx[0] -= RM[1][2] - RM[2][1]; sx[1] -= RM[2][0] - RM[0][2]; sx[2] -= RM[0][1] - RM[1][0];
+    const double sdot = dot3(p, sPd) - (RM[0][0] + RM[1][1] + RM[2][2]);
+    double sB[6];
+    sB[0] = sPd[0] * p[0] - RM[0][0];
+    sB[1] = 0.5 * ((sPd[0] * p[1] - RM[0][1]) + (sPd[1] * p[0] - RM[1][0]));
+    sB[2] = 0.5 * ((sPd[0] * p[2] - RM[0][2]) + (sPd[2] * p[0] - RM[2][0]));
+    sB[3] = sPd[1] * p[1] - RM[1][1];
+    sB[4] = 0.5 * ((sPd[1] * p[2] - RM[1][2]) + (sPd[2] * p[1] - RM[2][1]));
+    sB[5] = sPd[2] * p[2] - RM[2][2];
     // centre-of-mass term (weight w, planar): Pr = (R r_com)_xy, e = (p - centroid) with z = p_z
     double Pr3[3];
     rot(R, pb.r_com, Pr3);
-    const double w = P.com_weight;
     const double Pr[3] = {Pr3[0], Pr3[1], 0.0};
     const double pc[3] = {p[0] - centroid[0], p[1] - centroid[1], 0.0}; // pbar - rc
     const double ec[3] = {p[0] - centroid[0], p[1] - centroid[1], p[2]}; // p - rc (p enters skew(p) with its z)
     double cc[3];
     cross3(Pr, pc, cc);
     const double cdot = dot3(ec, Pr);
-    // gradient (6) and Hessian rows: G = 2 [[nl I + w diag(1,1,0), -skew(sPd + w Pr)], [skew(sPd + w Pr), B]]
+    // gradient (6) and Hessian: G = 2 [[nl I + w diag(1,1,0), -skew(q3)], [skew(q3), B]], q3 = sum Pd_k + w Pr
     const double g[6] = {sg[0] + w * (pc[0] + Pr[0]), sg[1] + w * (pc[1] + Pr[1]), sg[2], sx[0] + w * cc[0],
                          sx[1] + w * cc[1], sx[2] + w * cc[2]};
-    const double q3[3] = {sPd[0] + w * Pr[0], sPd[1] + w * Pr[1], sPd[2]}; // skew(q3) = sum D_k + w skew(Pr)
-    double Bm[6]; // symmetric 3x3, packed 00 01 02 11 12 22
-    Bm[0] = sB[0] - sdot + w * (Pr[0] * ec[0] - cdot);
-    Bm[1] = sB[1] + w * 0.5 * (Pr[0] * ec[1] + ec[0] * Pr[1]);
-    Bm[2] = sB[2] + w * 0.5 * (Pr[0] * ec[2] + ec[0] * Pr[2]);
-    Bm[3] = sB[3] - sdot + w * (Pr[1] * ec[1] - cdot);
-    Bm[4] = sB[4] + w * 0.5 * (Pr[1] * ec[2] + ec[1] * Pr[2]);
-    Bm[5] = sB[5] - sdot + w * (Pr[2] * ec[2] - cdot);
-    // full 6x6 (replicated), then my row
-    const double n0 = (double)nl + w, n2 = (double)nl;
-    const double Gfull[6][6] = {
-        {n0, 0, 0, 0, q3[2], -q3[1]},   {0, n0, 0, -q3[2], 0, q3[0]},  {0, 0, n2, q3[1], -q3[0], 0},
-        {0, -q3[2], q3[1], Bm[0], Bm[1], Bm[2]}, {q3[2], 0, -q3[0], Bm[1], Bm[3], Bm[4]}, {-q3[1], q3[0], 0, Bm[2], Bm[4], Bm[5]}};
-    double Gm[6] = {0, 0, 0, 0, 0, 0}, g0 = 0.0;
+    const double qx = 2.0 * (sPd[0] + w * Pr[0]), qy = 2.0 * (sPd[1] + w * Pr[1]), qz = 2.0 * sPd[2];
+    double B2[6]; // 2 B, symmetric 3x3, packed 00 01 02 11 12 22
+    B2[0] = 2.0 * (sB[0] - sdot + w * (Pr[0] * ec[0] - cdot));
+    B2[1] = 2.0 * sB[1] + w * (Pr[0] * ec[1] + ec[0] * Pr[1]);
+    B2[2] = 2.0 * sB[2] + w * (Pr[0] * ec[2] + ec[0] * Pr[2]);
+    B2[3] = 2.0 * (sB[3] - sdot + w * (Pr[1] * ec[1] - cdot));
+    B2[4] = 2.0 * sB[4] + w * (Pr[1] * ec[2] + ec[1] * Pr[2]);
+    B2[5] = 2.0 * (sB[5] - sdot + w * (Pr[2] * ec[2] - cdot));
+    QL_STAMP(21);
+    // my row of G: rows 0..2 = [diag(n0, n0, n2) | -S_c], rows 3..5 = [S_c | (2B)_c] with S_c row c3 of skew(2 q3);
+    // picked with the row index inside its block, not by a pass over the 36 elements
+    double Gm[6], g0 = 0.0;
+    {
+      const double nqx = -qx, nqy = -qy, nqz = -qz;
+      const double S0 = sel(c3 == 1, qz, sel(c3 == 2, nqy, 0.0));
+      const double S1 = sel(c3 == 0, nqz, sel(c3 == 2, qx, 0.0));
+      const double S2 = sel(c3 == 0, qy, sel(c3 == 1, nqx, 0.0));
+      const double Br0 = sel(c3 == 0, B2[0], sel(c3 == 1, B2[1], sel(c3 == 2, B2[2], 0.0)));
+      const double Br1 = sel(c3 == 0, B2[1], sel(c3 == 1, B2[3], sel(c3 == 2, B2[4], 0.0)));
+      const double Br2 = sel(c3 == 0, B2[2], sel(c3 == 1, B2[4], sel(c3 == 2, B2[5], 0.0)));
+      Gm[0] = sel(top, sel(c3 == 0, n0, 0.0), S0);
+      Gm[1] = sel(top, sel(c3 == 1, n0, 0.0), S1);
+      Gm[2] = sel(top, sel(c3 == 2, n2, 0.0), S2);
+      Gm[3] = sel(top, -S0, Br0);
+      Gm[4] = sel(top, -S1, Br1);
+      Gm[5] = sel(top, -S2, Br2);
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-      g0 = sel(lr == i, 2.0 * g[i], g0);
-#pragma unroll
-      for (int j = 0; j < 6; j++) Gm[j] = sel(lr == i, 2.0 * Gfull[i][j], Gm[j]);
+      for (int i = 0; i < 6; i++) g0 = sel(lr == i, 2.0 * g[i], g0);
     }
     // ---- constraints: my row of CI = -A', ci0 = max - value (PoseOptimizationFunctionConstraints.cpp:95-194)
     double a[6] = {0, 0, 0, 0, 0, 0}, bci0 = 0.0;
@@ -422,18 +519,15 @@ __device__ __forceinline__ int pose_sqp_coop(const PoseParamsDev &P, const PoseP
       // (G3 skew(Pr3))_c with G3 = (ga0, ga1, 0): column c of skew(Pr3) dotted with G3
       const double hs3 = ga1 * Pr3[2], hs4 = -ga0 * Pr3[2], hs5 = ga0 * Pr3[1] - ga1 * Pr3[0];
       const double hs_a[6] = {-ga0, -ga1, -0.0, hs3 * 1.0, hs4 * 1.0, hs5 * 1.0};
-      // limb-length bound of my leg slot: value |R'(f - p) - hip|, gradient through ln = (p + R hip - f)/|.|
-      const double df[3] = {lf[0] - p[0], lf[1] - p[1], lf[2] - p[2]};
-      double bf[3], Ph[3];
-      irot(R, df, bf);
-      const double ev[3] = {bf[0] - lh[0], bf[1] - lh[1], bf[2] - lh[2]};
-      const double len2 = dot3(ev, ev);
-      const double rl = rsqrt_nr(len2);
-      const double len = len2 * rl;
+      // limb-length bound of my leg slot: value |R'(f - p) - hip| = |f - p - R hip| (a rotation keeps the length), and the
+      // gradient runs along the same vector, ln = (p + R hip - f) / |.|: one rotation and one reciprocal square root
+      double Ph[3];
       rot(R, lh, Ph);
       double ln[3] = {p[0] + Ph[0] - lf[0], p[1] + Ph[1] - lf[1], p[2] + Ph[2] - lf[2]};
-      const double rn = rsqrt_nr(dot3(ln, ln));
-      ln[0] *= rn; ln[1] *= rn; ln[2] *= rn;
+      const double len2 = dot3(ln, ln);
+      const double rl = rsqrt_nr(len2);
+      const double len = len2 * rl;
+      ln[0] *= rl; ln[1] *= rl; ln[2] *= rl;
       double lx[3];
       cross3(ln, Ph, lx); // ln' skew(Ph) = (Ph x ln)' ... see below
       // CI rows 3..5 of the reference: ln[0] Hs[j] + ln[1] Hs[3+j] + ln[2] Hs[6+j] with Hs = skew(Ph)
@@ -449,9 +543,11 @@ __device__ __forceinline__ int pose_sqp_coop(const PoseParamsDev &P, const PoseP
         bci0 = 0.0;
       }
     }
+    QL_STAMP(22);
     // ---- QP and the update
     double x;
     const int st = qp6_coop(Gm, g0, a, bci0, cvalid, m, P.dummy_equality != 0, sqp_done, lds_row, x);
+    QL_STAMP(27);
     double dp[6];
     static_for<6>([&](auto I) { constexpr int i = I; dp[i] = bc<i>(x); });
     if (!sqp_done) {
@@ -468,6 +564,7 @@ __device__ __forceinline__ int pose_sqp_coop(const PoseParamsDev &P, const PoseP
         if (nrm2 < P.tol * P.tol && P.tol > 0.0) sqp_done = true; // |dp| < tol, sequencequadraticproblemsolver.cpp:72-76
       }
     }
+    QL_STAMP(28);
   }
   iters_out = k;
   return status;

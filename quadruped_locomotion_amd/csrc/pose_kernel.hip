@@ -59,6 +59,68 @@ __device__ __forceinline__ void load_pose_problem(const PoseParamsDev &P, const 
   for (int a = 0; a < 7; a++) pose[a] = s.pose ? ps[a] : (a == 3 ? 1.0 : 0.0);
 }
 
+// The same record fetched by the 16 lanes of a row together: every lane loads at most one element of each array (all loads
+// in flight before the first is consumed: one memory round trip for the whole wavefront), stores it at its place of the
+// record in LDS -- the per-leg arrays permuted into iteration order as above -- and the row reads the record back after a
+// wavefront-level fence (a row reads only what its own lanes wrote: no barrier).  One lane doing it alone, as
+// load_pose_problem does for the one-problem-per-lane kernels, took 2.1 us of a 14.5 us launch (tools/stamp_probe_pose.py).
+__device__ __forceinline__ void load_pose_problem_row(const PoseParamsDev &P, const PosePtrs &s, int64_t i, PoseProblem &pb,
+                                                      double *pose_lds) {
+  const int lr = threadIdx.x & 15;
+  const uint8_t *maskp = s.mask ? s.mask : reinterpret_cast<const uint8_t *>(s.stance);
+  const double *rcomp = s.rcom ? s.rcom : s.stance;
+  const int32_t *nvp = s.nverts ? s.nverts : reinterpret_cast<const int32_t *>(s.stance);
+  const double *posep = s.pose ? s.pose : s.stance;
+  // lanes 0..11: slot k = lr / 3, component a; the limb behind the slot.  (The batch constants are pinned in scalar
+  // registers first: left as loads from the parameter block, the selects below are folded into ONE indexed load, which
+  // sends the whole block to scratch memory.)
+  int lo[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) { lo[kk] = P.leg_order[kk]; asm volatile("" : "+s"(lo[kk])); }
+  const int k = lr < 12 ? (lr * 11) >> 5 : 3, a = lr < 12 ? lr - 3 * k : 0;
+  const int l = k == 0 ? lo[0] : k == 1 ? lo[1] : k == 2 ? lo[2] : lo[3];
+  const int k4 = lr & 3;
+  const int l4 = k4 == 0 ? lo[0] : k4 == 1 ? lo[1] : k4 == 2 ? lo[2] : lo[3];
+  const double st = s.stance[12 * i + 3 * l + a], nm = s.nominal[12 * i + 3 * l + a];
+  const double pl = s.polygon[8 * i + (lr & 7)];
+  const double ml = s.maxlen[4 * i + l4];
+  const double rc = rcomp[3 * i + (lr < 3 ? lr : 2)], ps = posep[7 * i + (lr < 7 ? lr : 6)];
+  const uint32_t m4 = *reinterpret_cast<const uint32_t *>(maskp + 4 * i);
+  const int32_t nv = nvp[i];
+  // hip of my slot's limb, component a (batch constants: selected, not loaded)
+  double hp = 0.0;
+#pragma unroll
+  for (int ll = 0; ll < 4; ll++) {
+    double h0 = P.hips[ll][0], h1 = P.hips[ll][1], h2 = P.hips[ll][2];
+    asm volatile("" : "+s"(h0), "+s"(h1), "+s"(h2));
+    const double h = a == 0 ? h0 : a == 1 ? h1 : h2;
+    hp = l == ll ? h : hp;
+  }
+  unsigned limb_mask = 0xFu, present = 0u;
+  if (s.mask) {
+    limb_mask = 0u;
+#pragma unroll
+    for (int ll = 0; ll < 4; ll++) limb_mask |= ((m4 >> (8 * ll)) & 0xFFu) ? (1u << ll) : 0u;
+  }
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) present |= ((limb_mask >> lo[kk]) & 1u) ? (1u << kk) : 0u;
+  if (lr < 12) {
+    (&pb.stance[0][0])[lr] = st;
+    (&pb.nominal[0][0])[lr] = nm;
+    (&pb.hips[0][0])[lr] = hp;
+  }
+  if (lr < 8) (&pb.polygon[0][0])[lr] = pl;
+  if (lr < 4) pb.max_len[lr] = ml;
+  if (lr < 3) pb.r_com[lr] = s.rcom ? rc : 0.0;
+  if (lr < 7) pose_lds[lr] = s.pose ? ps : (lr == 3 ? 1.0 : 0.0);
+  if (lr == 0) {
+    pb.n_vertices = s.nverts ? nv : 4;
+    pb.present = present;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+}
+
 // Lane-cooperative form (csrc/pose_coop.hpp): 16 lanes per problem, 4 problems per wavefront.
 __global__ __launch_bounds__(64) void pose_sqp_coop_kernel(const PoseParamsDev P, const PosePtrs s, int64_t B,
                                                            double *__restrict__ pose_out, int32_t *__restrict__ iters,
@@ -70,24 +132,22 @@ __global__ __launch_bounds__(64) void pose_sqp_coop_kernel(const PoseParamsDev P
   int64_t i = (int64_t)blockIdx.x * coop::kPoseCoopRows + row;
   const bool live = i < B;
   if (!live) i = B - 1;
-  if (lr == 0) { // one lane per problem fetches the record; the row reads it back from LDS
-    double ps[7];
-    load_pose_problem(P, s, i, pbs[row], ps);
-#pragma unroll
-    for (int a = 0; a < 7; a++) pose0[row][a] = ps[a];
-  }
-  __syncthreads();
+  QL_STAMP(16);
+  load_pose_problem_row(P, s, i, pbs[row], pose0[row]);
   double pose[7];
 #pragma unroll
   for (int a = 0; a < 7; a++) pose[a] = pose0[row][a];
   int it = 0;
+  QL_STAMP(17);
   const int st = coop::pose_sqp_coop(P, pbs[row], live, rows + row * coop::kPoseCoopLdsDoubles, pose, it);
+  QL_STAMP(29);
   if (lr == 0 && live) {
 #pragma unroll
     for (int a = 0; a < 7; a++) pose_out[7 * i + a] = pose[a];
     if (iters) iters[i] = it;
     status[i] = st;
   }
+  QL_STAMP(30);
 }
 
 // PoseOptimizationQP (position only) in the row layout, and PoseConstraintsChecker (one lane per problem)
@@ -100,13 +160,7 @@ __global__ __launch_bounds__(64) void pose_qp_coop_kernel(const PoseParamsDev P,
   int64_t i = (int64_t)blockIdx.x * coop::kPoseCoopRows + row;
   const bool live = i < B;
   if (!live) i = B - 1;
-  if (lr == 0) {
-    double ps[7];
-    load_pose_problem(P, s, i, pbs[row], ps);
-#pragma unroll
-    for (int a = 0; a < 7; a++) pose0[row][a] = ps[a];
-  }
-  __syncthreads();
+  load_pose_problem_row(P, s, i, pbs[row], pose0[row]);
   double pose[7];
 #pragma unroll
   for (int a = 0; a < 7; a++) pose[a] = pose0[row][a];
@@ -629,3 +683,5 @@ int qlamd_weighted_lsq_qp_batch(qlamd_context *ctx, int n, int k, int p, int m, 
 }
 
 } // extern "C"
+
+QLAMD_STAMPS_ACCESSOR(qlamd_debug_stamps_pose)

@@ -1041,3 +1041,5 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
 }
 
 } // extern "C"
+
+QLAMD_STAMPS_ACCESSOR(qlamd_debug_stamps_tick)

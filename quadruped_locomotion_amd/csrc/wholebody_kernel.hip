@@ -547,3 +547,5 @@ int qlamd_wholebody_solve_batch(qlamd_context *ctx, const qlamd_wholebody_params
 }
 
 } // extern "C"
+
+QLAMD_STAMPS_ACCESSOR(qlamd_debug_stamps_wholebody)

@@ -16,6 +16,6 @@ for label, (blob, off) in (("uniform", (one * B, np.arange(B + 1, dtype=np.int64
     for rep in range(3):
         capi.robot_state_unpack(ctx, blob, off)
         out = (C.c_ulonglong * 32)()
-        capi.lib().qlamd_debug_stamps(out, 32)
+        capi.lib().qlamd_debug_stamps_tick(out, 32)
         t = np.array(out[20:26], dtype=np.float64)
         print(label, "launch", rep, " ".join("%s %.2f us;" % (names[k], (t[k + 1] - t[k]) / 100.0) for k in range(5)), "total %.2f us" % ((t[5] - t[0]) / 100.0))
