@@ -99,6 +99,14 @@ def parse():
                     help="run the multi-GPU code path (process group + all-gather) even with one rank (self-test)")
     ap.add_argument("--overlap-gather", action="store_true",
                     help="capture the gathers on a second stream even with one rank (self-test of the multi-rank graph)")
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="collect the torques of this many consecutive steps with one collective (default 1: one per control step)")
+    ap.add_argument("--collect", default="rccl", choices=["rccl", "peer"],
+                    help="result collection: rccl = all-gather of the torque shards (default, BASELINE's north star); peer = "
+                         "every rank copies its shard into a buffer of every other rank (hipMemcpyAsync into IPC-mapped memory, "
+                         "no collective)")
+    ap.add_argument("--no-alternatives", action="store_true",
+                    help="several ranks: skip the `alternatives` object (the same steps with the other ways of collecting)")
     ap.add_argument("--no-gather", action="store_true",
                     help="several ranks without the per-step all-gather of the torques (scaling with / without it)")
     ap.add_argument("--ragged", action="store_true", help="full_tick: every message with its own layout")
@@ -531,25 +539,104 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_preset(gait, errors, with_gather, replays, second_without_gather):
-        """One workload preset on this rank's shard: warm-up, K steps captured as one hipGraph, `replays` timed samples."""
+    class PeerBuffers:
+        """Result collection without a collective: a [2][world][G][B][12] buffer per rank, allocated with hipMalloc (an IPC
+        handle needs the base of an allocation, which a tensor of torch's caching allocator is not), its IPC handle
+        exchanged once, every peer's buffer mapped; a step's collection is `world` device-to-device copies of this rank's
+        shard into slot `rank` of every rank's buffer, on the collection stream.  """
+
+        def __init__(self, group_doubles):
+            import ctypes as C
+            self.C = C
+            self.hip = C.CDLL("libamdhip64.so")
+
+            class Handle(C.Structure):
+                _fields_ = [("reserved", C.c_char * 64)]
+            self.Handle = Handle
+            self.hip.hipIpcOpenMemHandle.argtypes = [C.POINTER(C.c_void_p), Handle, C.c_uint]
+            self.hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+            self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            self.hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+            self.hip.hipFree.argtypes = [C.c_void_p]
+            self.hip.hipIpcGetMemHandle.argtypes = [C.POINTER(Handle), C.c_void_p]
+            self.hip.hipIpcCloseMemHandle.argtypes = [C.c_void_p]
+            self.group_bytes = group_doubles * 8               # one rank's shard of one group of steps
+            self.buf_bytes = self.group_bytes * world          # one of the two buffers
+            self.own = C.c_void_p()
+            self.check(self.hip.hipMalloc(C.byref(self.own), 2 * self.buf_bytes), "hipMalloc")
+            self.peers = [None] * world
+            self.peers[rank] = self.own.value
+            if world > 1:
+                h = Handle()
+                self.check(self.hip.hipIpcGetMemHandle(C.byref(h), self.own), "hipIpcGetMemHandle")
+                handles = [None] * world
+                dist.all_gather_object(handles, bytes(h.reserved))
+                for r in range(world):
+                    if r == rank:
+                        continue
+                    hr = Handle()
+                    C.memmove(C.byref(hr), handles[r], 64)
+                    ptr = C.c_void_p()
+                    self.check(self.hip.hipIpcOpenMemHandle(C.byref(ptr), hr, 1), "hipIpcOpenMemHandle")  # lazy peer access
+                    self.peers[r] = ptr.value
+                dist.barrier()
+
+        def check(self, rc, what):
+            if rc != 0:
+                raise RuntimeError("%s failed with HIP error %d" % (what, rc))
+
+        def scatter(self, buf, src_ptr, stream_handle):
+            """this rank's shard of buffer `buf` into slot `rank` of every rank's buffer"""
+            for r in range(world):
+                dst = self.peers[r] + buf * self.buf_bytes + rank * self.group_bytes
+                self.check(self.hip.hipMemcpyAsync(dst, src_ptr, self.group_bytes, 3, stream_handle), "hipMemcpyAsync")
+
+        def slot_equals(self, buf, slot, tensor):
+            host = np.empty(self.group_bytes // 8)
+            self.check(self.hip.hipMemcpy(host.ctypes.data, self.own.value + buf * self.buf_bytes + slot * self.group_bytes,
+                                          self.group_bytes, 2), "hipMemcpy")
+            return bool(np.array_equal(host, tensor.detach().cpu().numpy().ravel()))
+
+        def close(self):
+            for r in range(world):
+                if r != rank and self.peers[r]:
+                    self.hip.hipIpcCloseMemHandle(self.peers[r])
+            if world > 1:
+                dist.barrier()
+            self.hip.hipFree(self.own)
+
+    def run_preset(gait, errors, with_gather, replays, second_without_gather, collect="rccl", every=1):
+        """One workload preset on this rank's shard: warm-up, K steps captured as one hipGraph, `replays` timed samples.
+        every: steps per collection; collect: "rccl" (all-gather) or "peer" (copies into the peers' buffers)."""
         # rank r owns robots [r*B, (r+1)*B) of the global batch (contiguous shards, SURVEY.md 8e)
         state = synth.make_states(B, gait, offset=rank * B, errors=errors)
         d = capi.to_device(state, dev)
-        tau = [torch.zeros(B, 12, dtype=torch.float64, device=dev) for _ in range(2)]
+        G = max(1, every)
+        tau = [torch.zeros(G, B, 12, dtype=torch.float64, device=dev) for _ in range(2)]
         status = torch.full((B,), -1, dtype=torch.int32, device=dev)
-        gathered = [torch.zeros(world * B, 12, dtype=torch.float64, device=dev) for _ in range(2)] if with_gather else None
+        peer = PeerBuffers(G * B * 12) if (with_gather and collect == "peer") else None
+        gathered = ([torch.zeros(world, G, B, 12, dtype=torch.float64, device=dev) for _ in range(2)]
+                    if (with_gather and peer is None) else None)
+
+        def collect_now(k):  # the last step of its group, or the last step of all
+            return (k % G == G - 1) or (k == args.steps - 1)
+
+        def do_collect(buf, stream_handle):
+            if peer is not None:
+                peer.scatter(buf, tau[buf].data_ptr(), stream_handle)
+                return None
+            return dist.all_gather_into_tensor(gathered[buf].view(world * G * B, 12), tau[buf].view(G * B, 12), async_op=True)
 
         def step(k, wg, events=None):
-            buf = k & 1
+            buf = (k // G) & 1
             if events is not None:
                 events[0].record()
-            ctx.balance_solve_device(d, tau[buf], None, status, stream=stream)
+            ctx.balance_solve_device(d, tau[buf][k % G], None, status, stream=stream)
             if events is not None:
                 events[1].record()
-            if wg:
+            if wg and collect_now(k):
                 # result collection only; overlaps with the next step's solve (double-buffered)
-                return dist.all_gather_into_tensor(gathered[buf], tau[buf], async_op=True)
+                return do_collect(buf, stream)
             return None
 
         for k in range(args.warmup):
@@ -578,20 +665,27 @@ def main():
                     comm = torch.cuda.Stream() if overlap else None
                     gathered_ev = [None, None]
                     for k in range(args.steps):
-                        buf = k & 1
-                        if overlap and gathered_ev[buf] is not None:
+                        buf = (k // G) & 1
+                        if overlap and k % G == 0 and gathered_ev[buf] is not None:
                             side.wait_event(gathered_ev[buf])
-                        ctx.balance_solve_device(d, tau[buf], None, status, stream=cap)
-                        if overlap:  # RCCL collectives are capturable; they replay from the graph
+                        ctx.balance_solve_device(d, tau[buf][k % G], None, status, stream=cap)
+                        if not (wg and collect_now(k)):
+                            continue
+                        if overlap:  # RCCL collectives and peer copies are capturable; they replay from the graph
                             solved = torch.cuda.Event()
                             solved.record(side)
                             comm.wait_event(solved)
                             with torch.cuda.stream(comm):
-                                dist.all_gather_into_tensor(gathered[buf], tau[buf])
+                                if peer is not None:
+                                    peer.scatter(buf, tau[buf].data_ptr(), comm.cuda_stream)
+                                else:
+                                    dist.all_gather_into_tensor(gathered[buf].view(world * G * B, 12), tau[buf].view(G * B, 12))
                                 gathered_ev[buf] = torch.cuda.Event()
                                 gathered_ev[buf].record(comm)
-                        elif wg:
-                            dist.all_gather_into_tensor(gathered[buf], tau[buf])
+                        elif peer is not None:
+                            peer.scatter(buf, tau[buf].data_ptr(), cap)
+                        else:
+                            dist.all_gather_into_tensor(gathered[buf].view(world * G * B, 12), tau[buf].view(G * B, 12))
                     if overlap:
                         side.wait_stream(comm)  # join before the capture ends
             torch.cuda.current_stream().wait_stream(side)
@@ -667,11 +761,16 @@ def main():
 
         res = measure(with_gather)
         res["plain"] = measure(False) if (with_gather and second_without_gather) else None
-        if collective and rank == 0 and args.steps > 0 and with_gather:
-            # the gathered buffer holds every rank's torques in rank order
-            last = (args.steps - 1) & 1
-            assert torch.equal(gathered[last][rank * B:(rank + 1) * B], tau[last]), "all-gather layout"
+        if collective and args.steps > 0 and with_gather:
+            # the collected buffer holds every rank's torques in rank order (every rank checks its own slot)
+            last = ((args.steps - 1) // G) & 1
+            mine = peer.slot_equals(last, rank, tau[last]) if peer is not None else torch.equal(gathered[last][rank], tau[last])
+            flag = torch.tensor([1 if mine else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            assert int(flag.item()) == 1, "collected layout"
             res["gather_layout_ok"] = True
+        if peer is not None:
+            peer.close()
         ok = bool((status.cpu().numpy() == 0).all())
         if collective:
             okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
@@ -699,7 +798,22 @@ def main():
                     "note": "SQ_INSTS_VALU (rocprofv3 --pmc) x 4 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz)"}
         return roof, valu
 
-    res = run_preset(args.gait, args.errors, gather, args.replays, world > 1)
+    res = run_preset(args.gait, args.errors, gather, args.replays, world > 1, collect=args.collect, every=args.gather_every)
+    # The same steps with the other ways of collecting the results, so that a scaling run has something to compare the
+    # per-step all-gather (the default: BASELINE's north star) with: one all-gather per 8 steps, and the peer-copy form.
+    alternatives = None
+    if gather and (world > 1 or args.force_collective) and not args.no_alternatives:
+        alternatives = {}
+        for name, (col, ev) in (("rccl_every_8", ("rccl", 8)), ("peer_every_1", ("peer", 1)), ("peer_every_8", ("peer", 8))):
+            if col == args.collect and ev == args.gather_every:
+                continue
+            try:
+                r = run_preset(args.gait, args.errors, True, min(args.replays, 5), False, collect=col, every=ev)
+                alternatives[name] = {"value": world * B * args.steps / r["elapsed"], "ms_per_step": r["elapsed"] / args.steps * 1e3,
+                                      "collect": col, "gather_every": ev, "layout_ok": r.get("gather_layout_ok"),
+                                      "launch": "hipGraph of K steps" if r["graph"] else "eager"}
+            except Exception as e:  # an alternative that does not run costs the line nothing
+                alternatives[name] = {"error": repr(e)[:200]}
 
     # the other presets of the headline workload, same process, same batch (one GPU only; fewer samples each)
     also = None
@@ -734,12 +848,14 @@ def main():
                        "tracking_error_note": "half-widths of the uniform position (m) / rotation-vector (rad) / twist errors: "
                                               "SURVEY.md 8(d)'s 0.02 / 0.05 / 0.1 unless --errors calm (static only; `also` "
                                               "carries the other presets)",
-                       "result_collection": "rccl all_gather of torques" if gather else
+                       "result_collection": ("rccl all_gather of torques" if args.collect == "rccl" else
+                                             "copies of the torque shard into every rank's buffer (hipMemcpyAsync, IPC-mapped)") if gather else
                        ("none (--no-gather)" if collective else "none (single GPU)"),
                        "rccl_ranks": ranks_seen if collective else None,
                        "launch": "hipGraph of K steps" if res["graph"] else "eager",
                        "gather_stream": ("second captured stream" if res["overlap"] else "solve stream") if gather else None,
                        "gather_layout_ok": res.get("gather_layout_ok"),
+                       "collect": args.collect if gather else None, "gather_every": args.gather_every if gather else None,
                        "timed_region": "median of %d samples of exactly K steps, each between barrier + synchronize" % len(res["samples_ms"]),
                        "samples_ms": res["samples_ms"],
                        "all_status_ok": res["ok"]},
@@ -748,6 +864,8 @@ def main():
         if res["plain"] is not None:
             line["without_gather"] = {"value": total / res["plain"]["elapsed"], "ms_per_step": res["plain"]["elapsed"] / args.steps * 1e3,
                                       "samples_ms": res["plain"]["samples_ms"]}
+        if alternatives is not None:
+            line["alternatives"] = alternatives
         if valu:
             line["valu_issue"] = valu
         if also is not None:

@@ -100,7 +100,7 @@ def test_collective_path_with_one_rank():
     hipGraph, gathers on a second captured stream -- exercised with a single rank, then without the gather, then with
     eager launches (what the ranks fall back to when a capture fails)."""
     common = ("--force-collective", "--gait", "trot", "--batch", "8192", "--steps", "20", "--warmup", "3",
-              "--no-cpu-baseline", "--replays", "3")
+              "--no-cpu-baseline", "--replays", "3", "--no-alternatives")
     d = check(_bench(*common, "--overlap-gather"), want_cpu=False)
     c = d["config"]
     assert c["rccl_ranks"] == 1 and d["n_gpus"] == 1 and c["robots_per_gpu"] == 8192 and c["all_status_ok"] is True
@@ -114,6 +114,29 @@ def test_collective_path_with_one_rank():
     assert d["value"] > 0.8 * with_gather
     d = check(_bench(*common, "--overlap-gather", "--no-graph"), want_cpu=False)
     assert d["config"]["launch"] == "eager" and d["config"]["gather_layout_ok"] is True and d["config"]["all_status_ok"] is True
+
+
+@pytest.mark.gpu
+def test_collection_cadence_and_peer_copies_with_one_rank():
+    """--gather-every K (one all-gather per K steps), --collect peer (copies into the ranks' buffers instead of a
+    collective) and the `alternatives` object a several-rank line carries, each through the captured two-stream form."""
+    common = ("--force-collective", "--overlap-gather", "--gait", "trot", "--batch", "8192", "--steps", "20", "--warmup", "3",
+              "--no-cpu-baseline", "--replays", "3")
+    d = check(_bench(*common, "--gather-every", "4", "--no-alternatives"), want_cpu=False)
+    c = d["config"]
+    assert c["gather_every"] == 4 and c["collect"] == "rccl" and c["gather_layout_ok"] is True and c["all_status_ok"] is True
+    assert c["launch"] == "hipGraph of K steps" and "alternatives" not in d
+    d = check(_bench(*common, "--collect", "peer", "--no-alternatives"), want_cpu=False)
+    c = d["config"]
+    assert c["collect"] == "peer" and c["gather_every"] == 1 and c["gather_layout_ok"] is True and c["all_status_ok"] is True
+    assert c["result_collection"].startswith("copies of the torque shard") and c["launch"] == "hipGraph of K steps"
+    d = check(_bench(*common), want_cpu=False)  # the default: RCCL every step, the others measured beside it
+    assert d["config"]["collect"] == "rccl" and d["config"]["gather_every"] == 1
+    alt = d["alternatives"]
+    assert set(alt) == {"rccl_every_8", "peer_every_1", "peer_every_8"}
+    for name, a in alt.items():
+        assert "error" not in a, (name, a)
+        assert a["value"] > 0 and a["layout_ok"] is True, (name, a)
 
 
 def test_profile_collection_names_exist_in_the_sources():

@@ -57,6 +57,36 @@ def test_two_rank_shards_equal_one_global_batch(oracle, tmp_path):
     assert np.array_equal(gathered, tau)  # rank order == robot order, bitwise
 
 
+def _grouped_worker(rank, world, port, B, G, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # bench.py --gather-every G: the torques of G steps sit in one [G][B][12] buffer and travel with one all-gather into
+    # [world][G][B][12]; the stand-in value of (rank, step, robot, joint) makes the layout readable
+    tau = torch.zeros(G, B, 12, dtype=torch.float64)
+    for g in range(G):
+        tau[g] = rank * 1e6 + g * 1e3 + torch.arange(B * 12, dtype=torch.float64).reshape(B, 12) * 1e-3
+    gathered = torch.zeros(world, G, B, 12, dtype=torch.float64)
+    dist.all_gather_into_tensor(gathered.view(world * G * B, 12), tau.view(G * B, 12))
+    assert torch.equal(gathered[rank], tau)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "grouped.npy"), gathered.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grouped_gather_layout(tmp_path):
+    world, B, G = 2, 5, 3
+    mp.spawn(_grouped_worker, args=(world, _free_port(), B, G, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "grouped.npy")
+    for r in range(world):
+        for g in range(G):
+            want = r * 1e6 + g * 1e3 + np.arange(B * 12).reshape(B, 12) * 1e-3
+            assert np.array_equal(got[r, g], want)
+
+
 def _run_bench(*argv, env=None):
     import subprocess
     import sys
