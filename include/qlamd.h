@@ -43,6 +43,9 @@ extern "C" {
                                          ContactForceDistribution.cpp:103     */
 #define QLAMD_ERR_OUT_OF_MEMORY (-5)
 #define QLAMD_ERR_BUSY (-6)           /* another thread is inside a call on this context */
+#define QLAMD_ERR_NEEDS_RESERVE (-7)  /* the call would have to grow the context's device scratch while its stream is
+                                         being captured into a hipGraph (an allocation would break the capture): call
+                                         qlamd_reserve(ctx, max_batch) before the capture starts */
 
 /* ---- per-robot status words (int32) ------------------------------------ */
 #define QLAMD_STATUS_OK 0
@@ -141,8 +144,21 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
                          int device, qlamd_context **out);
 void qlamd_context_destroy(qlamd_context *ctx);
 
-/* Tuning knob: robots per wavefront.  4 = lane-cooperative latency kernel (16 lanes per robot);
- * 16 / 64 = one lane per robot (throughput kernel); 0 = choose from the batch size. */
+/* Device scratch of the context, allocated up front.  qlamd_full_tick_batch and qlamd_robot_state_unpack_batch keep
+ * per-robot intermediates (leg state codes, the command in force when the caller keeps none, the message-layout template)
+ * in device memory owned by the context and grow it on demand -- hipFree + hipMalloc inside the call, which synchronises
+ * the device and is illegal while the call's stream is being captured.  qlamd_reserve sizes that scratch for batches up
+ * to max_batch once (synchronous; call it before the first capture or before a latency-critical loop); a call that
+ * would still have to grow it inside a capture returns QLAMD_ERR_NEEDS_RESERVE instead of breaking the capture.
+ * QLAMD_MEM_HOST calls stage through a slab of their own that also grows on demand: host-buffer calls synchronise
+ * anyway and cannot be captured. */
+int qlamd_reserve(qlamd_context *ctx, int64_t max_batch);
+
+/* Which implementation of the balance step runs: robots per wavefront.  0 (default) and 4 = the lane-cooperative kernel
+ * (16 lanes per robot), the fast path at every batch size measured (1 K ... 1 M robots).  16 / 64 = one lane per robot:
+ * an independent second implementation (range-space Goldfarb-Idnani, Cholesky in registers) kept as a CROSS-CHECK of the
+ * first, not as a fast path -- it is slower everywhere, and with per-leg surface normals it needs more than the 512
+ * registers a lane can have and spills 384 / 480 bytes per lane to scratch memory. */
 int qlamd_set_robots_per_wave(qlamd_context *ctx, int robots_per_wave);
 
 /* Context options (set once after creation or between calls; never read from the process environment).

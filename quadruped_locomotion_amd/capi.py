@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libqlamd.so")
 
 OK = 0
-ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_LOADED, ERR_OUT_OF_MEMORY, ERR_BUSY = -1, -2, -3, -4, -5, -6
+ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_LOADED, ERR_OUT_OF_MEMORY, ERR_BUSY, ERR_NEEDS_RESERVE = -1, -2, -3, -4, -5, -6, -7
 STATUS_OK, STATUS_INFEASIBLE, STATUS_NOT_PD, STATUS_MAX_ITER = 0, 1, 2, 3
 MEM_DEVICE, MEM_HOST = 0, 1
 
@@ -28,6 +28,7 @@ EXPORTS = (
     "qlamd_joint_pid_default_params", "qlamd_swing_branch_batch",
     "qlamd_wholebody_default_params", "qlamd_wholebody_dynamics_batch", "qlamd_wholebody_solve_batch",
     "qlamd_full_tick_batch", "qlamd_set_option", "qlamd_tick_command_bytes", "qlamd_weighted_lsq_qp_batch",
+    "qlamd_reserve",
 )
 
 
@@ -188,6 +189,7 @@ def lib():
         L.qlamd_context_destroy.argtypes = [C.c_void_p]
         L.qlamd_context_destroy.restype = None
         L.qlamd_set_robots_per_wave.argtypes = [C.c_void_p, C.c_int]
+        L.qlamd_reserve.argtypes = [C.c_void_p, C.c_int64]
         L.qlamd_balance_solve_batch.argtypes = [C.c_void_p, C.POINTER(StateBatch), C.c_int64, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_virtual_wrench_batch.argtypes = [C.c_void_p, C.POINTER(StateBatch), C.c_int64, C.c_void_p,
@@ -287,6 +289,12 @@ class Context:
         if rc != OK:
             raise QlamdError(rc, "qlamd_set_option")
 
+    def reserve(self, max_batch):
+        """Size the context's device scratch for batches up to max_batch (qlamd_reserve): before capturing the whole tick."""
+        rc = lib().qlamd_reserve(self._h, C.c_int64(int(max_batch)))
+        if rc != OK:
+            raise QlamdError(rc, "qlamd_reserve")
+
     def set_robots_per_wave(self, rpw):
         rc = lib().qlamd_set_robots_per_wave(self._h, int(rpw))
         if rc != OK:
@@ -308,10 +316,8 @@ class Context:
             nw = np.ascontiguousarray(np.asarray(normals, dtype=np.float64).reshape(B, 12))
             keep.append(nw)
             sb.surface_normal = nw.ctypes.data
-        tau = np.zeros((B, 12)) if tau is None else tau
-        grf = (np.zeros((B, 12)) if grf is None else grf) if want_forces else None
-        for a in (tau, grf):
-            assert a is None or (a.dtype == np.float64 and a.flags["C_CONTIGUOUS"] and a.shape == (B, 12))
+        tau = _host_out(tau, B, "tau")
+        grf = _host_out(grf, B, "grf") if want_forces else None
         status = np.full(B, -1, dtype=np.int32)
         rc = lib().qlamd_balance_solve_batch(self._h, C.byref(sb), B, tau.ctypes.data,
                                              grf.ctypes.data if want_forces else None, status.ctypes.data,
@@ -392,14 +398,25 @@ def _ptr(a):
     return a.data_ptr() if hasattr(a, "data_ptr") else a.ctypes.data
 
 
+def _host_out(a, B, name):
+    """A caller-supplied host output array the library writes B * 96 bytes into: float64, C-contiguous, [B, 12] -- or a
+    fresh one.  (The library cannot see a numpy array's dtype or strides: a float32 or transposed array would be
+    overrun.)"""
+    if a is None:
+        return np.zeros((B, 12))
+    if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags["C_CONTIGUOUS"] and a.shape == (B, 12)):
+        raise ValueError("%s must be a C-contiguous float64 array of shape (%d, 12)" % (name, B))
+    return a
+
+
 def force_distribution(ctx, q, quat, support, wrench, normals=None, memory=MEM_HOST, tau=None, grf=None):
     """qlamd_force_distribution_batch with host (numpy) buffers -> (tau, grf, status)."""
     q = np.ascontiguousarray(q, dtype=np.float64); quat = np.ascontiguousarray(quat, dtype=np.float64)
     support = np.ascontiguousarray(support, dtype=np.uint8); wrench = np.ascontiguousarray(wrench, dtype=np.float64)
     normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float64)
     B = q.shape[0]
-    tau = np.zeros((B, 12)) if tau is None else tau
-    grf = np.zeros((B, 12)) if grf is None else grf
+    if memory == MEM_HOST:
+        tau, grf = _host_out(tau, B, "tau"), _host_out(grf, B, "grf")
     st = np.full(B, -1, dtype=np.int32)
     rc = lib().qlamd_force_distribution_batch(ctx._h, _ptr(q), _ptr(quat), _ptr(support), _ptr(normals), _ptr(wrench), B,
                                               _ptr(tau), _ptr(grf), _ptr(st), memory, None)
@@ -654,6 +671,8 @@ def weighted_lsq_qp(ctx, A, S, b, W, Ceq=None, ceq=None, D=None, d=None, f=None,
     if memory == MEM_HOST:
         x, st = np.zeros((B, n)), np.full(B, -1, dtype=np.int32)
     else:
+        if out is None:
+            raise ValueError("device memory: pass out=(x [B,n] float64, status [B] int32) as preallocated CUDA tensors")
         x, st = out
     rc = lib().qlamd_weighted_lsq_qp_batch(ctx._h, n, k, p, m, *[_ptr(a) for a in arrs], B, _ptr(x), _ptr(st), memory,
                                            C.c_void_p(stream) if stream else None)
@@ -711,8 +730,7 @@ def wholebody_solve(ctx, state, params=None, tau=None, grf=None):
     keep = []
     wb = _wholebody_batch(state, keep)
     B = state["q"].shape[0]
-    tau = np.zeros((B, 12)) if tau is None else tau
-    grf = np.zeros((B, 12)) if grf is None else grf
+    tau, grf = _host_out(tau, B, "tau"), _host_out(grf, B, "grf")
     st = np.full(B, -1, np.int32)
     rc = lib().qlamd_wholebody_solve_batch(ctx._h, C.byref(prm), C.byref(wb), B, _ptr(tau), _ptr(grf), _ptr(st), MEM_HOST, None)
     if rc != OK:

@@ -268,6 +268,7 @@ const char *qlamd_strerror(int code) {
     case QLAMD_ERR_NOT_LOADED: return "parameters not loaded";
     case QLAMD_ERR_OUT_OF_MEMORY: return "out of device memory";
     case QLAMD_ERR_BUSY: return "another thread is inside a call on this context";
+    case QLAMD_ERR_NEEDS_RESERVE: return "device scratch would have to grow inside a stream capture: call qlamd_reserve first";
     default: return "unknown error";
   }
 }

@@ -105,9 +105,15 @@ struct CallGuard {
   hipStream_t st;
   bool uses_stream;
   static bool capturing(hipStream_t s) {
+    // (the query itself counts as an unsafe call when `s` is the legacy stream and some other stream is being captured in
+    // global mode -- it would invalidate that capture; in relaxed mode it is a plain query)
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
     hipStreamCaptureStatus a = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &a) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a != hipStreamCaptureStatusNone;
+    const bool ok = hipStreamIsCapturing(s, &a) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    return ok && a != hipStreamCaptureStatusNone;
   }
   CallGuard(qlamd_context *ctx, hipStream_t stream, bool uses = true) : c(ctx), rc(QLAMD_OK), st(stream), uses_stream(uses) {
     const std::thread::id me = std::this_thread::get_id();
@@ -132,21 +138,25 @@ struct CallGuard {
   ~CallGuard() {
     if (!c) return;
     if (uses_stream) {
+      // A call whose stream is being captured queues nothing now: it is invisible to the eager ordering state (the event
+      // of the last eager call stays the one to wait for, and its stream the one compared with).
+      bool captured = false;
       if (c->multi_stream) {
-        // mark the end of this call's work for a later call on another stream
-        if (!capturing(st)) {
+        captured = capturing(st);
+        if (!captured) {
+          // mark the end of this call's work for a later call on another stream
           if (!c->done_event && hipEventCreateWithFlags(&c->done_event, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             c->done_event = nullptr;
           }
           c->done_recorded = c->done_event && hipEventRecord(c->done_event, st) == hipSuccess;
           if (!c->done_recorded) (void)hipGetLastError();
-        } else {
-          c->done_recorded = false;
         }
       }
-      c->last_stream = st;
-      c->had_work = true;
+      if (!captured) {
+        c->last_stream = st;
+        c->had_work = true;
+      }
     }
     std::lock_guard<std::mutex> lk(c->gate);
     c->depth--;

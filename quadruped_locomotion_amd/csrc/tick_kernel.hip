@@ -829,6 +829,7 @@ static int unpack_impl(qlamd_context *ctx, const uint8_t *messages, const int64_
     d_msg = (const uint8_t *)(sg.base + sg.items[i_msg].off) - offsets[0]; // the kernel indexes with the caller's offsets
   }
   if (!ctx->wire_tpl) { // zero = "no template yet": the first launch walks every message
+    if (rt::CallGuard::capturing(st)) return QLAMD_ERR_NEEDS_RESERVE;
     if (hipMalloc((void **)&ctx->wire_tpl, 2 * kTplWords * sizeof(uint32_t)) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;
     if (hipMemsetAsync(ctx->wire_tpl, 0, 2 * kTplWords * sizeof(uint32_t), st) != hipSuccess) return QLAMD_ERR_HIP;
   }
@@ -909,6 +910,26 @@ size_t qlamd_tick_command_bytes(int64_t batch) {
   return batch > 0 ? command_layout((size_t)batch, off) : 0;
 }
 
+int qlamd_reserve(qlamd_context *ctx, int64_t max_batch) {
+  if (!ctx || max_batch < 1) return QLAMD_ERR_INVALID_ARGUMENT;
+  QL_ENTER_NO_STREAM(ctx);
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  size_t coff[kCmdN];
+  const size_t scratch = align256((size_t)max_batch * 4) + command_layout((size_t)max_batch, coff);
+  if (ctx->tick_ws_bytes < scratch) {
+    if (hipDeviceSynchronize() != hipSuccess) return QLAMD_ERR_HIP; // earlier calls may still use the old block
+    if (ctx->tick_ws) (void)hipFree(ctx->tick_ws);
+    ctx->tick_ws = nullptr; ctx->tick_ws_bytes = 0;
+    if (hipMalloc(&ctx->tick_ws, scratch) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;
+    ctx->tick_ws_bytes = scratch;
+  }
+  if (!ctx->wire_tpl) {
+    if (hipMalloc((void **)&ctx->wire_tpl, 2 * kTplWords * sizeof(uint32_t)) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;
+    if (hipMemset(ctx->wire_tpl, 0, 2 * kTplWords * sizeof(uint32_t)) != hipSuccess) return QLAMD_ERR_HIP;
+  }
+  return QLAMD_OK;
+}
+
 int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, const qlamd_joint_pid_params *pid,
                           const qlamd_tick_batch *io, double period, int index_quirk, int64_t batch, int memory,
                           void *stream) {
@@ -967,6 +988,7 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
   // keeps none (then no command outlives the call: the flags are cleared first)
   const size_t scratch = align256(B * 4) + (d.command ? 0 : cmd_bytes);
   if (ctx->tick_ws_bytes < scratch) {
+    if (rt::CallGuard::capturing(st)) return QLAMD_ERR_NEEDS_RESERVE;
     if (ctx->tick_ws) (void)hipFree(ctx->tick_ws);
     ctx->tick_ws = nullptr; ctx->tick_ws_bytes = 0;
     if (hipMalloc(&ctx->tick_ws, scratch) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;

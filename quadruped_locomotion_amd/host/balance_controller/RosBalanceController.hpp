@@ -138,10 +138,20 @@ class RosBalanceController {
     appendLog();
     return solved;
   }
-  // the tail of update() (:606-716): one record per tick while fewer than log_length_ are held
+  // The tail of update() (:606-716): one record per tick.  In the reference the guard in front of it,
+  // `base_actual_pose_.size() < log_length_` (:607), counts a vector whose push_back is commented out (:645-646): the
+  // guard always holds and leg_states_, joint_command_ ... grow with every tick until starting() clears them.  The mirror
+  // does the same by default (no cap).  setLogLength(n) is an addition of the mirror, not reference behaviour: a cap for
+  // long-running callers, 0 = none.
   const std::vector<TickLogEntry> &log() const { return log_; }
   void clearLog() { log_.clear(); }
   void setLogLength(size_t n) { log_length_ = n; }
+  // controller_interface::Controller::starting / stopping (ros_balance_controller.cpp:1142-1156): starting() clears the
+  // tick log (leg_states_, joint_actual_, joint_command_, foot_desired_contact_, leg_phases_, desired_robot_state_,
+  // actual_robot_state_: the vectors one TickLogEntry holds), stopping() does nothing.  The ros::Time argument is dropped
+  // with the rest of ROS; both are ignored by the reference.
+  void starting() { log_.clear(); }
+  void stopping() {}
   // The same tick through ONE call of the C-ABI (qlamd_full_tick_batch, batch 1): message bytes in, 12 efforts out.
   // Equivalent to baseCommandCallback(msg) + footContactsCallback + updateFullTick(period); a message that cannot be
   // deserialised leaves the command of the last good one in force, as in the reference where it never reaches the
@@ -170,7 +180,7 @@ class RosBalanceController {
 
  private:
   void appendLog() {
-    if (log_.size() >= log_length_) return;                                          // :607
+    if (log_length_ != 0 && log_.size() >= log_length_) return;                      // the mirror's own cap; :607 never caps
     TickLogEntry e{};
     const double w = hw_.orientation[0], x = hw_.orientation[1], y = hw_.orientation[2], z = hw_.orientation[3];
     const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
@@ -189,7 +199,7 @@ class RosBalanceController {
     log_.push_back(e);
   }
   std::vector<TickLogEntry> log_;
-  size_t log_length_ = 10000;                                                        // log_length_, :17
+  size_t log_length_ = 0;                                                            // 0 = no cap (the reference's log_length_, :17, caps nothing)
   RobotStateHandleData hw_;
   BaseCommand cmd_;
   std::shared_ptr<qlamd::Context> ctx_;

@@ -158,7 +158,8 @@ int main(int argc, char **argv) {
     }
     std::sort(us.begin() + 50, us.end());
     std::printf("tick_latency_us %.1f %.1f\n", us[50 + 125], us[50 + 225]); // median and p90 after 50 warm-up ticks
-    // the in-memory log of update() (:606-716): one record per tick, capped at log_length_
+    // the in-memory log of update() (:606-716): one record per tick, never capped (the reference's guard counts a vector
+    // that is never filled); the mirror's own setLogLength() caps, starting() clears (:1142-1153)
     const auto &log = tick.log();
     std::printf("tick_log_size %zu\n", log.size());
     std::printf("tick_log0_contact_force"); for (double v : log.front().desired_contact_force) std::printf(" %.17g", v); std::printf("\n");
@@ -168,6 +169,14 @@ int main(int argc, char **argv) {
     tick.setLogLength(log.size() + 2);
     for (int rep = 0; rep < 5; ++rep) tick.updateFullTick(0.0025);
     std::printf("tick_log_capped %zu\n", tick.log().size());
+    tick.setLogLength(0);
+    for (int rep = 0; rep < 5; ++rep) tick.updateFullTick(0.0025);
+    std::printf("tick_log_uncapped %zu\n", tick.log().size());
+    tick.starting();
+    std::printf("tick_log_after_starting %zu\n", tick.log().size());
+    tick.updateFullTick(0.0025);
+    tick.stopping();
+    std::printf("tick_log_after_stopping %zu\n", tick.log().size());
     // the same first tick through the one-call entry on a fresh controller: identical efforts; then its latency
     double effort1[12] = {0};
     balance_controller::RobotStateHandleData hw1 = hw;

@@ -35,11 +35,17 @@ def solve_device(gpu, state, normals=None, rpw=0):
     return tau.cpu().numpy(), grf.cpu().numpy(), status.cpu().numpy()
 
 
-@pytest.mark.parametrize("gait", ["static", "trot"])
+# the three bench presets: static stance with SURVEY.md 8(d)'s literal tracking errors (the headline workload, what the
+# driver times), static stance with the calm errors, trot
+PRESETS = [("static", "survey"), ("static", "calm"), ("trot", None)]
+
+
+@pytest.mark.parametrize("gait,errors", PRESETS)
 @pytest.mark.parametrize("rpw", [0, 4, 16, 64])
-def test_batch_4096_matches_oracle(gpu, oracle, gait, rpw):
-    """BASELINE configs 2 and 3 at full size, every launch geometry."""
-    s = synth.make_states(4096, gait)
+def test_batch_4096_matches_oracle(gpu, oracle, gait, errors, rpw):
+    """BASELINE configs 2 and 3 at full size, every launch geometry, every preset of the bench (the preset the driver times
+    is checked on every geometry)."""
+    s = synth.make_states(4096, gait, errors=errors)
     tau, grf, status = solve_device(gpu, s, rpw=rpw)
     t0, g0, s0 = oracle.balance_batch(s, nthreads=8)
     assert (status == s0).all() and (status == 0).all()
@@ -49,10 +55,11 @@ def test_batch_4096_matches_oracle(gpu, oracle, gait, rpw):
     assert np.abs(grf - g0).max() < 1e-6
 
 
-def test_device_equals_host_mirror(gpu, oracle, mirror):
+@pytest.mark.parametrize("gait,errors", PRESETS)
+def test_device_equals_host_mirror(gpu, oracle, mirror, gait, errors):
     """The same arithmetic compiled for the host: agreement far below the oracle tolerance
     (differences come only from FMA contraction and libm vs device sqrt/acos)."""
-    s = synth.make_states(2048, "trot")
+    s = synth.make_states(2048, gait, errors=errors)
     tau, grf, status = solve_device(gpu, s)
     t1, g1, s1, _, _ = mirror.balance(oracle, s)
     assert (status == s1).all()

@@ -74,3 +74,19 @@ def test_header_is_plain_c_and_links_from_c(capi, tmp_path):
     assert out.returncode == 0, out.stderr
     rc = int(out.stdout.split()[0])
     assert rc == (0 if has_gpu() else capi.ERR_NO_DEVICE), out.stdout
+
+
+def test_output_arrays_are_validated_before_the_library_writes_into_them():
+    """float32, non-contiguous or wrongly shaped caller arrays would be overrun by B * 96 bytes: ValueError, not an assert
+    (python -O strips those), in every wrapper that takes them."""
+    import numpy as np
+    import pytest
+    from quadruped_locomotion_amd import capi
+    good = capi._host_out(np.zeros((5, 12)), 5, "tau")
+    assert good.shape == (5, 12) and capi._host_out(None, 3, "tau").shape == (3, 12)
+    for bad in (np.zeros((5, 12), np.float32), np.zeros((12, 5)).T, np.zeros((4, 12)), np.zeros(60), [[0.0] * 12] * 5):
+        with pytest.raises(ValueError):
+            capi._host_out(bad, 5, "tau")
+    with pytest.raises(ValueError):
+        capi.weighted_lsq_qp(None, np.zeros((1, 6, 12)), np.ones((1, 6)), np.zeros((1, 6)), np.ones((1, 12)),
+                             memory=capi.MEM_DEVICE, out=None)

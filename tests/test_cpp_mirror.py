@@ -132,7 +132,9 @@ def test_mirror_full_tick_matches_oracle(oracle, tmp_path):
     assert np.abs(out["tick_effort"][:3] - swing).max() < 1e-8
     # the in-memory log (ros_balance_controller.cpp:606-716): 301 ticks so far, the first record holds the first tick's
     # efforts, state codes, phases, and the desired contact forces (-x) rotated into the world frame (:656-661)
-    assert out["tick_log_size"][0] == 301 and out["tick_log_capped"][0] == 303      # stops at log_length_
+    assert out["tick_log_size"][0] == 301                                           # no cap by default, as in the reference
+    assert out["tick_log_capped"][0] == 303 and out["tick_log_uncapped"][0] == 308  # the mirror's own setLogLength()
+    assert out["tick_log_after_starting"][0] == 0 and out["tick_log_after_stopping"][0] == 1  # starting() clears (:1142-1153)
     assert np.array_equal(out["tick_log0_effort"], out["tick_effort"]) and list(out["tick_log0_leg_state"]) == [0, 2, 2, 2]
     Rm = oracle.quat_to_matrix(quat)
     want = np.concatenate([Rm @ (-r["grf"][3 * l:3 * l + 3]) for l in range(4)])

@@ -219,3 +219,43 @@ def test_full_tick_errors():
     empty["messages"] = np.zeros(0, np.uint8)
     capi.full_tick(ctx, empty, 0.0025)
     assert (empty["status"] == 4).all() and (empty["message_status"] != 0).all()
+
+
+def test_captured_tick_needs_its_scratch_reserved():
+    """A whole tick captured into a hipGraph on a fresh context: the first call would have to allocate the context's
+    device scratch, which would break the capture -- it refuses with QLAMD_ERR_NEEDS_RESERVE instead; after
+    qlamd_reserve(ctx, max_batch) the capture goes through and the replayed tick equals an eager one bit for bit."""
+    import torch
+    from quadruped_locomotion_amd import capi
+    B, period = 256, 0.0025
+    msgs, tin = make_tick_inputs(B, 0)
+
+    def device_io():
+        keep = fresh_state(B, capi)
+        keep["leg_state_code"] = None   # ask the context to hold the leg state codes: that is part of its scratch
+        return {k: (torch.from_numpy(v).to("cuda:0") if v is not None else None) for k, v in dict(tin, **keep).items()}
+
+    ref_io = device_io()
+    capi.full_tick(capi.Context(), ref_io, period, memory=capi.MEM_DEVICE)
+    torch.cuda.synchronize()
+
+    ctx = capi.Context()
+    io = device_io()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            with pytest.raises(capi.QlamdError) as e:
+                capi.full_tick(ctx, io, period, memory=capi.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+            assert e.value.code == capi.ERR_NEEDS_RESERVE
+    torch.cuda.synchronize()
+    ctx.reserve(B)
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            capi.full_tick(ctx, io, period, memory=capi.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+    g.replay()
+    torch.cuda.synchronize()
+    for k in ("joint_effort", "status", "message_status", "limb_state", "support", "pid_error_last"):
+        assert torch.equal(io[k], ref_io[k]), k
+    assert (io["status"].cpu().numpy() == 0).sum() > B // 2
