@@ -189,7 +189,8 @@ def lib():
         L.qlamd_context_destroy.argtypes = [C.c_void_p]
         L.qlamd_context_destroy.restype = None
         L.qlamd_set_robots_per_wave.argtypes = [C.c_void_p, C.c_int]
-        L.qlamd_reserve.argtypes = [C.c_void_p, C.c_int64]
+        if hasattr(L, "qlamd_reserve"):  # (absent from libraries of earlier revisions that tools/experiments/variants.py builds)
+            L.qlamd_reserve.argtypes = [C.c_void_p, C.c_int64]
         L.qlamd_balance_solve_batch.argtypes = [C.c_void_p, C.POINTER(StateBatch), C.c_int64, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.qlamd_virtual_wrench_batch.argtypes = [C.c_void_p, C.POINTER(StateBatch), C.c_int64, C.c_void_p,

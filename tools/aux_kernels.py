@@ -11,6 +11,9 @@ import torch  # before the C-ABI library: both bring a HIP runtime, torch's must
 
 from quadruped_locomotion_amd import capi, synth
 
+if "--lib" in sys.argv:  # a variant build (tools/experiments/variants.py)
+    capi.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+
 B, REPS = 4096, 5
 ctx = capi.Context()
 rng = np.random.default_rng(0)
