@@ -422,7 +422,6 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
   // or turn every branch into execution-mask bookkeeping.
   // Terminates: at most kMaxOuter adds, every drop undoes an earlier add, a failed add bans its row until the next add.
   double z = 0.0, r = 0.0, zn = 0.0, zinv = 0.0, t = 0.0, tl1 = 0.0, tl2 = 0.0, ratio = 0.0;
-  bool have_dirs = false; // wave-uniform: the directions of the pass at hand follow from the drops just made
   // ---- a full step that adds the candidate: H -= z z'/d, N* <- [N* - r z'/d ; z'/d], the new row goes to the lowest
   // free slot lane; then the selection of the next candidate in the shadow of the update
   const auto add_step = [&]() -> bool {
@@ -537,29 +536,40 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     for (;;) {
       unsigned long long add_m = 0ull;
       for (;;) { // passes in which every live row adds
-        if (!have_dirs) general_dirs();
-        have_dirs = false;
+        general_dirs();
         add_m = __builtin_amdgcn_ballot_w64(step_lengths());
         if (~(add_m | done_m) != 0ull) break;
         note_finished(add_step());
         if (~done_m == 0ull) break;
       }
-      const unsigned long long live_m = ~done_m;
-      if (live_m == 0ull) break;
-      const unsigned long long drop_m = __builtin_amdgcn_ballot_w64(tl1 < tl2) & live_m & ~add_m;
+      if (~done_m == 0ull) break;
+      // ---- a pass in which some live row cannot add yet.  Every pass ends with an add for every live row: the rows whose
+      // step is blocked drop the blocking constraint first -- the straight drop path, then the step lengths again from the
+      // continued directions, repeated while any of them is still blocked -- and then all live rows add together.  (Until
+      // round 3 such a pass did one step per row: the rows that dropped came back for their add in the next pass, and a
+      // wavefront paid 1.03 us for it where this form pays 0.5 us per round of drops: the slowest wavefront of the
+      // survey-literal batch 19.8 -> 16.9 us above the floor, tools/experiments/lockstep_schemes.py.)  A row that does
+      // neither (a degenerate add, a dual step only, an infeasible problem) takes the general predicated form and sits
+      // the rest of the pass out.
+      unsigned long long gen_m = 0ull; // rows that took the general form in this pass
       bool fin = false;
-      if ((live_m & ~add_m & ~drop_m) == 0ull) {
-        // ---- every live row either drops a constraint or adds one: the rows that drop take the straight drop path, then
-        // the rows that add the straight add path (ghost rows ride along on both).  When every live row has dropped, the
-        // next pass starts from the continued directions.
-        const bool any_add = (add_m & live_m) != 0ull;
-        if (in(drop_m | done_m)) drop_step();
-        if (any_add) {
-          if (in(add_m | done_m)) fin = add_step();
+      for (;;) {
+        const unsigned long long live_m = ~done_m & ~gen_m;
+        const unsigned long long drop_m = __builtin_amdgcn_ballot_w64(tl1 < tl2) & live_m & ~add_m;
+        const unsigned long long other_m = live_m & ~add_m & ~drop_m;
+        if (other_m != 0ull) {
+          if (in(other_m)) fin = general_pass(false);
+          gen_m |= other_m;
         }
-        have_dirs = !any_add;
-      } else {
-        if (in(live_m)) fin = general_pass(in(add_m));
+        if (drop_m == 0ull) break;
+        if (in(drop_m | done_m)) drop_step();
+        add_m = __builtin_amdgcn_ballot_w64(step_lengths());
+      }
+      const unsigned long long adders_m = add_m & ~done_m & ~gen_m;
+      if (adders_m != 0ull) {
+        bool fin_add = false;
+        if (in(adders_m | done_m)) fin_add = add_step();
+        fin = fin || (fin_add && in(adders_m));
       }
       note_finished(fin);
       if (~done_m == 0ull) break;

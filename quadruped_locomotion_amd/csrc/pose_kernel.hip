@@ -193,23 +193,6 @@ __device__ __forceinline__ void load_sfo(const PosePtrs &s, const double *__rest
     for (int a = 0; a < 3; a++) sfo[l][a] = src[12 * i + 3 * l + a];
 }
 
-// PoseOptimizationGeometric and the whole BaseAuto::optimizePose sequence in the row layout
-__device__ __forceinline__ void load_row_problem(const PoseParamsDev &P, const PosePtrs &s, const double *sfo_in,
-                                                 const double *min_len, int64_t i, PoseProblem &pb, double (&io)[24]) {
-  // one lane per problem fetches the record; pose (7), stance for orientation (12) and minimal lengths (4) go through io
-  double ps[7], sfo[4][3];
-  load_pose_problem(P, s, i, pb, ps);
-  load_sfo(s, sfo_in, i, sfo);
-#pragma unroll
-  for (int a = 0; a < 7; a++) io[a] = ps[a];
-#pragma unroll
-  for (int l = 0; l < 4; l++)
-#pragma unroll
-    for (int a = 0; a < 3; a++) io[7 + 3 * l + a] = sfo[l][a];
-#pragma unroll
-  for (int k = 0; k < 4; k++) io[19 + k] = min_len ? min_len[4 * i + P.leg_order[k]] : 0.0;
-}
-
 // PoseOptimizationGeometric on its own: one problem per lane (pose_core.hpp's serial form: Kabsch matrix, cyclic Jacobi,
 // heading and roll / pitch).  No QP is involved and nothing is shared between the lanes of a row, so the row layout has
 // nothing to offer here: the 16-lane form of the same arithmetic (coop::pose_geometric_coop, the first stage of
@@ -241,8 +224,23 @@ __global__ __launch_bounds__(64) void base_auto_coop_kernel(const PoseParamsDev 
   int64_t i = (int64_t)blockIdx.x * coop::kPoseCoopRows + row;
   const bool live = i < B;
   if (!live) i = B - 1;
-  if (lr == 0) load_row_problem(P, s, sfo_in, min_len, i, pbs[row], io[row]);
-  __syncthreads();
+  {
+    // the record by the 16 lanes of the row (load_pose_problem_row), the stance for orientation (lanes 0..11, limb order)
+    // and the minimal lengths (lanes 0..3, iteration order) beside it: io = pose (7) | sfo (12) | min_len (4)
+    const double *src = sfo_in ? sfo_in : s.stance; // default: the stance itself (all four limbs needed, :76-77)
+    const double sf = src[12 * i + (lr < 12 ? lr : 0)];
+    int lo[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) { lo[kk] = P.leg_order[kk]; asm volatile("" : "+s"(lo[kk])); }
+    const int k4 = lr & 3;
+    const int l4 = k4 == 0 ? lo[0] : k4 == 1 ? lo[1] : k4 == 2 ? lo[2] : lo[3];
+    const double mnl = (min_len ? min_len : s.maxlen)[4 * i + l4];
+    load_pose_problem_row(P, s, i, pbs[row], io[row]);
+    if (lr < 12) io[row][7 + lr] = sf;
+    if (lr < 4) io[row][19 + lr] = min_len ? mnl : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
   double pose[7], sfo[4][3], mn[4];
 #pragma unroll
   for (int l = 0; l < 4; l++)
