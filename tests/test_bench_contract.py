@@ -1,5 +1,5 @@
 """The one-line JSON contract of bench.py: every key the driver reads, with the types and relations it relies on.
-CPU: the committed line of the last measured run (profiles/r3/bench_static_b4096.json).  GPU: short live runs."""
+CPU: the committed line of the last measured run (profiles/r4/bench_static_b4096.json).  GPU: short live runs."""
 import json
 import os
 import subprocess
@@ -38,7 +38,7 @@ def check(line, want_cpu=True):
 
 
 def test_committed_bench_line_follows_the_contract():
-    path = os.path.join(ROOT, "profiles", "r3", "bench_static_b4096.json")
+    path = os.path.join(ROOT, "profiles", "r4", "bench_static_b4096.json")
     d = check(open(path).read().strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["config"]["robots_per_gpu"] == 4096 and d["config"]["all_status_ok"] is True
     # round 2: the input is disclosed, the timed region is a median of samples, PMC numbers carry their source
@@ -153,7 +153,7 @@ def test_profile_collection_names_exist_in_the_sources():
     kernels = set(re.findall(r"__global__[^;{]*?\bvoid\s+(\w+)\s*\(", text))
     for name, kernel, batch, args in cp.WORKLOADS:
         assert kernel in kernels, kernel
-    idx = json.load(open(os.path.join(ROOT, "profiles", "r3", "pmc_index.json")))
+    idx = json.load(open(os.path.join(ROOT, "profiles", "r4", "pmc_index.json")))
     have = {(r["kernel"], r["batch"], r["workload"]) for r in idx["records"]}
     assert have == {(k, b, n) for n, k, b, _ in cp.WORKLOADS}
     assert all("fetch_bytes" in r and "write_bytes" in r and "valu_insts" in r for r in idx["records"])

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Everything a round commits under profiles/rN, in one GPU-box call:
-#   bash tools/collect_round.sh r3        -> gpurun_out/r3_final/ (copy the summaries into profiles/r3/ afterwards)
+#   bash tools/collect_round.sh r4        -> gpurun_out/r4_final/ (copy the summaries into profiles/r4/ afterwards)
 # 1. rocprofv3 kernel statistics and PMC passes (tools/collect_profiles.py) -> pmc_index.json, kernel_stats_*.csv
 # 2. the bench lines of every workload (the PMC index is put where bench.py looks for it first)
 # 3. kernel durations of the auxiliary entries, the single-wavefront latency probe, host-buffer latencies
 set -u
-R=${1:-r3}
+R=${1:-r4}
 OUT=gpurun_out/${R}_final
 mkdir -p $OUT profiles/$R
 python3 tools/collect_profiles.py $OUT > $OUT/collect_profiles.log 2>&1
@@ -39,4 +39,26 @@ python3 tools/latency_b1.py 2>&1 | grep -v amdgpu > $OUT/host_buffer_latency.txt
 python3 tools/write_bw.py 2>&1 | grep -v amdgpu > $OUT/write_bandwidth.txt
 ./tools/ubench/issue_model > $OUT/issue_model.txt 2>&1
 ./tools/ubench/rcp_accuracy > $OUT/rcp_accuracy.txt 2>&1
+# round 4: issue rate against the rows enabled in EXEC, the row-mix / batch-mix / per-wavefront probes of the balance
+# kernel, the segment stamps of the pose kernel (diagnostic build), the C++ multi-GPU host with one rank
+./tools/ubench/exec_mask_model > $OUT/exec_mask_model.txt 2>&1
+python3 tools/experiments/row_mix_probe.py 2>&1 | grep -v amdgpu > $OUT/row_mix_probe.txt
+python3 tools/experiments/batch_mix_probe.py 2>&1 | grep -v amdgpu > $OUT/batch_mix_probe.txt
+python3 tools/experiments/wave_scan.py 2>&1 | grep -v amdgpu > $OUT/wave_scan.txt
+python3 tools/experiments/variant_bench.py 2>&1 | grep -v amdgpu > $OUT/variant_bench.txt
+[ -f scratch_bin/libqlamd_stamps.so ] && python3 tools/stamp_probe_pose.py 2>&1 | grep -v amdgpu > $OUT/pose_sqp_segments.txt
+python3 - > $OUT/multi_gpu_cpp_one_rank.txt 2>&1 <<'PY'
+import os, subprocess, sys, tempfile
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import test_multi_gpu_cpp as T
+from quadruped_locomotion_amd import synth
+T.build_demo()
+d = tempfile.mkdtemp()
+for B in (8192, 65536):
+    st = os.path.join(d, "s%d.bin" % B)
+    T.write_states(st, synth.make_states(B, "trot"))
+    for every in (1, 8):
+        p = T.run("--states", st, "--robots", str(B), "--ranks", "1", "--rank", "0", "--steps", "200", "--gather-every", str(every))
+        print(p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr.strip())
+PY
 ls $OUT
