@@ -38,6 +38,9 @@ constexpr int kPoseCoopLdsDoubles = 8 * 6 + 6 + 6 * 6; // per problem: normals b
 // x_out = component lr of the minimiser on variable lanes.
 // n: number of real variables (6 for the SQP step; 3 for the position-only QP, whose rows 3..5 of G are identity
 // padding -- those variables stay 0 and do not enter the traces behind the termination tolerance).
+// kDiagTop: the leading 3x3 block of G is diagonal (the position block of the pose Hessian, 2 (nl I + w diag(1, 1, 0)), and
+// the position-only QP, whose G is diagonal altogether): its three pivots are known without elimination.
+template <bool kDiagTop = false>
 __device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const double (&a)[6], double bci0, bool cvalid,
                                         int m, bool dummy_eq, bool skip, double *lds_row, double &x_out, int n = 6) {
   const int lr = threadIdx.x & 15;
@@ -66,9 +69,32 @@ __device__ __forceinline__ int qp6_coop(const double (&Gm)[6], double g0, const 
   double my_pivot = 1.0;
   // as in force_qp_coop.hpp: the column of the NEXT pivot is updated first, so that its reciprocal (seed + one Newton
   // step: the refinement and the next SQP iteration work on G itself) is under way while the other columns are updated
-  double d = bc<0>(H[0]);
-  static_for<6>([&](auto K) {
-    constexpr int k = K;
+  constexpr int kFirst = kDiagTop ? 3 : 0;
+  if constexpr (kDiagTop) {
+    // rows 0..2 do not meet in the first three columns, so their pivots are the diagonal entries as they stand, the three
+    // reciprocals run side by side, and the three eliminations touch columns 3..5 (and their own column) only: nine
+    // broadcast-FMAs in any order instead of three rounds of the serial chain pivot -> reciprocal -> factor -> update
+    double nfk[3], pk[3];
+    static_for<3>([&](auto K) {
+      constexpr int k = K;
+      const double dk = bc<k>(H[k]);
+      bad = bad || !(dk > 0.0);
+      pk[k] = rcp_nr1(dk);
+      const bool piv = lr == k;
+      my_pivot = piv ? dk : my_pivot;
+      nfk[k] = -(piv ? (1.0 - pk[k]) : H[k] * pk[k]);
+    });
+    static_for<3>([&](auto K) {
+      constexpr int k = K;
+      fmac_bc<k, k == 0>(H[3], H[3], nfk[k]);
+      fmac_bc<k>(H[4], H[4], nfk[k]);
+      fmac_bc<k>(H[5], H[5], nfk[k]);
+    });
+    static_for<3>([&](auto K) { constexpr int k = K; H[k] = lr == k ? pk[k] : nfk[k]; });
+  }
+  double d = bc<kFirst>(H[kFirst]);
+  static_for<6 - kFirst>([&](auto K) {
+    constexpr int k = kFirst + decltype(K)::value;
     bad = bad || !(d > 0.0);
     const double p = rcp_nr1(d);
     const bool piv = lr == k;
@@ -436,8 +462,13 @@ __device__ __forceinline__ int pose_sqp_coop(const PoseParamsDev &P, const PoseP
   }
   const double w = P.com_weight;
   const double n0 = 2.0 * ((double)nl + w), n2 = 2.0 * (double)nl;
-  const int c3 = lr < 3 ? lr : (lr < 6 ? lr - 3 : 3); // my row inside its 3x3 block; 3: no row
-  const bool top = lr < 3;
+  double ut[3], ub[3], Gd[3]; // unit vector of my position row / rotation row (zero when I carry none); my part of the diagonal
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    ut[j] = lr == j ? 1.0 : 0.0;
+    ub[j] = lr == 3 + j ? 1.0 : 0.0;
+    Gd[j] = lr == j ? (j < 2 ? n0 : n2) : 0.0;
+  }
 
   int k = 0, status = kStatusOk;
   bool sqp_done = !live;
@@ -490,25 +521,18 @@ __device__ __forceinline__ int pose_sqp_coop(const PoseParamsDev &P, const PoseP
     B2[4] = 2.0 * sB[4] + w * (Pr[1] * ec[2] + ec[1] * Pr[2]);
     B2[5] = 2.0 * (sB[5] - sdot + w * (Pr[2] * ec[2] - cdot));
     QL_STAMP(21);
-    // my row of G: rows 0..2 = [diag(n0, n0, n2) | -S_c], rows 3..5 = [S_c | (2B)_c] with S_c row c3 of skew(2 q3);
-    // picked with the row index inside its block, not by a pass over the 36 elements
-    double Gm[6], g0 = 0.0;
+    // my row of G: rows 0..2 = [diag(n0, n0, n2) | -S_c], rows 3..5 = [S_c | (2B)_c] with S_c = e_c x 2q the row c of
+    // skew(2 q3) -- written with the lane's unit vectors (ut for a position row, ub for a rotation row, zero otherwise:
+    // loop constants), so that the row is 27 multiply-adds instead of a pass of selects over the blocks
+    double Gm[6], g0;
     {
-      const double nqx = -qx, nqy = -qy, nqz = -qz;
-      const double S0 = sel(c3 == 1, qz, sel(c3 == 2, nqy, 0.0));
-      const double S1 = sel(c3 == 0, nqz, sel(c3 == 2, qx, 0.0));
-      const double S2 = sel(c3 == 0, qy, sel(c3 == 1, nqx, 0.0));
-      const double Br0 = sel(c3 == 0, B2[0], sel(c3 == 1, B2[1], sel(c3 == 2, B2[2], 0.0)));
-      const double Br1 = sel(c3 == 0, B2[1], sel(c3 == 1, B2[3], sel(c3 == 2, B2[4], 0.0)));
-      const double Br2 = sel(c3 == 0, B2[2], sel(c3 == 1, B2[4], sel(c3 == 2, B2[5], 0.0)));
-      Gm[0] = sel(top, sel(c3 == 0, n0, 0.0), S0);
-      Gm[1] = sel(top, sel(c3 == 1, n0, 0.0), S1);
-      Gm[2] = sel(top, sel(c3 == 2, n2, 0.0), S2);
-      Gm[3] = sel(top, -S0, Br0);
-      Gm[4] = sel(top, -S1, Br1);
-      Gm[5] = sel(top, -S2, Br2);
-#pragma unroll
-      for (int i = 0; i < 6; i++) g0 = sel(lr == i, 2.0 * g[i], g0);
+      Gm[0] = Gd[0] + (ub[1] * qz - ub[2] * qy);
+      Gm[1] = Gd[1] + (ub[2] * qx - ub[0] * qz);
+      Gm[2] = Gd[2] + (ub[0] * qy - ub[1] * qx);
+      Gm[3] = (qy * ut[2] - qz * ut[1]) + (ub[0] * B2[0] + ub[1] * B2[1] + ub[2] * B2[2]);
+      Gm[4] = (qz * ut[0] - qx * ut[2]) + (ub[0] * B2[1] + ub[1] * B2[3] + ub[2] * B2[4]);
+      Gm[5] = (qx * ut[1] - qy * ut[0]) + (ub[0] * B2[2] + ub[1] * B2[4] + ub[2] * B2[5]);
+      g0 = 2.0 * ((ut[0] * g[0] + ut[1] * g[1] + ut[2] * g[2]) + (ub[0] * g[3] + ub[1] * g[4] + ub[2] * g[5]));
     }
     // ---- constraints: my row of CI = -A', ci0 = max - value (PoseOptimizationFunctionConstraints.cpp:95-194)
     double a[6] = {0, 0, 0, 0, 0, 0}, bci0 = 0.0;
@@ -537,16 +561,13 @@ __device__ __forceinline__ int pose_sqp_coop(const PoseParamsDev &P, const PoseP
 #pragma unroll
       for (int i = 0; i < 6; i++) a[i] = sel(hs, hs_a[i], ll_a[i]);
       bci0 = sel(hs, hs_b, lmax - len);
-      if (!cvalid) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) a[i] = 0.0;
-        bci0 = 0.0;
-      }
+      // (a lane without a valid constraint keeps whatever this computes: its key is masked by cvalid in the QP, its
+      // normal is never selected, its slack never summed)
     }
     QL_STAMP(22);
     // ---- QP and the update
     double x;
-    const int st = qp6_coop(Gm, g0, a, bci0, cvalid, m, P.dummy_equality != 0, sqp_done, lds_row, x);
+    const int st = qp6_coop<true>(Gm, g0, a, bci0, cvalid, m, P.dummy_equality != 0, sqp_done, lds_row, x);
     QL_STAMP(27);
     double dp[6];
     static_for<6>([&](auto I) { constexpr int i = I; dp[i] = bc<i>(x); });
@@ -607,7 +628,7 @@ __device__ __forceinline__ int pose_qp_coop(const PoseParamsDev &P, const PosePr
     bci0 = sel(me, gb[j] - (GA[j][0] * Rr[0] + GA[j][1] * Rr[1]), bci0);
   }
   double x;
-  const int st = qp6_coop(Gm, g0, a, bci0, cvalid, m, P.dummy_equality != 0, !live, lds_row, x, 3);
+  const int st = qp6_coop<true>(Gm, g0, a, bci0, cvalid, m, P.dummy_equality != 0, !live, lds_row, x, 3);
   const double x0 = bc<0>(x), x1 = bc<1>(x), x2 = bc<2>(x);
   if (st == kStatusOk) { pose[0] = x0; pose[1] = x1; pose[2] = x2; }
   return st;
