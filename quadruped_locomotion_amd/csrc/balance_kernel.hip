@@ -139,9 +139,15 @@ __global__ __launch_bounds__(64) void balance_step_kernel(const DeviceParams *__
 // shared) costs 2.3 us at 4096 robots and 20 % at 65536 -- the barrier behind the table ties the start of four
 // wavefronts together and workgroups leave their compute unit only when their slowest wavefront has finished.
 constexpr int kCoopWaves = 1;
-// (at least two wavefronts per SIMD, i.e. at most 256 registers: the large-batch throughput halves without it)
-template <bool kPerLeg>
-__global__ __launch_bounds__(64 * kCoopWaves, 2) void balance_coop_kernel(const DeviceParams *__restrict__ Pp, const StatePtrs s,
+#ifndef QLAMD_THROUGHPUT_BATCH
+#define QLAMD_THROUGHPUT_BATCH 16384 // robots from which the three-wavefront form of the balance kernel runs
+#endif
+// kMinWaves wavefronts per SIMD at least: 2 (at most 256 registers: the large-batch throughput halves without it) for the
+// latency form, 3 (at most 168 registers; 12 wavefronts x 13 056 bytes of LDS fit a compute unit) for the throughput form
+// that large batches take (QLAMD_THROUGHPUT_BATCH): two wavefronts of dependent instruction streams cannot fill a SIMD's
+// issue port (2 x one instruction per 5.5 cycles against one per 4), three can.
+template <bool kPerLeg, int kMinWaves>
+__global__ __launch_bounds__(64 * kCoopWaves, kMinWaves) void balance_coop_kernel(const DeviceParams *__restrict__ Pp, const StatePtrs s,
                                                                       int64_t B, double *__restrict__ tau,
                                                                       double *__restrict__ grf, int32_t *__restrict__ status) {
   __shared__ double tab[4 * kTabPerLeg];
@@ -470,10 +476,13 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
     case 4: {
       const unsigned grid = (unsigned)((batch + 4 * kCoopWaves - 1) / (4 * kCoopWaves));
       if (s.normals)
-        hipLaunchKernelGGL(balance_coop_kernel<true>, dim3(grid), dim3(64 * kCoopWaves), 0, st, ctx->d_params, s, batch,
+        hipLaunchKernelGGL((balance_coop_kernel<true, 2>), dim3(grid), dim3(64 * kCoopWaves), 0, st, ctx->d_params, s, batch,
+                           d_tau, d_grf, d_status);
+      else if (batch >= QLAMD_THROUGHPUT_BATCH)
+        hipLaunchKernelGGL((balance_coop_kernel<false, 3>), dim3(grid), dim3(64 * kCoopWaves), 0, st, ctx->d_params, s, batch,
                            d_tau, d_grf, d_status);
       else
-        hipLaunchKernelGGL(balance_coop_kernel<false>, dim3(grid), dim3(64 * kCoopWaves), 0, st, ctx->d_params, s, batch,
+        hipLaunchKernelGGL((balance_coop_kernel<false, 2>), dim3(grid), dim3(64 * kCoopWaves), 0, st, ctx->d_params, s, batch,
                            d_tau, d_grf, d_status);
       e = hipGetLastError();
       break;

@@ -18,8 +18,12 @@
 namespace qlamd {
 namespace coop {
 
-// LDS of one robot: N* export for the refinement, row export for drops (slots 144..155)
-constexpr int kCoopLdsDoubles = 12 * 12 + 12 + 2; // ... and a zero (slot 156) for lanes that have no component to read
+// LDS of one robot: 144 doubles.  After the loop: the N* export of the refinement.  During the loop: what a finished row
+// latches (slots 0..47), the row a drop exports (kDropSlot..+11) and a zero for lanes that have no component of it to read.
+// (144 and not more: with the model table and the normals table a wavefront then needs 13 056 bytes of LDS, and twelve
+// wavefronts -- three per SIMD -- fit a compute unit's 160 KB.)
+constexpr int kCoopLdsDoubles = 12 * 12;
+constexpr int kDropSlot = 48, kZeroSlot = 60;
 // rows of the wavefront's table of constraint normals ([row kind][lane]) the QP uses: 5, and 3 more with kTorque
 constexpr int kForceQpNrmRows = 5, kForceQpNrmRowsTorque = 8;
 struct ForceQp {
@@ -218,7 +222,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     const double nrm[5] = {myn, mu * myn + myt1, mu * myn - myt1, mu * myn + myt2, mu * myn - myt2};
 #pragma unroll
     for (int k = 0; k < 5; k++) lds_nrm[64 * k + ((int)threadIdx.x & 63)] = nrm[k];
-    lds_row[156] = 0.0;
+    lds_row[kZeroSlot] = 0.0;
     if constexpr (kTorque) {
 #pragma unroll
       for (int k = 0; k < 3; k++) lds_nrm[64 * (5 + k) + ((int)threadIdx.x & 63)] = Q.jrow[k];
@@ -235,7 +239,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
   //     rows, independent ones 5.5 -> 6.7 with one; tools/experiments/row_mix_probe.py on this kernel), and the slowest
   //     robot of a small batch spends most of its passes as the only live row of its wavefront;
   // (2) every branch of the loop compares scalar masks: no execution-mask bookkeeping per pass.
-  const int nt_slot = comp ? 144 + myidx : 156; // where a drop reads its component of n~ (a zero on spare lanes)
+  const int nt_slot = comp ? kDropSlot + myidx : kZeroSlot; // where a drop reads its component of n~ (a zero on spare lanes)
   double zb = 0.0;                              // 1/16 on ghost rows
   double s_up = 0.0, s_lo = 0.0; // kTorque: slacks of my joint's torque bounds, set by slacks()
   const auto slacks = [&](double xx, double &s_min, double &s_fric) {
@@ -383,7 +387,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
   const auto drop_vectors = [&](int lpos) {
     if (lr == lpos) {
 #pragma unroll
-      for (int j = 0; j < 12; j++) lds_row[144 + j] = Ns[j];
+      for (int j = 0; j < 12; j++) lds_row[kDropSlot + j] = Ns[j];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)

@@ -52,9 +52,11 @@ def test_no_dpp_hazard_in_the_library(tu, tmp_path):
     assert total > 100 or tu != "balance_kernel.hip"
     assert not problems, problems[:5]
     if tu == "balance_kernel.hip":
-        # the hot kernel: two wavefronts per SIMD (at most 256 registers), nothing spilled to scratch memory
+        # the hot kernel: two wavefronts per SIMD for the latency form (at most 256 registers), three for the throughput form
+        # that large batches take (at most 168), nothing spilled to scratch memory
         md = kernel_isa.meta(path)
         hot = {k: v for k, v in md.items() if "balance_coop_kernel" in k}
-        assert len(hot) == 2
+        assert len(hot) == 3
         for name, m in hot.items():
-            assert m["vgpr"] + m.get("agpr", 0) <= 256 and m.get("scratch", 0) == 0, (name, m)
+            cap = 168 if "ELi3EE" in name else 256
+            assert m["vgpr"] + m.get("agpr", 0) <= cap and m.get("scratch", 0) == 0, (name, m)
