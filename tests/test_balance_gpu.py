@@ -393,3 +393,23 @@ def test_calls_on_alternating_streams_stay_ordered(oracle):
     for k in range(3, 6):
         assert (outs[k][2].cpu().numpy() == 0).all()
     ctx.close()
+
+
+def test_throughput_form_equals_latency_form_bit_for_bit(gpu, oracle):
+    """From 16 384 robots the balance kernel runs in its three-wavefronts-per-SIMD instantiation (168 registers); smaller
+    batches take the 256-register one.  Same source, same arithmetic: the same robots solved as one batch of 32 768 and
+    as eight batches of 4096 must agree bit for bit (and with the oracle on a sample)."""
+    capi, ctx, torch = gpu
+    B = 32768
+    s = synth.make_states(B, "trot")
+    tau, grf, status = solve_device(gpu, s)
+    parts_tau, parts_grf, parts_st = [], [], []
+    for k in range(8):
+        sl = {key: np.ascontiguousarray(v[4096 * k:4096 * (k + 1)]) for key, v in s.items()}
+        t, g, st = solve_device(gpu, sl)
+        parts_tau.append(t); parts_grf.append(g); parts_st.append(st)
+    assert np.array_equal(status, np.concatenate(parts_st)) and (status == 0).all()
+    assert np.array_equal(tau, np.concatenate(parts_tau)) and np.array_equal(grf, np.concatenate(parts_grf))
+    idx = np.arange(0, B, 97)
+    t0, _, s0 = oracle.balance_batch({k: np.ascontiguousarray(v[idx]) for k, v in s.items()}, nthreads=8)
+    assert (s0 == 0).all() and np.abs(tau[idx] - t0).max() < TAU_TOL
