@@ -71,6 +71,99 @@ def pmc_record(kernel, batch, workload):
     return None, "%s: no record for %s / %d / %s" % (rel, kernel, batch, workload)
 
 
+class PeerBuffers:
+    """Result collection without a collective: a [2][world][G][B][12] buffer per rank, allocated with hipMalloc (an IPC
+    handle needs the base of an allocation, which a tensor of torch's caching allocator is not), its IPC handle
+    exchanged once, every peer's buffer mapped; a step's collection is `world` device-to-device copies of this rank's
+    shard into slot `rank` of every rank's buffer, on the collection stream.  """
+
+    def __init__(self, group_doubles, rank, world, dev, dist, torch):
+        import ctypes as C
+        self.rank, self.world, self.dev, self.dist, self.torch = rank, world, dev, dist, torch
+        self.C = C
+        self.hip = C.CDLL("libamdhip64.so")
+
+        class Handle(C.Structure):
+            _fields_ = [("reserved", C.c_char * 64)]
+        self.Handle = Handle
+        self.hip.hipIpcOpenMemHandle.argtypes = [C.POINTER(C.c_void_p), Handle, C.c_uint]
+        self.hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.hip.hipFree.argtypes = [C.c_void_p]
+        self.hip.hipIpcGetMemHandle.argtypes = [C.POINTER(Handle), C.c_void_p]
+        self.hip.hipIpcCloseMemHandle.argtypes = [C.c_void_p]
+        self.group_bytes = group_doubles * 8               # one rank's shard of one group of steps
+        self.buf_bytes = self.group_bytes * self.world          # one of the two buffers
+        # Every step that can fail on one rank only is followed by a consensus: a rank that raised while the others
+        # went on into the next collective would hang the whole job.
+        self.own = C.c_void_p()
+        self.peers = [None] * self.world
+        self.failed = False
+        h, ok = Handle(), True
+        ok = ok and self.hip.hipMalloc(C.byref(self.own), 2 * self.buf_bytes) == 0
+        self.peers[self.rank] = self.own.value
+        if self.world > 1:
+            ok = ok and self.hip.hipIpcGetMemHandle(C.byref(h), self.own) == 0
+            handles = [None] * self.world
+            self.dist.all_gather_object(handles, (bool(ok), bytes(h)))  # the 64 raw bytes (a c_char field reads as a C string)
+            ok = all(flag for flag, _ in handles)
+            if ok:
+                for r in range(self.world):
+                    if r == self.rank:
+                        continue
+                    hr = Handle()
+                    C.memmove(C.byref(hr), handles[r][1], 64)
+                    ptr = C.c_void_p()
+                    if self.hip.hipIpcOpenMemHandle(C.byref(ptr), hr, 1) != 0:  # 1 = lazy peer access
+                        ok = False
+                        break
+                    self.peers[r] = ptr.value
+            agreed = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=self.dev)
+            self.dist.all_reduce(agreed, op=self.dist.ReduceOp.MIN)
+            ok = bool(agreed.item())
+        if not ok:
+            self.close(barrier=False)
+            raise RuntimeError("peer buffers: allocation or IPC mapping failed on some rank")
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed with HIP error %d" % (what, rc))
+
+    def scatter(self, buf, src_ptr, stream_handle):
+        """this rank's shard of buffer `buf` into slot `rank` of every rank's buffer (a failed copy is remembered, not
+        raised: the ranks agree on it at the next consensus point, run_preset)"""
+        for r in range(self.world):
+            dst = self.peers[r] + buf * self.buf_bytes + self.rank * self.group_bytes
+            if self.hip.hipMemcpyAsync(dst, src_ptr, self.group_bytes, 3, stream_handle) != 0:
+                self.failed = True
+
+    def agree_no_failure(self):
+        flag = self.torch.tensor([1 if self.failed else 0], dtype=self.torch.int32, device=self.dev)
+        if self.world > 1:
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+        if int(flag.item()):
+            raise RuntimeError("peer buffers: a device-to-device copy failed on some rank")
+
+    def slot_equals(self, buf, slot, tensor):
+        import numpy as np
+        host = np.empty(self.group_bytes // 8)
+        self.check(self.hip.hipMemcpy(host.ctypes.data, self.own.value + buf * self.buf_bytes + slot * self.group_bytes,
+                                      self.group_bytes, 2), "hipMemcpy")
+        return bool(np.array_equal(host, tensor.detach().cpu().numpy().ravel()))
+
+    def close(self, barrier=True):
+        for r in range(self.world):
+            if r != self.rank and self.peers[r]:
+                self.hip.hipIpcCloseMemHandle(self.peers[r])
+                self.peers[r] = None
+        if self.world > 1 and barrier:
+            self.dist.barrier()  # nobody frees a buffer a peer still has mapped and in use
+        if self.own:
+            self.hip.hipFree(self.own)
+            self.own = None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -539,72 +632,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    class PeerBuffers:
-        """Result collection without a collective: a [2][world][G][B][12] buffer per rank, allocated with hipMalloc (an IPC
-        handle needs the base of an allocation, which a tensor of torch's caching allocator is not), its IPC handle
-        exchanged once, every peer's buffer mapped; a step's collection is `world` device-to-device copies of this rank's
-        shard into slot `rank` of every rank's buffer, on the collection stream.  """
-
-        def __init__(self, group_doubles):
-            import ctypes as C
-            self.C = C
-            self.hip = C.CDLL("libamdhip64.so")
-
-            class Handle(C.Structure):
-                _fields_ = [("reserved", C.c_char * 64)]
-            self.Handle = Handle
-            self.hip.hipIpcOpenMemHandle.argtypes = [C.POINTER(C.c_void_p), Handle, C.c_uint]
-            self.hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-            self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-            self.hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-            self.hip.hipFree.argtypes = [C.c_void_p]
-            self.hip.hipIpcGetMemHandle.argtypes = [C.POINTER(Handle), C.c_void_p]
-            self.hip.hipIpcCloseMemHandle.argtypes = [C.c_void_p]
-            self.group_bytes = group_doubles * 8               # one rank's shard of one group of steps
-            self.buf_bytes = self.group_bytes * world          # one of the two buffers
-            self.own = C.c_void_p()
-            self.check(self.hip.hipMalloc(C.byref(self.own), 2 * self.buf_bytes), "hipMalloc")
-            self.peers = [None] * world
-            self.peers[rank] = self.own.value
-            if world > 1:
-                h = Handle()
-                self.check(self.hip.hipIpcGetMemHandle(C.byref(h), self.own), "hipIpcGetMemHandle")
-                handles = [None] * world
-                dist.all_gather_object(handles, bytes(h.reserved))
-                for r in range(world):
-                    if r == rank:
-                        continue
-                    hr = Handle()
-                    C.memmove(C.byref(hr), handles[r], 64)
-                    ptr = C.c_void_p()
-                    self.check(self.hip.hipIpcOpenMemHandle(C.byref(ptr), hr, 1), "hipIpcOpenMemHandle")  # lazy peer access
-                    self.peers[r] = ptr.value
-                dist.barrier()
-
-        def check(self, rc, what):
-            if rc != 0:
-                raise RuntimeError("%s failed with HIP error %d" % (what, rc))
-
-        def scatter(self, buf, src_ptr, stream_handle):
-            """this rank's shard of buffer `buf` into slot `rank` of every rank's buffer"""
-            for r in range(world):
-                dst = self.peers[r] + buf * self.buf_bytes + rank * self.group_bytes
-                self.check(self.hip.hipMemcpyAsync(dst, src_ptr, self.group_bytes, 3, stream_handle), "hipMemcpyAsync")
-
-        def slot_equals(self, buf, slot, tensor):
-            host = np.empty(self.group_bytes // 8)
-            self.check(self.hip.hipMemcpy(host.ctypes.data, self.own.value + buf * self.buf_bytes + slot * self.group_bytes,
-                                          self.group_bytes, 2), "hipMemcpy")
-            return bool(np.array_equal(host, tensor.detach().cpu().numpy().ravel()))
-
-        def close(self):
-            for r in range(world):
-                if r != rank and self.peers[r]:
-                    self.hip.hipIpcCloseMemHandle(self.peers[r])
-            if world > 1:
-                dist.barrier()
-            self.hip.hipFree(self.own)
-
     def run_preset(gait, errors, with_gather, replays, second_without_gather, collect="rccl", every=1):
         """One workload preset on this rank's shard: warm-up, K steps captured as one hipGraph, `replays` timed samples.
         every: steps per collection; collect: "rccl" (all-gather) or "peer" (copies into the peers' buffers)."""
@@ -614,7 +641,7 @@ def main():
         G = max(1, every)
         tau = [torch.zeros(G, B, 12, dtype=torch.float64, device=dev) for _ in range(2)]
         status = torch.full((B,), -1, dtype=torch.int32, device=dev)
-        peer = PeerBuffers(G * B * 12) if (with_gather and collect == "peer") else None
+        peer = PeerBuffers(G * B * 12, rank, world, dev, dist, torch) if (with_gather and collect == "peer") else None
         gathered = ([torch.zeros(world, G, B, 12, dtype=torch.float64, device=dev) for _ in range(2)]
                     if (with_gather and peer is None) else None)
 
@@ -644,6 +671,8 @@ def main():
             if w is not None:
                 w.wait()
         fence()
+        if peer is not None:
+            peer.agree_no_failure()
 
         # ---- K steps as one hipGraph ------------------------------------------------------------
         # The K steps (solve, plus the all-gather of the torques when there are several ranks) are captured once into a
@@ -760,6 +789,8 @@ def main():
                         graph=graph is not None, overlap=overlap)
 
         res = measure(with_gather)
+        if peer is not None:
+            peer.agree_no_failure()
         res["plain"] = measure(False) if (with_gather and second_without_gather) else None
         if collective and args.steps > 0 and with_gather:
             # the collected buffer holds every rank's torques in rank order (every rank checks its own slot)
