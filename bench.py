@@ -178,6 +178,10 @@ def parse():
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--replays", type=int, default=11,
                     help="timed samples of exactly K steps each (barrier + synchronize on both sides); the median is reported")
+    ap.add_argument("--settle-ms", type=float, default=150.0,
+                    help="untimed replays of the captured steps for this long before the timed samples: the shader clock of a GPU "
+                         "that has just been idle keeps rising for the first ~10 ms of work (samples of K = 20 steps fell from "
+                         "0.520 to 0.500 ms over the eleven samples of one run without it)")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU-only check of the multi-rank launcher, sharding and gather layout over gloo: no solve, no measurement")
     ap.add_argument("--wholebody-form", default="auto", choices=["auto", "leg", "row"],
@@ -737,6 +741,20 @@ def main():
                 if graph is not None:
                     graph.replay()  # one untimed replay (instantiation / upload)
                     fence()
+                    # ... and untimed replays until the clocks have settled (every rank the same number: no host clock involved
+                    # in the count once it is agreed on)
+                    t_one = time.perf_counter()
+                    graph.replay()
+                    fence()
+                    t_one = max(time.perf_counter() - t_one, 1e-5)
+                    n_settle = int(min(2000, max(0.0, args.settle_ms * 1e-3) / t_one))
+                    if collective:
+                        nt = torch.tensor([n_settle], dtype=torch.int32, device=dev)
+                        dist.all_reduce(nt, op=dist.ReduceOp.MAX)
+                        n_settle = int(nt.item())
+                    for _ in range(n_settle):
+                        graph.replay()
+                    fence()
             return graph, overlap
 
         def sample(graph, wg):
@@ -888,6 +906,7 @@ def main():
                        "gather_layout_ok": res.get("gather_layout_ok"),
                        "collect": args.collect if gather else None, "gather_every": args.gather_every if gather else None,
                        "timed_region": "median of %d samples of exactly K steps, each between barrier + synchronize" % len(res["samples_ms"]),
+                       "settle_ms": args.settle_ms,
                        "samples_ms": res["samples_ms"],
                        "all_status_ok": res["ok"]},
             "roofline": roof,
