@@ -28,7 +28,8 @@ namespace coop {
 constexpr int kQpCoopRows = 4;
 template <int N, int KC = 2>
 struct QpCoopLds {
-  enum { kRows = KC == 2 ? 24 : 16 * KC, kCt = 0, kNrow = kRows * N, kNst = kRows * N + N, kTotal = kRows * N + N + N * N };
+  enum { kRows = KC == 2 ? 24 : 16 * KC, kCt = 0, kNrow = kRows * N, kNst = kRows * N + N, kLatch = kRows * N + N + N * N,
+         kZero = kLatch + 48, kTotal = kLatch + 50 }; // kLatch: what a finished row keeps for the epilogue (ghost rows, force_qp_coop.hpp); kZero: a zero
 };
 
 // Gm: row lr of G (identity row for a variable that is not free, zero for lr >= N); g0: component lr; ne: component
@@ -49,7 +50,7 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
   const bool var = lr < n;
   const double eps = 2.220446049250313e-16;
   const double inf = INFINITY;
-  double *ct = lds_row + L::kCt, *nrow = lds_row + L::kNrow, *nst = lds_row + L::kNst;
+  double *ct = lds_row + L::kCt, *nrow = lds_row + L::kNrow, *nst = lds_row + L::kNst, *latched = lds_row + L::kLatch;
 
   // normals by constraint into LDS: variable lane i reads a_p[i] = ct[N p + i]
 #pragma unroll
@@ -177,11 +178,20 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
   int q = 0, iters = 0, status = kStatusOk;
   const double psi_tol = (double)(m_tol >= 0 ? m_tol : m) * eps * c1 * c2 * 100.0; // m_tol: rows that exist, when m counts slots
   double rnorm2 = 1.0;
-  bool done = skip;
+  // Finished rows ride along as ghost rows (force_qp_coop.hpp: full EXEC, scalar-mask loop control): their candidate
+  // normal is 0 (nlim: the lanes that take a component of the chosen normal, none on a ghost row) and their slot of the drop
+  // export reads a zero, so z = r = n~ = 0 and the rank-one updates add exact zeros; z'n_p and n~'G n~ are biased to 1 (zb);
+  // their results wait in LDS (latched).
+  unsigned long long done_m = 0ull;
+  int nlim = N;
+  int nt_slot = L::kNrow + (lr < N ? lr : 0);
+  double zb = 0.0;
   int ip = 0;
   double sp = 0.0, ucand = 0.0, npj = 0.0;
-  if (bad && !skip) { status = kStatusNotPd; done = true; }
-  if (eq_inconsistent && !bad && !skip) { status = kStatusInfeasible; done = true; }
+  bool fin_before = skip; // rows that never enter the loop
+  if (bad && !skip) { status = kStatusNotPd; fin_before = true; }
+  if (eq_inconsistent && !bad && !skip) { status = kStatusInfeasible; fin_before = true; }
+  lds_row[L::kZero] = 0.0;
   const int neq = (has_eq ? 1 : 0) + ((has_eq2 && !eq2_dependent) ? 1 : 0) + neq_rows; // equalities that took a dimension
   const unsigned lanebit = 1u << lr;
   const int row_addr = ((int)threadIdx.x & 48) << 2;
@@ -205,7 +215,7 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
   double vec = 0.0, hc = 0.0, nc = 0.0;
   // kMode 0: before the first step (no update, every live row selects); 1: general (rows in `resel` select, `fresh`
   // after an add); 2: every live row has just added a constraint
-  const auto update_and_select = [&](auto Mode, bool resel, bool fresh) {
+  const auto update_and_select = [&](auto Mode, bool resel, bool fresh, bool finished = false) -> bool {
     constexpr int kMode = decltype(Mode)::value;
     if constexpr (kMode == 1) {
       iters += (resel && fresh) ? 1 : 0;
@@ -243,7 +253,7 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
     const int vhi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(myv));
     const int key_ip = wl + 16 * (((int)key >> 4) & 3);
     const double np_tab = ct[N * key_ip + vlane];
-    const double np_new = lr < N ? np_tab : 0.0;
+    const double np_new = lr < nlim ? np_tab : 0.0;
     const bool any = (int)key < 0;
     const double vsel = __hiloint2double(vhi, vlo);
     bool feasible = false;
@@ -256,20 +266,43 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
       feasible = close && (fabs(psi) <= psi_tol);
     }
     const bool stop = !any || feasible || iters > kMaxOuter; // :271-274
+    bool fin = stop;
     if constexpr (kMode == 1) {
       status = (resel && stop && iters > kMaxOuter) ? kStatusMaxIter : status;
-      done = done || (resel && stop);
+      fin = (resel && stop) || finished;
       const bool take = resel && !stop;
       ip = take ? key_ip : ip;
       sp = sel(take, vsel, sp);
       ucand = sel(take, 0.0, ucand);
       npj = sel(take, np_new, npj);
-    } else {
-      status = (!done && stop && iters > kMaxOuter) ? kStatusMaxIter : status;
-      done = done || stop;
+    } else { // (a ghost row's status is latched: what this writes to it is never read)
+      status = (stop && iters > kMaxOuter) ? kStatusMaxIter : status;
       ip = key_ip; sp = vsel; ucand = 0.0; npj = np_new;
     }
+    return fin;
   };
+  const auto update_only = [&]() {
+    static_for<N>([&](auto J) {
+      constexpr int j = J;
+      fmac_bc<j, j == 0>(H[j], vec, hc);
+      fmac_bc<j>(Ns[j], vec, nc);
+    });
+  };
+  // called where control is uniform, with the rows that have just finished: they latch their results and turn into ghosts
+  const auto note_finished = [&](bool fin) {
+    const unsigned long long fin_m = __builtin_amdgcn_ballot_w64(fin);
+    const unsigned long long newly_m = fin_m & ~done_m;
+    done_m |= fin_m;
+    if (newly_m != 0ull) {
+      if (__builtin_amdgcn_inverse_ballot_w64(newly_m)) {
+        latched[lr] = x;
+        reinterpret_cast<int2 *>(latched + 16)[lr] = make_int2((int)used, idk);
+        reinterpret_cast<int2 *>(latched + 32)[lr] = make_int2(q, status);
+        nlim = 0; nt_slot = L::kZero; zb = 0.0625; npj = 0.0;
+      }
+    }
+  };
+  double drop_einv = 0.0;
   const auto drop_vectors = [&](int lpos) {
     if (lr == lpos) {
 #pragma unroll
@@ -277,11 +310,12 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0xC07F);
-    const double nt_me = lr < N ? nrow[vlane] : 0.0;
+    const double nt_me = lr < N ? lds_row[nt_slot] : 0.0;
     const int drop_id = __shfl(idk, lpos, 16);
     double Gn = 0.0;
     static_for<N>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(Gn, nt_me, Gm[j]); });
-    const double einv = rcp_nr1(row_sum(nt_me * Gn));
+    const double einv = rcp_nr1(row_sum(fma(nt_me, Gn, zb)));
+    drop_einv = einv;
     double coef = 0.0;
     static_for<N>([&](auto J) { constexpr int j = J; fmac_bc<j, j == 0>(coef, Gn, Ns[j]); });
     vec = nt_me;
@@ -290,87 +324,159 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
     return drop_id;
   };
 
-  update_and_select(std::integral_constant<int, 0>{}, true, true);
+  {
+    // lanes that are not here count as finished (ballots never see them); rows that failed before the loop finish now
+    done_m = ~__builtin_amdgcn_ballot_w64(true);
+    const bool fin0 = update_and_select(std::integral_constant<int, 0>{}, true, true);
+    note_finished(fin0 || fin_before);
+  }
 
-  for (;;) {
-    double z = 0.0, r = 0.0, zn = 0.0, zinv = 0.0, t = 0.0, tl1 = 0.0, tl2 = 0.0, ratio = 0.0;
-    bool is_add = false;
-    while (!done) {
-      double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
-      static_for<N>([&](auto J) {
-        constexpr int j = J;
-        fmac_bc<j, j == 0>(za[j % 3], npj, H[j]);
-        fmac_bc<j>(ra[j % 3], npj, Ns[j]);
-      });
-      z = (za[0] + za[1]) + za[2];
-      r = (ra[0] + ra[1]) + ra[2];
-      const bool slot = (used & lanebit) != 0u;
-      zn = row_sum(z * npj);
-      const float zf = (float)z;
-      const double zz = (double)row_sum_f32(zf * zf);
-      const double ur = u * rcp_nr1(r);
-      ratio = sel(slot && r > 0.0, ur, inf);
-      tl1 = row_min(ratio);
-      zinv = rcp_nr(zn);
-      const double t2v = -sp * zinv;
-      // with n - (equality) constraints active the null space is empty and z is exactly 0 in the reference (J2 has
-      // no columns); the explicit projector only leaves ~1e-7 of drift there, which must not pass for a direction
-      const bool exhausted = q + neq >= n_free;
-      tl2 = sel((int)(!exhausted) & (int)(fabs(zz) > eps) & (int)(!(t2v < 0.0)), t2v, inf);
-      t = vmin(tl1, tl2);
-      is_add = (tl2 < inf) && (tl2 <= tl1) && (zn > eps * eps * rnorm2); // full step (:384), add_constraint succeeds (:392)
-      if (__builtin_amdgcn_ballot_w64(!is_add) != 0ull) break;
-      x += t * z;
-      u = fma(-t, r, u);
-      const int newlane = __ffs(~used & ((1u << N) - 1u)) - 1;
-      const bool newslot = lr == newlane;
-      vec = z * zinv;
-      hc = -z;
-      nc = sel(newslot, 1.0, -r);
-      u = sel(newslot, ucand + t, u);
-      idk = newslot ? ip : idk;
-      used |= 1u << newlane;
-      act_mask |= one << ip;
-      rnorm2 = vmax(rnorm2, zn);
-      q += 1;
-      update_and_select(std::integral_constant<int, 2>{}, true, true);
+  // Loop as in force_qp_coop.hpp: scalar masks of the rows that have finished / add / drop in the pass at hand; an inner
+  // loop of the passes in which every live row adds; otherwise the blocked rows drop inside the pass (straight drop path,
+  // step lengths again from the continued directions) until every live row can add, and then all add together; the
+  // general predicated form for a row that does neither.
+  double z = 0.0, r = 0.0, zn = 0.0, zinv = 0.0, t = 0.0, tl1 = 0.0, tl2 = 0.0, ratio = 0.0;
+  const auto in = [](unsigned long long mm) -> bool { return __builtin_amdgcn_inverse_ballot_w64(mm); };
+  const auto directions = [&]() {
+    double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
+    static_for<N>([&](auto J) {
+      constexpr int j = J;
+      fmac_bc<j, j == 0>(za[j % 3], npj, H[j]);
+      fmac_bc<j>(ra[j % 3], npj, Ns[j]);
+    });
+    z = (za[0] + za[1]) + za[2];
+    r = (ra[0] + ra[1]) + ra[2];
+    zn = row_sum(fma(z, npj, zb));
+  };
+  // step lengths (QuadProg++.cc:304-331); returns whether the pass is a full step that adds the candidate
+  const auto step_lengths = [&]() -> bool {
+    const bool slot = (used & lanebit) != 0u;
+    const float zf = (float)z;
+    const double zz = (double)row_sum_f32(zf * zf);
+    const double ur = u * rcp_nr1(r);
+    ratio = sel(slot && r > 0.0, ur, inf);
+    tl1 = row_min(ratio);
+    zinv = rcp_nr(zn);
+    const double t2v = -sp * zinv;
+    // with n - (equality) constraints active the null space is empty and z is exactly 0 in the reference (J2 has
+    // no columns); the explicit projector only leaves ~1e-7 of drift there, which must not pass for a direction
+    const bool exhausted = q + neq >= n_free;
+    tl2 = sel((int)(!exhausted) & (int)(fabs(zz) > eps) & (int)(!(t2v < 0.0)), t2v, inf);
+    t = vmin(tl1, tl2);
+    return (tl2 < inf) && (tl2 <= tl1) && (zn > eps * eps * rnorm2); // full step (:384), add_constraint succeeds (:392)
+  };
+  const auto add_step = [&]() -> bool {
+    x += t * z;
+    u = fma(-t, r, u);
+    const int newlane = __ffs(~used & ((1u << N) - 1u)) - 1;
+    const bool newslot = lr == newlane;
+    vec = z * zinv;
+    hc = -z;
+    nc = sel(newslot, 1.0, -r);
+    u = sel(newslot, ucand + t, u);
+    idk = newslot ? ip : idk;
+    used |= 1u << newlane;
+    act_mask |= one << ip;
+    rnorm2 = vmax(rnorm2, zn);
+    q += 1;
+    return update_and_select(std::integral_constant<int, 2>{}, true, true);
+  };
+  // a partial step (t1 < t2), or a dual step only when t2 is infinite: the blocking constraint leaves the working set and the
+  // same candidate continues; its directions follow from the rank-one update just made (force_qp_coop.hpp)
+  const auto drop_step = [&]() {
+    const double tp = (tl2 >= inf) ? 0.0 : t;
+    x += tp * z;
+    u = fma(-t, r, u);
+    ucand += t;
+    sp += tp * zn;
+    const int lpos = row_first(ratio == tl1 && ratio < inf);
+    const double r_lpos = __shfl(r, lpos, 16);
+    const int drop_id = drop_vectors(lpos);
+    act_mask &= ~(one << drop_id);
+    used &= ~(1u << lpos);
+    q--;
+    update_only();
+    z = fma(hc, r_lpos, z);
+    r = fma(nc, r_lpos, r);
+    zn = fma(r_lpos * r_lpos, drop_einv, zn);
+  };
+  const auto general_pass = [&](bool is_add) -> bool {
+    const bool infeasible = !(t < inf);                            // :339-344
+    const bool dual_only = (tl2 >= inf);
+    const bool full = !infeasible && !dual_only && (tl2 <= tl1);   // :384
+    const bool degenerate = full && !is_add;                       // add_constraint failure (:392)
+    const bool is_drop = !infeasible && !full;
+    if (infeasible) status = kStatusInfeasible;
+    const double tp = (infeasible || dual_only || degenerate) ? 0.0 : t;
+    const double td = (infeasible || degenerate) ? 0.0 : t;
+    x += tp * z;
+    u = fma(-td, r, u);
+    ucand += td;
+    sp += tp * zn;
+    const int newlane = __ffs(~used & ((1u << N) - 1u)) - 1;
+    const bool newslot = is_add && (lr == newlane);
+    vec = is_add ? z * zinv : 0.0;
+    hc = is_add ? -z : 0.0;
+    nc = sel(newslot, 1.0, sel(is_add, -r, 0.0));
+    u = newslot ? ucand : u;
+    idk = newslot ? ip : idk;
+    used |= is_add ? (1u << newlane) : 0u;
+    act_mask |= is_add ? (one << ip) : (mask_t)0;
+    rnorm2 = is_add ? vmax(rnorm2, zn) : rnorm2;
+    q += is_add ? 1 : 0;
+    excl |= degenerate ? (one << ip) : (mask_t)0;
+    int lpos = 16;
+    if (is_drop) {
+      lpos = row_first(ratio == tl1 && ratio < inf);
+      const int drop_id = drop_vectors(lpos);
+      act_mask &= ~(one << drop_id);
+      used &= ~(1u << lpos);
+      q--;
     }
-    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
-    if (!done) {
-      const bool infeasible = !(t < inf);                            // :339-344
-      const bool dual_only = (tl2 >= inf);
-      const bool full = !infeasible && !dual_only && (tl2 <= tl1);   // :384
-      const bool degenerate = full && !is_add;                       // add_constraint failure (:392)
-      const bool is_drop = !infeasible && !full;
-      if (infeasible) { status = kStatusInfeasible; done = true; }
-      const double tp = (infeasible || dual_only || degenerate) ? 0.0 : t;
-      const double td = (infeasible || degenerate) ? 0.0 : t;
-      x += tp * z;
-      u = fma(-td, r, u);
-      ucand += td;
-      sp += tp * zn;
-      const int newlane = __ffs(~used & ((1u << N) - 1u)) - 1;
-      const bool newslot = is_add && (lr == newlane);
-      vec = is_add ? z * zinv : 0.0;
-      hc = is_add ? -z : 0.0;
-      nc = sel(newslot, 1.0, sel(is_add, -r, 0.0));
-      u = newslot ? ucand : u;
-      idk = newslot ? ip : idk;
-      used |= is_add ? (1u << newlane) : 0u;
-      act_mask |= is_add ? (one << ip) : (mask_t)0;
-      rnorm2 = is_add ? vmax(rnorm2, zn) : rnorm2;
-      q += is_add ? 1 : 0;
-      excl |= degenerate ? (one << ip) : (mask_t)0;
-      int lpos = 16;
-      if (is_drop) {
-        lpos = row_first(ratio == tl1 && ratio < inf);
-        const int drop_id = drop_vectors(lpos);
-        act_mask &= ~(one << drop_id);
-        used &= ~(1u << lpos);
-        q--;
+    return update_and_select(std::integral_constant<int, 1>{}, full, is_add, infeasible);
+  };
+  if (~done_m != 0ull) {
+    for (;;) {
+      unsigned long long add_m = 0ull;
+      for (;;) { // passes in which every live row adds
+        directions();
+        add_m = __builtin_amdgcn_ballot_w64(step_lengths());
+        if (~(add_m | done_m) != 0ull) break;
+        note_finished(add_step());
+        if (~done_m == 0ull) break;
       }
-      update_and_select(std::integral_constant<int, 1>{}, full, is_add);
+      if (~done_m == 0ull) break;
+      unsigned long long gen_m = 0ull; // rows that took the general form in this pass
+      bool fin = false;
+      for (;;) {
+        const unsigned long long live_m = ~done_m & ~gen_m;
+        // a dual step only (t2 infinite) with a blocking constraint is a drop as well; without one the problem is infeasible
+        const unsigned long long drop_m = __builtin_amdgcn_ballot_w64(tl1 < tl2) & live_m & ~add_m;
+        const unsigned long long other_m = live_m & ~add_m & ~drop_m;
+        if (other_m != 0ull) {
+          if (in(other_m)) fin = general_pass(false);
+          gen_m |= other_m;
+        }
+        if (drop_m == 0ull) break;
+        if (in(drop_m | done_m)) drop_step();
+        add_m = __builtin_amdgcn_ballot_w64(step_lengths());
+      }
+      const unsigned long long adders_m = add_m & ~done_m & ~gen_m;
+      if (adders_m != 0ull) {
+        bool fin_add = false;
+        if (in(adders_m | done_m)) fin_add = add_step();
+        fin = fin || fin_add;
+      }
+      note_finished(fin);
+      if (~done_m == 0ull) break;
     }
+  }
+  {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    x = latched[lr];
+    const int2 la = reinterpret_cast<const int2 *>(latched + 16)[lr], lb = reinterpret_cast<const int2 *>(latched + 32)[lr];
+    used = (unsigned)la.x; idk = la.y; q = lb.x; status = lb.y;
   }
   // one refinement pass on the final working set (see balance_coop.hpp)
   if (status == kStatusOk && q > 0 && !skip) {
