@@ -393,12 +393,15 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
     const double nt_me = lds_row[nt_slot];
     const int drop_id = __shfl(idk, lpos, 16);
-    double Gn = 0.0;
-    static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(Gn, nt_me, Gm[j]); });
+    // (three partial sums each: a single accumulator makes twelve dependent broadcast-FMAs, 8.5 cycles apiece, of each product)
+    double ga[3] = {0.0, 0.0, 0.0};
+    static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(ga[j % 3], nt_me, Gm[j]); });
+    const double Gn = (ga[0] + ga[1]) + ga[2];
     const double einv = rcp_nr1(row_sum(fma(nt_me, Gn, zb)));
     drop_einv = einv;
-    double coef = 0.0;
-    static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(coef, Gn, Ns[j]); });
+    double ca[3] = {0.0, 0.0, 0.0};
+    static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(ca[j % 3], Gn, Ns[j]); });
+    const double coef = (ca[0] + ca[1]) + ca[2];
     vec = nt_me;
     hc = nt_me * einv;
     // the dropped slot's own coefficient is n~'G n~ / e = 1: with exactly -1 its row N*[lpos][j] - n~_j is exactly 0
