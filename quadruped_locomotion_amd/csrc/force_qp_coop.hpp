@@ -165,10 +165,11 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
 
   QL_STAMP(6);
   // ---------------------------------------------------------------- active-set loop
-  // One pass of the loop = one step of the dual method (an add or a drop) followed by the rank-one update of H and
-  // N*, with the selection of the next violated constraint (QuadProg++.cc:252-274) computed on the new x in the
-  // shadow of that update: the two are independent, so the broadcast chain of the update fills the wait states of
-  // the selection's cross-lane reduction and vice versa.  Slots are NOT compacted on a drop: a freed slot lane is
+  // One pass of the loop = one outer iteration of the dual method for every live row: zero or more drops of a blocking
+  // constraint (each a rank-one update of H and N*), then the add of the candidate (another one), with the selection of the
+  // next violated constraint (QuadProg++.cc:252-274) computed on the new x in the shadow of that last update: the two are
+  // independent, so the broadcast chain of the update fills the wait states of the selection's cross-lane reduction and
+  // vice versa.  Slots are NOT compacted on a drop: a freed slot lane is
   // reused by the next add (the order of the slots only breaks exact ties in the blocking-constraint search).
   //
   // A lone wavefront issues one instruction every ~4.5 cycles whatever its kind (tools/ubench/issue_model.hip), so a

@@ -557,14 +557,14 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   const int st_row = __shfl(st, 0, 16);
   if (mine && sane && staged && st_row != kWireTruncated) wire_lds_extract_row(msg, rec[row], anchors[row], lr);
   QL_STAMP(23);
-  // ---- the template for the next launch (block 0, first message)
+  // ---- the template for the next launch (block 0, first message).  Its body goes out here; its valid word goes last,
+  // behind a fence (a template is never valid before all of it is in memory) -- at the very END of the block's work, where
+  // the fence finds the body's stores long complete: placed here it held block 0, and with it the launch, up for 2 us.
+  uint32_t tpl_valid_word = 0u;
   if (logger) {
     const uint32_t nf0 = __shfl(nf, 0, 16), end0 = __shfl(end_pos, 0, 16);
     if (hit) {
-      for (int k = lr; k < kTplWords; k += 16)
-        if (k != kTplValid) tpl_out[k] = tpl[k]; // still in force
-      __threadfence();
-      if (lr == 0) tpl_out[kTplValid] = tpl[kTplValid];
+      tpl_valid_word = tpl[kTplValid]; // still in force: the body is copied below, by the whole block
     } else {
       // the walk has already left its (position, value) pairs in tpl_out; valid only if the message was well-formed
       const bool good = sane && staged && st_row != kWireTruncated && nf0 <= (uint32_t)kTplMaxFields;
@@ -573,10 +573,12 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
         tpl_out[kTplMissing] = st_row == kWireMissingField ? 1u : 0u; tpl_out[kTplFields] = nf0;
       }
       for (int k = lr; k < kAnCount; k += 16) tpl_out[kTplAnchors + k] = anchors[0][k];
-      // the valid word goes last, behind a fence: a template is never valid before all of it is in memory
-      __threadfence();
-      if (lr == 0) tpl_out[kTplValid] = good ? kTplMagic : 0u;
+      tpl_valid_word = good ? kTplMagic : 0u;
     }
+  }
+  if (blockIdx.x == 0 && __builtin_amdgcn_readfirstlane((int)hit) != 0) { // row 0 hit: all 64 lanes copy the template
+    for (int k = tid; k < kTplWords; k += 64)
+      if (k != kTplValid) tpl_out[k] = tpl[k];
   }
   __syncthreads();
   QL_STAMP(24);
@@ -604,6 +606,10 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   if (leg_state_mode) {
     __syncthreads(); // the block's records (and valid flags) are in memory
     if (tid < n) leg_state_robot(ls, leg_state_mode == 2, i0 + tid);
+  }
+  if (logger) {
+    __threadfence();
+    if (lr == 0) tpl_out[kTplValid] = tpl_valid_word;
   }
 }
 

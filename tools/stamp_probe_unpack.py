@@ -1,4 +1,4 @@
-"""Diagnostic: s_memtime stamps (100 MHz) at the segment boundaries of robot_state_unpack_kernel, block 0 lane 0
+"""Diagnostic: s_memtime stamps (shader clock, 2.41 GHz) at the segment boundaries of robot_state_unpack_kernel, block 0 lane 0
 (needs scratch_bin/libqlamd_stamps.so built with -DQLAMD_STAMPS)."""
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,4 +18,4 @@ for label, (blob, off) in (("uniform", (one * B, np.arange(B + 1, dtype=np.int64
         out = (C.c_ulonglong * 32)()
         capi.lib().qlamd_debug_stamps_tick(out, 32)
         t = np.array(out[20:26], dtype=np.float64)
-        print(label, "launch", rep, " ".join("%s %.2f us;" % (names[k], (t[k + 1] - t[k]) / 100.0) for k in range(5)), "total %.2f us" % ((t[5] - t[0]) / 100.0))
+        print(label, "launch", rep, " ".join("%s %.2f us;" % (names[k], (t[k + 1] - t[k]) / 2408.0) for k in range(5)), "total %.2f us" % ((t[5] - t[0]) / 2408.0))
