@@ -66,7 +66,25 @@ def counters(db, kernel):
     return {c: sum(v[5:]) / len(v[5:]) if len(v) > 10 else sum(v) / len(v) for c, v in acc.items()}
 
 
+def derive(rec):
+    """Derived figures of a record, from its own counters and kernel average: the fraction of the chip's VALU issue slots the
+    launch used (a wave64 VALU instruction holds its SIMD16 for 4 cycles; 1024 SIMDs at 2.4 GHz) and the mean lifetime of a
+    wavefront (SQ_WAVE_CYCLES counts in units of 4 cycles)."""
+    c = rec.get("counters", {})
+    if "SQ_INSTS_VALU" in c and rec.get("kernel_avg_us"):
+        rec["valu_issue_frac"] = c["SQ_INSTS_VALU"] * 4.0 / (1024 * rec["kernel_avg_us"] * 1e-6 * 2.4e9)
+    if c.get("SQ_WAVES") and "SQ_WAVE_CYCLES" in c:
+        rec["mean_wave_lifetime_us"] = c["SQ_WAVE_CYCLES"] / c["SQ_WAVES"] * 4.0 / 2.4e3
+
+
 def main():
+    if sys.argv[1] == "--derive":  # add the derived figures to an index collected before they existed
+        path = sys.argv[2]
+        idx = json.load(open(path))
+        for rec in idx["records"]:
+            derive(rec)
+        json.dump(idx, open(path, "w"), indent=1, sort_keys=True)
+        return
     out = os.path.abspath(sys.argv[1])
     os.makedirs(out, exist_ok=True)
     import bench
@@ -114,6 +132,7 @@ def main():
             rec["write_bytes"] = c["WRITE_SIZE"] * 1024.0
         if "SQ_INSTS_VALU" in c:
             rec["valu_insts"] = c["SQ_INSTS_VALU"]
+        derive(rec)
         rec["incomplete"] = bool(rec["failed_passes"]) or not all(k in rec for k in ("fetch_bytes", "write_bytes", "valu_insts", "kernel_avg_us"))
         records.append(rec)
         print(json.dumps(rec))
