@@ -137,6 +137,10 @@ def test_collection_cadence_and_peer_copies_with_one_rank():
     for name, a in alt.items():
         assert "error" not in a, (name, a)
         assert a["value"] > 0 and a["layout_ok"] is True, (name, a)
+    # alternatives that do not come back in time cost the line their object only (the watchdog prints the line and ends the rank)
+    d = check(_bench(*common, "--alternatives-timeout", "0.05"), want_cpu=False)
+    assert d["config"]["gather_layout_ok"] is True and d["value"] > 0
+    assert "not finished" in d["alternatives"]["error"]
 
 
 def test_profile_collection_names_exist_in_the_sources():
