@@ -1,20 +1,22 @@
-"""GPU soak: a million control steps, 262 144 whole-body steps and 65 536 pose optimisations against the oracle."""
+"""GPU soak: a million control steps per preset (trot, static-calm, static-survey), 262 144 whole-body steps and 65 536 pose optimisations against the oracle."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from quadruped_locomotion_amd import capi, synth
 from oracle import oracle as O
 ctx = capi.Context()
-for gait in ("trot", "static"):
+# usage: soak.py [first robot index of the balance batches, default 0]  (another index range = other seeds of every robot)
+FIRST = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+for gait, errors in (("trot", None), ("static", "calm"), ("static", "survey")):
     worst = 0.0; bad = 0; n = 0
     for chunk in range(8):
         B = 131072
-        s = synth.make_states(B, gait, offset=chunk * B)
+        s = synth.make_states(B, gait, offset=FIRST + chunk * B, errors=errors)
         tau, grf, st = ctx.balance_solve_host(s)
         t0, g0, s0 = O.balance_batch(s, nthreads=32)
         bad += int((st != s0).sum()); ok = (st == 0) & (s0 == 0)
         worst = max(worst, float(np.abs(tau[ok] - t0[ok]).max())); n += B
-    print("balance %s: %d robots, status mismatches %d, max |dtau| %.3e" % (gait, n, bad, worst))
+    print("balance %s%s: robots %d..%d, status mismatches %d, max |dtau| %.3e" % (gait, "-" + errors if errors else "", FIRST, FIRST + n, bad, worst))
 for gait in ("trot", "static"):
     worst = 0.0; bad = 0; n = 0
     for chunk in range(4):
