@@ -136,7 +136,7 @@ class PeerBuffers:
         raised: the ranks agree on it at the next consensus point, run_preset)"""
         for r in range(self.world):
             dst = self.peers[r] + buf * self.buf_bytes + self.rank * self.group_bytes
-            if self.hip.hipMemcpyAsync(dst, src_ptr, self.group_bytes, 3, stream_handle) != 0:
+            if self.hip.hipMemcpyAsync(dst, src_ptr, self.group_bytes, 4, stream_handle) != 0:  # 4 = hipMemcpyDefault: the runtime takes the devices from the pointers
                 self.failed = True
 
     def agree_no_failure(self):
