@@ -637,9 +637,9 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if collective:
+        if collective:  # the barrier is device work of its own (an all-reduce): synchronize again behind it
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     def run_preset(gait, errors, with_gather, replays, second_without_gather, collect="rccl", every=1):
         """One workload preset on this rank's shard: warm-up, K steps captured as one hipGraph, `replays` timed samples.
