@@ -42,6 +42,8 @@ python3 tools/write_bw.py 2>&1 | grep -v amdgpu > $OUT/write_bandwidth.txt
 # round 4: issue rate against the rows enabled in EXEC, the row-mix / batch-mix / per-wavefront probes of the balance
 # kernel, the segment stamps of the pose kernel (diagnostic build), the C++ multi-GPU host with one rank
 ./tools/ubench/exec_mask_model > $OUT/exec_mask_model.txt 2>&1
+./tools/ubench/tail64_model > $OUT/tail64_model.txt 2>&1
+python3 tools/experiments/half_wave_probe.py 2>&1 | grep -v amdgpu > $OUT/half_wave_probe.txt
 python3 tools/experiments/row_mix_probe.py 2>&1 | grep -v amdgpu > $OUT/row_mix_probe.txt
 python3 tools/experiments/batch_mix_probe.py 2>&1 | grep -v amdgpu > $OUT/batch_mix_probe.txt
 python3 tools/experiments/wave_scan.py 2>&1 | grep -v amdgpu > $OUT/wave_scan.txt
