@@ -9,8 +9,10 @@ outputs resident in HBM.
   python bench.py [--gpus N] [--steps K] [--warmup W] [--gait static|trot] [--batch B]
 
 N = 1: BASELINE configs[1], batch = 4096 robots, static 4-contact stance with SURVEY.md 8(d)'s literal tracking errors
-       (0.02 m / 0.05 rad / 0.1); the same line carries an `also` object with the other presets measured in the same
-       process (static-calm, trot), each with its kernel time, roofline fraction and PMC provenance.
+       (0.02 m / 0.05 rad / 0.1); the same line carries an `also` object with every other BASELINE config measured in the
+       same process (static-calm and trot at 4096 robots, trot at 8192 and 65 536 robots, the pose SQP at 4096 problems),
+       each with its kernel time, roofline fraction and PMC provenance, `unplaced` (the same steps through the plain
+       entry) and `scale_point` (8192 trot robots per GPU: the workload every line at every N carries).
 N > 1: BASELINE configs[3], 8192 trot robots per GPU (65 536 on 8 GPUs), one rank per GPU; every rank
 solves its own contiguous shard (weak scaling: robots are independent, no data-path collective) and the
 joint torques are all-gathered over RCCL/xGMI for result collection, as the north star asks.  Started
@@ -212,6 +214,11 @@ def parse():
     ap.add_argument("--no-gather", action="store_true",
                     help="several ranks without the per-step all-gather of the torques (scaling with / without it)")
     ap.add_argument("--ragged", action="store_true", help="full_tick: every message with its own layout")
+    ap.add_argument("--method", default="placed", choices=["placed", "plain"],
+                    help="placed (default): every step is one qlamd_balance_solve_placed_batch call that runs in the placement made "
+                         "during the previous step from the iteration counts of the step before it, reports its own counts and "
+                         "leaves the placement for the next step -- all of it inside the timed region; plain: qlamd_balance_solve_batch "
+                         "(robot s in slot s), the headline of rounds 1-4.  The line carries the other one in `also` / `unplaced`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -641,12 +648,31 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run_preset(gait, errors, with_gather, replays, second_without_gather, collect="rccl", every=1):
+    def run_preset(gait, errors, with_gather, replays, second_without_gather, collect="rccl", every=1, batch=None,
+                   method="plain", prev_tick=False):
         """One workload preset on this rank's shard: warm-up, K steps captured as one hipGraph, `replays` timed samples.
-        every: steps per collection; collect: "rccl" (all-gather) or "peer" (copies into the peers' buffers)."""
+        every: steps per collection; collect: "rccl" (all-gather) or "peer" (copies into the peers' buffers).
+        method "placed": the caller's loop of include/qlamd.h -- step k runs in order[k & 1], writes iters[k & 1] and makes
+        order[(k + 1) & 1] from iters[(k - 1) & 1]; prev_tick: odd steps run on the states one control period (2.5 ms) later,
+        so that every placement in use was made from the counts of OTHER states, as at 400 Hz."""
+        B = batch or args.batch
         # rank r owns robots [r*B, (r+1)*B) of the global batch (contiguous shards, SURVEY.md 8e)
         state = synth.make_states(B, gait, offset=rank * B, errors=errors)
-        d = capi.to_device(state, dev)
+        ds = [capi.to_device(state, dev)]
+        if prev_tick:
+            ds.append(capi.to_device(synth.next_tick_states(state, 0.0025), dev))
+        d = ds[0]
+        placed = method == "placed"
+        orders = [torch.arange(B, dtype=torch.int32, device=dev) for _ in range(2)] if placed else None
+        its = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)] if placed else None
+
+        def solve(k, out, st):
+            if placed:
+                ctx.balance_solve_placed_device(ds[k % len(ds)], out, None, status, order=orders[k & 1], iterations=its[k & 1],
+                                                prev_iterations=its[(k - 1) & 1], next_order=orders[(k + 1) & 1],
+                                                policy=capi.PLACEMENT_AUTO, stream=st)
+            else:
+                ctx.balance_solve_device(ds[k % len(ds)], out, None, status, stream=st)
         G = max(1, every)
         tau = [torch.zeros(G, B, 12, dtype=torch.float64, device=dev) for _ in range(2)]
         status = torch.full((B,), -1, dtype=torch.int32, device=dev)
@@ -667,7 +693,7 @@ def main():
             buf = (k // G) & 1
             if events is not None:
                 events[0].record()
-            ctx.balance_solve_device(d, tau[buf][k % G], None, status, stream=stream)
+            solve(k, tau[buf][k % G], stream)
             if events is not None:
                 events[1].record()
             if wg and collect_now(k):
@@ -706,7 +732,7 @@ def main():
                         buf = (k // G) & 1
                         if overlap and k % G == 0 and gathered_ev[buf] is not None:
                             side.wait_event(gathered_ev[buf])
-                        ctx.balance_solve_device(d, tau[buf][k % G], None, status, stream=cap)
+                        solve(k, tau[buf][k % G], cap)
                         if not (wg and collect_now(k)):
                             continue
                         if overlap:  # RCCL collectives and peer copies are capturable; they replay from the graph
@@ -831,15 +857,20 @@ def main():
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             ok = bool(okt.item())
         res["ok"] = ok
+        res["batch"], res["method"] = B, method
+        if placed:
+            it = its[(args.steps - 1) & 1].cpu().numpy()
+            res["iterations"] = {"mean": float(it.mean()), "max": int(it.max())}
         return res
 
     def roofline_of(res, gait, errors):
         """roofline and valu_issue objects of one preset from its kernel time and the committed PMC record."""
-        kernel_ms = res["kernel_ms"]
-        algo_bytes = ALGO_BYTES_PER_STEP * B
+        kernel_ms, Bp, placed = res["kernel_ms"], res["batch"], res["method"] == "placed"
+        # placed: + robot_order in, iterations out, prev_iterations in, next_robot_order out (4 B each)
+        algo_bytes = (ALGO_BYTES_PER_STEP + (16 if placed else 0)) * Bp
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        wl = "static-%s" % errors if gait == "static" else "trot"
-        rec, prov = pmc_record("balance_coop_kernel", B, wl)
+        wl = ("static-%s" % errors if gait == "static" else "trot") + ("+placed" if placed else "")
+        rec, prov = pmc_record("balance_coop_kernel", Bp, wl)
         have = rec is not None and "fetch_bytes" in rec and "write_bytes" in rec
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": int(rec["fetch_bytes"] + rec["write_bytes"]) if have else None, "traffic_source": prov,
@@ -852,21 +883,136 @@ def main():
                     "note": "SQ_INSTS_VALU (rocprofv3 --pmc) x 4 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz)"}
         return roof, valu
 
-    res = run_preset(args.gait, args.errors, gather, args.replays, world > 1, collect=args.collect, every=args.gather_every)
-    # the other presets of the headline workload, same process, same batch (one GPU only; fewer samples each)
-    also = None
+    def entry(r, gait, errors, note=None):
+        """One `also` / `scale_point` record of a finished preset."""
+        roof, valu = roofline_of(r, gait, errors)
+        e = {"value": r["batch"] * args.steps / r["elapsed"], "unit": "solves/s", "ms_per_step": r["elapsed"] / args.steps * 1e3,
+             "kernel_ms": r["kernel_ms"], "batch": r["batch"], "method": r["method"],
+             "tracking_error": list(synth.tracking_error(gait, errors)),
+             "all_status_ok": r["ok"], "roofline_frac": roof["frac"], "traffic": roof["traffic"],
+             "valu_issue_frac": valu["frac"] if valu else None, "pmc_source": roof["traffic_source"]}
+        if "iterations" in r:
+            e["iterations"] = r["iterations"]
+        if note:
+            e["note"] = note
+        return e
+
+    def pose_sqp_entry(batch):
+        """BASELINE configs[4] inside the headline line: batch pose optimisations, exactly 5 SQP iterations each, the K calls
+        captured and timed like every other preset."""
+        pb = synth.make_pose_problems(batch)
+        prm = capi.default_pose_params()
+        prm.tolerance, prm.max_iterations = 0.0, 5
+        dp = {k: torch.from_numpy(v).to(dev) for k, v in pb.items()}
+        out = (torch.zeros(batch, 7, dtype=torch.float64, device=dev), torch.zeros(batch, dtype=torch.int32, device=dev),
+               torch.zeros(batch, dtype=torch.int32, device=dev))
+        for _ in range(max(2, min(args.warmup, 5))):
+            capi.pose_sqp(ctx, dp, prm, memory=capi.MEM_DEVICE, out=out, stream=stream)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                cap = torch.cuda.current_stream().cuda_stream
+                for _ in range(args.steps):
+                    capi.pose_sqp(ctx, dp, prm, memory=capi.MEM_DEVICE, out=out, stream=cap)
+        torch.cuda.current_stream().wait_stream(side)
+        graph.replay()
+        torch.cuda.synchronize()
+        t_end = time.perf_counter() + 0.05
+        while time.perf_counter() < t_end:
+            graph.replay()
+        torch.cuda.synchronize()
+        el = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            graph.replay()
+            torch.cuda.synchronize()
+            el.append(time.perf_counter() - t0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        kernel_ms = e0.elapsed_time(e1) / args.steps
+        elapsed = float(np.median(el))
+        rec, prov = pmc_record("pose_sqp_coop_kernel", batch, "pose_sqp")
+        frac = 424.0 * batch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS  # SURVEY.md 8(d): 46 doubles in + 7 out per solve
+        return {"value": batch * args.steps / elapsed, "unit": "pose-SQP solves/s", "ms_per_step": elapsed / args.steps * 1e3,
+                "kernel_ms": kernel_ms, "batch": batch, "method": "qlamd_pose_sqp_batch, 5 SQP iterations x inner QP (n = 6, m = 8, dummy equality)",
+                "all_status_ok": bool((out[2] == 0).all().item()), "roofline_frac": frac,
+                "traffic": int(rec["fetch_bytes"] + rec["write_bytes"]) if rec and "fetch_bytes" in rec and "write_bytes" in rec else None,
+                "valu_issue_frac": (rec["valu_insts"] * 4.0 / (N_SIMD * kernel_ms * 1e-3 * SHADER_CLOCK_HZ)) if rec and rec.get("valu_insts") else None,
+                "pmc_source": prov}
+
+    B = args.batch
+    method = args.method if not args.rpw else "plain"  # (the one-lane kernels of --rpw know no placement)
+    other = "plain" if method == "placed" else "placed"
+    res = run_preset(args.gait, args.errors, gather, args.replays, world > 1, collect=args.collect, every=args.gather_every, method=method)
+    headline_is_survey_4096 = args.gait == "static" and args.errors == "survey"
+    # the same preset by the other method (every rank takes part: the preset's consensus steps are collectives)
+    unplaced = run_preset(args.gait, args.errors, False, min(args.replays, 5), False, method=other) if not args.rpw else None
+    # The other presets and every other BASELINE config, same process (one GPU only; fewer samples each):
+    #   static-calm, trot at the headline batch; trot_b8192 (one rank's shard of configs[3]) and trot_b65536 (its global
+    #   batch on one GPU); pose_sqp_b4096 (configs[4]); the headline preset with placement hints from OTHER states.
+    also, scale_point = None, None
+    SCALE_B = 8192
     if world == 1 and not collective and not args.no_also:
         also = {}
         for gait, errors in (("static", "calm"), ("static", "survey"), ("trot", "survey")):
             if gait == args.gait and (gait == "trot" or errors == args.errors):
                 continue
-            r = run_preset(gait, errors, False, min(args.replays, 5), False)
-            roof, valu = roofline_of(r, gait, errors)
-            also["static-%s" % errors if gait == "static" else "trot"] = {
-                "value": B * args.steps / r["elapsed"], "ms_per_step": r["elapsed"] / args.steps * 1e3,
-                "kernel_ms": r["kernel_ms"], "tracking_error": list(synth.tracking_error(gait, errors)),
-                "all_status_ok": r["ok"], "roofline_frac": roof["frac"], "traffic": roof["traffic"],
-                "valu_issue_frac": valu["frac"] if valu else None, "pmc_source": roof["traffic_source"]}
+            # (a robot holding its pose needs no pass: nothing to place, and a caller would not ask for it)
+            m = "plain" if (gait, errors) == ("static", "calm") else method
+            also["static-%s" % errors if gait == "static" else "trot"] = entry(run_preset(gait, errors, False, min(args.replays, 5), False, method=m), gait, errors)
+        if method == "placed":
+            r = run_preset(args.gait, args.errors, False, min(args.replays, 5), False, method="placed", prev_tick=True)
+            also["%s-prev-tick-hints" % ("static-%s" % args.errors if args.gait == "static" else "trot")] = entry(
+                r, args.gait, args.errors,
+                note="odd steps run on the states one control period (2.5 ms) later than even steps: every placement in use was "
+                     "made from the iteration counts of OTHER states, as for a caller at 400 Hz")
+        for name, bb in (("trot_b8192", 8192), ("trot_b65536", 65536)):
+            if args.gait == "trot" and bb == B:
+                continue
+            r = run_preset("trot", "survey", False, min(args.replays, 5), False, batch=bb, method=method)
+            also[name] = entry(r, "trot", "survey")
+            if method == "placed":
+                rp = run_preset("trot", "survey", False, min(args.replays, 5), False, batch=bb, method="plain")
+                also[name]["unplaced"] = {"value": bb * args.steps / rp["elapsed"], "ms_per_step": rp["elapsed"] / args.steps * 1e3,
+                                          "kernel_ms": rp["kernel_ms"], "all_status_ok": rp["ok"]}
+        try:
+            also["pose_sqp_b4096"] = pose_sqp_entry(4096)
+        except Exception as e:  # a side measurement must not cost the line
+            also["pose_sqp_b4096"] = {"error": repr(e)[:200]}
+    # scale_point: the workload every line at every N carries, so that a weak-scaling curve can be drawn across lines:
+    # 8192 trot robots per GPU (configs[3]'s shard).  efficiency(N) = scale_point(N).value / (N * scale_point(1).without_gather)
+    if args.gait == "trot" and B == SCALE_B:
+        sp_res, sp_plain = res, None
+    elif world == 1 and not collective and not args.no_also:
+        sp_res, sp_plain = None, None
+    else:
+        sp_res = run_preset("trot", "survey", gather, min(args.replays, 5), world > 1, collect=args.collect, every=args.gather_every,
+                            batch=SCALE_B, method=method)
+        sp_plain = None
+    if rank == 0:
+        if sp_res is not None:
+            scale_point = {"robots_per_gpu": SCALE_B, "gait": "trot", "n_gpus": world, "method": sp_res["method"],
+                           "value": world * SCALE_B * args.steps / sp_res["elapsed"],
+                           "ms_per_step": sp_res["elapsed"] / args.steps * 1e3,
+                           "without_gather": (world * SCALE_B * args.steps / sp_res["plain"]["elapsed"]) if sp_res.get("plain") else
+                                             (world * SCALE_B * args.steps / sp_res["elapsed"] if not gather else None),
+                           "result_collection": "rccl all_gather of torques" if gather else "none"}
+        elif also is not None and "trot_b8192" in also:
+            t8 = also["trot_b8192"]
+            scale_point = {"robots_per_gpu": SCALE_B, "gait": "trot", "n_gpus": 1, "method": t8["method"], "value": t8["value"],
+                           "ms_per_step": t8["ms_per_step"], "without_gather": t8["value"],
+                           "result_collection": "none (one GPU: the result is already whole)",
+                           **({"unplaced": t8["unplaced"]} if "unplaced" in t8 else {})}
+        if scale_point is not None:
+            scale_point["definition"] = ("8192 trot robots per GPU (BASELINE configs[3]'s shard), same method and timed region as "
+                                         "`value`; weak-scaling efficiency(N) = scale_point(N).value / (N x scale_point(1).without_gather)")
 
     line = None
     if rank == 0:
@@ -883,6 +1029,16 @@ def main():
                                    % (B, "static 4-contact stance" if args.gait == "static"
                                       else "trot gait (2<->4 contacts)"),
                        "robots_per_gpu": B, "global_batch": world * B, "gait": args.gait, "seed": synth.SEED,
+                       "method": method,
+                       "method_note": ("every step is ONE launch of qlamd_balance_solve_placed_batch: it solves all robots in the "
+                                       "placement (which four robots share a wavefront) that the previous step's launch made from "
+                                       "the iteration counts of the step before it, writes its own counts, and makes the next "
+                                       "step's placement with one extra wavefront -- hints, placement and solve all inside the timed "
+                                       "region; results bit for bit those of the plain entry (tests/test_placement_gpu.py); "
+                                       "`unplaced` = the same steps through qlamd_balance_solve_batch (robot s in slot s), the "
+                                       "headline of rounds 1-4") if method == "placed" else
+                                      "qlamd_balance_solve_batch: robot s in slot s of the launch",
+                       "iterations": res.get("iterations"),
                        "tracking_error": list(synth.tracking_error(args.gait, args.errors)),
                        "tracking_error_note": "half-widths of the uniform position (m) / rotation-vector (rad) / twist errors: "
                                               "SURVEY.md 8(d)'s 0.02 / 0.05 / 0.1 unless --errors calm (static only; `also` "
@@ -906,6 +1062,10 @@ def main():
                                       "samples_ms": res["plain"]["samples_ms"]}
         if valu:
             line["valu_issue"] = valu
+        if unplaced is not None:
+            line["unplaced" if method == "placed" else "placed"] = entry(unplaced, args.gait, args.errors)
+        if scale_point is not None:
+            line["scale_point"] = scale_point
         if also is not None:
             line["also"] = also
         if cpu is not None:
@@ -930,8 +1090,15 @@ def main():
     alternatives = None
     if gather and (world > 1 or args.force_collective) and not args.no_alternatives:
         def give_up():
-            emit({"error": "not finished after %g s; the rest of the line is complete" % args.alternatives_timeout})
-            os._exit(0)
+            # A hung alternative (a collective or a mapped peer buffer some rank never reaches): the line, complete but for
+            # this object, is written with the error in it.  The process cannot be unwound past a hung device call, so it
+            # ends here: with 0 when the line is out (the measurement is whole, the error is in `alternatives.error`), with 3
+            # when it is not -- a launcher must never read success from a rank that printed nothing.
+            try:
+                emit({"error": "not finished after %g s; the rest of the line is complete" % args.alternatives_timeout})
+                os._exit(0 if (emitted[0] or rank != 0) else 3)
+            except BaseException:
+                os._exit(3)
         guard = threading.Timer(args.alternatives_timeout, give_up)
         guard.daemon = True
         guard.start()
@@ -939,13 +1106,22 @@ def main():
         for name, (col, ev) in (("rccl_every_8", ("rccl", 8)), ("peer_every_1", ("peer", 1)), ("peer_every_8", ("peer", 8))):
             if col == args.collect and ev == args.gather_every:
                 continue
+            err = None
             try:
-                r = run_preset(args.gait, args.errors, True, min(args.replays, 5), False, collect=col, every=ev)
+                r = run_preset(args.gait, args.errors, True, min(args.replays, 5), False, collect=col, every=ev, method=method)
                 alternatives[name] = {"value": world * B * args.steps / r["elapsed"], "ms_per_step": r["elapsed"] / args.steps * 1e3,
                                       "collect": col, "gather_every": ev, "layout_ok": r.get("gather_layout_ok"),
                                       "launch": "hipGraph of K steps" if r["graph"] else "eager"}
             except Exception as e:  # an alternative that does not run costs the line nothing
-                alternatives[name] = {"error": repr(e)[:200]}
+                err = repr(e)[:200]
+                alternatives[name] = {"error": err}
+            # a failure on one rank only would leave the others in the next alternative's collectives: agree, and stop here
+            bad = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if int(bad.item()):
+                if err is None:
+                    alternatives[name] = {"error": "failed on another rank"}
+                break
         guard.cancel()
     emit(alternatives)
 

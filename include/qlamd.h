@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define QLAMD_VERSION_MAJOR 0
-#define QLAMD_VERSION_MINOR 4
+#define QLAMD_VERSION_MINOR 5
 
 /* ---- return codes of the API calls ------------------------------------- */
 #define QLAMD_OK 0
@@ -151,7 +151,12 @@ void qlamd_context_destroy(qlamd_context *ctx);
  * to max_batch once (synchronous; call it before the first capture or before a latency-critical loop); a call that
  * would still have to grow it inside a capture returns QLAMD_ERR_NEEDS_RESERVE instead of breaking the capture.
  * QLAMD_MEM_HOST calls stage through a slab of their own that also grows on demand: host-buffer calls synchronise
- * anyway and cannot be captured. */
+ * anyway and cannot be captured.  qlamd_reserve itself must not be called while a stream is being captured (it would
+ * have to synchronise the device): it then returns QLAMD_ERR_NEEDS_RESERVE and leaves the scratch as it was.
+ * Capturing the whole tick: run ONE eager tick first.  The message parser keeps the field layout of the last message it
+ * walked as a template for the next launch; a captured launch reads, on every replay, the template that was
+ * in force when it was captured, i.e. the one the last eager launch left -- without one the replays walk every message
+ * (about 10 us slower per 4096-robot tick, results identical). */
 int qlamd_reserve(qlamd_context *ctx, int64_t max_batch);
 
 /* Which implementation of the balance step runs: robots per wavefront.  0 (default) and 4 = the lane-cooperative kernel
@@ -213,6 +218,68 @@ int qlamd_force_distribution_batch(qlamd_context *ctx, const double *joint_posit
                                    const uint8_t *support_leg, const double *surface_normal,
                                    const double *virtual_wrench, int64_t batch, double *joint_effort,
                                    double *contact_force, int32_t *status, int memory, void *stream);
+
+/* ---- placement: who shares a wavefront ---------------------------------------------------------
+ * The hot kernel runs four robots per wavefront in lockstep; each robot's active-set loop (ContactForceDistribution.cpp:385-514
+ * in the reference, QuadProg++.cc:216-445 for the method) takes a data-dependent number of add / drop passes, a wavefront
+ * lasts as long as the union of its four robots' passes, and a launch of a few thousand robots as long as its slowest
+ * wavefront.  By default slot s of a launch (row s % 4 of wavefront s / 4) takes robot s.  The placed entries take the
+ * assignment from the caller, report how much work each robot was, and can leave the placement for the next control step:
+ *   robot_order       [B] in, or NULL (identity): robot_order[s] = index of the robot that sits in slot s.  A permutation
+ *                     of 0..B-1.  Results are written at the robot's own index and are bit for bit those of the plain entry
+ *                     whatever the permutation (a robot's arithmetic never leaves its 16 lanes).  QLAMD_MEM_HOST:
+ *                     checked (QLAMD_ERR_INVALID_ARGUMENT unless every robot appears exactly once); QLAMD_MEM_DEVICE: not
+ *                     checked -- an entry outside [0, B) leaves its slot empty, a robot that is missing is not solved (its
+ *                     outputs stay untouched), one that appears twice is solved twice with the same result.
+ *   iterations        [B] out, or NULL: outer iterations of each robot's QP (QuadProg++'s `iter`: one per constraint
+ *                     selected; 0 for a robot without a stance leg or with status QLAMD_STATUS_NOT_PD).
+ *   prev_iterations   [B] in and
+ *   next_robot_order  [B] out, both or neither: the placement (by `policy`) that follows from the counts in prev_iterations
+ *                     -- the `iterations` of the caller's previous call -- for the caller's next call.  Up to 8704 robots
+ *                     it is made by one extra wavefront inside the solve's own launch, in its shadow: no launch, no time
+ *                     between two control steps; beyond that by qlamd_placement_from_iterations' launches behind the solve.
+ *                     Must not alias robot_order / iterations (two buffers of each, used in turn).
+ * The hint is free for a caller that runs at 400 Hz (balance_controller_manager.cpp:48): the iteration counts of the last
+ * control steps predict this one's (same count for 94 % of the robots of the bench batches one period later, rank
+ * correlation 0.99: tools/experiments/placement_model.py).  The loop of such a caller, with two buffers of each kind:
+ *     tick k:  placement = { order[k & 1], iters[k & 1], iters[(k - 1) & 1], order[(k + 1) & 1], QLAMD_PLACEMENT_AUTO };
+ *              qlamd_balance_solve_placed_batch(ctx, &state, B, &placement, effort, NULL, status, QLAMD_MEM_DEVICE, stream);
+ * (tick k runs in the placement made during tick k - 1 from the counts of tick k - 2; start with identity orders and zero
+ * counts).  Policies:
+ *   QLAMD_PLACEMENT_LATENCY     the hardest quarter of the robots one per wavefront, each joined by the three easiest left:
+ *                               for batches of about one or two wavefronts per SIMD (4096 - 8192 robots on an MI355X),
+ *                               where the launch lasts as long as its slowest wavefront
+ *   QLAMD_PLACEMENT_THROUGHPUT  robots sorted by iteration count, hardest first, four neighbours per wavefront: the union
+ *                               of four similar sequences is the shortest there is; for batches that fill every SIMD
+ *                               several times over
+ *   QLAMD_PLACEMENT_AUTO        by batch size (latency below 16 384 robots)
+ * A placement computed from stale or wrong hints costs time, never correctness.  Not available with
+ * qlamd_set_robots_per_wave(16 | 64) (QLAMD_ERR_INVALID_ARGUMENT): one lane is one robot there and nothing is shared.
+ * Other arguments as qlamd_balance_solve_batch / qlamd_force_distribution_batch; the arrays of `placement` live in the
+ * memory space of the call; placement = NULL is the plain entry. */
+#define QLAMD_PLACEMENT_AUTO 0
+#define QLAMD_PLACEMENT_LATENCY 1
+#define QLAMD_PLACEMENT_THROUGHPUT 2
+typedef struct qlamd_placement {
+  const int32_t *robot_order;
+  int32_t *iterations;
+  const int32_t *prev_iterations;
+  int32_t *next_robot_order;
+  int policy;                       /* QLAMD_PLACEMENT_*, for next_robot_order */
+} qlamd_placement;
+int qlamd_balance_solve_placed_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch,
+                                     const qlamd_placement *placement, double *joint_effort, double *contact_force,
+                                     int32_t *status, int memory, void *stream);
+int qlamd_force_distribution_placed_batch(qlamd_context *ctx, const double *joint_position, const double *base_orientation,
+                                          const uint8_t *support_leg, const double *surface_normal,
+                                          const double *virtual_wrench, int64_t batch, const qlamd_placement *placement,
+                                          double *joint_effort, double *contact_force, int32_t *status, int memory,
+                                          void *stream);
+/* The placement on its own: iterations [B] in (any counts: only their order matters; negative counts count as 0, counts
+ * above 23 as 23), robot_order [B] out.  A stable counting sort on the device (ties by robot index: the result is a
+ * function of the counts alone); 6 us at 4096 robots, 26 us at 65 536. */
+int qlamd_placement_from_iterations(qlamd_context *ctx, const int32_t *iterations, int64_t batch, int policy,
+                                    int32_t *robot_order, int memory, void *stream);
 
 /* ---- swing-leg torque ----------------------------------------------------
  * Replaces MyRobotSolver::update (single_leg_test/lib/model_test_header.cpp:412-503) for the legs

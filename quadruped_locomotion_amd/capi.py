@@ -28,7 +28,8 @@ EXPORTS = (
     "qlamd_joint_pid_default_params", "qlamd_swing_branch_batch",
     "qlamd_wholebody_default_params", "qlamd_wholebody_dynamics_batch", "qlamd_wholebody_solve_batch",
     "qlamd_full_tick_batch", "qlamd_set_option", "qlamd_tick_command_bytes", "qlamd_weighted_lsq_qp_batch",
-    "qlamd_reserve",
+    "qlamd_reserve", "qlamd_balance_solve_placed_batch", "qlamd_force_distribution_placed_batch",
+    "qlamd_placement_from_iterations",
 )
 
 
@@ -42,6 +43,12 @@ class BalanceParams(C.Structure):
         ("gravity", C.c_double), ("grav_comp_percentage", C.c_double),
         ("com_in_base", C.c_double * 3), ("hip_in_base", (C.c_double * 3) * 4),
     ]
+
+
+class Placement(C.Structure):
+    """qlamd_placement"""
+    _fields_ = [("robot_order", C.c_void_p), ("iterations", C.c_void_p), ("prev_iterations", C.c_void_p),
+                ("next_robot_order", C.c_void_p), ("policy", C.c_int)]
 
 
 class RobotModel(C.Structure):
@@ -193,6 +200,13 @@ def lib():
             L.qlamd_reserve.argtypes = [C.c_void_p, C.c_int64]
         L.qlamd_balance_solve_batch.argtypes = [C.c_void_p, C.POINTER(StateBatch), C.c_int64, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        if hasattr(L, "qlamd_balance_solve_placed_batch"):
+            L.qlamd_balance_solve_placed_batch.argtypes = [C.c_void_p, C.POINTER(StateBatch), C.c_int64, C.POINTER(Placement),
+                                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+            L.qlamd_force_distribution_placed_batch.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.POINTER(Placement)] + [
+                C.c_void_p] * 3 + [C.c_int, C.c_void_p]
+            L.qlamd_placement_from_iterations.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int,
+                                                          C.c_void_p]
         L.qlamd_virtual_wrench_batch.argtypes = [C.c_void_p, C.POINTER(StateBatch), C.c_int64, C.c_void_p,
                                                  C.c_int, C.c_void_p]
         L.qlamd_leg_kinematics_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
@@ -344,6 +358,77 @@ class Context:
         if rc != OK:
             raise QlamdError(rc, "qlamd_balance_solve_batch")
 
+    def balance_solve_placed_device(self, dstate, tau, grf, status, order=None, iterations=None, prev_iterations=None,
+                                    next_order=None, policy=0, stream=None):
+        """qlamd_balance_solve_placed_batch on torch CUDA tensors: order = int32 [B] permutation (slot -> robot) or None,
+        iterations = int32 [B] output or None; prev_iterations / next_order = the counts of the previous call and the
+        placement for the next one (both or neither).  Asynchronous."""
+        sb = StateBatch()
+        B = dstate["q"].shape[0]
+        for key, field, _ in FIELD_OF_KEY:
+            setattr(sb, field, dstate[key].data_ptr())
+        sb.support_leg = dstate["stance"].data_ptr()
+        if dstate.get("normals") is not None:
+            sb.surface_normal = dstate["normals"].data_ptr()
+        for name, t in (("order", order), ("iterations", iterations), ("prev_iterations", prev_iterations), ("next_order", next_order)):
+            if t is not None and (str(t.dtype) != "torch.int32" or t.numel() != B or not t.is_contiguous()):
+                raise ValueError("%s must be a contiguous int32 tensor of %d elements" % (name, B))
+        pl = Placement(_ptr(order), _ptr(iterations), _ptr(prev_iterations), _ptr(next_order), int(policy))
+        rc = lib().qlamd_balance_solve_placed_batch(self._h, C.byref(sb), B, C.byref(pl), tau.data_ptr(),
+                                                    grf.data_ptr() if grf is not None else None, status.data_ptr(),
+                                                    MEM_DEVICE, C.c_void_p(stream) if stream else None)
+        if rc != OK:
+            raise QlamdError(rc, "qlamd_balance_solve_placed_batch")
+
+    def balance_solve_placed_host(self, state, order=None, normals=None, want_forces=True, prev_iterations=None, policy=0):
+        """qlamd_balance_solve_placed_batch with host (numpy) buffers -> (tau, grf, status, iterations[, next_order])."""
+        B = int(np.asarray(state["q"]).reshape(-1, 12).shape[0])
+        sb, keep = StateBatch(), []
+        for key, field, k in FIELD_OF_KEY:
+            a = np.ascontiguousarray(np.asarray(state[key], dtype=np.float64).reshape(B, k))
+            keep.append(a)
+            setattr(sb, field, a.ctypes.data)
+        st = np.ascontiguousarray(np.asarray(state["stance"], dtype=np.uint8).reshape(B, 4))
+        sb.support_leg = st.ctypes.data
+        if normals is not None:
+            nw = np.ascontiguousarray(np.asarray(normals, dtype=np.float64).reshape(B, 12))
+            keep.append(nw)
+            sb.surface_normal = nw.ctypes.data
+        if order is not None:
+            order = np.ascontiguousarray(np.asarray(order, dtype=np.int32).reshape(B))
+        nxt = None
+        if prev_iterations is not None:
+            prev_iterations = np.ascontiguousarray(np.asarray(prev_iterations, dtype=np.int32).reshape(B))
+            nxt = np.full(B, -1, dtype=np.int32)
+        tau = np.zeros((B, 12))
+        grf = np.zeros((B, 12)) if want_forces else None
+        status = np.full(B, -1, dtype=np.int32)
+        iters = np.full(B, -1, dtype=np.int32)
+        pl = Placement(_ptr(order), iters.ctypes.data, _ptr(prev_iterations), _ptr(nxt), int(policy))
+        rc = lib().qlamd_balance_solve_placed_batch(self._h, C.byref(sb), B, C.byref(pl), tau.ctypes.data,
+                                                    grf.ctypes.data if want_forces else None, status.ctypes.data, MEM_HOST, None)
+        if rc != OK:
+            raise QlamdError(rc, "qlamd_balance_solve_placed_batch")
+        return (tau, grf, status, iters) if nxt is None else (tau, grf, status, iters, nxt)
+
+    def placement_from_iterations(self, iterations, order=None, policy=0, stream=None):
+        """qlamd_placement_from_iterations: numpy int32 [B] -> numpy order (synchronous), or torch int32 CUDA tensors
+        (order preallocated, asynchronous on `stream`)."""
+        if hasattr(iterations, "data_ptr"):
+            B = iterations.numel()
+            if order is None or str(order.dtype) != "torch.int32" or order.numel() != B or str(iterations.dtype) != "torch.int32":
+                raise ValueError("device memory: pass int32 tensors iterations and order of equal length")
+            rc = lib().qlamd_placement_from_iterations(self._h, iterations.data_ptr(), B, int(policy), order.data_ptr(),
+                                                       MEM_DEVICE, C.c_void_p(stream) if stream else None)
+        else:
+            it = np.ascontiguousarray(np.asarray(iterations, dtype=np.int32).reshape(-1))
+            B = it.shape[0]
+            order = np.full(B, -1, dtype=np.int32)
+            rc = lib().qlamd_placement_from_iterations(self._h, it.ctypes.data, B, int(policy), order.ctypes.data, MEM_HOST, None)
+        if rc != OK:
+            raise QlamdError(rc, "qlamd_placement_from_iterations")
+        return order
+
     def virtual_wrench_device(self, dstate, wrench, stream=None):
         sb = StateBatch()
         for key, field, _ in FIELD_OF_KEY:
@@ -418,6 +503,8 @@ def force_distribution(ctx, q, quat, support, wrench, normals=None, memory=MEM_H
     B = q.shape[0]
     if memory == MEM_HOST:
         tau, grf = _host_out(tau, B, "tau"), _host_out(grf, B, "grf")
+    elif tau is None or grf is None:
+        raise ValueError("device memory: pass preallocated tau / grf tensors")
     st = np.full(B, -1, dtype=np.int32)
     rc = lib().qlamd_force_distribution_batch(ctx._h, _ptr(q), _ptr(quat), _ptr(support), _ptr(normals), _ptr(wrench), B,
                                               _ptr(tau), _ptr(grf), _ptr(st), memory, None)
@@ -763,6 +850,7 @@ def wholebody_dynamics_device(ctx, dstate, M, h, Jc, gravity=9.81, stream=None):
 OPT_ON_FAILURE, OPT_REFINE_PASSES, OPT_DYNAMICS_FORM = 1, 2, 5
 DYNAMICS_AUTO, DYNAMICS_LEG, DYNAMICS_ROW = 0, 1, 2
 ON_FAILURE_ZERO, ON_FAILURE_KEEP = 0, 1
+PLACEMENT_AUTO, PLACEMENT_LATENCY, PLACEMENT_THROUGHPUT = 0, 1, 2
 STATUS_NO_COMMAND = 4
 STATUS_DEPENDENT_EQUALITY = 5
 

@@ -35,6 +35,7 @@ struct CoopPtrs {
   const double *wrench; // [B][6] or NULL: externally supplied (F_B, T_B)
   const uint8_t *live;  // [B] or NULL: 0 = leave this robot alone (whole tick: no command in force), nothing is written
   int support_only;     // whole tick: write the efforts of the support legs only (the swing branch owns the others)
+  int32_t *iterations;  // [B] or NULL: outer iterations of each robot's QP (a placement hint for the next control step)
 };
 
 // One robot per 16-lane row.  lds_tab: 256-double model table; lds_row: this robot's private
@@ -307,9 +308,10 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   Q.mu = mu; Q.f_min = f_min;
   Q.on = on; Q.comp = comp; Q.nS = nS; Q.refine_passes = P.refine_passes;
   double x;
-  const int status = force_qp_coop<false>(Q, lds_row, lds_nrm, x);
+  int qp_iters;
+  const int status = force_qp_coop<false>(Q, lds_row, lds_nrm, x, qp_iters);
   if (status == kStatusNotPd) {
-    if (lr == 0 && robot_live) status_out[i] = kStatusNotPd;
+    if (lr == 0 && robot_live) { status_out[i] = kStatusNotPd; if (s.iterations) s.iterations[i] = 0; }
     if (comp && robot_live && !P.keep_on_failure && (on || !s.support_only)) { tau_out[12 * i + myidx] = 0.0; if (grf_out) grf_out[12 * i + myidx] = 0.0; }
     return;
   }
@@ -335,7 +337,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       tau_out[12 * i + myidx] = live ? t : 0.0;
       if (grf_out) grf_out[12 * i + myidx] = live ? x : 0.0;
     }
-    if (lr == 0 && robot_live) status_out[i] = status;
+    if (lr == 0 && robot_live) { status_out[i] = status; if (s.iterations) s.iterations[i] = qp_iters; }
   }
   QL_STAMP(9);
   QL_STAMP(10);

@@ -17,6 +17,12 @@ struct StatePtrs {
   const uint8_t *live;  // [B] or NULL: 0 = robot left alone (nothing written)
   int support_only;     // whole tick: only the support legs' efforts are written (the swing branch, which writes the
                         // others, runs beside this kernel on another stream)
+  const int32_t *order; // [B] or NULL: slot s of the launch (row s % 4 of wavefront s / 4) takes robot order[s]
+  int32_t *iterations;  // [B] or NULL: outer iterations of each robot's QP
+  // the placement of the NEXT launch, made by one extra wavefront in the shadow of this one (placement_wave below)
+  const int32_t *prev_iterations; // [B]: the counts it is made from (the previous launch's `iterations`)
+  int32_t *next_order;            // [B] or NULL: where it goes
+  int place_throughput;           // policy: 0 latency, 1 throughput
 };
 
 __device__ __forceinline__ void load_robot(const StatePtrs &s, int64_t i, RobotIn &in) {
@@ -134,6 +140,207 @@ __global__ __launch_bounds__(64) void balance_step_kernel(const DeviceParams *__
   }
 }
 
+// Placement of the robots into the slots of the next launch from the iteration counts of the last one
+// (qlamd_placement_from_iterations): a stable counting sort by iteration count, hardest first (ties by robot index), then
+// the slot of each rank by policy:
+//   throughput  slot = rank: four neighbours of the sorted list share a wavefront.  The union of four similar add / drop
+//               sequences is the shortest there is, which is what counts once every SIMD holds several wavefronts, and the
+//               long wavefronts start first.
+//   latency     the hardest quarter one per wavefront (row 0 of wavefront r = rank r), each joined by the three easiest
+//               robots still to be had (rank B-1-e sits in row 1 + e % 3 of wavefront e / 3): a launch of one wavefront
+//               per SIMD lasts as long as its slowest wavefront, and next to three robots that finish early a hard robot
+//               runs at the speed it has alone (finished rows ride along as ghost rows, force_qp_coop.hpp).
+// It sits between two control steps of a caller that wants the hint used at once, so it is built for latency: one
+// workgroup of 1024 lanes takes 1024 G consecutive robots, robot g * 1024 + lane in its round g.  A robot's ordinal among
+// the robots of its wavefront and round with the same count is the return value of ONE LDS atomic on the counter
+// [bin][round][wavefront] (the lanes of one instruction that meet on an address are served in lane order); an exclusive
+// scan over the 512 G counters in (bin, round, wavefront) order turns them into first ranks; rank -> slot -> one store.
+// Batches beyond 4096 robots take several workgroups, which need the counts of the other workgroups per bin: a first
+// launch (placement_hist_kernel) leaves them in the context's scratch.
+constexpr int kPlaceThreads = 1024, kPlaceWaves = kPlaceThreads / 64, kPlaceBins = 24, kPlaceRounds = 4;
+__device__ __forceinline__ int place_bin(int v) { // bin 0 = hardest (the clamp compiles to one v_med3_i32)
+  const int h = v < 0 ? 0 : (v >= kPlaceBins ? kPlaceBins - 1 : v);
+  return kPlaceBins - 1 - h;
+}
+__global__ __launch_bounds__(kPlaceThreads) void placement_hist_kernel(const int32_t *__restrict__ iters, int64_t B, int64_t per_block,
+                                                                      uint32_t *__restrict__ blockhist) {
+  __shared__ uint32_t h[kPlaceBins];
+  if (threadIdx.x < kPlaceBins) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t lo = (int64_t)blockIdx.x * per_block, hi = lo + per_block < B ? lo + per_block : B;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kPlaceThreads) atomicAdd(&h[place_bin(iters[i])], 1u);
+  __syncthreads();
+  if (threadIdx.x < kPlaceBins) blockhist[(int64_t)blockIdx.x * kPlaceBins + threadIdx.x] = h[threadIdx.x];
+}
+template <int G>
+__global__ __launch_bounds__(kPlaceThreads) void placement_kernel(const int32_t *__restrict__ iters, int64_t B, int throughput,
+                                                                 const uint32_t *__restrict__ blockhist, int32_t *__restrict__ order) {
+  constexpr int kN = kPlaceBins * G * kPlaceWaves, kPer = (kN + kPlaceThreads - 1) / kPlaceThreads; // counters, counters per lane in the scan
+  __shared__ uint32_t cnt[kN];
+  __shared__ uint32_t wtot[kPlaceWaves];
+  __shared__ uint32_t bin_base[kPlaceBins];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t first = (int64_t)blockIdx.x * (kPlaceThreads * G);
+  int v[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) { // all loads in flight before the first atomic
+    const int64_t i = first + g * kPlaceThreads + t;
+    v[g] = i < B ? place_bin(iters[i]) : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < kPer; k++)
+    if (t + k * kPlaceThreads < kN) cnt[t + k * kPlaceThreads] = 0;
+  __shared__ uint32_t tot[kPlaceBins], before[kPlaceBins];
+  if (gridDim.x > 1) {
+    // several workgroups: robots of the harder bins anywhere, and of my bin in the workgroups before mine
+    if (t < kPlaceBins) { tot[t] = 0; before[t] = 0; }
+    __syncthreads();
+    for (unsigned e = t; e < gridDim.x * kPlaceBins; e += kPlaceThreads) {
+      const unsigned blk = e / kPlaceBins, b = e - blk * kPlaceBins;
+      const uint32_t c = blockhist[e];
+      atomicAdd(&tot[b], c);
+      if (blk < blockIdx.x) atomicAdd(&before[b], c);
+    }
+    __syncthreads();
+    if (t < kPlaceBins) {
+      uint32_t harder = 0;
+      for (int b = 0; b < kPlaceBins; b++) harder += b < t ? tot[b] : 0u;
+      bin_base[t] = harder + before[t];
+    }
+  }
+  __syncthreads();
+  uint32_t ord[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) ord[g] = v[g] >= 0 ? atomicAdd(&cnt[(v[g] * G + g) * kPlaceWaves + wave], 1u) : 0u;
+  __syncthreads();
+  // exclusive scan of the counters in place: kPer consecutive counters per lane, then lanes, then wavefronts
+  uint32_t c[kPer], mine = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) { c[k] = t * kPer + k < kN ? cnt[t * kPer + k] : 0u; mine += c[k]; }
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(incl, d, 64);
+    incl += lane >= d ? o : 0u;
+  }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  uint32_t run = incl - mine;
+#pragma unroll
+  for (int w = 0; w < kPlaceWaves; w++) run += w < wave ? wtot[w] : 0u;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    if (t * kPer + k < kN) cnt[t * kPer + k] = run;
+    run += c[k];
+  }
+  __syncthreads();
+  const int64_t W = (B + 3) / 4;
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    if (v[g] < 0) continue;
+    int64_t r = cnt[(v[g] * G + g) * kPlaceWaves + wave] + ord[g];
+    if (gridDim.x > 1) r += (int64_t)bin_base[v[g]] - cnt[v[g] * G * kPlaceWaves]; // my workgroup's harder bins come off
+    int64_t slot = r;
+    if (!throughput) {
+      const int64_t e = B - 1 - r;
+      slot = r < W ? 4 * r : 4 * (e / 3) + 1 + e % 3;
+    }
+    order[slot] = (int32_t)(first + g * kPlaceThreads + t);
+  }
+}
+
+// The same placement by ONE wavefront, for the extra workgroup a placed launch carries when the caller asks for the next
+// launch's placement (qlamd_placement::next_robot_order): it runs in the shadow of the solve -- a launch of a few thousand
+// robots lasts 13-24 us, this wavefront 13 us at 4096 robots and 22 at 8192 -- instead of as a launch of its own between two
+// control steps (6-9 us).  Rounds of 64 robots; counters [bin][round] in the workgroup's LDS (the solve's 13 056 bytes: up
+// to kShadowMaxRobots robots).  Pass 1 counts (LDS atomics without a return value), an exclusive scan in (bin, round)
+// order turns the counters into first ranks, pass 2 takes each robot's rank as the return value of one more atomic on its
+// counter (lanes that meet on a counter are served in lane order: rank order = index order within a count).
+// A lone wavefront issues one instruction per ~5.5 cycles and waits out every memory round trip, so the loop bodies are
+// counted in instructions (32-bit index arithmetic, the division by 3 as a multiplication, one clamp per count),
+// kShadowChunk rounds have their loads in flight together, and the last, ragged rounds are the only ones that check
+// indices.  Measured and dropped (profiles/r5/placed_probe.txt): ONE atomic pass whose return values are kept until the
+// scan is done -- in registers (13 000 instructions of unrolled code), as bytes in LDS (16 us at 4096 robots: sub-word LDS
+// stores) or as words of four rounds (14.6 us, and 16 KB of LDS per workgroup cost every placed launch 0.3 us).
+constexpr int kShadowLdsBytes = (4 * kTabPerLeg + 4 * coop::kCoopLdsDoubles + coop::kCoopNrmDoubles) * 8;
+constexpr int kShadowMaxRounds = kShadowLdsBytes / (kPlaceBins * 4);
+constexpr int64_t kShadowMaxRobots = 64 * (int64_t)kShadowMaxRounds;
+constexpr int kShadowChunk = 32;
+typedef __attribute__((address_space(3))) uint32_t lds_u32; // (a generic pointer would turn the atomics into flat ones)
+template <bool kThroughput>
+__device__ __forceinline__ uint32_t place_slot(uint32_t rk, uint32_t B, uint32_t W) {
+  if constexpr (kThroughput) return rk;
+  const uint32_t e = B - 1u - rk, q = __umulhi(e, 0xAAAAAAABu) >> 1; // e / 3
+  return rk < W ? 4u * rk : 4u * q + 1u + (e - 3u * q);
+}
+__device__ __forceinline__ void placement_wave(const int32_t *__restrict__ iters, int64_t B64, int throughput,
+                                               int32_t *__restrict__ order, lds_u32 *cnt) {
+  const uint32_t lane = threadIdx.x & 63u, B = (uint32_t)B64, W = (B + 3u) >> 2;
+  const uint32_t R = (B + 63u) >> 6, full = B >> 6, N = kPlaceBins * R; // rounds, rounds without a missing robot, counters
+  for (uint32_t k = lane; k < N; k += 64) cnt[k] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  const auto counter = [&](int v, uint32_t r) -> lds_u32 * { return cnt + (uint32_t)place_bin(v) * R + r; };
+  // ---- pass 1: count
+  for (uint32_t r0 = 0; r0 < R; r0 += kShadowChunk) {
+    if (r0 + kShadowChunk <= full) {
+      int v[kShadowChunk];
+#pragma unroll
+      for (int k = 0; k < kShadowChunk; k++) v[k] = iters[(r0 + k) * 64u + lane];
+#pragma unroll
+      for (int k = 0; k < kShadowChunk; k++)
+        (void)__hip_atomic_fetch_add(counter(v[k], r0 + k), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      for (uint32_t r = r0; r < R && r < r0 + kShadowChunk; r++) {
+        const uint32_t i = r * 64u + lane;
+        if (i < B) (void)__hip_atomic_fetch_add(counter(iters[i], r), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // ---- exclusive scan in (bin, round) order: `per` consecutive counters per lane
+  {
+    const uint32_t per = (N + 63u) >> 6, k0 = lane * per, k1 = k0 + per < N ? k0 + per : N;
+    uint32_t mine = 0;
+    for (uint32_t k = k0; k < k1; k++) mine += cnt[k];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d, 64);
+      incl += lane >= (uint32_t)d ? o : 0u;
+    }
+    uint32_t run = incl - mine;
+    for (uint32_t k = k0; k < k1; k++) { const uint32_t c = cnt[k]; cnt[k] = run; run += c; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // ---- pass 2: a robot's rank is what one more atomic on its counter returns
+  const auto pass2 = [&](auto Thr) {
+    constexpr bool kThr = decltype(Thr)::value;
+    for (uint32_t r0 = 0; r0 < R; r0 += kShadowChunk) {
+      if (r0 + kShadowChunk <= full) {
+        int v[kShadowChunk];
+        uint32_t rk[kShadowChunk];
+#pragma unroll
+        for (int k = 0; k < kShadowChunk; k++) v[k] = iters[(r0 + k) * 64u + lane];
+#pragma unroll
+        for (int k = 0; k < kShadowChunk; k++)
+          rk[k] = __hip_atomic_fetch_add(counter(v[k], r0 + k), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int k = 0; k < kShadowChunk; k++) order[place_slot<kThr>(rk[k], B, W)] = (int32_t)((r0 + k) * 64u + lane);
+      } else {
+        for (uint32_t r = r0; r < R && r < r0 + kShadowChunk; r++) {
+          const uint32_t i = r * 64u + lane;
+          if (i < B) {
+            const uint32_t rk = __hip_atomic_fetch_add(counter(iters[i], r), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            order[place_slot<kThr>(rk, B, W)] = (int32_t)i;
+          }
+        }
+      }
+    }
+  };
+  if (throughput) pass2(std::true_type{});
+  else pass2(std::false_type{});
+}
+
 // Latency form: 16 lanes per robot, 4 robots per wavefront (balance_coop.hpp), kCoopWaves wavefronts per workgroup.
 // One wavefront per workgroup is the measured optimum: four (one workgroup per compute unit, the model table in LDS
 // shared) costs 2.3 us at 4096 robots and 20 % at 65536 -- the barrier behind the table ties the start of four
@@ -146,20 +353,41 @@ constexpr int kCoopWaves = 1;
 // latency form, 3 (at most 168 registers; 12 wavefronts x 13 056 bytes of LDS fit a compute unit) for the throughput form
 // that large batches take (QLAMD_THROUGHPUT_BATCH): two wavefronts of dependent instruction streams cannot fill a SIMD's
 // issue port (2 x one instruction per 5.5 cycles against one per 4), three can.
-template <bool kPerLeg, int kMinWaves>
+// kPlaced: the caller says which robot sits in which slot of the launch (qlamd_balance_solve_placed_batch): the four robots
+// of a wavefront run in lockstep, so a wavefront lasts as long as the union of their passes, and a launch of a few
+// thousand robots as long as its slowest wavefront -- WHO shares a wavefront decides both.  The slot's
+// robot index is one more load in front of the robot's own (a dependent round trip at the head of the launch), which is
+// why the plain entry keeps a kernel without it.  An entry outside [0, B) leaves its row empty.
+template <bool kPerLeg, int kMinWaves, bool kPlaced = false>
 __global__ __launch_bounds__(64 * kCoopWaves, kMinWaves) void balance_coop_kernel(const DeviceParams *__restrict__ Pp, const StatePtrs s,
                                                                       int64_t B, double *__restrict__ tau,
                                                                       double *__restrict__ grf, int32_t *__restrict__ status) {
-  __shared__ double tab[4 * kTabPerLeg];
-  __shared__ double rows[4 * kCoopWaves * coop::kCoopLdsDoubles];
-  __shared__ double nrm[kCoopWaves * coop::kCoopNrmDoubles];
+  constexpr bool kShadow = kPlaced && kMinWaves == 2; // (batches of the three-wavefront form are beyond kShadowMaxRobots)
+  __shared__ double lds[4 * kTabPerLeg + 4 * kCoopWaves * coop::kCoopLdsDoubles + kCoopWaves * coop::kCoopNrmDoubles];
+  static_assert(sizeof(lds) >= kShadowLdsBytes || kCoopWaves != 1, "the shadow wavefront's counters live in the solve's LDS");
+  double *tab = lds, *rows = lds + 4 * kTabPerLeg, *nrm = rows + 4 * kCoopWaves * coop::kCoopLdsDoubles;
   const DeviceParams &P = *Pp;
   const int row = threadIdx.x >> 4, wave = threadIdx.x >> 6;
-  int64_t i = (int64_t)blockIdx.x * (4 * kCoopWaves) + row;
-  const bool live = i < B;
+  unsigned block = blockIdx.x;
+  if constexpr (kShadow) {
+    // the first workgroup of a launch that also places the next one (it starts first and has the whole launch to finish in)
+    if (s.next_order) {
+      if (block == 0) { placement_wave(s.prev_iterations, B, s.place_throughput, s.next_order, (lds_u32 *)lds); return; }
+      block -= 1;
+    }
+  }
+  int64_t i = (int64_t)block * (4 * kCoopWaves) + row;
+  bool live = i < B;
   if (!live) i = B - 1;
+  if constexpr (kPlaced) {
+    if (s.order) {
+      const int64_t o = s.order[i];
+      live = live && o >= 0 && o < B;
+      i = live ? o : B - 1;
+    }
+  }
   const coop::CoopPtrs cp{s.q, s.pos, s.quat, s.linvel, s.angvel, s.dpos, s.dquat, s.dlinvel, s.dangvel, s.stance,
-                          s.normals, s.wrench, s.live, s.support_only};
+                          s.normals, s.wrench, s.live, s.support_only, kPlaced ? s.iterations : nullptr};
 #ifdef QLAMD_STAMPS
 #pragma unroll 1
   for (int rep = 0; rep < 2; rep++) // second pass runs with a warm instruction cache
@@ -303,6 +531,8 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
   ctx->wire_flip = 0;
   ctx->tick_ws = nullptr;
   ctx->tick_ws_bytes = 0;
+  ctx->place_ws = nullptr;
+  ctx->place_ws_bytes = 0;
   ctx->on_failure = QLAMD_ON_FAILURE_ZERO;
   ctx->dynamics_form = QLAMD_DYNAMICS_AUTO;
   ctx->depth = 0;
@@ -324,12 +554,17 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
     ctx->base_I[5] = I[5] + bm * (cc - c[2] * c[2]);
   }
   ctx->d_params = nullptr;
+  // (the placement scratch for batches up to 1 M robots comes with the context: 24 KB, and no placement call of a
+  // sensible size ever has to allocate inside a stream capture)
+  const size_t place_bytes = (size_t)256 * kPlaceBins * sizeof(uint32_t);
   if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&ctx->d_params, sizeof(DeviceParams)) != hipSuccess ||
-      hipMemcpy(ctx->d_params, &ctx->params, sizeof(DeviceParams), hipMemcpyHostToDevice) != hipSuccess) {
+      hipMemcpy(ctx->d_params, &ctx->params, sizeof(DeviceParams), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMalloc(&ctx->place_ws, place_bytes) != hipSuccess) {
     if (ctx->d_params) (void)hipFree(ctx->d_params);
     delete ctx;
     return QLAMD_ERR_HIP;
   }
+  ctx->place_ws_bytes = place_bytes;
   *out = ctx;
   return QLAMD_OK;
 }
@@ -341,6 +576,7 @@ void qlamd_context_destroy(qlamd_context *ctx) {
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->wire_tpl) (void)hipFree(ctx->wire_tpl);
   if (ctx->tick_ws) (void)hipFree(ctx->tick_ws);
+  if (ctx->place_ws) (void)hipFree(ctx->place_ws);
   if (ctx->d_params) (void)hipFree(ctx->d_params);
   if (ctx->done_event) (void)hipEventDestroy(ctx->done_event);
   delete ctx;
@@ -381,10 +617,64 @@ int qlamd_set_option(qlamd_context *ctx, int option, int value) {
 } // extern "C"
 
 // live: device pointer [B] or NULL (whole tick, QLAMD_MEM_DEVICE only): robots with 0 are left alone
+namespace {
+// qlamd_placement_from_iterations on device pointers (the caller holds the context's guard)
+int launch_placement(qlamd_context *ctx, const int32_t *d_it, int64_t batch, int throughput, int32_t *d_ord, hipStream_t st) {
+  if (batch <= kPlaceRounds * kPlaceThreads)
+    hipLaunchKernelGGL(placement_kernel<kPlaceRounds>, dim3(1), dim3(kPlaceThreads), 0, st, d_it, batch, throughput, nullptr, d_ord);
+  else {
+    // several workgroups (the LDS atomics of one compute unit serve about one robot per cycle: 4096 robots per workgroup
+    // keep a launch at 3-4 us whatever the batch): their counts per bin go through the context's placement scratch
+    // (sized for 1 M robots when the context is created; growing it is an allocation, which a stream capture cannot take)
+    const int64_t per_block = (int64_t)kPlaceRounds * kPlaceThreads;
+    const unsigned nb = (unsigned)((batch + per_block - 1) / per_block);
+    const size_t need = (size_t)nb * kPlaceBins * sizeof(uint32_t);
+    if (ctx->place_ws_bytes < need) {
+      if (CallGuard::capturing(st)) return QLAMD_ERR_NEEDS_RESERVE;
+      if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
+      if (ctx->place_ws) (void)hipFree(ctx->place_ws);
+      ctx->place_ws = nullptr;
+      ctx->place_ws_bytes = 0;
+      if (hipMalloc(&ctx->place_ws, need) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;
+      ctx->place_ws_bytes = need;
+    }
+    hipLaunchKernelGGL(placement_hist_kernel, dim3(nb), dim3(kPlaceThreads), 0, st, d_it, batch, per_block, (uint32_t *)ctx->place_ws);
+    hipLaunchKernelGGL(placement_kernel<kPlaceRounds>, dim3(nb), dim3(kPlaceThreads), 0, st, d_it, batch, throughput,
+                       (const uint32_t *)ctx->place_ws, d_ord);
+  }
+  return hipGetLastError() == hipSuccess ? QLAMD_OK : QLAMD_ERR_HIP;
+}
+bool throughput_policy(int policy, int64_t batch) {
+  return policy == QLAMD_PLACEMENT_THROUGHPUT || (policy == QLAMD_PLACEMENT_AUTO && batch >= QLAMD_THROUGHPUT_BATCH);
+}
+} // namespace
+
+// pl: the placed entries' arrays (NULL otherwise), in the memory space of the call
 int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, const double *wrench, const uint8_t *live, int support_only,
                             int64_t batch, double *joint_effort, double *contact_force, int32_t *status, int memory,
-                            void *stream) {
+                            void *stream, const qlamd_placement *pl) {
   if (!ctx || !in_user || batch < 0 || !joint_effort || !status) return QLAMD_ERR_INVALID_ARGUMENT;
+  const int32_t *order = pl ? pl->robot_order : nullptr;
+  int32_t *iterations = pl ? pl->iterations : nullptr;
+  const int32_t *prev_iterations = pl ? pl->prev_iterations : nullptr;
+  int32_t *next_order = pl ? pl->next_robot_order : nullptr;
+  if ((prev_iterations != nullptr) != (next_order != nullptr)) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (next_order && pl->policy != QLAMD_PLACEMENT_AUTO && pl->policy != QLAMD_PLACEMENT_LATENCY && pl->policy != QLAMD_PLACEMENT_THROUGHPUT)
+    return QLAMD_ERR_INVALID_ARGUMENT;
+  if (next_order && (next_order == order || prev_iterations == iterations)) return QLAMD_ERR_INVALID_ARGUMENT; // read and written by one launch
+  const bool placed = order || iterations || next_order;
+  // the one-lane kernels of qlamd_set_robots_per_wave know no placement (a lane is a robot there: nothing is shared)
+  if (placed && pick_rpw(ctx, batch) != 4) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (placed && batch > INT32_MAX) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (order && memory == QLAMD_MEM_HOST) {
+    // host memory can be checked: every robot exactly once
+    std::vector<uint8_t> seen((size_t)batch, 0);
+    for (int64_t k = 0; k < batch; k++) {
+      const int32_t o = order[k];
+      if (o < 0 || o >= batch || seen[(size_t)o]) return QLAMD_ERR_INVALID_ARGUMENT;
+      seen[(size_t)o] = 1;
+    }
+  }
   qlamd_state_batch filled = *in_user;
   const qlamd_state_batch *in = &filled;
   if (!filled.joint_position || !filled.base_orientation || !filled.support_leg) return QLAMD_ERR_INVALID_ARGUMENT;
@@ -421,11 +711,13 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
                            in->base_linear_velocity, in->base_angular_velocity, in->desired_position,
                            in->desired_orientation, in->desired_linear_velocity,
                            in->desired_angular_velocity, in->support_leg, in->surface_normal, wrench};
-    size_t off[15], total = 0;
+    size_t off[17], total = 0;
     for (int k = 0; k < 12; k++) { off[k] = total; total += align256(sz[k]); }
+    off[15] = total; total += align256(order ? B * 4 : 0);
     off[12] = total; total += align256(B * 96);
     off[13] = total; total += align256(B * 96);
     off[14] = total; total += align256(B * 4);
+    off[16] = total; total += align256(iterations ? B * 4 : 0);
     int rc = ensure_ws(ctx, total);
     if (rc != QLAMD_OK) return rc;
     char *w = (char *)ctx->ws;
@@ -441,6 +733,7 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
       char *h = (char *)ctx->pinned;
       for (int k = 0; k < 12; k++)
         if (sz[k]) memcpy(h + off[k], src[k], sz[k]);
+      if (order) memcpy(h + off[15], order, B * 4);
       if (keep) {
         memcpy(h + off[12], joint_effort, B * 96);
         if (contact_force) memcpy(h + off[13], contact_force, B * 96);
@@ -450,6 +743,7 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
       for (int k = 0; k < 12; k++)
         if (sz[k] && hipMemcpyAsync(w + off[k], src[k], sz[k], hipMemcpyHostToDevice, st) != hipSuccess)
           return QLAMD_ERR_HIP;
+      if (order && hipMemcpyAsync(w + off[15], order, B * 4, hipMemcpyHostToDevice, st) != hipSuccess) return QLAMD_ERR_HIP;
       if (keep) {
         if (hipMemcpyAsync(w + off[12], joint_effort, B * 96, hipMemcpyHostToDevice, st) != hipSuccess) return QLAMD_ERR_HIP;
         if (contact_force && hipMemcpyAsync(w + off[13], contact_force, B * 96, hipMemcpyHostToDevice, st) != hipSuccess)
@@ -460,7 +754,9 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
                   (const double *)(w + off[3]), (const double *)(w + off[4]), (const double *)(w + off[5]),
                   (const double *)(w + off[6]), (const double *)(w + off[7]), (const double *)(w + off[8]),
                   (const uint8_t *)(w + off[9]), in->surface_normal ? (const double *)(w + off[10]) : nullptr,
-                  wrench ? (const double *)(w + off[11]) : nullptr, nullptr, 0};
+                  wrench ? (const double *)(w + off[11]) : nullptr, nullptr, 0,
+                  order ? (const int32_t *)(w + off[15]) : nullptr, iterations ? (int32_t *)(w + off[16]) : nullptr,
+                  nullptr, nullptr, 0};
     d_tau = (double *)(w + off[12]);
     d_grf = contact_force ? (double *)(w + off[13]) : nullptr;
     d_status = (int32_t *)(w + off[14]);
@@ -468,22 +764,33 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
     s = StatePtrs{in->joint_position, in->base_position, in->base_orientation, in->base_linear_velocity,
                   in->base_angular_velocity, in->desired_position, in->desired_orientation,
                   in->desired_linear_velocity, in->desired_angular_velocity, in->support_leg,
-                  in->surface_normal, wrench, live, support_only};
+                  in->surface_normal, wrench, live, support_only, order, iterations, nullptr, nullptr, 0};
+    // the next launch's placement: by one more wavefront of this launch when its counters fit the workgroup's LDS
+    static_assert(kShadowMaxRobots < QLAMD_THROUGHPUT_BATCH, "the shadow wavefront exists in the two-wavefront form only");
+    if (next_order && batch <= kShadowMaxRobots) {
+      s.prev_iterations = prev_iterations;
+      s.next_order = next_order;
+      s.place_throughput = throughput_policy(pl->policy, batch) ? 1 : 0;
+    }
   }
 
   hipError_t e;
   switch (pick_rpw(ctx, batch)) {
     case 4: {
-      const unsigned grid = (unsigned)((batch + 4 * kCoopWaves - 1) / (4 * kCoopWaves));
-      if (s.normals)
-        hipLaunchKernelGGL((balance_coop_kernel<true, 2>), dim3(grid), dim3(64 * kCoopWaves), 0, st, ctx->d_params, s, batch,
-                           d_tau, d_grf, d_status);
-      else if (batch >= QLAMD_THROUGHPUT_BATCH)
-        hipLaunchKernelGGL((balance_coop_kernel<false, 3>), dim3(grid), dim3(64 * kCoopWaves), 0, st, ctx->d_params, s, batch,
-                           d_tau, d_grf, d_status);
-      else
-        hipLaunchKernelGGL((balance_coop_kernel<false, 2>), dim3(grid), dim3(64 * kCoopWaves), 0, st, ctx->d_params, s, batch,
-                           d_tau, d_grf, d_status);
+      const unsigned grid = (unsigned)((batch + 4 * kCoopWaves - 1) / (4 * kCoopWaves)) + (s.next_order ? 1u : 0u);
+#define QL_LAUNCH_COOP(PERLEG, WAVES)                                                                                        \
+  do {                                                                                                                       \
+    if (placed)                                                                                                              \
+      hipLaunchKernelGGL((balance_coop_kernel<PERLEG, WAVES, true>), dim3(grid), dim3(64 * kCoopWaves), 0, st, ctx->d_params, \
+                         s, batch, d_tau, d_grf, d_status);                                                                  \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((balance_coop_kernel<PERLEG, WAVES, false>), dim3(grid), dim3(64 * kCoopWaves), 0, st,              \
+                         ctx->d_params, s, batch, d_tau, d_grf, d_status);                                                   \
+  } while (0)
+      if (s.normals) QL_LAUNCH_COOP(true, 2);
+      else if (batch >= QLAMD_THROUGHPUT_BATCH) QL_LAUNCH_COOP(false, 3);
+      else QL_LAUNCH_COOP(false, 2);
+#undef QL_LAUNCH_COOP
       e = hipGetLastError();
       break;
     }
@@ -491,6 +798,10 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
     default: e = launch_balance<64>(ctx, s, batch, d_tau, d_grf, d_status, st); break;
   }
   if (e != hipSuccess) return QLAMD_ERR_HIP;
+  if (next_order && memory == QLAMD_MEM_DEVICE && !s.next_order) { // too many robots for the shadow wavefront: launches of their own
+    const int rc = launch_placement(ctx, prev_iterations, batch, throughput_policy(pl->policy, batch) ? 1 : 0, next_order, st);
+    if (rc != QLAMD_OK) return rc;
+  }
 
   if (memory == QLAMD_MEM_HOST && small_host) {
     char *h = (char *)ctx->pinned, *w = (char *)ctx->ws;
@@ -499,14 +810,18 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
     memcpy(joint_effort, h + ((char *)d_tau - w), B * 96);
     if (contact_force) memcpy(contact_force, h + ((char *)d_grf - w), B * 96);
     memcpy(status, h + ((char *)d_status - w), B * 4);
+    if (iterations) memcpy(iterations, h + ((char *)s.iterations - w), B * 4);
   } else if (memory == QLAMD_MEM_HOST) {
     if (hipMemcpyAsync(joint_effort, d_tau, B * 96, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
     if (contact_force &&
         hipMemcpyAsync(contact_force, d_grf, B * 96, hipMemcpyDeviceToHost, st) != hipSuccess)
       return QLAMD_ERR_HIP;
     if (hipMemcpyAsync(status, d_status, B * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
+    if (iterations && hipMemcpyAsync(iterations, s.iterations, B * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
   }
+  if (next_order && memory == QLAMD_MEM_HOST)
+    return qlamd_placement_from_iterations(ctx, prev_iterations, batch, pl->policy, next_order, QLAMD_MEM_HOST, stream);
   return QLAMD_OK;
 }
 
@@ -529,6 +844,51 @@ int qlamd_force_distribution_batch(qlamd_context *ctx, const double *joint_posit
   in.support_leg = support_leg;
   in.surface_normal = surface_normal;
   return balance_impl(ctx, &in, virtual_wrench, nullptr, 0, batch, joint_effort, contact_force, status, memory, stream);
+}
+
+int qlamd_balance_solve_placed_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch, const qlamd_placement *placement,
+                                     double *joint_effort, double *contact_force, int32_t *status, int memory, void *stream) {
+  return balance_impl(ctx, in, nullptr, nullptr, 0, batch, joint_effort, contact_force, status, memory, stream, placement);
+}
+
+int qlamd_force_distribution_placed_batch(qlamd_context *ctx, const double *joint_position, const double *base_orientation,
+                                          const uint8_t *support_leg, const double *surface_normal,
+                                          const double *virtual_wrench, int64_t batch, const qlamd_placement *placement,
+                                          double *joint_effort, double *contact_force, int32_t *status, int memory, void *stream) {
+  if (!virtual_wrench) return QLAMD_ERR_INVALID_ARGUMENT;
+  qlamd_state_batch in;
+  memset(&in, 0, sizeof(in));
+  in.joint_position = joint_position;
+  in.base_orientation = base_orientation;
+  in.support_leg = support_leg;
+  in.surface_normal = surface_normal;
+  return balance_impl(ctx, &in, virtual_wrench, nullptr, 0, batch, joint_effort, contact_force, status, memory, stream, placement);
+}
+
+int qlamd_placement_from_iterations(qlamd_context *ctx, const int32_t *iterations, int64_t batch, int policy,
+                                    int32_t *robot_order, int memory, void *stream) {
+  if (!ctx || !iterations || !robot_order || batch < 0 || batch > INT32_MAX) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (policy != QLAMD_PLACEMENT_AUTO && policy != QLAMD_PLACEMENT_LATENCY && policy != QLAMD_PLACEMENT_THROUGHPUT)
+    return QLAMD_ERR_INVALID_ARGUMENT;
+  if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return QLAMD_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  QL_ENTER(ctx, st);
+  const size_t B = (size_t)batch;
+  const int32_t *d_it = iterations;
+  int32_t *d_ord = robot_order;
+  Staged sg;
+  if (memory == QLAMD_MEM_HOST) {
+    const int a = sg.add(iterations, B * 4, true, false), o = sg.add(robot_order, B * 4, false, true);
+    const int rc = sg.upload(ctx, st);
+    if (rc != QLAMD_OK) return rc;
+    d_it = sg.dev<const int32_t>(a);
+    d_ord = sg.dev<int32_t>(o);
+  }
+  const int rc = launch_placement(ctx, d_it, batch, throughput_policy(policy, batch) ? 1 : 0, d_ord, st);
+  if (rc != QLAMD_OK) return rc;
+  return memory == QLAMD_MEM_HOST ? sg.finish(st) : QLAMD_OK;
 }
 
 int qlamd_virtual_wrench_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch, double *wrench,

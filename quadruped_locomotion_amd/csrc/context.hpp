@@ -8,6 +8,7 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <vector>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -24,6 +25,8 @@ struct qlamd_context {
   double base_m, base_h[3], base_I[6]; // base_link about the base origin (whole-body entries)
   void *tick_ws;       // intermediates of qlamd_full_tick_batch (grown on demand)
   size_t tick_ws_bytes;
+  void *place_ws;      // per-workgroup bin counts of qlamd_placement_from_iterations beyond 16 384 robots
+  size_t place_ws_bytes;
   uint32_t *wire_tpl;  // two layout templates of robot_state_unpack_kernel (read one, write the other), or NULL
   int wire_flip;
   // HOST-memory mode staging (grown on demand)
@@ -140,9 +143,11 @@ struct CallGuard {
     if (uses_stream) {
       // A call whose stream is being captured queues nothing now: it is invisible to the eager ordering state (the event
       // of the last eager call stays the one to wait for, and its stream the one compared with).
+      // (asked whenever the answer matters: not for a call on the stream of the last eager call of a one-stream context,
+      // whose state this leaves as it is either way)
       bool captured = false;
+      if (c->multi_stream || !c->had_work || st != c->last_stream) captured = capturing(st);
       if (c->multi_stream) {
-        captured = capturing(st);
         if (!captured) {
           // mark the end of this call's work for a later call on another stream
           if (!c->done_event && hipEventCreateWithFlags(&c->done_event, hipEventDisableTiming) != hipSuccess) {
@@ -180,7 +185,8 @@ inline int pick_rpw(const qlamd_context *ctx, int64_t batch) {
   return ctx->rpw_override ? ctx->rpw_override : 4;
 }
 int balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, const double *wrench, const uint8_t *live, int support_only,
-                 int64_t batch, double *joint_effort, double *contact_force, int32_t *status, int memory, void *stream);
+                 int64_t batch, double *joint_effort, double *contact_force, int32_t *status, int memory, void *stream,
+                 const qlamd_placement *pl = nullptr);
 
 inline int ensure_ws(qlamd_context *ctx, size_t bytes) {
   if (ctx->ws_bytes >= bytes) return QLAMD_OK;

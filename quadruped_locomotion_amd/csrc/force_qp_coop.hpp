@@ -15,6 +15,15 @@
 
 #include "coop_lanes.hpp"
 
+// The ghost rows of the active-set loop (below) lean on IEEE semantics: a finished row's candidate normal is zero, so its
+// step length is infinite, its first ghost step turns its x into NaN (inf * 0), every comparison on its slacks is false from
+// then on and its selection key is 0 -- which points at the table entry its latch zeroed.  Under finite-math assumptions
+// the compiler may fold those comparisons and a ghost row whose slacks are still slightly violated (one that stopped on
+// the feasibility tolerance, QuadProg++.cc:246) would pick a real normal and disturb the H and N* its refinement reads.
+#if defined(__FAST_MATH__) || (defined(__FINITE_MATH_ONLY__) && __FINITE_MATH_ONLY__)
+#error "force_qp_coop.hpp needs IEEE inf / NaN semantics: do not build this translation unit with -ffast-math / -ffinite-math-only"
+#endif
+
 namespace qlamd {
 namespace coop {
 
@@ -94,9 +103,11 @@ __device__ __forceinline__ void force_qp_objective(const double S[6], double w_r
   g0 = sel(row_on, g0v, 0.0);
 }
 
-// Returns the status; x: my component of the minimiser (valid for kStatusOk).
+// Returns the status; x: my component of the minimiser (valid for kStatusOk); iters_out: outer iterations taken
+// (QuadProg++'s `iter`, QuadProg++.cc:216,262: one per candidate selected, the last one finds none) -- what a caller can
+// hand back as a placement hint on the next control step (qlamd_placement_from_iterations).
 template <bool kTorque>
-__device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, double *lds_nrm, double &x) {
+__device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, double *lds_nrm, double &x, int &iters_out) {
   using mask_t = std::conditional_t<kTorque, unsigned long long, unsigned>;
   constexpr int kKinds = kTorque ? 11 : 5;
   const int lr = threadIdx.x & 15, leg = lr >> 2, c = lr & 3;
@@ -150,7 +161,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     // (it only feeds the termination tolerance psi_tol)
     const double rp = rsqrt_nr(my_pivot);
     c2 = row_sum(sel(row_on, rp, 0.0));
-    if (bad && nS > 0) return kStatusNotPd;
+    if (bad && nS > 0) { iters_out = 0; return kStatusNotPd; }
   }
 
   QL_STAMP(5);
@@ -271,7 +282,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     if (newly) {
       lds_row[lr] = x;
       reinterpret_cast<int2 *>(lds_row + 16)[lr] = make_int2((int)used, idk);
-      reinterpret_cast<int2 *>(lds_row + 32)[lr] = make_int2(q, status);
+      reinterpret_cast<int2 *>(lds_row + 32)[lr] = make_int2(q | (iters << 8), status);
       lds_row[nt_slot] = 0.0;
       lds_nrm[64 * 1 + ((int)threadIdx.x & 63)] = 0.0; // a finished row's key is 0: lane 0, friction row 1
       zb = 0.0625; npj = 0.0;
@@ -588,7 +599,8 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     __builtin_amdgcn_s_waitcnt(0xC07F);
     x = lds_row[lr];
     const int2 a = reinterpret_cast<const int2 *>(lds_row + 16)[lr], b = reinterpret_cast<const int2 *>(lds_row + 32)[lr];
-    used = (unsigned)a.x; idk = a.y; q = b.x; status = b.y;
+    used = (unsigned)a.x; idk = a.y; q = b.x & 255; status = b.y;
+    iters_out = b.x >> 8;
   }
 
   QL_STAMP(7);

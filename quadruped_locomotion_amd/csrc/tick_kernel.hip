@@ -839,9 +839,16 @@ static int unpack_impl(qlamd_context *ctx, const uint8_t *messages, const int64_
     if (hipMalloc((void **)&ctx->wire_tpl, 2 * kTplWords * sizeof(uint32_t)) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;
     if (hipMemsetAsync(ctx->wire_tpl, 0, 2 * kTplWords * sizeof(uint32_t), st) != hipSuccess) return QLAMD_ERR_HIP;
   }
+  // Launches read one half of the template block and leave the next launch's template in the other, and the host flips
+  // -- for eager launches.  A captured launch is replayed with the pointers it was captured with, so it reads the half in
+  // force at capture time on every replay and nothing is flipped (the capture may be discarded): the template the graph
+  // reads is the one the last EAGER launch left.  Run one eager tick before capturing (include/qlamd.h); without one the
+  // graph's template is "none" and every replay walks every message -- slower, never wrong.  (Reading and writing one half
+  // instead would let a block that starts late see block 0's new field list with the old extraction anchors.)
+  const bool captured = rt::CallGuard::capturing(st);
   const uint32_t *tpl_in = ctx->wire_tpl + kTplWords * ctx->wire_flip;
   uint32_t *tpl_out = ctx->wire_tpl + kTplWords * (ctx->wire_flip ^ 1);
-  ctx->wire_flip ^= 1;
+  if (!captured) ctx->wire_flip ^= 1;
   hipLaunchKernelGGL(robot_state_unpack_kernel, dim3((unsigned)((batch + kWireMsgsPerBlock - 1) / kWireMsgsPerBlock)),
                      dim3(64), kWireLdsBytes, st, d_msg, d_off, batch, o, d_st, tpl_in, tpl_out, valid,
                      ls ? *ls : LegStatePtrs{}, ls ? leg_state_mode : 0);
@@ -923,7 +930,17 @@ int qlamd_reserve(qlamd_context *ctx, int64_t max_batch) {
   size_t coff[kCmdN];
   const size_t scratch = align256((size_t)max_batch * 4) + command_layout((size_t)max_batch, coff);
   if (ctx->tick_ws_bytes < scratch) {
-    if (hipDeviceSynchronize() != hipSuccess) return QLAMD_ERR_HIP; // earlier calls may still use the old block
+    // Growing means a device synchronisation and a free, neither of which is legal while a stream is being captured (the
+    // header says so: reserve BEFORE the capture).  The runtime refuses the synchronisation then; that refusal is
+    // reported as what it is rather than as a HIP failure, and nothing has been freed.
+    {
+      const hipError_t e = hipDeviceSynchronize(); // earlier calls may still use the old block
+      if (e == hipErrorStreamCaptureUnsupported || e == hipErrorStreamCaptureImplicit || e == hipErrorStreamCaptureInvalidated) {
+        (void)hipGetLastError();
+        return QLAMD_ERR_NEEDS_RESERVE;
+      }
+      if (e != hipSuccess) return QLAMD_ERR_HIP;
+    }
     if (ctx->tick_ws) (void)hipFree(ctx->tick_ws);
     ctx->tick_ws = nullptr; ctx->tick_ws_bytes = 0;
     if (hipMalloc(&ctx->tick_ws, scratch) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;

@@ -131,6 +131,27 @@ def make_states(batch, gait="static", seed=SEED, offset=0, errors=None):
                 des_angvel=des_angvel, stance=stance)
 
 
+def _quat_rotate(q, v):
+    """v rotated by the unit quaternion q (w, x, y, z), row-wise."""
+    w, u = q[:, :1], q[:, 1:]
+    t = 2.0 * np.cross(u, v)
+    return v + w * t + np.cross(u, t)
+
+
+def next_tick_states(state, dt):
+    """The same robots one control period later, to first order in dt: the measured pose integrated with the measured
+    twist, the desired pose with the desired twist (base_angvel / des_angvel are expressed in the base frame,
+    VirtualModelController.cpp:150-151), joints, twists and stance flags unchanged.  For benchmarks whose placement hints
+    must come from OTHER states than the ones being solved (bench.py, tools/experiments/placement_model.py)."""
+    s = {k: np.array(v, copy=True) for k, v in state.items()}
+    s["base_pos"] = state["base_pos"] + dt * state["base_linvel"]
+    s["des_pos"] = state["des_pos"] + dt * state["des_linvel"]
+    for pose, twist in (("base_quat", "base_angvel"), ("des_quat", "des_angvel")):
+        omega_world = _quat_rotate(state["base_quat"], state[twist])
+        s[pose] = _quat_mul(_quat_exp(dt * omega_world), state[pose])
+    return s
+
+
 # ---------------------------------------------------------------------------------------------
 # Pose-optimisation problems (BASELINE config 5), SURVEY.md section 8(d):
 # the SquareUp family of free_gait_core/test/PoseOptimizationSQPTest.cpp:111-199 with seeded

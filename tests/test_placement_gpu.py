@@ -1,0 +1,231 @@
+"""Placement of robots into wavefronts (qlamd_balance_solve_placed_batch, qlamd_force_distribution_placed_batch,
+qlamd_placement_from_iterations): whatever the placement, every robot gets bit for bit the result of the plain entry --
+what is checked against the oracle elsewhere (tests/test_balance_gpu.py) therefore holds for every placement -- and the
+iteration counts are those of the reference's method (QuadProg++.cc:216-445, restated in oracle/oracle_quadprog.c)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from quadruped_locomotion_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    from quadruped_locomotion_amd import capi
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    capi.lib()
+    ctx = capi.Context(device=0)
+    yield capi, ctx, torch
+    ctx.close()
+
+
+def plain(gpu, d, B, normals=False):
+    capi, ctx, torch = gpu
+    tau = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+    grf = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+    status = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+    ctx.balance_solve_device(d, tau, grf, status, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return tau.cpu().numpy(), grf.cpu().numpy(), status.cpu().numpy()
+
+
+def placed(gpu, d, B, order, fill=np.nan):
+    capi, ctx, torch = gpu
+    tau = torch.full((B, 12), fill, dtype=torch.float64, device="cuda:0")
+    grf = torch.full((B, 12), fill, dtype=torch.float64, device="cuda:0")
+    status = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+    iters = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+    o = None if order is None else torch.from_numpy(np.ascontiguousarray(order, dtype=np.int32)).to("cuda:0")
+    ctx.balance_solve_placed_device(d, tau, grf, status, order=o, iterations=iters,
+                                    stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return tau.cpu().numpy(), grf.cpu().numpy(), status.cpu().numpy(), iters.cpu().numpy()
+
+
+def reference_placement(iters, throughput):
+    """The documented placement (include/qlamd.h), restated: stable sort by iteration count (clipped to 23), hardest first."""
+    B = len(iters)
+    rank_to_robot = np.argsort(-np.clip(iters, 0, 23), kind="stable")
+    if throughput:
+        return rank_to_robot.astype(np.int32)
+    W = (B + 3) // 4
+    order = np.full(B, -1, dtype=np.int32)
+    for r, robot in enumerate(rank_to_robot):
+        e = B - 1 - r
+        order[4 * r if r < W else 4 * (e // 3) + 1 + e % 3] = robot
+    return order
+
+
+@pytest.mark.parametrize("gait,errors,B", [("static", "survey", 4096), ("trot", None, 4099), ("trot", None, 16385), ("static", "calm", 7)])
+def test_results_are_bit_equal_under_any_placement(gpu, oracle, gait, errors, B):
+    """Identity, a random permutation, the reversed order and both placements of the library, at batch sizes that leave
+    the last wavefront ragged and on both forms of the kernel (two / three wavefronts per SIMD from 16 384 robots)."""
+    capi, ctx, torch = gpu
+    s = synth.make_states(B, gait, errors=errors)
+    d = capi.to_device(s)
+    t0, g0, s0 = plain(gpu, d, B)
+    assert (s0 == 0).all()
+    rng = np.random.default_rng(5)
+    t1, g1, s1, it1 = placed(gpu, d, B, None)
+    assert np.array_equal(t1, t0) and np.array_equal(g1, g0) and np.array_equal(s1, s0)
+    assert (it1 >= 0).all() and it1.max() <= 41
+    # the reference's own count (the restated QuadProg++): equal wherever no tie in the pivot rule is broken differently
+    n_check = min(B, 512)
+    it_ref = np.array([oracle.balance_step(s, i)["iters"] for i in range(n_check)])
+    has_qp = s["stance"][:n_check].any(axis=1)
+    assert (it1[:n_check][~has_qp] == 0).all()
+    # (rows whose slacks agree to 18 bits enter in lane order here: another path to the same minimiser, a few passes apart)
+    assert (it1[:n_check][has_qp] == it_ref[has_qp]).mean() > 0.9
+    assert np.abs(it1[:n_check] - it_ref).max() <= 6
+    orders = [rng.permutation(B), np.arange(B)[::-1].copy()]
+    for policy in (capi.PLACEMENT_LATENCY, capi.PLACEMENT_THROUGHPUT, capi.PLACEMENT_AUTO):
+        orders.append(ctx.placement_from_iterations(it1, policy=policy))
+    for order in orders:
+        assert sorted(order.tolist()) == list(range(B))
+        t, g, st, it = placed(gpu, d, B, order)
+        assert np.array_equal(t, t0) and np.array_equal(g, g0) and np.array_equal(st, s0) and np.array_equal(it, it1)
+
+
+def test_placement_kernel_matches_the_documented_rule(gpu):
+    """Host and device memory, both policies, ragged sizes, counts beyond the 23 the sort distinguishes, negative counts."""
+    capi, ctx, torch = gpu
+    rng = np.random.default_rng(11)
+    for B in (1, 2, 3, 5, 64, 255, 256, 257, 4096, 4099, 65536 + 3):
+        it = rng.integers(-2, 45, size=B).astype(np.int32)
+        for policy, thr in ((capi.PLACEMENT_LATENCY, False), (capi.PLACEMENT_THROUGHPUT, True)):
+            want = reference_placement(np.maximum(it, 0), thr)
+            got_h = ctx.placement_from_iterations(it, policy=policy)
+            assert np.array_equal(got_h, want), (B, policy)
+            d_it = torch.from_numpy(it).to("cuda:0")
+            d_or = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+            ctx.placement_from_iterations(d_it, order=d_or, policy=policy, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_or.cpu().numpy(), want), (B, policy)
+        auto = ctx.placement_from_iterations(it, policy=capi.PLACEMENT_AUTO)
+        assert np.array_equal(auto, reference_placement(np.maximum(it, 0), B >= 16384))
+
+
+def test_latency_placement_puts_the_hardest_robots_next_to_the_easiest(gpu):
+    """What the placement is for: the hardest quarter one per wavefront, the three easiest robots in wavefront 0."""
+    capi, ctx, torch = gpu
+    s = synth.make_states(4096, "static", errors="survey")
+    d = capi.to_device(s)
+    _, _, _, it = placed(gpu, d, 4096, None)
+    order = ctx.placement_from_iterations(it, policy=capi.PLACEMENT_LATENCY)
+    hard = it[order[0::4]]
+    assert (np.diff(hard) <= 0).all() and hard[0] == it.max()
+    assert it[order[1:4]].max() == np.sort(it)[2]
+    assert hard.min() >= np.sort(it)[::-1][1023]
+
+
+def test_host_memory_order_is_validated_and_device_order_cannot_corrupt(gpu):
+    capi, ctx, torch = gpu
+    B = 64
+    s = synth.make_states(B, "trot")
+    tau, grf, st, it = ctx.balance_solve_placed_host(s, order=np.arange(B)[::-1])
+    t0, g0, s0 = ctx.balance_solve_host(s)
+    assert np.array_equal(tau, t0) and np.array_equal(grf, g0) and np.array_equal(st, s0) and (it >= 0).all()
+    for bad in (np.zeros(B), np.r_[np.arange(B - 1), B], np.r_[np.arange(B - 1), -1]):
+        with pytest.raises(capi.QlamdError) as e:
+            ctx.balance_solve_placed_host(s, order=bad)
+        assert e.value.code == capi.ERR_INVALID_ARGUMENT
+    # device memory is not checked: an entry outside [0, B) leaves its slot empty and the robot it displaced untouched
+    d = capi.to_device(s)
+    order = np.arange(B, dtype=np.int32)
+    order[5], order[17] = -3, B + 100
+    t, g, stt, itt = placed(gpu, d, B, order, fill=7.0)
+    for i in (5, 17):
+        assert (t[i] == 7.0).all() and (g[i] == 7.0).all() and stt[i] == -1 and itt[i] == -1
+    keep = np.setdiff1d(np.arange(B), [5, 17])
+    assert np.array_equal(t[keep], t0[keep]) and np.array_equal(stt[keep], s0[keep])
+
+
+def test_one_lane_kernels_refuse_a_placement(gpu):
+    capi, ctx, torch = gpu
+    s = synth.make_states(64, "trot")
+    ctx.set_robots_per_wave(16)
+    try:
+        with pytest.raises(capi.QlamdError) as e:
+            ctx.balance_solve_placed_host(s, order=np.arange(64))
+        assert e.value.code == capi.ERR_INVALID_ARGUMENT
+    finally:
+        ctx.set_robots_per_wave(0)
+
+
+def test_force_distribution_placed_equals_the_plain_entry(gpu):
+    capi, ctx, torch = gpu
+    B = 1027
+    s = synth.make_states(B, "trot")
+    d = capi.to_device(s)
+    w = torch.zeros(B, 6, dtype=torch.float64, device="cuda:0")
+    ctx.virtual_wrench_device(d, w, stream=torch.cuda.current_stream().cuda_stream)
+    out = {}
+    for name in ("plain", "placed"):
+        tau = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+        grf = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+        st = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+        it = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+        order = torch.from_numpy(np.random.default_rng(3).permutation(B).astype(np.int32)).to("cuda:0")
+        args = [ctx._h, d["q"].data_ptr(), d["base_quat"].data_ptr(), d["stance"].data_ptr(), None, w.data_ptr(), B]
+        if name == "plain":
+            rc = capi.lib().qlamd_force_distribution_batch(*args, tau.data_ptr(), grf.data_ptr(), st.data_ptr(), capi.MEM_DEVICE, None)
+        else:
+            pl = capi.Placement(order.data_ptr(), it.data_ptr(), None, None, 0)
+            rc = capi.lib().qlamd_force_distribution_placed_batch(*args, C.byref(pl), tau.data_ptr(), grf.data_ptr(),
+                                                                  st.data_ptr(), capi.MEM_DEVICE, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        out[name] = (tau.cpu().numpy(), grf.cpu().numpy(), st.cpu().numpy())
+    for a, b in zip(out["plain"], out["placed"]):
+        assert np.array_equal(a, b)
+    assert (it.cpu().numpy() >= 0).all()
+
+
+@pytest.mark.parametrize("B", [4096, 4099, 8192, 8704, 8705, 16385, 70])
+def test_next_placement_made_inside_the_solve_equals_the_placement_entry(gpu, B):
+    """prev_iterations -> next_robot_order: by one extra wavefront of the solve's own launch up to 8704 robots, by launches of
+    their own beyond -- the same placement as qlamd_placement_from_iterations either way, and the solve's results untouched."""
+    capi, ctx, torch = gpu
+    s = synth.make_states(B, "trot")
+    d = capi.to_device(s)
+    t0, g0, s0 = plain(gpu, d, B)
+    rng = np.random.default_rng(B)
+    prev = rng.integers(0, 30, size=B).astype(np.int32)
+    d_prev = torch.from_numpy(prev).to("cuda:0")
+    for policy in (capi.PLACEMENT_LATENCY, capi.PLACEMENT_THROUGHPUT, capi.PLACEMENT_AUTO):
+        want = ctx.placement_from_iterations(prev, policy=policy)
+        tau = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+        grf = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+        status = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+        iters = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+        nxt = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+        order = torch.from_numpy(rng.permutation(B).astype(np.int32)).to("cuda:0")
+        ctx.balance_solve_placed_device(d, tau, grf, status, order=order, iterations=iters, prev_iterations=d_prev,
+                                        next_order=nxt, policy=policy, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(nxt.cpu().numpy(), want), policy
+        assert np.array_equal(tau.cpu().numpy(), t0) and np.array_equal(grf.cpu().numpy(), g0)
+        assert np.array_equal(status.cpu().numpy(), s0) and (iters.cpu().numpy() >= 0).all()
+    # host memory: the same through the staged path; one of the pair alone, or aliased buffers, are refused
+    if B <= 4099:
+        out = ctx.balance_solve_placed_host(s, prev_iterations=prev, policy=capi.PLACEMENT_LATENCY)
+        assert np.array_equal(out[4], ctx.placement_from_iterations(prev, policy=capi.PLACEMENT_LATENCY))
+        assert np.array_equal(out[0], t0)
+        pl = capi.Placement(None, None, d_prev.data_ptr(), None, 0)
+        sb = capi.StateBatch()
+        for key, field, _ in capi.FIELD_OF_KEY:
+            setattr(sb, field, d[key].data_ptr())
+        sb.support_leg = d["stance"].data_ptr()
+        tau = torch.zeros(B, 12, dtype=torch.float64, device="cuda:0")
+        status = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+        rc = capi.lib().qlamd_balance_solve_placed_batch(ctx._h, C.byref(sb), B, C.byref(pl), tau.data_ptr(), None, status.data_ptr(),
+                                                         capi.MEM_DEVICE, None)
+        assert rc == capi.ERR_INVALID_ARGUMENT
+        pl = capi.Placement(None, d_prev.data_ptr(), d_prev.data_ptr(), status.data_ptr(), 0)
+        rc = capi.lib().qlamd_balance_solve_placed_batch(ctx._h, C.byref(sb), B, C.byref(pl), tau.data_ptr(), None, status.data_ptr(),
+                                                         capi.MEM_DEVICE, None)
+        assert rc == capi.ERR_INVALID_ARGUMENT
