@@ -179,7 +179,8 @@ def parse():
     ap.add_argument("--errors", default="survey", choices=["calm", "survey"],
                     help="static stance tracking errors: survey = SURVEY.md 8(d)'s literal 0.02 m / 0.05 rad / 0.1 (default), "
                          "calm = 0.004 / 0.005 / 0.01 (a robot holding its pose: constraints mostly inactive, DESIGN.md 2)")
-    ap.add_argument("--no-also", action="store_true", help="skip the `also` object (the other presets of the headline workload)")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the `also` / `unplaced` / `scale_point` objects (the other presets, methods and configs)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--replays", type=int, default=11,
                     help="timed samples of exactly K steps each (barrier + synchronize on both sides); the median is reported")
@@ -953,7 +954,8 @@ def main():
     res = run_preset(args.gait, args.errors, gather, args.replays, world > 1, collect=args.collect, every=args.gather_every, method=method)
     headline_is_survey_4096 = args.gait == "static" and args.errors == "survey"
     # the same preset by the other method (every rank takes part: the preset's consensus steps are collectives)
-    unplaced = run_preset(args.gait, args.errors, False, min(args.replays, 5), False, method=other) if not args.rpw else None
+    unplaced = (run_preset(args.gait, args.errors, False, min(args.replays, 5), False, method=other)
+                if not (args.rpw or args.no_also) else None)
     # The other presets and every other BASELINE config, same process (one GPU only; fewer samples each):
     #   static-calm, trot at the headline batch; trot_b8192 (one rank's shard of configs[3]) and trot_b65536 (its global
     #   batch on one GPU); pose_sqp_b4096 (configs[4]); the headline preset with placement hints from OTHER states.
@@ -990,7 +992,7 @@ def main():
     # 8192 trot robots per GPU (configs[3]'s shard).  efficiency(N) = scale_point(N).value / (N * scale_point(1).without_gather)
     if args.gait == "trot" and B == SCALE_B:
         sp_res, sp_plain = res, None
-    elif world == 1 and not collective and not args.no_also:
+    elif args.no_also or (world == 1 and not collective):  # (one GPU: taken from also["trot_b8192"] below)
         sp_res, sp_plain = None, None
     else:
         sp_res = run_preset("trot", "survey", gather, min(args.replays, 5), world > 1, collect=args.collect, every=args.gather_every,

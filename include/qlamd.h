@@ -275,9 +275,18 @@ int qlamd_force_distribution_placed_batch(qlamd_context *ctx, const double *join
                                           const double *virtual_wrench, int64_t batch, const qlamd_placement *placement,
                                           double *joint_effort, double *contact_force, int32_t *status, int memory,
                                           void *stream);
+/* The same for the other entries that run a lane-cooperative active-set QP -- qlamd_qp_solve_batch,
+ * qlamd_weighted_lsq_qp_batch, qlamd_wholebody_solve_batch -- without a second set of signatures: the placement is handed to
+ * the context and taken (and cleared) by the NEXT call of one of these three on it, whichever it is.  QLAMD_MEM_DEVICE
+ * calls only (a host-memory call that finds a placement pending returns QLAMD_ERR_INVALID_ARGUMENT and clears it).
+ * robot_order / iterations index the call's problems; with prev_iterations / next_robot_order the placement for the
+ * caller's next call is made by qlamd_placement_from_iterations' launches behind the solve, on its stream.
+ * placement = NULL withdraws a pending one.  (qlamd_balance_solve_batch and the other entries ignore it.) */
+int qlamd_place_next_call(qlamd_context *ctx, const qlamd_placement *placement);
+
 /* The placement on its own: iterations [B] in (any counts: only their order matters; negative counts count as 0, counts
  * above 23 as 23), robot_order [B] out.  A stable counting sort on the device (ties by robot index: the result is a
- * function of the counts alone); 6 us at 4096 robots, 26 us at 65 536. */
+ * function of the counts alone); 6 us at 4096 robots, 9 us from 8192 robots up (two launches). */
 int qlamd_placement_from_iterations(qlamd_context *ctx, const int32_t *iterations, int64_t batch, int policy,
                                     int32_t *robot_order, int memory, void *stream);
 

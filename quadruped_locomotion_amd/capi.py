@@ -29,7 +29,7 @@ EXPORTS = (
     "qlamd_wholebody_default_params", "qlamd_wholebody_dynamics_batch", "qlamd_wholebody_solve_batch",
     "qlamd_full_tick_batch", "qlamd_set_option", "qlamd_tick_command_bytes", "qlamd_weighted_lsq_qp_batch",
     "qlamd_reserve", "qlamd_balance_solve_placed_batch", "qlamd_force_distribution_placed_batch",
-    "qlamd_placement_from_iterations",
+    "qlamd_placement_from_iterations", "qlamd_place_next_call",
 )
 
 
@@ -207,6 +207,7 @@ def lib():
                 C.c_void_p] * 3 + [C.c_int, C.c_void_p]
             L.qlamd_placement_from_iterations.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int,
                                                           C.c_void_p]
+            L.qlamd_place_next_call.argtypes = [C.c_void_p, C.POINTER(Placement)]
         L.qlamd_virtual_wrench_batch.argtypes = [C.c_void_p, C.POINTER(StateBatch), C.c_int64, C.c_void_p,
                                                  C.c_int, C.c_void_p]
         L.qlamd_leg_kinematics_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
@@ -410,6 +411,16 @@ class Context:
         if rc != OK:
             raise QlamdError(rc, "qlamd_balance_solve_placed_batch")
         return (tau, grf, status, iters) if nxt is None else (tau, grf, status, iters, nxt)
+
+    def place_next_call(self, order=None, iterations=None, prev_iterations=None, next_order=None, policy=0):
+        """qlamd_place_next_call with torch int32 CUDA tensors (or all None to withdraw a pending placement)."""
+        if order is None and iterations is None and next_order is None:
+            rc = lib().qlamd_place_next_call(self._h, None)
+        else:
+            pl = Placement(_ptr(order), _ptr(iterations), _ptr(prev_iterations), _ptr(next_order), int(policy))
+            rc = lib().qlamd_place_next_call(self._h, C.byref(pl))
+        if rc != OK:
+            raise QlamdError(rc, "qlamd_place_next_call")
 
     def placement_from_iterations(self, iterations, order=None, policy=0, stream=None):
         """qlamd_placement_from_iterations: numpy int32 [B] -> numpy order (synchronous), or torch int32 CUDA tensors

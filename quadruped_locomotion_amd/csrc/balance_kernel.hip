@@ -533,6 +533,7 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
   ctx->tick_ws_bytes = 0;
   ctx->place_ws = nullptr;
   ctx->place_ws_bytes = 0;
+  ctx->has_next_placement = false;
   ctx->on_failure = QLAMD_ON_FAILURE_ZERO;
   ctx->dynamics_form = QLAMD_DYNAMICS_AUTO;
   ctx->depth = 0;
@@ -647,7 +648,15 @@ int launch_placement(qlamd_context *ctx, const int32_t *d_it, int64_t batch, int
 bool throughput_policy(int policy, int64_t batch) {
   return policy == QLAMD_PLACEMENT_THROUGHPUT || (policy == QLAMD_PLACEMENT_AUTO && batch >= QLAMD_THROUGHPUT_BATCH);
 }
+bool valid_policy(int policy) {
+  return policy == QLAMD_PLACEMENT_AUTO || policy == QLAMD_PLACEMENT_LATENCY || policy == QLAMD_PLACEMENT_THROUGHPUT;
+}
 } // namespace
+
+int qlamd::rt::placement_launch(qlamd_context *ctx, const int32_t *d_iterations, int64_t batch, int policy, int32_t *d_order,
+                                hipStream_t st) {
+  return launch_placement(ctx, d_iterations, batch, throughput_policy(policy, batch) ? 1 : 0, d_order, st);
+}
 
 // pl: the placed entries' arrays (NULL otherwise), in the memory space of the call
 int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, const double *wrench, const uint8_t *live, int support_only,
@@ -863,6 +872,20 @@ int qlamd_force_distribution_placed_batch(qlamd_context *ctx, const double *join
   in.support_leg = support_leg;
   in.surface_normal = surface_normal;
   return balance_impl(ctx, &in, virtual_wrench, nullptr, 0, batch, joint_effort, contact_force, status, memory, stream, placement);
+}
+
+int qlamd_place_next_call(qlamd_context *ctx, const qlamd_placement *placement) {
+  if (!ctx) return QLAMD_ERR_INVALID_ARGUMENT;
+  QL_ENTER_NO_STREAM(ctx);
+  ctx->has_next_placement = false;
+  if (!placement) return QLAMD_OK;
+  if ((placement->prev_iterations != nullptr) != (placement->next_robot_order != nullptr)) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (placement->next_robot_order && !valid_policy(placement->policy)) return QLAMD_ERR_INVALID_ARGUMENT;
+  if (placement->next_robot_order && (placement->next_robot_order == placement->robot_order || placement->prev_iterations == placement->iterations))
+    return QLAMD_ERR_INVALID_ARGUMENT;
+  ctx->next_placement = *placement;
+  ctx->has_next_placement = true;
+  return QLAMD_OK;
 }
 
 int qlamd_placement_from_iterations(qlamd_context *ctx, const int32_t *iterations, int64_t batch, int policy,

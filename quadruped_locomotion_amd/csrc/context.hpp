@@ -25,8 +25,10 @@ struct qlamd_context {
   double base_m, base_h[3], base_I[6]; // base_link about the base origin (whole-body entries)
   void *tick_ws;       // intermediates of qlamd_full_tick_batch (grown on demand)
   size_t tick_ws_bytes;
-  void *place_ws;      // per-workgroup bin counts of qlamd_placement_from_iterations beyond 16 384 robots
+  void *place_ws;      // per-workgroup bin counts of qlamd_placement_from_iterations beyond 4096 robots
   size_t place_ws_bytes;
+  qlamd_placement next_placement; // qlamd_place_next_call: taken (and cleared) by the next QP entry that knows placements
+  bool has_next_placement;
   uint32_t *wire_tpl;  // two layout templates of robot_state_unpack_kernel (read one, write the other), or NULL
   int wire_flip;
   // HOST-memory mode staging (grown on demand)
@@ -187,6 +189,49 @@ inline int pick_rpw(const qlamd_context *ctx, int64_t batch) {
 int balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user, const double *wrench, const uint8_t *live, int support_only,
                  int64_t batch, double *joint_effort, double *contact_force, int32_t *status, int memory, void *stream,
                  const qlamd_placement *pl = nullptr);
+
+// qlamd_placement_from_iterations on device pointers, for entries that hold the context's guard already (balance_kernel.hip)
+int placement_launch(qlamd_context *ctx, const int32_t *d_iterations, int64_t batch, int policy, int32_t *d_order, hipStream_t st);
+
+// The placement a lane-cooperative QP kernel runs in (qlamd_place_next_call): which problem sits in which slot of the
+// launch, and where the iteration counts go.  Both NULL = slot s takes problem s.
+struct PlacePtrs {
+  const int32_t *order;
+  int32_t *iterations;
+};
+#ifdef __HIPCC__
+// problem index of slot `slot` (row slot % 4 of wavefront slot / 4); live = the slot holds a problem (an order entry
+// outside [0, B) leaves it empty); dead slots compute on problem B - 1 and write nothing
+__device__ __forceinline__ int64_t placed_index(const PlacePtrs &pp, int64_t slot, int64_t B, bool &live) {
+  live = slot < B;
+  int64_t i = live ? slot : B - 1;
+  if (pp.order) {
+    const int64_t o = pp.order[i];
+    live = live && o >= 0 && o < B;
+    i = live ? o : B - 1;
+  }
+  return i;
+}
+#endif
+// Takes the pending placement of qlamd_place_next_call, if any, for a QLAMD_MEM_DEVICE call of `batch` problems.
+// Returns QLAMD_OK and fills pp / *next (next->next_robot_order != NULL when a following placement was asked for), or
+// QLAMD_ERR_INVALID_ARGUMENT for a host-memory call (the placement's arrays are device arrays).
+inline int take_placement(qlamd_context *ctx, int memory, int64_t batch, PlacePtrs *pp, qlamd_placement *next) {
+  *pp = PlacePtrs{nullptr, nullptr};
+  memset(next, 0, sizeof(*next));
+  if (!ctx->has_next_placement) return QLAMD_OK;
+  const qlamd_placement pl = ctx->next_placement;
+  ctx->has_next_placement = false;
+  if (memory != QLAMD_MEM_DEVICE || batch > INT32_MAX) return QLAMD_ERR_INVALID_ARGUMENT;
+  pp->order = pl.robot_order;
+  pp->iterations = pl.iterations;
+  *next = pl;
+  return QLAMD_OK;
+}
+inline int finish_placement(qlamd_context *ctx, const qlamd_placement &pl, int64_t batch, hipStream_t st) {
+  if (!pl.next_robot_order) return QLAMD_OK;
+  return placement_launch(ctx, pl.prev_iterations, batch, pl.policy, pl.next_robot_order, st);
+}
 
 inline int ensure_ws(qlamd_context *ctx, size_t bytes) {
   if (ctx->ws_bytes >= bytes) return QLAMD_OK;

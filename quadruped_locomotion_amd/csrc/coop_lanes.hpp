@@ -51,8 +51,28 @@ static __device__ unsigned long long g_stamps[64];
     if (blockIdx.x == 0 && threadIdx.x == 0)                                                \
       for (int k_ = 0; k_ < 8; k_++) ::qlamd::coop::g_stamps[16 + k_] = ql_acc_[k_];        \
   } while (0)
+// one stamp per WORKGROUP (slot = which event, up to four per unit; workgroups beyond kBlockStamps are not recorded):
+// s_memrealtime, the 100 MHz counter that is one clock for the whole device (s_memtime counts per XCD), read back through
+// qlamd_debug_block_stamps_*.  Which workgroup a launch waits for, and what it was doing.
+constexpr int kBlockStamps = 2048;
+static __device__ unsigned long long g_block_stamps[4][kBlockStamps];
+#define QLAMD_BLOCK_STAMPS_ACCESSOR(name)                                                                                \
+  extern "C" int name(unsigned long long *out, int slot, int n) {                                                        \
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(::qlamd::coop::g_block_stamps), sizeof(unsigned long long) * n,           \
+                               sizeof(unsigned long long) * ::qlamd::coop::kBlockStamps * slot) == hipSuccess ? 0 : -1; \
+  }
+#define QL_BLOCK_STAMP(slot)                                                                \
+  do {                                                                                      \
+    unsigned long long t_;                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < ::qlamd::coop::kBlockStamps) ::qlamd::coop::g_block_stamps[slot][blockIdx.x] = t_; \
+  } while (0)
 #else
 #define QLAMD_STAMPS_ACCESSOR(name)
+#define QLAMD_BLOCK_STAMPS_ACCESSOR(name)
+#define QL_BLOCK_STAMP(slot)
 #define QL_STAMP(k)
 #define QL_SEG_DECL
 #define QL_SEG_START

@@ -267,13 +267,12 @@ __global__ __launch_bounds__(64) void qp_coop_kernel(int n, int p, int m, const 
                                                      const double *__restrict__ g0, const double *__restrict__ CE,
                                                      const double *__restrict__ ce0, const double *__restrict__ CI,
                                                      const double *__restrict__ ci0, int64_t B, double *__restrict__ x,
-                                                     double *__restrict__ obj, int32_t *__restrict__ status) {
+                                                     double *__restrict__ obj, int32_t *__restrict__ status, const PlacePtrs pp) {
   typedef coop::QpCoopLds<N, KC> L;
   __shared__ double rows[coop::kQpCoopRows * L::kTotal];
   const int row = threadIdx.x >> 4, lr = threadIdx.x & 15;
-  int64_t i = (int64_t)blockIdx.x * coop::kQpCoopRows + row;
-  const bool live = i < B;
-  if (!live) i = B - 1;
+  bool live;
+  const int64_t i = placed_index(pp, (int64_t)blockIdx.x * coop::kQpCoopRows + row, B, live);
   // every load is issued unconditionally with a clamped index; values outside the problem are replaced afterwards
   const int rv = lr < n ? lr : 0;               // my variable (row of G)
   int cs[KC];                                   // my inequalities
@@ -309,13 +308,15 @@ __global__ __launch_bounds__(64) void qp_coop_kernel(int n, int p, int m, const 
 #pragma unroll
   for (int s = 0; s < KC; s++) b[s] = v[s] ? b[s] : 0.0;
   double xo, fo;
+  int its = 0;
   const int st = coop::qp_coop_impl<N, KC>(Gm, gl, n, n, m, p > 0, ne, e0, a, b, v, !live, rows + row * L::kTotal, xo, fo,
-                                           p > 1, ne2, e02);
+                                           p > 1, ne2, e02, nullptr, nullptr, 0, -1, nullptr, &its);
   if (live) {
     if (var) x[(size_t)i * n + lr] = xo;
     if (lr == 0) {
       if (obj) obj[i] = fo;
       status[i] = st;
+      if (pp.iterations) pp.iterations[i] = its;
     }
   }
 }
@@ -332,14 +333,14 @@ __global__ __launch_bounds__(64) void weighted_lsq_qp_kernel(int n, int k, int p
                                                              const double *__restrict__ W, const double *__restrict__ C,
                                                              const double *__restrict__ cc, const double *__restrict__ D,
                                                              const double *__restrict__ dlo, const double *__restrict__ fup,
-                                                             int64_t B, double *__restrict__ x, int32_t *__restrict__ status) {
+                                                             int64_t B, double *__restrict__ x, int32_t *__restrict__ status,
+                                                             const PlacePtrs pp) {
   typedef coop::QpCoopLds<N, 3> L;
   __shared__ double rows[coop::kQpCoopRows * L::kTotal];
   __shared__ double eq_dirs[coop::kQpCoopRows * 12 * N]; // step directions of the equality rows (refinement sweep)
   const int row = threadIdx.x >> 4, lr = threadIdx.x & 15;
-  int64_t i = (int64_t)blockIdx.x * coop::kQpCoopRows + row;
-  const bool live = i < B;
-  if (!live) i = B - 1;
+  bool live;
+  const int64_t i = placed_index(pp, (int64_t)blockIdx.x * coop::kQpCoopRows + row, B, live);
   const bool var = lr < n;
   const int rv = var ? lr : 0;
   double Gm[N], gl = 0.0;
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(64) void weighted_lsq_qp_kernel(int n, int k, int p
   int cnt = mine;
   cnt += __shfl_xor(cnt, 8, 16); cnt += __shfl_xor(cnt, 4, 16); cnt += __shfl_xor(cnt, 2, 16); cnt += __shfl_xor(cnt, 1, 16);
   double xo, fo;
-  int st;
+  int st, its = 0;
   const double *Ci = C ? C + (size_t)i * p * n : nullptr, *ci = cc ? cc + (size_t)i * p : nullptr;
   // Slots 24..47 hold the upper bounds.  The reference's problem has none at all (f = DBL_MAX throughout,
   // ContactForceDistribution.cpp:246,329): when no problem of this wavefront has one, the two-rows-per-lane form of the
@@ -406,14 +407,17 @@ __global__ __launch_bounds__(64) void weighted_lsq_qp_kernel(int n, int k, int p
     const double(&b2)[2] = reinterpret_cast<const double(&)[2]>(b);
     const bool(&v2)[2] = reinterpret_cast<const bool(&)[2]>(v);
     st = coop::qp_coop_impl<N, 2>(Gm, gl, n, n, 24, false, 0.0, 0.0, a2, b2, v2, !live, rows + row * L::kTotal, xo, fo, false, 0.0,
-                                  0.0, Ci, ci, C ? p : 0, cnt, eq_dirs + row * 12 * N);
+                                  0.0, Ci, ci, C ? p : 0, cnt, eq_dirs + row * 12 * N, &its);
   } else {
     st = coop::qp_coop_impl<N, 3>(Gm, gl, n, n, 48, false, 0.0, 0.0, a, b, v, !live, rows + row * L::kTotal, xo, fo, false, 0.0,
-                                  0.0, Ci, ci, C ? p : 0, cnt, eq_dirs + row * 12 * N);
+                                  0.0, Ci, ci, C ? p : 0, cnt, eq_dirs + row * 12 * N, &its);
   }
   if (live) {
     if (var) x[(size_t)i * n + lr] = xo;
-    if (lr == 0) status[i] = st;
+    if (lr == 0) {
+      status[i] = st;
+      if (pp.iterations) pp.iterations[i] = its;
+    }
   }
 }
 
@@ -598,6 +602,9 @@ int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
   QL_ENTER(ctx, st);
+  PlacePtrs pp;
+  qlamd_placement pl;
+  { const int rc = take_placement(ctx, memory, batch, &pp, &pl); if (rc != QLAMD_OK) return rc; }
   const size_t B = (size_t)batch;
   const double *dG = G, *dg0 = g0, *dCE = CE, *dce0 = ce0, *dCI = CI, *dci0 = ci0;
   double *dx = x, *dobj = objective;
@@ -623,7 +630,7 @@ int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *
   {
     const unsigned cgrid = (unsigned)((batch + coop::kQpCoopRows - 1) / coop::kQpCoopRows);
     auto launch = [&](auto kern) {
-      hipLaunchKernelGGL(kern, dim3(cgrid), dim3(64), 0, st, n, p, m, dG, dg0, dCE, dce0, dCI, dci0, batch, dx, dobj, dst);
+      hipLaunchKernelGGL(kern, dim3(cgrid), dim3(64), 0, st, n, p, m, dG, dg0, dCE, dce0, dCI, dci0, batch, dx, dobj, dst, pp);
     };
     if (m > 24) {
       if (n <= 6) launch(qp_coop_kernel<6, 3>); else launch(qp_coop_kernel<12, 3>);
@@ -632,6 +639,7 @@ int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *
     }
   }
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  { const int rc = finish_placement(ctx, pl, batch, st); if (rc != QLAMD_OK) return rc; }
   if (memory == QLAMD_MEM_HOST) {
     if (hipMemcpyAsync(x, dx, B * n * 8, hipMemcpyDeviceToHost, st) != hipSuccess) return QLAMD_ERR_HIP;
     if (objective && hipMemcpyAsync(objective, dobj, B * 8, hipMemcpyDeviceToHost, st) != hipSuccess)
@@ -654,6 +662,9 @@ int qlamd_weighted_lsq_qp_batch(qlamd_context *ctx, int n, int k, int p, int m, 
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
   QL_ENTER(ctx, st);
+  PlacePtrs pp;
+  qlamd_placement pl;
+  { const int rc = take_placement(ctx, memory, batch, &pp, &pl); if (rc != QLAMD_OK) return rc; }
   const size_t B = (size_t)batch;
   const double *dA = A, *dS = S, *db = b, *dW = W, *dC = p ? C : nullptr, *dc = p ? c : nullptr, *dD = m ? D : nullptr,
                *dd = m ? d : nullptr, *df = m ? f : nullptr;
@@ -673,10 +684,11 @@ int qlamd_weighted_lsq_qp_batch(qlamd_context *ctx, int n, int k, int p, int m, 
   }
   const unsigned grid = (unsigned)((batch + coop::kQpCoopRows - 1) / coop::kQpCoopRows);
   if (n <= 6)
-    hipLaunchKernelGGL(weighted_lsq_qp_kernel<6>, dim3(grid), dim3(64), 0, st, n, k, p, m, dA, dS, db, dW, dC, dc, dD, dd, df, batch, dx, dst);
+    hipLaunchKernelGGL(weighted_lsq_qp_kernel<6>, dim3(grid), dim3(64), 0, st, n, k, p, m, dA, dS, db, dW, dC, dc, dD, dd, df, batch, dx, dst, pp);
   else
-    hipLaunchKernelGGL(weighted_lsq_qp_kernel<12>, dim3(grid), dim3(64), 0, st, n, k, p, m, dA, dS, db, dW, dC, dc, dD, dd, df, batch, dx, dst);
+    hipLaunchKernelGGL(weighted_lsq_qp_kernel<12>, dim3(grid), dim3(64), 0, st, n, k, p, m, dA, dS, db, dW, dC, dc, dD, dd, df, batch, dx, dst, pp);
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  { const int rc = finish_placement(ctx, pl, batch, st); if (rc != QLAMD_OK) return rc; }
   return memory == QLAMD_MEM_HOST ? sg.finish(st) : QLAMD_OK;
 }
 

@@ -43,7 +43,7 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
                                             bool skip, double *lds_row, double &x_out, double &f_out, bool has_eq2 = false,
                                             double ne2 = 0.0, double ce02 = 0.0, const double *eq_rows = nullptr,
                                             const double *eq_rhs = nullptr, int p_rows = 0, int m_tol = -1,
-                                            double *eq_store = nullptr) {
+                                            double *eq_store = nullptr, int *iters_out = nullptr) {
   typedef QpCoopLds<N, KC> L;
   typedef typename std::conditional<(KC > 2), unsigned long long, unsigned>::type mask_t;
   const int lr = threadIdx.x & 15;
@@ -297,7 +297,7 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
       if (__builtin_amdgcn_inverse_ballot_w64(newly_m)) {
         latched[lr] = x;
         reinterpret_cast<int2 *>(latched + 16)[lr] = make_int2((int)used, idk);
-        reinterpret_cast<int2 *>(latched + 32)[lr] = make_int2(q, status);
+        reinterpret_cast<int2 *>(latched + 32)[lr] = make_int2(q | (iters << 8), status);
         nlim = 0; nt_slot = L::kZero; zb = 0.0625; npj = 0.0;
       }
     }
@@ -476,7 +476,8 @@ __device__ __forceinline__ int qp_coop_impl(const double (&Gm)[N], double g0, in
     __builtin_amdgcn_s_waitcnt(0xC07F);
     x = latched[lr];
     const int2 la = reinterpret_cast<const int2 *>(latched + 16)[lr], lb = reinterpret_cast<const int2 *>(latched + 32)[lr];
-    used = (unsigned)la.x; idk = la.y; q = lb.x; status = lb.y;
+    used = (unsigned)la.x; idk = la.y; q = lb.x & 255; status = lb.y;
+    if (iters_out) *iters_out = lb.x >> 8;
   }
   // one refinement pass on the final working set (see balance_coop.hpp)
   if (status == kStatusOk && q > 0 && !skip) {

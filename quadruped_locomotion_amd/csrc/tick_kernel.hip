@@ -134,6 +134,7 @@ __global__ __launch_bounds__(64, 2) void tick_solve_kernel(const DeviceParams *_
   __shared__ double tab[4 * kTabPerLeg];
   __shared__ double rows[4 * coop::kCoopLdsDoubles];
   __shared__ double nrm[coop::kCoopNrmDoubles];
+  QL_BLOCK_STAMP(2);
   if (blockIdx.x < nbal) {
     const int row = threadIdx.x >> 4;
     int64_t i = (int64_t)blockIdx.x * 4 + row;
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(64, 2) void tick_solve_kernel(const DeviceParams *_
   } else {
     swing_branch_block(*Pp, sw.SP, sw.pid, sw.s, sw.b, sw.period, B, effort, (int64_t)(blockIdx.x - nbal), tab);
   }
+  QL_BLOCK_STAMP(3);
 }
 
 // ---- leg state machine (row f2): one robot per lane, flags and a few doubles in, flags out ----------
@@ -463,6 +465,7 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   const int64_t i0 = (int64_t)blockIdx.x * kWireMsgsPerBlock;
   const int n = (int)((B - i0) < kWireMsgsPerBlock ? (B - i0) : kWireMsgsPerBlock);
   QL_STAMP(20);
+  QL_BLOCK_STAMP(0);
   const int64_t a = offsets[i0], b = offsets[i0 + n];
   // the template's loads go out first, its LDS stores follow the staging loop
   uint32_t tplv[(kTplWords + 63) / 64];
@@ -611,6 +614,7 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
     __threadfence();
     if (lr == 0) tpl_out[kTplValid] = tpl_valid_word;
   }
+  QL_BLOCK_STAMP(1);
 }
 
 } // namespace
@@ -1088,3 +1092,4 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
 } // extern "C"
 
 QLAMD_STAMPS_ACCESSOR(qlamd_debug_stamps_tick)
+QLAMD_BLOCK_STAMPS_ACCESSOR(qlamd_debug_block_stamps_tick)

@@ -310,7 +310,8 @@ __global__ __launch_bounds__(64) void wholebody_dynamics_leg_kernel(const Device
 template <bool kPerLeg>
 __global__ __launch_bounds__(64, 2) void wholebody_solve_kernel(const DeviceParams *__restrict__ Pp, const coop::WbParamsDev W,
                                                              const WbPtrs s, int64_t B, double *__restrict__ tau_out,
-                                                             double *__restrict__ grf_out, int32_t *__restrict__ status_out) {
+                                                             double *__restrict__ grf_out, int32_t *__restrict__ status_out,
+                                                             const PlacePtrs pp) {
   using namespace coop;
   __shared__ double tab[4 * kTabPerLeg];
   __shared__ double rows[4 * kCoopLdsDoubles];
@@ -319,9 +320,8 @@ __global__ __launch_bounds__(64, 2) void wholebody_solve_kernel(const DevicePara
   TabStage ts;
   ts.issue(P);
   const int row = threadIdx.x >> 4, lr = threadIdx.x & 15, leg = lr >> 2, c = lr & 3;
-  const int64_t i0 = (int64_t)blockIdx.x * 4 + row;
-  const bool live = i0 < B;
-  const int64_t i = live ? i0 : B - 1;
+  bool live;
+  const int64_t i = placed_index(pp, (int64_t)blockIdx.x * 4 + row, B, live);
   const int jq = 3 * leg + (c < 3 ? c : 2);
   WbLaneIn in;
   in.load(s, i, jq);
@@ -405,7 +405,10 @@ __global__ __launch_bounds__(64, 2) void wholebody_solve_kernel(const DevicePara
     tau_out[12 * i + 3 * leg + c] = ok ? tq : 0.0;
     if (grf_out) grf_out[12 * i + 3 * leg + c] = f;
   }
-  if (lr == 0 && live) status_out[i] = st;
+  if (lr == 0 && live) {
+    status_out[i] = st;
+    if (pp.iterations) pp.iterations[i] = st == kStatusNotPd ? 0 : qp_iters;
+  }
 }
 
 } // namespace
@@ -508,6 +511,9 @@ int qlamd_wholebody_solve_batch(qlamd_context *ctx, const qlamd_wholebody_params
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
   QL_ENTER(ctx, st);
+  PlacePtrs pp;
+  qlamd_placement pl;
+  { const int rc = take_placement(ctx, memory, batch, &pp, &pl); if (rc != QLAMD_OK) return rc; }
   const size_t B = (size_t)batch;
   WbPtrs s{in->joint_position, in->joint_velocity, in->base_orientation, in->base_linear_velocity,
            in->base_angular_velocity, in->desired_base_acceleration, in->desired_joint_acceleration, in->support_leg,
@@ -539,10 +545,11 @@ int qlamd_wholebody_solve_batch(qlamd_context *ctx, const qlamd_wholebody_params
   const coop::WbParamsDev W = wb_params_of(ctx, params->torque_weight, params->torque_limit, params->gravity);
   const unsigned grid = (unsigned)((batch + 3) / 4);
   if (s.normals)
-    hipLaunchKernelGGL(wholebody_solve_kernel<true>, dim3(grid), dim3(64), 0, st, ctx->d_params, W, s, batch, dtau, dgrf, dst);
+    hipLaunchKernelGGL(wholebody_solve_kernel<true>, dim3(grid), dim3(64), 0, st, ctx->d_params, W, s, batch, dtau, dgrf, dst, pp);
   else
-    hipLaunchKernelGGL(wholebody_solve_kernel<false>, dim3(grid), dim3(64), 0, st, ctx->d_params, W, s, batch, dtau, dgrf, dst);
+    hipLaunchKernelGGL(wholebody_solve_kernel<false>, dim3(grid), dim3(64), 0, st, ctx->d_params, W, s, batch, dtau, dgrf, dst, pp);
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  { const int rc = finish_placement(ctx, pl, batch, st); if (rc != QLAMD_OK) return rc; }
   if (memory == QLAMD_MEM_HOST) return sg.finish(st);
   return QLAMD_OK;
 }

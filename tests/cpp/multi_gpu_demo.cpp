@@ -1,65 +1,35 @@
-// The sharded balance solve driven from C++: one process per GPU, a qlamd context per device, contiguous shards of the
-// global batch, and the joint efforts of all shards collected on every rank with ONE RCCL all-gather per control step --
-// the host side BASELINE's north star asks for ("host code stays C++ ... shard the batch across 8xMI355X with RCCL
-// all-gather over xGMI only for result collection"), without torch: qlamd.h, the HIP runtime and rccl.h only.
+// The sharded balance solve driven from C++ -- a thin caller of quadruped_locomotion_amd/host/qlamd/sharded.hpp
+// (ShardedBalanceSolver: one process per GPU, a qlamd context per device, contiguous shards of the global batch, the joint
+// efforts of all shards collected on every rank with ONE RCCL all-gather per control step or per G steps), without torch:
+// qlamd.h, the HIP runtime and rccl.h only.
 //
-//   multi_gpu_demo --states FILE --robots N [--rank R --ranks W --id-file F] [--steps K] [--out FILE] [--gather-every G]
-//   multi_gpu_demo --selftest-sharding          (no GPU: prints the shard of every rank for a few batch sizes)
+//   multi_gpu_demo --states FILE --robots N [--rank R --ranks W --id-file F] [--steps K] [--out FILE] [--gather-every G] [--plain]
+//   multi_gpu_demo --selftest-sharding                       (no GPU: prints the shard of every rank for a few batch sizes)
+//   multi_gpu_demo --selftest-rendezvous --rank R --ranks W --id-file F
+//                                                            (no GPU, no RCCL call: the ranks exchange a 128-byte id through
+//                                                             the same exchange_id() the real run uses and print its checksum)
 //
 // --states: the global batch as written by tests/test_multi_gpu_cpp.py -- ten float64 arrays [N][k] one after the other
 //   in the order of qlamd_state_batch (k = 12 3 4 3 3 3 4 3 3) followed by support_leg [N][4] uint8.
-// Rank r solves robots [r * B, (r + 1) * B) with B = N / W (the last rank takes the remainder: shard_of below) on device
-// LOCAL_RANK (default r) and owns row block r of the gathered [N][12] array.
-// Rendezvous: rank 0 writes the ncclUniqueId to --id-file (atomically, by rename), the others wait for the file.
-// Pipeline (as bench.py's hipGraph form, here with plain streams and events): the solve of step k writes torque buffer
-// k & 1 on the solve stream; the gather of step k reads it on the gather stream and overlaps the solve of step k + 1,
-// which writes the other buffer; the solve of step k + 2 waits for gather k before it reuses the buffer.
-// With --gather-every G the efforts of G consecutive steps are collected by one all-gather of G * B * 96 bytes per rank.
+// Rank r solves robots shard_of(r, W, N) on device LOCAL_RANK (default r) and owns row block r of the gathered array.
+// --plain: qlamd_balance_solve_batch instead of the placed loop (qlamd_balance_solve_placed_batch, include/qlamd.h).
 // Exit codes: 0 ok, 2 usage, 3 no device, 4 a library call failed.
-#include <hip/hip_runtime_api.h>
-#include <rccl/rccl.h>
-
-#include <chrono>
-#include <cstdint>
-#include <cstdio>
 #include <cstdlib>
-#include <cstring>
 #include <string>
-#include <thread>
 #include <vector>
 
-#include "qlamd.h"
+#include "qlamd/sharded.hpp"
+
+using qlamd::host::Shard;
+using qlamd::host::shard_of;
+using qlamd::host::slot_of;
 
 namespace {
-
-struct Shard { int64_t first, count; };
-
-// contiguous shards; the remainder of N / W goes to the last rank (the all-gather needs equal counts: every rank's slot
-// is ceil-sized, see slot_of)
-Shard shard_of(int rank, int ranks, int64_t robots) {
-  const int64_t per = robots / ranks;
-  Shard s{per * rank, per};
-  if (rank == ranks - 1) s.count = robots - s.first;
-  return s;
-}
-int64_t slot_of(int ranks, int64_t robots) { // robots per all-gather slot: the largest shard
-  return shard_of(ranks - 1, ranks, robots).count;
-}
 
 #define HIP_OK(call)                                                                                      \
   do {                                                                                                    \
     const hipError_t e_ = (call);                                                                         \
     if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #call, hipGetErrorString(e_)); return 4; }  \
-  } while (0)
-#define NCCL_OK(call)                                                                                     \
-  do {                                                                                                    \
-    const ncclResult_t e_ = (call);                                                                       \
-    if (e_ != ncclSuccess) { std::fprintf(stderr, "%s: %s\n", #call, ncclGetErrorString(e_)); return 4; } \
-  } while (0)
-#define QL_OK(call)                                                                                       \
-  do {                                                                                                    \
-    const int e_ = (call);                                                                                \
-    if (e_ != QLAMD_OK) { std::fprintf(stderr, "%s: %s\n", #call, qlamd_strerror(e_)); return e_ == QLAMD_ERR_NO_DEVICE ? 3 : 4; } \
   } while (0)
 
 int selftest_sharding() {
@@ -76,6 +46,22 @@ int selftest_sharding() {
   return 0;
 }
 
+int selftest_rendezvous(int rank, int ranks, const std::string &id_path) {
+  static_assert(sizeof(ncclUniqueId) == 128, "the id the ranks exchange");
+  ncclUniqueId id;
+  std::memset(&id, 0, sizeof(id));
+  const int rc = qlamd::host::exchange_id(rank, id_path, &id, sizeof(id), [](void *p) {
+    unsigned char *b = static_cast<unsigned char *>(p);
+    for (int k = 0; k < 128; ++k) b[k] = (unsigned char)(37 * k + 11); // what ncclGetUniqueId would fill in
+    return 0;
+  });
+  if (rc != 0) { std::fprintf(stderr, "rank %d: no id through %s\n", rank, id_path.c_str()); return 4; }
+  unsigned long sum = 0;
+  for (int k = 0; k < 128; ++k) sum = sum * 131 + static_cast<unsigned char>(id.internal[k]);
+  std::printf("rank %d of %d id checksum %lu\n", rank, ranks, sum);
+  return 0;
+}
+
 } // namespace
 
 int main(int argc, char **argv) {
@@ -83,11 +69,14 @@ int main(int argc, char **argv) {
   int64_t robots = 0;
   int rank = std::getenv("RANK") ? std::atoi(std::getenv("RANK")) : 0;
   int ranks = std::getenv("WORLD_SIZE") ? std::atoi(std::getenv("WORLD_SIZE")) : 1;
-  int steps = 20, gather_every = 1;
+  int steps = 20;
+  bool rendezvous_only = false;
+  qlamd::host::ShardedBalanceSolver::Options opt;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     const auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
     if (a == "--selftest-sharding") return selftest_sharding();
+    else if (a == "--selftest-rendezvous") rendezvous_only = true;
     else if (a == "--states") states_path = next();
     else if (a == "--out") out_path = next();
     else if (a == "--id-file") id_path = next();
@@ -95,13 +84,18 @@ int main(int argc, char **argv) {
     else if (a == "--rank") rank = std::atoi(next());
     else if (a == "--ranks") ranks = std::atoi(next());
     else if (a == "--steps") steps = std::atoi(next());
-    else if (a == "--gather-every") gather_every = std::atoi(next());
+    else if (a == "--gather-every") opt.gather_every = std::atoi(next());
+    else if (a == "--plain") opt.placed = false;
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
   }
-  if (states_path.empty() || robots <= 0 || ranks < 1 || rank < 0 || rank >= ranks || steps < 1 || gather_every < 1 ||
+  if (rendezvous_only) {
+    if (ranks < 1 || rank < 0 || rank >= ranks || id_path.empty()) return 2;
+    return selftest_rendezvous(rank, ranks, id_path);
+  }
+  if (states_path.empty() || robots <= 0 || ranks < 1 || rank < 0 || rank >= ranks || steps < 1 || opt.gather_every < 1 ||
       (ranks > 1 && id_path.empty())) {
     std::fprintf(stderr, "usage: multi_gpu_demo --states FILE --robots N [--rank R --ranks W --id-file F] [--steps K] "
-                         "[--gather-every G] [--out FILE] | --selftest-sharding\n");
+                         "[--gather-every G] [--plain] [--out FILE] | --selftest-sharding | --selftest-rendezvous ...\n");
     return 2;
   }
   const int device = std::getenv("LOCAL_RANK") ? std::atoi(std::getenv("LOCAL_RANK")) : rank;
@@ -141,110 +135,64 @@ int main(int argc, char **argv) {
   in.desired_orientation = dfield[6]; in.desired_linear_velocity = dfield[7]; in.desired_angular_velocity = dfield[8];
   in.support_leg = dsupport;
 
-  // ---- one context per device; RCCL communicator
+  // ---- the communicator id (rank 0 creates it, the others wait for the file), then the solver of this rank
+  ncclUniqueId id;
+  if (qlamd::host::exchange_id(rank, id_path, &id, sizeof(id), [](void *p) {
+        return ncclGetUniqueId(static_cast<ncclUniqueId *>(p)) == ncclSuccess ? 0 : -1;
+      }) != 0) {
+    std::fprintf(stderr, "rank %d: no communicator id\n", rank);
+    return 4;
+  }
   qlamd_balance_params params;
   qlamd_balance_default_params(&params);
-  qlamd_context *ctx = nullptr;
-  QL_OK(qlamd_context_create(&params, nullptr, device, &ctx));
-  ncclUniqueId id;
-  if (rank == 0) {
-    NCCL_OK(ncclGetUniqueId(&id));
-    if (!id_path.empty()) {
-      const std::string tmp = id_path + ".tmp";
-      std::FILE *g = std::fopen(tmp.c_str(), "wb");
-      if (!g || std::fwrite(&id, sizeof(id), 1, g) != 1) { std::fprintf(stderr, "cannot write %s\n", tmp.c_str()); return 4; }
-      std::fclose(g);
-      std::rename(tmp.c_str(), id_path.c_str());
-    }
-  } else {
-    std::FILE *g = nullptr;
-    for (int tries = 0; tries < 600 && !(g = std::fopen(id_path.c_str(), "rb")); ++tries)
-      std::this_thread::sleep_for(std::chrono::milliseconds(100));
-    if (!g || std::fread(&id, sizeof(id), 1, g) != 1) { std::fprintf(stderr, "no id in %s\n", id_path.c_str()); return 4; }
-    std::fclose(g);
+  qlamd::host::ShardedBalanceSolver solver;
+  {
+    const int rc = solver.init(rank, ranks, device, robots, params, id, opt);
+    if (rc != 0) { std::fprintf(stderr, "init: %s\n", solver.error()); return rc == -2 ? 3 : 4; }
   }
-  ncclComm_t comm;
-  NCCL_OK(ncclCommInitRank(&comm, ranks, id, rank));
-
-  // ---- buffers: two sets, each holding the efforts of `gather_every` steps of this shard (slot-sized rows, so that every
-  // rank contributes the same count) and the gathered result [ranks][gather_every][slot][12]
-  const size_t shard_doubles = (size_t)gather_every * slot * 12, all_doubles = shard_doubles * ranks;
-  double *tau[2], *all[2];
-  int32_t *status = nullptr;
-  for (int b = 0; b < 2; ++b) {
-    HIP_OK(hipMalloc((void **)&tau[b], shard_doubles * 8));
-    HIP_OK(hipMemset(tau[b], 0, shard_doubles * 8));
-    HIP_OK(hipMalloc((void **)&all[b], all_doubles * 8));
-  }
-  HIP_OK(hipMalloc((void **)&status, (size_t)B * 4));
-  hipStream_t s_solve, s_gather;
-  HIP_OK(hipStreamCreateWithFlags(&s_solve, hipStreamNonBlocking));
-  HIP_OK(hipStreamCreateWithFlags(&s_gather, hipStreamNonBlocking));
-  hipEvent_t solved[2], gathered[2], t0, t1;
-  for (int b = 0; b < 2; ++b) {
-    HIP_OK(hipEventCreateWithFlags(&solved[b], hipEventDisableTiming));
-    HIP_OK(hipEventCreateWithFlags(&gathered[b], hipEventDisableTiming));
-  }
-  HIP_OK(hipEventCreate(&t0));
-  HIP_OK(hipEventCreate(&t1));
-
   const auto run = [&](int nsteps, bool with_gather) -> int {
-    bool pending[2] = {false, false};
-    for (int k = 0; k < nsteps; ++k) {
-      const int group = k / gather_every, b = group & 1, within = k % gather_every;
-      if (within == 0 && pending[b]) { HIP_OK(hipStreamWaitEvent(s_solve, gathered[b], 0)); pending[b] = false; }
-      QL_OK(qlamd_balance_solve_batch(ctx, &in, B, tau[b] + (size_t)within * slot * 12, nullptr, status, QLAMD_MEM_DEVICE, s_solve));
-      if (with_gather && (within == gather_every - 1 || k == nsteps - 1)) {
-        HIP_OK(hipEventRecord(solved[b], s_solve));
-        HIP_OK(hipStreamWaitEvent(s_gather, solved[b], 0));
-        NCCL_OK(ncclAllGather(tau[b], all[b], shard_doubles, ncclDouble, comm, s_gather));
-        HIP_OK(hipEventRecord(gathered[b], s_gather));
-        pending[b] = true;
-      }
-    }
-    HIP_OK(hipStreamSynchronize(s_solve));
-    HIP_OK(hipStreamSynchronize(s_gather));
+    solver.reset_steps();
+    for (int k = 0; k < nsteps; ++k)
+      if (solver.step(in, with_gather) != 0) { std::fprintf(stderr, "step: %s\n", solver.error()); return 4; }
+    if (solver.finish_group(with_gather) != 0 || solver.drain() != 0) { std::fprintf(stderr, "drain: %s\n", solver.error()); return 4; }
     return 0;
   };
   if (int rc = run(4, true)) return rc; // warm-up (RCCL sets its channels up on the first collective)
 
   double ms[2] = {0.0, 0.0};
   for (int with_gather = 1; with_gather >= 0; --with_gather) {
-    // every rank starts together: a tiny all-reduce as barrier
-    NCCL_OK(ncclAllReduce(status, status, 1, ncclInt32, ncclMax, comm, s_gather));
-    HIP_OK(hipStreamSynchronize(s_gather));
+    if (solver.barrier() != 0) { std::fprintf(stderr, "barrier: %s\n", solver.error()); return 4; } // every rank starts together
     const auto w0 = std::chrono::steady_clock::now();
     if (int rc = run(steps, with_gather != 0)) return rc;
     ms[with_gather] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
   }
-  // the last gathered group, back on the host: [ranks][slot][12] of its last step
-  const int last_group = (steps - 1) / gather_every, lb = last_group & 1, last_within = (steps - 1) % gather_every;
-  if (!out_path.empty() && rank == 0) {
-    // re-run with the gather so that all[lb] holds the last step (the timed no-gather loop ran last)
-    if (int rc = run(steps, true)) return rc;
-    std::vector<double> h(all_doubles);
-    HIP_OK(hipMemcpy(h.data(), all[lb], all_doubles * 8, hipMemcpyDeviceToHost));
-    std::FILE *g = std::fopen(out_path.c_str(), "wb");
-    if (!g) { std::fprintf(stderr, "cannot write %s\n", out_path.c_str()); return 4; }
-    for (int r = 0; r < ranks; ++r) {
-      const Shard s = shard_of(r, ranks, robots);
-      const double *src = h.data() + (size_t)r * shard_doubles + (size_t)last_within * slot * 12;
-      std::fwrite(src, 8, (size_t)s.count * 12, g);
+  // the last gathered group, back on the host: [ranks][G][slot][12]; its last step's rows go to --out in robot order
+  const int G = opt.gather_every;
+  const int64_t last_group = (steps - 1) / G;
+  const int last_within = (steps - 1) % G;
+  if (!out_path.empty()) {
+    if (int rc = run(steps, true)) return rc; // (the timed loop without the gather ran last; the collective needs every rank)
+    if (rank == 0) {
+      std::vector<double> h(solver.gathered_doubles());
+      HIP_OK(hipMemcpy(h.data(), solver.gathered(last_group), h.size() * 8, hipMemcpyDeviceToHost));
+      std::FILE *g = std::fopen(out_path.c_str(), "wb");
+      if (!g) { std::fprintf(stderr, "cannot write %s\n", out_path.c_str()); return 4; }
+      for (int r = 0; r < ranks; ++r) {
+        const Shard s = shard_of(r, ranks, robots);
+        const double *src = h.data() + (size_t)r * G * slot * 12 + (size_t)last_within * slot * 12;
+        std::fwrite(src, 8, (size_t)s.count * 12, g);
+      }
+      std::fclose(g);
     }
-    std::fclose(g);
-  } else if (!out_path.empty()) {
-    if (int rc = run(steps, true)) return rc; // the collective needs every rank
   }
   std::vector<int32_t> hs((size_t)B);
-  HIP_OK(hipMemcpy(hs.data(), status, (size_t)B * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(hs.data(), solver.status(), (size_t)B * 4, hipMemcpyDeviceToHost));
   int64_t failed = 0;
   for (int32_t v : hs) failed += v != QLAMD_STATUS_OK;
-  std::printf("rank %d of %d device %d robots %lld+%lld steps %d gather_every %d : %.1f us/step with the all-gather, %.1f without, "
+  std::printf("rank %d of %d device %d robots %lld+%lld steps %d gather_every %d %s : %.1f us/step with the all-gather, %.1f without, "
               "%lld robots with status != ok\n",
-              rank, ranks, device, (long long)sh.first, (long long)B, steps, gather_every, 1e3 * ms[1] / steps, 1e3 * ms[0] / steps,
-              (long long)failed);
-
-  ncclCommDestroy(comm);
-  qlamd_context_destroy(ctx);
+              rank, ranks, device, (long long)sh.first, (long long)B, steps, G, opt.placed ? "placed" : "plain",
+              1e3 * ms[1] / steps, 1e3 * ms[0] / steps, (long long)failed);
+  solver.destroy();
   return 0;
 }

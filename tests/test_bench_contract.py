@@ -1,5 +1,5 @@
 """The one-line JSON contract of bench.py: every key the driver reads, with the types and relations it relies on.
-CPU: the committed line of the last measured run (profiles/r4/bench_static_b4096.json).  GPU: short live runs."""
+CPU: the committed line of the last measured run (profiles/r5/bench_static_b4096.json).  GPU: short live runs."""
 import json
 import os
 import subprocess
@@ -37,8 +37,33 @@ def check(line, want_cpu=True):
     return d
 
 
+ALSO = {"static-calm", "trot", "static-survey-prev-tick-hints", "trot_b8192", "trot_b65536", "pose_sqp_b4096"}
+ALSO_KEYS = ("value", "ms_per_step", "kernel_ms", "roofline_frac", "valu_issue_frac", "all_status_ok")
+
+
+def check_round5(d):
+    """What round 5 added to the default line: the placed loop as the method, the same steps through the plain entry beside
+    it, every BASELINE config in `also`, and the scale point a weak-scaling curve is drawn from."""
+    assert d["config"]["method"] == "placed" and "placement" in d["config"]["method_note"]
+    u = d["unplaced"]
+    assert u["method"] == "plain" and u["all_status_ok"] is True and u["batch"] == 4096 and u["ms_per_step"] > 0
+    assert set(d["also"]) == ALSO
+    for name, a in d["also"].items():
+        for k in ALSO_KEYS:
+            assert k in a, (name, k)
+        assert a["all_status_ok"] is True and a["value"] > 0 and a["kernel_ms"] > 0 and 0 < a["roofline_frac"] < 1, name
+    assert d["also"]["static-calm"]["tracking_error"] == [0.004, 0.005, 0.01] and d["also"]["static-calm"]["method"] == "plain"
+    assert d["also"]["trot_b8192"]["batch"] == 8192 and d["also"]["trot_b65536"]["batch"] == 65536
+    assert d["also"]["trot_b8192"]["unplaced"]["ms_per_step"] > 0 and d["also"]["trot_b65536"]["unplaced"]["all_status_ok"] is True
+    assert "note" in d["also"]["static-survey-prev-tick-hints"] and d["also"]["static-survey-prev-tick-hints"]["method"] == "placed"
+    sp = d["scale_point"]
+    assert sp["robots_per_gpu"] == 8192 and sp["gait"] == "trot" and sp["n_gpus"] == d["n_gpus"]
+    assert sp["value"] > 0 and sp["without_gather"] > 0 and "efficiency" in sp["definition"]
+    assert abs(sp["value"] - d["also"]["trot_b8192"]["value"]) < 1e-6 * sp["value"]
+
+
 def test_committed_bench_line_follows_the_contract():
-    path = os.path.join(ROOT, "profiles", "r4", "bench_static_b4096.json")
+    path = os.path.join(ROOT, "profiles", "r5", "bench_static_b4096.json")
     d = check(open(path).read().strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["config"]["robots_per_gpu"] == 4096 and d["config"]["all_status_ok"] is True
     # round 2: the input is disclosed, the timed region is a median of samples, PMC numbers carry their source
@@ -46,12 +71,13 @@ def test_committed_bench_line_follows_the_contract():
     # round 3: the driver-timed workload is SURVEY 8(d)'s literal one, the other presets ride along, the CPU baseline is a
     # sustained rate of pinned threads, every PMC record says which FETCH_SIZE rule it got
     assert d["config"]["gait"] == "static" and d["config"]["tracking_error"] == [0.02, 0.05, 0.1]
-    assert set(d["also"]) == {"static-calm", "trot"} and all(a["all_status_ok"] for a in d["also"].values())
-    assert d["also"]["static-calm"]["tracking_error"] == [0.004, 0.005, 0.01]
     c = d["cpu_baseline"]
     assert c["cpu_model"] and c["value"] >= 0.9 * max(c["thread_sweep"].values()) and c["thread_sweep_seconds_each"] >= 1.5
     assert d["roofline"]["traffic"] and "FETCH_SIZE" in d["roofline"]["traffic_rule"]
     assert d["valu_issue"]["frac"] >= 0.25
+    # round 5
+    check_round5(d)
+    assert d["ms_per_step"] < d["unplaced"]["ms_per_step"]   # the placement pays on the headline preset
 
 
 @pytest.mark.gpu
@@ -86,12 +112,13 @@ def test_live_default_line_is_the_contract_workload_and_carries_the_other_preset
     `also` object with static-calm and trot measured in the same process."""
     d = check(_bench("--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--replays", "3"), want_cpu=False)
     assert d["config"]["gait"] == "static" and d["config"]["tracking_error"] == [0.02, 0.05, 0.1]
-    assert set(d["also"]) == {"static-calm", "trot"}
+    check_round5(d)
     for name, a in d["also"].items():
-        assert a["all_status_ok"] is True and a["value"] > 0 and a["kernel_ms"] > 0 and 0 < a["roofline_frac"] < 1, name
-        assert "pmc_source" in a and "valu_issue_frac" in a
-    assert d["also"]["static-calm"]["tracking_error"] == [0.004, 0.005, 0.01]
+        assert "pmc_source" in a, name
     assert d["also"]["static-calm"]["kernel_ms"] < d["roofline"]["kernel_ms"]     # the calm preset is the lighter one
+    # the plain entry as the method: the placed loop rides along instead
+    d = check(_bench("--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--replays", "3", "--method", "plain"), want_cpu=False)
+    assert d["config"]["method"] == "plain" and d["placed"]["method"] == "placed" and d["placed"]["all_status_ok"] is True
 
 
 @pytest.mark.gpu
@@ -107,6 +134,8 @@ def test_collective_path_with_one_rank():
     assert c["launch"] == "hipGraph of K steps" and c["gather_stream"] == "second captured stream"
     assert c["result_collection"] == "rccl all_gather of torques" and c["gather_layout_ok"] is True
     assert "also" not in d and "cpu_baseline" not in d
+    sp = d["scale_point"]     # every line at every N carries it; here it IS the line's workload
+    assert sp["robots_per_gpu"] == 8192 and abs(sp["value"] - d["value"]) < 1e-6 * d["value"] and sp["method"] == d["config"]["method"]
     with_gather = d["value"]
     d = check(_bench(*common, "--no-gather"), want_cpu=False)
     assert d["config"]["result_collection"] == "none (--no-gather)" and d["config"]["rccl_ranks"] == 1
@@ -157,7 +186,7 @@ def test_profile_collection_names_exist_in_the_sources():
     kernels = set(re.findall(r"__global__[^;{]*?\bvoid\s+(\w+)\s*\(", text))
     for name, kernel, batch, args in cp.WORKLOADS:
         assert kernel in kernels, kernel
-    idx = json.load(open(os.path.join(ROOT, "profiles", "r4", "pmc_index.json")))
+    idx = json.load(open(os.path.join(ROOT, "profiles", "r5", "pmc_index.json")))
     have = {(r["kernel"], r["batch"], r["workload"]) for r in idx["records"]}
     assert have == {(k, b, n) for n, k, b, _ in cp.WORKLOADS}
     assert all("fetch_bytes" in r and "write_bytes" in r and "valu_insts" in r for r in idx["records"])

@@ -33,7 +33,7 @@ def build_demo():
     build.build()
     pkg = os.path.join(ROOT, "quadruped_locomotion_amd")
     subprocess.check_call([HIPCC, "-std=c++17", "-O1", "-Wall", "-x", "c++", "-D__HIP_PLATFORM_AMD__",
-                           "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-o", BIN,
+                           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(pkg, "host"), "-I/opt/rocm/include", "-o", BIN,
                            os.path.join(ROOT, "tests", "cpp", "multi_gpu_demo.cpp"), "-L" + pkg, "-lqlamd",
                            "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath," + pkg], stderr=subprocess.DEVNULL)
 
@@ -76,6 +76,34 @@ def test_demo_builds_and_shards_partition_the_batch():
         assert p.returncode == 3  # no device: the demo, like the library, has no CPU path
 
 
+@needs_hipcc
+def test_id_file_rendezvous_between_two_processes(tmp_path):
+    """What ranks > 0 do before ncclCommInitRank: wait for the file rank 0 publishes (written aside and renamed, so that a
+    reader sees nothing or all of it).  Two processes go through exchange_id() of host/qlamd/sharded.hpp -- the waiting rank
+    started first -- with a 128-byte pattern in place of ncclGetUniqueId's id; no GPU, no RCCL call."""
+    import time
+    build_demo()
+    idf = str(tmp_path / "nccl.id")
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    waiter = subprocess.Popen([BIN, "--selftest-rendezvous", "--rank", "1", "--ranks", "2", "--id-file", idf],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    time.sleep(0.5)
+    assert waiter.poll() is None          # still waiting: nothing has been published
+    p0 = run("--selftest-rendezvous", "--rank", "0", "--ranks", "2", "--id-file", idf)
+    out1, err1 = waiter.communicate(timeout=60)
+    assert p0.returncode == 0 and waiter.returncode == 0, p0.stderr + err1
+    c0, c1 = p0.stdout.split()[-1], out1.split()[-1]
+    assert c0 == c1 and p0.stdout.startswith("rank 0 of 2") and out1.startswith("rank 1 of 2")
+    want = 0
+    for k in range(128):
+        want = (want * 131 + (37 * k + 11) % 256) % (1 << 64)
+    assert int(c0) == want
+    assert not os.path.exists(idf + ".tmp")
+    # nobody publishes: the waiting rank gives up with an error instead of hanging (timeout shortened through the file's absence)
+    p = run("--selftest-rendezvous", "--rank", "0", "--ranks", "2", "--id-file", str(tmp_path / "no_such_dir" / "id"))
+    assert p.returncode == 4
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("gather_every", [1, 4])
 def test_one_rank_pipeline_equals_the_python_path(gpu, tmp_path, gather_every):
@@ -85,11 +113,15 @@ def test_one_rank_pipeline_equals_the_python_path(gpu, tmp_path, gather_every):
     state = synth.make_states(B, "trot")
     states, out = str(tmp_path / "states.bin"), str(tmp_path / "tau.bin")
     write_states(states, state)
-    p = run("--states", states, "--robots", str(B), "--ranks", "1", "--rank", "0", "--steps", "10",
-            "--gather-every", str(gather_every), "--out", out)
-    assert p.returncode == 0, p.stdout + p.stderr
-    assert "0 robots with status != ok" in p.stdout
-    got = np.fromfile(out, dtype=np.float64).reshape(B, 12)
+    got = None
+    for extra in ((), ("--plain",)):  # the placed loop of the header and the plain entry: the same efforts
+        p = run("--states", states, "--robots", str(B), "--ranks", "1", "--rank", "0", "--steps", "10",
+                "--gather-every", str(gather_every), "--out", out, *extra)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert "0 robots with status != ok" in p.stdout and ("plain" if extra else "placed") in p.stdout
+        now = np.fromfile(out, dtype=np.float64).reshape(B, 12)
+        assert got is None or np.array_equal(got, now)
+        got = now
     d = capi.to_device(state)
     tau = torch.zeros(B, 12, dtype=torch.float64, device="cuda:0")
     status = torch.zeros(B, dtype=torch.int32, device="cuda:0")

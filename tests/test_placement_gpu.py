@@ -229,3 +229,90 @@ def test_next_placement_made_inside_the_solve_equals_the_placement_entry(gpu, B)
         rc = capi.lib().qlamd_balance_solve_placed_batch(ctx._h, C.byref(sb), B, C.byref(pl), tau.data_ptr(), None, status.data_ptr(),
                                                          capi.MEM_DEVICE, None)
         assert rc == capi.ERR_INVALID_ARGUMENT
+
+
+def _force_qps(torch, B):
+    """The golden force QPs (n = 12, m = 20) tiled to B problems, on the device, in both forms the library takes."""
+    import os
+    from conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "qp_goldens.npz"))
+    reps = B // 128
+    tile = lambda a: np.ascontiguousarray(np.tile(a, (reps,) + (1,) * (a.ndim - 1)))  # noqa: E731
+    dev = lambda a: torch.from_numpy(a).to("cuda:0")  # noqa: E731
+    qp = tuple(dev(tile(g["n12_" + k])) for k in ("G", "g0", "CI", "ci0"))
+    lam, V = np.linalg.eigh(g["n12_G"] - 1e-4 * np.eye(12))
+    A = np.sqrt(np.clip(lam, 0.0, None))[:, :, None] * np.transpose(V, (0, 2, 1))
+    b = np.stack([-np.linalg.lstsq(A[i].T, g["n12_g0"][i], rcond=None)[0] for i in range(128)])
+    D, d = np.transpose(g["n12_CI"], (0, 2, 1)), -g["n12_ci0"]
+    lsq = tuple(dev(tile(a)) for a in (A, np.ones((128, 12)), b, np.full((128, 12), 1e-4), D, d, np.full(d.shape, 1.7976931348623157e308)))
+    return qp, lsq
+
+
+def test_place_next_call_on_the_other_qp_entries(gpu):
+    """qlamd_place_next_call: the dense QP batch, the weighted least-squares entry and the whole-body step take a placement
+    through the context -- same results bit for bit under any placement, iteration counts out, the placement for the next
+    call made behind the solve, and a pending placement is used exactly once."""
+    capi, ctx, torch = gpu
+    B = 1024
+    L = capi.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    (G, g0, CI, ci0), (A, S, b, W, D, d, f) = _force_qps(torch, B)
+    wb = capi.to_device(synth.make_wholebody_states(B, "trot"))
+    i32 = lambda fill: torch.full((B,), fill, dtype=torch.int32, device="cuda:0")  # noqa: E731
+
+    def qp():
+        x, obj, st = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0"), torch.zeros(B, dtype=torch.float64, device="cuda:0"), i32(-1)
+        rc = L.qlamd_qp_solve_batch(ctx._h, 12, 0, 20, G.data_ptr(), g0.data_ptr(), None, None, CI.data_ptr(), ci0.data_ptr(), B,
+                                    x.data_ptr(), obj.data_ptr(), st.data_ptr(), capi.MEM_DEVICE, C.c_void_p(stream))
+        assert rc == 0
+        return x, obj, st
+
+    def lsq():
+        x, st = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0"), i32(-1)
+        capi.weighted_lsq_qp(ctx, A, S, b, W, None, None, D, d, f, memory=capi.MEM_DEVICE, out=(x, st), stream=stream)
+        return x, st
+
+    def whole():
+        tau = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+        grf = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+        st = i32(-1)
+        capi.wholebody_solve_device(ctx, wb, tau, grf, st, stream=stream)
+        return tau, grf, st
+
+    rng = np.random.default_rng(2)
+    for entry in (qp, lsq, whole):
+        ref = [t.cpu().numpy() for t in (entry(), torch.cuda.synchronize())[0]]
+        it = i32(-1)
+        ctx.place_next_call(iterations=it)
+        got = [t.cpu().numpy() for t in (entry(), torch.cuda.synchronize())[0]]
+        for a, r in zip(got, ref):
+            assert np.array_equal(a, r, equal_nan=True)
+        itn = it.cpu().numpy()
+        assert (itn >= 0).all() and itn.max() > 2
+        # used once: the next call runs unplaced and writes no counts
+        it.fill_(-7)
+        _ = entry()
+        torch.cuda.synchronize()
+        assert (it.cpu().numpy() == -7).all()
+        it.copy_(torch.from_numpy(itn))
+        for order in (rng.permutation(B).astype(np.int32), ctx.placement_from_iterations(itn, policy=capi.PLACEMENT_LATENCY)):
+            o = torch.from_numpy(order).to("cuda:0")
+            it3, nxt = i32(-1), i32(-1)
+            ctx.place_next_call(order=o, iterations=it3, prev_iterations=it, next_order=nxt, policy=capi.PLACEMENT_THROUGHPUT)
+            got = [t.cpu().numpy() for t in (entry(), torch.cuda.synchronize())[0]]
+            for a, r in zip(got, ref):
+                assert np.array_equal(a, r, equal_nan=True)
+            assert np.array_equal(it3.cpu().numpy(), itn)
+            assert np.array_equal(nxt.cpu().numpy(), ctx.placement_from_iterations(itn, policy=capi.PLACEMENT_THROUGHPUT))
+    # a host-memory call that finds a placement pending refuses and clears it; NULL withdraws one
+    ctx.place_next_call(iterations=i32(-1))
+    with pytest.raises(capi.QlamdError) as e:
+        capi.wholebody_solve(ctx, synth.make_wholebody_states(8, "trot"))
+    assert e.value.code == capi.ERR_INVALID_ARGUMENT
+    capi.wholebody_solve(ctx, synth.make_wholebody_states(8, "trot"))
+    it4 = i32(-7)
+    ctx.place_next_call(iterations=it4)
+    ctx.place_next_call()
+    _ = whole()
+    torch.cuda.synchronize()
+    assert (it4.cpu().numpy() == -7).all()

@@ -29,11 +29,17 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = [
     # name, kernel substring, batch, bench.py arguments
-    ("static-survey", "balance_coop_kernel", 4096, ["--gait", "static", "--errors", "survey"]),
-    ("static-calm", "balance_coop_kernel", 4096, ["--gait", "static", "--errors", "calm"]),
-    ("trot", "balance_coop_kernel", 4096, ["--gait", "trot"]),
-    ("trot", "balance_coop_kernel", 65536, ["--gait", "trot", "--batch", "65536"]),
-    ("trot", "balance_coop_kernel", 8192, ["--gait", "trot", "--batch", "8192"]),
+    # (+placed: bench.py's default method since round 5 -- every step one qlamd_balance_solve_placed_batch launch that also
+    # makes the next step's placement; the others: the plain entry, the headline of rounds 1-4)
+    ("static-survey+placed", "balance_coop_kernel", 4096, ["--gait", "static", "--errors", "survey", "--method", "placed"]),
+    ("trot+placed", "balance_coop_kernel", 4096, ["--gait", "trot", "--method", "placed"]),
+    ("trot+placed", "balance_coop_kernel", 8192, ["--gait", "trot", "--batch", "8192", "--method", "placed"]),
+    ("trot+placed", "balance_coop_kernel", 65536, ["--gait", "trot", "--batch", "65536", "--method", "placed"]),
+    ("static-survey", "balance_coop_kernel", 4096, ["--gait", "static", "--errors", "survey", "--method", "plain"]),
+    ("static-calm", "balance_coop_kernel", 4096, ["--gait", "static", "--errors", "calm", "--method", "plain"]),
+    ("trot", "balance_coop_kernel", 4096, ["--gait", "trot", "--method", "plain"]),
+    ("trot", "balance_coop_kernel", 65536, ["--gait", "trot", "--batch", "65536", "--method", "plain"]),
+    ("trot", "balance_coop_kernel", 8192, ["--gait", "trot", "--batch", "8192", "--method", "plain"]),
     ("pose_sqp", "pose_sqp_coop_kernel", 4096, ["--workload", "pose_sqp"]),
     ("wholebody-trot", "wholebody_solve_kernel", 4096, ["--workload", "wholebody", "--gait", "trot"]),
     ("wholebody_dynamics", "wholebody_dynamics_leg_kernel", 1048576, ["--workload", "wholebody_dynamics", "--batch", "1048576"]),
@@ -91,7 +97,7 @@ def main():
     records = []
     bench_py = os.path.join(ROOT, "bench.py")
     for name, kernel, batch, args in WORKLOADS:
-        tag = "%s_b%d" % (name.replace("-", "_"), batch)
+        tag = "%s_b%d" % (name.replace("-", "_").replace("+", "_"), batch)
         rec = dict(kernel=kernel, batch=batch, workload=name, source_hash=bench.source_hash(), files=[], failed_passes=[])
         # kernel durations (the K steps as one hipGraph, as the bench line is measured)
         d = os.path.join(out, "raw", tag + "_stats")

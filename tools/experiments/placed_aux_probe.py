@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""qlamd_place_next_call on the other lane-cooperative QP entries: the dense QP batch and the weighted least-squares entry on
+the golden force QPs (n = 12, m = 20, tiled to 4096 problems), the whole-body step on trot / static states -- microseconds
+per launch of a captured graph, unplaced and in the latency / throughput placement made from the entry's own iteration
+counts.  usage: placed_aux_probe.py [--lib ...] [--batch 4096]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from variant_bench import timed  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=None)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--reps", type=int, default=100)
+    args = ap.parse_args()
+    import torch
+    from quadruped_locomotion_amd import capi, synth
+    from test_placement_gpu import _force_qps
+    if args.lib:
+        capi.LIB_PATH = os.path.abspath(args.lib)
+    ctx = capi.Context(device=0)
+    L, B = capi.lib(), args.batch
+    (G, g0, CI, ci0), (A, S, b, W, D, d, f) = _force_qps(torch, B)
+    x = torch.zeros(B, 12, dtype=torch.float64, device="cuda:0")
+    obj = torch.zeros(B, dtype=torch.float64, device="cuda:0")
+    st = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    tau, grf = torch.zeros(B, 12, dtype=torch.float64, device="cuda:0"), torch.zeros(B, 12, dtype=torch.float64, device="cuda:0")
+
+    def qp(cap):
+        rc = L.qlamd_qp_solve_batch(ctx._h, 12, 0, 20, G.data_ptr(), g0.data_ptr(), None, None, CI.data_ptr(), ci0.data_ptr(), B,
+                                    x.data_ptr(), obj.data_ptr(), st.data_ptr(), capi.MEM_DEVICE, C.c_void_p(cap))
+        assert rc == 0
+
+    def lsq(cap):
+        capi.weighted_lsq_qp(ctx, A, S, b, W, None, None, D, d, f, memory=capi.MEM_DEVICE, out=(x, st), stream=cap)
+    entries = [("qp_coop_kernel<12> (golden force QPs)", qp), ("weighted_lsq_qp_kernel<12>", lsq)]
+    for gait in ("trot", "static"):
+        wb = capi.to_device(synth.make_wholebody_states(B, gait))
+        entries.append(("wholebody_solve_kernel %s" % gait, lambda cap, wb=wb: capi.wholebody_solve_device(ctx, wb, tau, grf, st, stream=cap)))
+    for name, entry in entries:
+        it = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+        ctx.place_next_call(iterations=it)
+        entry(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        itn = it.cpu().numpy()
+        res = ["unplaced %.2f" % timed(entry, args.reps)]
+        for pname, pol in (("latency", capi.PLACEMENT_LATENCY), ("throughput", capi.PLACEMENT_THROUGHPUT)):
+            order = torch.from_numpy(ctx.placement_from_iterations(itn, policy=pol)).to("cuda:0")
+
+            def placed(cap):
+                ctx.place_next_call(order=order, iterations=it)
+                entry(cap)
+            res.append("%s %.2f" % (pname, timed(placed, args.reps)))
+        print("%-42s %5d problems (iterations mean %.1f max %d) | %s" % (name, B, itn.mean(), itn.max(), " | ".join(res)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
