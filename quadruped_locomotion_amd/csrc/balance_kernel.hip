@@ -23,6 +23,8 @@ struct StatePtrs {
   const int32_t *prev_iterations; // [B]: the counts it is made from (the previous launch's `iterations`)
   int32_t *next_order;            // [B] or NULL: where it goes
   int place_throughput;           // policy: 0 latency, 1 throughput
+  const uint32_t *prev_working_set; // [B] or NULL: warm start (kWarm instantiations)
+  uint32_t *working_set;            // [B] or NULL
 };
 
 __device__ __forceinline__ void load_robot(const StatePtrs &s, int64_t i, RobotIn &in) {
@@ -358,7 +360,8 @@ constexpr int kCoopWaves = 1;
 // thousand robots as long as its slowest wavefront -- WHO shares a wavefront decides both.  The slot's
 // robot index is one more load in front of the robot's own (a dependent round trip at the head of the launch), which is
 // why the plain entry keeps a kernel without it.  An entry outside [0, B) leaves its row empty.
-template <bool kPerLeg, int kMinWaves, bool kPlaced = false>
+// kWarm (with kPlaced): every robot's QP starts from the working set the caller hands in (force_qp_coop.hpp).
+template <bool kPerLeg, int kMinWaves, bool kPlaced = false, bool kWarm = false>
 __global__ __launch_bounds__(64 * kCoopWaves, kMinWaves) void balance_coop_kernel(const DeviceParams *__restrict__ Pp, const StatePtrs s,
                                                                       int64_t B, double *__restrict__ tau,
                                                                       double *__restrict__ grf, int32_t *__restrict__ status) {
@@ -387,12 +390,13 @@ __global__ __launch_bounds__(64 * kCoopWaves, kMinWaves) void balance_coop_kerne
     }
   }
   const coop::CoopPtrs cp{s.q, s.pos, s.quat, s.linvel, s.angvel, s.dpos, s.dquat, s.dlinvel, s.dangvel, s.stance,
-                          s.normals, s.wrench, s.live, s.support_only, kPlaced ? s.iterations : nullptr};
+                          s.normals, s.wrench, s.live, s.support_only, kPlaced ? s.iterations : nullptr,
+                          kWarm ? s.prev_working_set : nullptr, kWarm ? s.working_set : nullptr};
 #ifdef QLAMD_STAMPS
 #pragma unroll 1
   for (int rep = 0; rep < 2; rep++) // second pass runs with a warm instruction cache
 #endif
-  coop::coop_robot<kPerLeg, 64 * kCoopWaves>(P, cp, i, live, tab, rows + row * coop::kCoopLdsDoubles, nrm + wave * coop::kCoopNrmDoubles, tau, grf,
+  coop::coop_robot<kPerLeg, 64 * kCoopWaves, kWarm>(P, cp, i, live, tab, rows + row * coop::kCoopLdsDoubles, nrm + wave * coop::kCoopNrmDoubles, tau, grf,
                             status);
 }
 
@@ -671,7 +675,12 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
   if (next_order && pl->policy != QLAMD_PLACEMENT_AUTO && pl->policy != QLAMD_PLACEMENT_LATENCY && pl->policy != QLAMD_PLACEMENT_THROUGHPUT)
     return QLAMD_ERR_INVALID_ARGUMENT;
   if (next_order && (next_order == order || prev_iterations == iterations)) return QLAMD_ERR_INVALID_ARGUMENT; // read and written by one launch
-  const bool placed = order || iterations || next_order;
+  const uint32_t *prev_ws = pl ? pl->prev_working_set : nullptr;
+  uint32_t *ws = pl ? pl->working_set : nullptr;
+  const bool warm = prev_ws || ws;
+  if (warm && memory != QLAMD_MEM_DEVICE) return QLAMD_ERR_INVALID_ARGUMENT; // (a host-buffer call is bound by its copies)
+  if (warm && prev_ws == ws) return QLAMD_ERR_INVALID_ARGUMENT;              // read and written by one launch
+  const bool placed = order || iterations || next_order || warm;
   // the one-lane kernels of qlamd_set_robots_per_wave know no placement (a lane is a robot there: nothing is shared)
   if (placed && pick_rpw(ctx, batch) != 4) return QLAMD_ERR_INVALID_ARGUMENT;
   if (placed && batch > INT32_MAX) return QLAMD_ERR_INVALID_ARGUMENT;
@@ -774,6 +783,8 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
                   in->base_angular_velocity, in->desired_position, in->desired_orientation,
                   in->desired_linear_velocity, in->desired_angular_velocity, in->support_leg,
                   in->surface_normal, wrench, live, support_only, order, iterations, nullptr, nullptr, 0};
+    s.prev_working_set = prev_ws;
+    s.working_set = ws;
     // the next launch's placement: by one more wavefront of this launch when its counters fit the workgroup's LDS
     static_assert(kShadowMaxRobots < QLAMD_THROUGHPUT_BATCH, "the shadow wavefront exists in the two-wavefront form only");
     if (next_order && batch <= kShadowMaxRobots) {
@@ -789,7 +800,10 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
       const unsigned grid = (unsigned)((batch + 4 * kCoopWaves - 1) / (4 * kCoopWaves)) + (s.next_order ? 1u : 0u);
 #define QL_LAUNCH_COOP(PERLEG, WAVES)                                                                                        \
   do {                                                                                                                       \
-    if (placed)                                                                                                              \
+    if (warm)                                                                                                                \
+      hipLaunchKernelGGL((balance_coop_kernel<PERLEG, WAVES, true, true>), dim3(grid), dim3(64 * kCoopWaves), 0, st,         \
+                         ctx->d_params, s, batch, d_tau, d_grf, d_status);                                                   \
+    else if (placed)                                                                                                         \
       hipLaunchKernelGGL((balance_coop_kernel<PERLEG, WAVES, true>), dim3(grid), dim3(64 * kCoopWaves), 0, st, ctx->d_params, \
                          s, batch, d_tau, d_grf, d_status);                                                                  \
     else                                                                                                                     \

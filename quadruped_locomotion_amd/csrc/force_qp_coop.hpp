@@ -47,6 +47,9 @@ struct ForceQp {
   // kTorque only.  tau = tau0 - J_leg' f:  J[c][k] and J[k][c] of my leg (0 unless on && comp)
   double jrow[3], jcol[3];
   double tq_up, tq_lo;           // tau_max - tau0_c, tau_max + tau0_c
+  // kWarm only: the working set to start from (bit 5 leg + kind, as written to `ws_out` by an earlier solve) and the
+  // stance legs as a bit mask (rows of other legs are left out of it)
+  unsigned warm, stance;
 };
 
 // My row of G and my entry of g0 for the objective  |A f - F|^2_S + w_reg |f|^2  (A = [1 ... ; [r_leg]x ...], the
@@ -106,8 +109,18 @@ __device__ __forceinline__ void force_qp_objective(const double S[6], double w_r
 // Returns the status; x: my component of the minimiser (valid for kStatusOk); iters_out: outer iterations taken
 // (QuadProg++'s `iter`, QuadProg++.cc:216,262: one per candidate selected, the last one finds none) -- what a caller can
 // hand back as a placement hint on the next control step (qlamd_placement_from_iterations).
-template <bool kTorque>
-__device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, double *lds_nrm, double &x, int &iters_out) {
+// kWarm: the dual method starts from the working set Q.warm instead of the empty one -- the final working set of the same
+// robot's previous control step, which at 400 Hz is this step's final set for 96 % of the robots of the bench batches
+// (tools/experiments/warm_start_model.py) -- and the final working set goes to ws_out.  The rows are installed as equalities
+// one after the other (directions, a full step onto the row, the rank-one update: no step lengths, no selection), then the
+// slots whose multiplier came out negative are dropped, most negative first, until the pair is dual feasible; from there the
+// method runs as always, so a set that no longer fits costs passes, not the answer (the minimiser is unique).  The passes a
+// robot then still needs are its `iters_out`.  QuadProg++ has no such entry (solve_quadprog always starts from the
+// unconstrained minimiser, QuadProg++.cc:216-233): iteration counts no longer match the reference's one for one, torques do.
+template <bool kTorque, bool kWarm = false>
+__device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, double *lds_nrm, double &x, int &iters_out,
+                                             unsigned *ws_out = nullptr) {
+  static_assert(!(kTorque && kWarm), "the warm start knows the balance step's five row kinds only");
   using mask_t = std::conditional_t<kTorque, unsigned long long, unsigned>;
   constexpr int kKinds = kTorque ? 11 : 5;
   const int lr = threadIdx.x & 15, leg = lr >> 2, c = lr & 3;
@@ -422,6 +435,66 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     return drop_id;
   };
 
+  if constexpr (kWarm) {
+    // ---- warm start: install the previous working set (rows of legs that still support), then drop negative multipliers
+    unsigned wm = Q.warm & (((Q.stance & 1u) ? 0x1Fu : 0u) | ((Q.stance & 2u) ? 0x3E0u : 0u) | ((Q.stance & 4u) ? 0x7C00u : 0u) |
+                            ((Q.stance & 8u) ? 0xF8000u : 0u));
+    for (;;) {
+      const bool has = wm != 0u;
+      if (__builtin_amdgcn_ballot_w64(has) == 0ull) break;
+      const int p = has ? __ffs(wm) - 1 : 0;
+      wm &= wm - 1u;
+      const int pleg = id_leg(p), kind = p - 5 * pleg;
+      const double np_tab = lds_nrm[64 * kind + ((int)threadIdx.x & 63)];
+      npj = (has && pleg == leg) ? np_tab : 0.0;
+      // directions as in a pass; z'n_p of a row without a candidate is 0: biased to 1, its step is 0
+      double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
+      static_for<12>([&](auto J) {
+        constexpr int j = J;
+        fmac_bc<lane_of(j), j == 0>(za[j % 3], npj, H[j]);
+        fmac_bc<lane_of(j)>(ra[j % 3], npj, Ns[j]);
+      });
+      const double zw = (za[0] + za[1]) + za[2], rw = (ra[0] + ra[1]) + ra[2];
+      const double znw = row_sum(zw * npj);
+      const double s_p = row_sum(npj * x) - sel(kind == 0, f_min, 0.0); // slack of the row at x
+      // a row that depends on the rows installed before it (z'n_p at rounding level: H entries reach 1 / w_reg = 1e4) is left out
+      const bool ok = has && znw > 1e-9;
+      const double zi = rcp_nr(sel(ok, znw, 1.0));
+      const double tw = sel(ok, -s_p * zi, 0.0);
+      x = fma(tw, zw, x);
+      u = fma(-tw, rw, u);
+      const int newlane = __ffs(~used & 0xFFFu) - 1;
+      const bool newslot = ok && lr == newlane;
+      vec = sel(ok, zw * zi, 0.0);
+      hc = sel(ok, -zw, 0.0);
+      nc = sel(newslot, 1.0, sel(ok, -rw, 0.0));
+      u = sel(newslot, tw, u);
+      idk = newslot ? p : idk;
+      used |= ok ? (1u << newlane) : 0u;
+      act_mask |= ok ? (one << p) : 0;
+      rnorm2 = sel(ok, vmax(rnorm2, znw), rnorm2);
+      q += ok ? 1 : 0;
+      update_only();
+    }
+    for (;;) { // at most q rounds: every round frees a slot and none is taken
+      const bool slot = (used & lanebit) != 0u;
+      const double umin = row_min(sel(slot, u, inf));
+      const bool neg = umin < 0.0;
+      if (__builtin_amdgcn_ballot_w64(neg) == 0ull) break;
+      const int lpos = neg ? row_first(slot && u == umin) : 0;
+      const double uk = __shfl(u, lpos, 16);
+      const int drop_id = drop_vectors(lpos); // vec = n~, hc = n~ / e, nc = -(N* G n~) / e (-1 on the slot's own lane)
+      // x -= (n~ / e) u_k, u -= (N* G n~ / e) u_k: the minimiser and the multipliers without the dropped row
+      x = sel(neg, fma(-hc, uk, x), x);
+      u = sel(neg, fma(nc, uk, u), u);
+      vec = sel(neg, vec, 0.0); hc = sel(neg, hc, 0.0); nc = sel(neg, nc, 0.0);
+      act_mask &= neg ? ~(one << drop_id) : ~(mask_t)0;
+      used &= neg ? ~(1u << lpos) : ~0u;
+      q -= neg ? 1 : 0;
+      update_only();
+    }
+    npj = 0.0;
+  }
   {
     // lanes that are not here (rows that have left with kStatusNotPd) count as finished: ballots never see them
     done_m = ~__builtin_amdgcn_ballot_w64(true);
@@ -601,6 +674,14 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     const int2 a = reinterpret_cast<const int2 *>(lds_row + 16)[lr], b = reinterpret_cast<const int2 *>(lds_row + 32)[lr];
     used = (unsigned)a.x; idk = a.y; q = b.x & 255; status = b.y;
     iters_out = b.x >> 8;
+  }
+  if constexpr (kWarm) { // the final working set as a bit mask: the OR over the slot lanes of a row
+    unsigned w = ((used >> lr) & 1u) ? (1u << idk) : 0u;
+    w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x128, 0xF, 0xF, true);
+    w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x124, 0xF, 0xF, true);
+    w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x122, 0xF, 0xF, true);
+    w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x121, 0xF, 0xF, true);
+    if (ws_out) *ws_out = status == kStatusOk ? w : 0u;
   }
 
   QL_STAMP(7);

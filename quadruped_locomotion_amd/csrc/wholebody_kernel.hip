@@ -393,6 +393,7 @@ __global__ __launch_bounds__(64, 2) void wholebody_solve_kernel(const DevicePara
   Q.on = on; Q.comp = comp; Q.nS = nS; Q.refine_passes = P.refine_passes;
   Q.tq_up = W.tau_max - tau0; Q.tq_lo = W.tau_max + tau0;
   double x = 0.0;
+  Q.warm = 0u; Q.stance = 0u;
   int qp_iters;
   const int st = force_qp_coop<true>(Q, rows + kCoopLdsDoubles * row, nrm, x, qp_iters);
 

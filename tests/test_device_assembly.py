@@ -56,7 +56,7 @@ def test_no_dpp_hazard_in_the_library(tu, tmp_path):
         # that large batches take (at most 168), nothing spilled to scratch memory
         md = kernel_isa.meta(path)
         hot = {k: v for k, v in md.items() if "balance_coop_kernel" in k}
-        assert len(hot) == 6   # per-leg normals / latency form / throughput form, each plain and placed
+        assert len(hot) == 9   # per-leg normals / latency form / throughput form, each plain, placed and placed + warm start
         for name, m in hot.items():
             cap = 168 if "ELi3E" in name else 256
             assert m["vgpr"] + m.get("agpr", 0) <= cap and m.get("scratch", 0) == 0, (name, m)
