@@ -215,7 +215,7 @@ def parse():
     ap.add_argument("--no-gather", action="store_true",
                     help="several ranks without the per-step all-gather of the torques (scaling with / without it)")
     ap.add_argument("--ragged", action="store_true", help="full_tick: every message with its own layout")
-    ap.add_argument("--method", default="placed", choices=["placed", "plain"],
+    ap.add_argument("--method", default="placed", choices=["placed", "plain", "warm"],
                     help="placed (default): every step is one qlamd_balance_solve_placed_batch call that runs in the placement made "
                          "during the previous step from the iteration counts of the step before it, reports its own counts and "
                          "leaves the placement for the next step -- all of it inside the timed region; plain: qlamd_balance_solve_batch "
@@ -663,12 +663,17 @@ def main():
         if prev_tick:
             ds.append(capi.to_device(synth.next_tick_states(state, 0.0025), dev))
         d = ds[0]
-        placed = method == "placed"
+        placed, warm = method == "placed", method == "warm"
         orders = [torch.arange(B, dtype=torch.int32, device=dev) for _ in range(2)] if placed else None
-        its = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)] if placed else None
+        its = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)] if (placed or warm) else None
+        wss = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)] if warm else None
 
         def solve(k, out, st):
-            if placed:
+            if warm:
+                # every robot's active-set loop starts from its final working set of the step before (include/qlamd.h)
+                ctx.balance_solve_placed_device(ds[k % len(ds)], out, None, status, iterations=its[k & 1],
+                                                prev_working_set=wss[(k - 1) & 1], working_set=wss[k & 1], stream=st)
+            elif placed:
                 ctx.balance_solve_placed_device(ds[k % len(ds)], out, None, status, order=orders[k & 1], iterations=its[k & 1],
                                                 prev_iterations=its[(k - 1) & 1], next_order=orders[(k + 1) & 1],
                                                 policy=capi.PLACEMENT_AUTO, stream=st)
@@ -859,18 +864,19 @@ def main():
             ok = bool(okt.item())
         res["ok"] = ok
         res["batch"], res["method"] = B, method
-        if placed:
+        if placed or warm:
             it = its[(args.steps - 1) & 1].cpu().numpy()
             res["iterations"] = {"mean": float(it.mean()), "max": int(it.max())}
         return res
 
     def roofline_of(res, gait, errors):
         """roofline and valu_issue objects of one preset from its kernel time and the committed PMC record."""
-        kernel_ms, Bp, placed = res["kernel_ms"], res["batch"], res["method"] == "placed"
-        # placed: + robot_order in, iterations out, prev_iterations in, next_robot_order out (4 B each)
-        algo_bytes = (ALGO_BYTES_PER_STEP + (16 if placed else 0)) * Bp
+        kernel_ms, Bp, placed, warm = res["kernel_ms"], res["batch"], res["method"] == "placed", res["method"] == "warm"
+        # placed: + robot_order in, iterations out, prev_iterations in, next_robot_order out (4 B each);
+        # warm: + iterations out, previous working set in, working set out
+        algo_bytes = (ALGO_BYTES_PER_STEP + (16 if placed else 12 if warm else 0)) * Bp
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        wl = ("static-%s" % errors if gait == "static" else "trot") + ("+placed" if placed else "")
+        wl = ("static-%s" % errors if gait == "static" else "trot") + ("+placed" if placed else "+warm" if warm else "")
         rec, prov = pmc_record("balance_coop_kernel", Bp, wl)
         have = rec is not None and "fetch_bytes" in rec and "write_bytes" in rec
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -950,8 +956,9 @@ def main():
 
     B = args.batch
     method = args.method if not args.rpw else "plain"  # (the one-lane kernels of --rpw know no placement)
-    other = "plain" if method == "placed" else "placed"
-    res = run_preset(args.gait, args.errors, gather, args.replays, world > 1, collect=args.collect, every=args.gather_every, method=method)
+    other = "placed" if method == "plain" else "plain"
+    res = run_preset(args.gait, args.errors, gather, args.replays, world > 1, collect=args.collect, every=args.gather_every, method=method,
+                     prev_tick=method == "warm")
     headline_is_survey_4096 = args.gait == "static" and args.errors == "survey"
     # the same preset by the other method (every rank takes part: the preset's consensus steps are collectives)
     unplaced = (run_preset(args.gait, args.errors, False, min(args.replays, 5), False, method=other)
@@ -975,6 +982,16 @@ def main():
                 r, args.gait, args.errors,
                 note="odd steps run on the states one control period (2.5 ms) later than even steps: every placement in use was "
                      "made from the iteration counts of OTHER states, as for a caller at 400 Hz")
+        WARM_NOTE = ("warm start: every robot's active-set loop starts from its final working set of the step before "
+                     "(qlamd_placement::prev_working_set), odd steps on the states one control period (2.5 ms) later than even "
+                     "steps, so that the set always comes from OTHER states; efforts within 1e-7 of the cold start's "
+                     "(tests/test_warm_start_gpu.py), iteration counts no longer QuadProg++'s")
+
+        def warm_of(gait, errors, bb):
+            rw = run_preset(gait, errors, False, min(args.replays, 5), False, batch=bb, method="warm", prev_tick=True)
+            return entry(rw, gait, errors, note=WARM_NOTE)
+        if not args.rpw:
+            also["%s-warm" % ("static-%s" % args.errors if args.gait == "static" else "trot")] = warm_of(args.gait, args.errors, B)
         for name, bb in (("trot_b8192", 8192), ("trot_b65536", 65536)):
             if args.gait == "trot" and bb == B:
                 continue
@@ -984,6 +1001,9 @@ def main():
                 rp = run_preset("trot", "survey", False, min(args.replays, 5), False, batch=bb, method="plain")
                 also[name]["unplaced"] = {"value": bb * args.steps / rp["elapsed"], "ms_per_step": rp["elapsed"] / args.steps * 1e3,
                                           "kernel_ms": rp["kernel_ms"], "all_status_ok": rp["ok"]}
+            if not args.rpw:
+                w = warm_of("trot", "survey", bb)
+                also[name]["warm"] = {k: w[k] for k in ("value", "ms_per_step", "kernel_ms", "all_status_ok", "iterations", "roofline_frac")}
         try:
             also["pose_sqp_b4096"] = pose_sqp_entry(4096)
         except Exception as e:  # a side measurement must not cost the line
@@ -1011,7 +1031,8 @@ def main():
             scale_point = {"robots_per_gpu": SCALE_B, "gait": "trot", "n_gpus": 1, "method": t8["method"], "value": t8["value"],
                            "ms_per_step": t8["ms_per_step"], "without_gather": t8["value"],
                            "result_collection": "none (one GPU: the result is already whole)",
-                           **({"unplaced": t8["unplaced"]} if "unplaced" in t8 else {})}
+                           **({"unplaced": t8["unplaced"]} if "unplaced" in t8 else {}),
+                           **({"warm": t8["warm"]} if "warm" in t8 else {})}
         if scale_point is not None:
             scale_point["definition"] = ("8192 trot robots per GPU (BASELINE configs[3]'s shard), same method and timed region as "
                                          "`value`; weak-scaling efficiency(N) = scale_point(N).value / (N x scale_point(1).without_gather)")
@@ -1038,7 +1059,11 @@ def main():
                                        "step's placement with one extra wavefront -- hints, placement and solve all inside the timed "
                                        "region; results bit for bit those of the plain entry (tests/test_placement_gpu.py); "
                                        "`unplaced` = the same steps through qlamd_balance_solve_batch (robot s in slot s), the "
-                                       "headline of rounds 1-4") if method == "placed" else
+                                       "headline of rounds 1-4; `also[\"...-warm\"]` = the same robots with every active-set loop "
+                                       "started from its final working set of the step before") if method == "placed" else
+                                      ("qlamd_balance_solve_placed_batch with prev_working_set / working_set: every robot's "
+                                       "active-set loop starts from its final working set of the step before; odd steps run on the "
+                                       "states one control period (2.5 ms) later than even steps") if method == "warm" else
                                       "qlamd_balance_solve_batch: robot s in slot s of the launch",
                        "iterations": res.get("iterations"),
                        "tracking_error": list(synth.tracking_error(args.gait, args.errors)),
@@ -1065,7 +1090,7 @@ def main():
         if valu:
             line["valu_issue"] = valu
         if unplaced is not None:
-            line["unplaced" if method == "placed" else "placed"] = entry(unplaced, args.gait, args.errors)
+            line["placed" if method == "plain" else "unplaced"] = entry(unplaced, args.gait, args.errors)
         if scale_point is not None:
             line["scale_point"] = scale_point
         if also is not None:

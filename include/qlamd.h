@@ -275,7 +275,8 @@ typedef struct qlamd_placement {
    * multiplier comes out negative are dropped, and the method of the reference continues from there -- a set that no longer
    * fits (other stance legs, other loads) costs passes, never the answer: the minimiser is unique, efforts and forces agree
    * with the cold start's to the solver's accuracy (1e-8), statuses are the same.  What does change: `iterations` counts the
-   * passes still needed, no longer QuadProg++'s `iter` (solve_quadprog has no warm start, QuadProg++.cc:216-233). */
+   * rows installed and dropped by the warm start plus the passes still needed, no longer QuadProg++'s `iter`
+   * (solve_quadprog has no warm start, QuadProg++.cc:216-233) -- still what the robot cost, so still the placement hint. */
   const uint32_t *prev_working_set;
   uint32_t *working_set;
 } qlamd_placement;

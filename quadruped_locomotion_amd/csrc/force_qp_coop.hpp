@@ -435,6 +435,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     return drop_id;
   };
 
+  int warm_updates = 0; // rank-one updates of the warm start (kWarm)
   if constexpr (kWarm) {
     // ---- warm start: install the previous working set (rows of legs that still support), then drop negative multipliers
     unsigned wm = Q.warm & (((Q.stance & 1u) ? 0x1Fu : 0u) | ((Q.stance & 2u) ? 0x3E0u : 0u) | ((Q.stance & 4u) ? 0x7C00u : 0u) |
@@ -457,8 +458,9 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
       const double zw = (za[0] + za[1]) + za[2], rw = (ra[0] + ra[1]) + ra[2];
       const double znw = row_sum(zw * npj);
       const double s_p = row_sum(npj * x) - sel(kind == 0, f_min, 0.0); // slack of the row at x
-      // a row that depends on the rows installed before it (z'n_p at rounding level: H entries reach 1 / w_reg = 1e4) is left out
-      const bool ok = has && znw > 1e-9;
+      // a row that depends on the rows installed before it is left out: z'n_p is then rounding noise, which with the entries
+      // of H reaching 1 / w_reg = 1e4 means up to 1e-10, while an independent row has z'n_p >= |n|^2 / trace(G) ~ 1e-3
+      const bool ok = has && znw > 1e-6;
       const double zi = rcp_nr(sel(ok, znw, 1.0));
       const double tw = sel(ok, -s_p * zi, 0.0);
       x = fma(tw, zw, x);
@@ -474,6 +476,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
       act_mask |= ok ? (one << p) : 0;
       rnorm2 = sel(ok, vmax(rnorm2, znw), rnorm2);
       q += ok ? 1 : 0;
+      warm_updates += ok ? 1 : 0;
       update_only();
     }
     for (;;) { // at most q rounds: every round frees a slot and none is taken
@@ -491,6 +494,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
       act_mask &= neg ? ~(one << drop_id) : ~(mask_t)0;
       used &= neg ? ~(1u << lpos) : ~0u;
       q -= neg ? 1 : 0;
+      warm_updates += neg ? 1 : 0;
       update_only();
     }
     npj = 0.0;
@@ -673,7 +677,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     x = lds_row[lr];
     const int2 a = reinterpret_cast<const int2 *>(lds_row + 16)[lr], b = reinterpret_cast<const int2 *>(lds_row + 32)[lr];
     used = (unsigned)a.x; idk = a.y; q = b.x & 255; status = b.y;
-    iters_out = b.x >> 8;
+    iters_out = (b.x >> 8) + warm_updates; // what this robot cost: the installs and drops of a warm start count as passes
   }
   if constexpr (kWarm) { // the final working set as a bit mask: the OR over the slot lanes of a row
     unsigned w = ((used >> lr) & 1u) ? (1u << idk) : 0u;
@@ -686,7 +690,9 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
 
   QL_STAMP(7);
   // ---------------------------------------------------------------- refinement on the final working set
-  if (status == kStatusOk && q > 0) {
+  // (a warm start that installed rows and dropped them all again ends with an empty set and operators that have drifted all
+  // the same: it is refined like any other)
+  if (status == kStatusOk && (q > 0 || (kWarm && warm_updates > 0))) {
     // export N* through LDS once: lane (leg,c) needs column myidx of N*
     if (lr < 12) {
 #pragma unroll
@@ -701,7 +707,12 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     const int lg = kTorque ? ((idk * 47) >> 9) : id_leg(idk), tt = idk - kKinds * lg;
     const bool myslot = (used >> lr) & 1u;
     const int src = myslot ? (4 * lg + (tt == 0 ? 0 : (tt < 5 ? tt - 1 : (tt - 5) >> 1))) : 0;
-    for (int pass = 0; pass < Q.refine_passes; pass++) {
+    // The explicit operators drift with every rank-one update; one pass is enough for the ~30 updates of the longest cold
+    // start (6.3 M control steps against the oracle: 4e-8).  A warm start from a set that does not fit -- installs and drops
+    // of rows that a cold start would never have touched -- can do more updates than that: a pass more per 16 of them.
+    int passes = Q.refine_passes;
+    if constexpr (kWarm) passes += warm_updates > 0 ? iters_out >> 4 : 0; // (no set handed in: the cold start, bit for bit)
+    for (int pass = 0; pass < passes; pass++) {
       // (1) reduced gradient: x -= H (G x + g0)
       double grad = g0;
       static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(grad, x, Gm[j]); });

@@ -37,7 +37,7 @@ def check(line, want_cpu=True):
     return d
 
 
-ALSO = {"static-calm", "trot", "static-survey-prev-tick-hints", "trot_b8192", "trot_b65536", "pose_sqp_b4096"}
+ALSO = {"static-calm", "trot", "static-survey-prev-tick-hints", "static-survey-warm", "trot_b8192", "trot_b65536", "pose_sqp_b4096"}
 ALSO_KEYS = ("value", "ms_per_step", "kernel_ms", "roofline_frac", "valu_issue_frac", "all_status_ok")
 
 
@@ -56,6 +56,10 @@ def check_round5(d):
     assert d["also"]["trot_b8192"]["batch"] == 8192 and d["also"]["trot_b65536"]["batch"] == 65536
     assert d["also"]["trot_b8192"]["unplaced"]["ms_per_step"] > 0 and d["also"]["trot_b65536"]["unplaced"]["all_status_ok"] is True
     assert "note" in d["also"]["static-survey-prev-tick-hints"] and d["also"]["static-survey-prev-tick-hints"]["method"] == "placed"
+    w = d["also"]["static-survey-warm"]
+    assert w["method"] == "warm" and "working set" in w["note"] and w["ms_per_step"] < d["unplaced"]["ms_per_step"]
+    assert d["also"]["trot_b8192"]["warm"]["all_status_ok"] is True and d["also"]["trot_b65536"]["warm"]["ms_per_step"] > 0
+    assert d["scale_point"]["warm"]["value"] > 0
     sp = d["scale_point"]
     assert sp["robots_per_gpu"] == 8192 and sp["gait"] == "trot" and sp["n_gpus"] == d["n_gpus"]
     assert sp["value"] > 0 and sp["without_gather"] > 0 and "efficiency" in sp["definition"]

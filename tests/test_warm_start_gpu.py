@@ -1,0 +1,122 @@
+"""Warm start of the balance step's active-set loop (qlamd_placement::prev_working_set / working_set): the loop starts from
+the working set the caller hands in instead of the empty one.  The minimiser is unique, so whatever the set -- the robot's own
+final set of the previous control step, a stale one, garbage -- efforts, forces and statuses are those of the cold start to
+the solver's accuracy, and the oracle's within the north star's 1e-6."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from quadruped_locomotion_amd import synth
+
+pytestmark = pytest.mark.gpu
+TAU_TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    from quadruped_locomotion_amd import capi
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    capi.lib()
+    ctx = capi.Context(device=0)
+    yield capi, ctx, torch
+    ctx.close()
+
+
+def solve(gpu, d, B, prev_ws=None, want_ws=True, order=None):
+    capi, ctx, torch = gpu
+    tau = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+    grf = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+    status = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+    iters = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+    ws = torch.full((B,), -1, dtype=torch.int32, device="cuda:0") if want_ws else None
+    p = None if prev_ws is None else torch.from_numpy(np.ascontiguousarray(prev_ws).view(np.int32)).to("cuda:0")
+    o = None if order is None else torch.from_numpy(np.ascontiguousarray(order, dtype=np.int32)).to("cuda:0")
+    ctx.balance_solve_placed_device(d, tau, grf, status, order=o, iterations=iters, prev_working_set=p, working_set=ws,
+                                    stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return (tau.cpu().numpy(), grf.cpu().numpy(), status.cpu().numpy(), iters.cpu().numpy(),
+            None if ws is None else ws.cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.parametrize("gait,errors,B", [("static", "survey", 4096), ("trot", None, 4099), ("static", "calm", 1024), ("trot", None, 16385)])
+def test_warm_start_reaches_the_cold_start_s_answer(gpu, oracle, gait, errors, B):
+    capi, ctx, torch = gpu
+    s = synth.make_states(B, gait, errors=errors)
+    d = capi.to_device(s)
+    t0, g0, s0, it0, ws0 = solve(gpu, d, B)                       # cold through the warm kernel (no set handed in)
+    tp = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+    gp = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+    sp = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+    ctx.balance_solve_device(d, tp, gp, sp, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(t0, tp.cpu().numpy()) and np.array_equal(g0, gp.cpu().numpy()) and np.array_equal(s0, sp.cpu().numpy())
+    assert (s0 == 0).all()
+    # the working set written is the set of active rows: a bit per row, only rows of stance legs, as many as fit the variables
+    stance_bits = np.zeros(B, dtype=np.uint32)
+    for leg in range(4):
+        stance_bits |= np.where(s["stance"][:, leg] != 0, np.uint32(0x1F << (5 * leg)), np.uint32(0))
+    assert ((ws0 & ~stance_bits) == 0).all() and (ws0 < (1 << 20)).all()
+    nact = np.array([bin(int(w)).count("1") for w in ws0])
+    assert (nact <= 3 * s["stance"].astype(bool).sum(axis=1)).all() and nact.max() >= 4
+    # (1) its own final set: nothing left to do but one selection that finds no violated row
+    t1, g1, s1, it1, ws1 = solve(gpu, d, B, prev_ws=ws0)
+    assert np.array_equal(s1, s0) and np.array_equal(ws1, ws0)
+    assert np.abs(t1 - t0).max() < 1e-7 and np.abs(g1 - g0).max() < 1e-7
+    nset = np.array([bin(int(w)).count("1") for w in ws0])
+    assert ((it1 - nset) <= 1).mean() > 0.99 and (it1 - nset).max() <= 3 and (it1 >= nset).all()   # installs + one selection
+    # (2) the set of the state one control period earlier -- what a 400 Hz caller has
+    prev = synth.next_tick_states(s, -0.0025)
+    _, _, sprev, _, ws_prev = solve(gpu, capi.to_device(prev), B)
+    t2, g2, s2, it2, ws2 = solve(gpu, d, B, prev_ws=ws_prev)
+    assert np.array_equal(s2, s0)
+    assert np.abs(t2 - t0).max() < 1e-7 and np.abs(g2 - g0).max() < 1e-7
+    assert (ws2 == ws0).mean() > 0.999          # the same vertex (a degenerate one may be named by another basis)
+    assert (it2 - nset).mean() < 1.5            # the passes still needed once the previous set is installed
+    # (3) garbage: random sets, every row at once, rows of swing legs, both signs of a friction pair
+    rng = np.random.default_rng(7)
+    for junk in (rng.integers(0, 1 << 20, size=B, dtype=np.uint32), np.full(B, (1 << 20) - 1, dtype=np.uint32),
+                 np.full(B, 0b00110_00110_00110_00110, dtype=np.uint32), rng.integers(0, 1 << 32, size=B, dtype=np.uint64).astype(np.uint32)):
+        t3, g3, s3, it3, ws3 = solve(gpu, d, B, prev_ws=junk)
+        assert np.array_equal(s3, s0)
+        assert np.abs(t3 - t0).max() < 1e-6 and np.abs(g3 - g0).max() < 1e-6, (np.abs(t3 - t0).max(), np.abs(g3 - g0).max())
+    # (4) against the oracle, and together with a placement
+    to, go, so = oracle.balance_batch(s, nthreads=8)
+    order = rng.permutation(B).astype(np.int32)
+    t4, g4, s4, _, _ = solve(gpu, d, B, prev_ws=ws_prev, order=order)
+    assert np.array_equal(t4, t2) and np.array_equal(s4, s2)      # placement never changes a result
+    assert np.array_equal(s2, so) and np.abs(t2 - to).max() < TAU_TOL and np.abs(g2 - go).max() < 1e-6
+
+
+def test_warm_start_arguments(gpu):
+    capi, ctx, torch = gpu
+    B = 64
+    s = synth.make_states(B, "trot")
+    d = capi.to_device(s)
+    tau = torch.zeros(B, 12, dtype=torch.float64, device="cuda:0")
+    status = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    ws = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    with pytest.raises(capi.QlamdError) as e:   # read and written by one launch
+        ctx.balance_solve_placed_device(d, tau, None, status, prev_working_set=ws, working_set=ws)
+    assert e.value.code == capi.ERR_INVALID_ARGUMENT
+    # host memory: refused (a host-buffer call is bound by its copies)
+    sb, keep = capi.StateBatch(), []
+    for key, field, k in capi.FIELD_OF_KEY:
+        a = np.ascontiguousarray(s[key], dtype=np.float64).reshape(B, k)
+        keep.append(a)
+        setattr(sb, field, a.ctypes.data)
+    st8 = np.ascontiguousarray(s["stance"], dtype=np.uint8)
+    sb.support_leg = st8.ctypes.data
+    h_tau, h_st, h_ws = np.zeros((B, 12)), np.zeros(B, np.int32), np.zeros(B, np.uint32)
+    pl = capi.Placement(None, None, None, None, 0, None, h_ws.ctypes.data)
+    rc = capi.lib().qlamd_balance_solve_placed_batch(ctx._h, C.byref(sb), B, C.byref(pl), h_tau.ctypes.data, None, h_st.ctypes.data,
+                                                     capi.MEM_HOST, None)
+    assert rc == capi.ERR_INVALID_ARGUMENT
+    # the one-lane kernels know neither
+    ctx.set_robots_per_wave(64)
+    try:
+        with pytest.raises(capi.QlamdError):
+            ctx.balance_solve_placed_device(d, tau, None, status, working_set=ws)
+    finally:
+        ctx.set_robots_per_wave(0)

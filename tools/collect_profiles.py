@@ -35,6 +35,9 @@ WORKLOADS = [
     ("trot+placed", "balance_coop_kernel", 4096, ["--gait", "trot", "--method", "placed"]),
     ("trot+placed", "balance_coop_kernel", 8192, ["--gait", "trot", "--batch", "8192", "--method", "placed"]),
     ("trot+placed", "balance_coop_kernel", 65536, ["--gait", "trot", "--batch", "65536", "--method", "placed"]),
+    ("static-survey+warm", "balance_coop_kernel", 4096, ["--gait", "static", "--errors", "survey", "--method", "warm"]),
+    ("trot+warm", "balance_coop_kernel", 8192, ["--gait", "trot", "--batch", "8192", "--method", "warm"]),
+    ("trot+warm", "balance_coop_kernel", 65536, ["--gait", "trot", "--batch", "65536", "--method", "warm"]),
     ("static-survey", "balance_coop_kernel", 4096, ["--gait", "static", "--errors", "survey", "--method", "plain"]),
     ("static-calm", "balance_coop_kernel", 4096, ["--gait", "static", "--errors", "calm", "--method", "plain"]),
     ("trot", "balance_coop_kernel", 4096, ["--gait", "trot", "--method", "plain"]),

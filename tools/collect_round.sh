@@ -23,6 +23,7 @@ b trot_b8192_force_collective_no_gather --force-collective --no-gather --gait tr
 b trot_b8192_force_collective_plain --force-collective --overlap-gather --method plain --gait trot --batch 8192 --steps 100 --warmup 10 --no-cpu-baseline --no-alternatives
 # the driver's own arguments (K = 20, W = 5): what BENCH_rNN.json will hold
 b static_b4096_driver_args --steps 20 --warmup 5
+b static_b4096_warm --method warm --steps 200 --warmup 20 --no-cpu-baseline --no-also
 # round 5: where the one-rank collection cost goes -- kernel trace of the solve + all-gather pipeline on two captured streams
 ( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/fc_raw -o fc -- python3 $GRAFT_REPO_ROOT/bench.py --force-collective --overlap-gather --gait trot --batch 8192 --steps 100 --warmup 10 --no-cpu-baseline --no-alternatives --replays 3 > /dev/null 2>&1 )
 python3 tools/rocpd_kernels.py $(find $OUT/fc_raw -name "*_results.db" | head -1) $OUT/kernel_stats_trot_b8192_force_collective.csv > /dev/null 2>&1
@@ -60,6 +61,7 @@ python3 tools/experiments/variant_bench.py 2>&1 | grep -v amdgpu > $OUT/variant_
 # qlamd_place_next_call), the head of a launch by argument passing / record layout, the whole tick workgroup by workgroup
 python3 tools/experiments/placed_probe.py --grid 2>&1 | grep -v amdgpu > $OUT/placed_probe.txt
 python3 tools/experiments/placed_aux_probe.py 2>&1 | grep -v amdgpu > $OUT/placed_aux_probe.txt
+python3 tools/experiments/warm_probe.py 2>&1 | grep -v amdgpu > $OUT/warm_probe.txt
 ( ./tools/ubench/launch_head; ./tools/ubench/launch_head_preload ) > $OUT/launch_head.txt 2>&1
 [ -f scratch_bin/libqlamd_stamps.so ] && ( python3 tools/stamp_probe_tick_blocks.py; python3 tools/stamp_probe_tick_blocks.py --ragged ) 2>&1 | grep -v amdgpu > $OUT/tick_block_stamps.txt
 python3 - > $OUT/multi_gpu_cpp_one_rank.txt 2>&1 <<'PY'
