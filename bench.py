@@ -510,17 +510,28 @@ def bench_full_tick(args):
                 leg_mode=np.zeros((B, 4), np.uint8), support=np.ones((B, 4), np.uint8), pid_error_last=np.zeros((B, 12)),
                 pid_error_integral=np.zeros((B, 12)), joint_effort=np.zeros((B, 12)), leg_state_code=np.zeros((B, 4), np.int8), status=np.full(B, -1, np.int32),
                 message_status=np.full(B, -1, np.int32), command=np.zeros(capi.tick_command_bytes(B), np.uint8))
+    warm = args.method == "warm"
+    if warm:  # the tick keeps every robot's working set between ticks and starts its balance solve from it
+        host["working_set"] = np.zeros(B, np.uint32)
     dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to("cuda:0") for k, v in host.items()}
+    devs = [dev]
+    if warm:
+        # odd ticks run on the measured states one control period later: the set always comes from OTHER states
+        s2 = synth.next_tick_states(s, 0.0025)
+        later = dict(dev)
+        for key, field in (("base_pos", "base_position"), ("base_quat", "base_orientation")):
+            later[field] = torch.from_numpy(np.ascontiguousarray(s2[key])).to("cuda:0")
+        devs.append(later)
     ctx = capi.Context(device=0)
     stream = torch.cuda.current_stream().cuda_stream
-    for _ in range(max(args.warmup, 2)):
-        capi.full_tick(ctx, dev, 0.0025, memory=capi.MEM_DEVICE, stream=stream)
+    for k in range(max(args.warmup, 2)):
+        capi.full_tick(ctx, devs[k % len(devs)], 0.0025, memory=capi.MEM_DEVICE, stream=stream)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(args.steps):
-        capi.full_tick(ctx, dev, 0.0025, memory=capi.MEM_DEVICE, stream=stream)
+    for k in range(args.steps):
+        capi.full_tick(ctx, devs[k % len(devs)], 0.0025, memory=capi.MEM_DEVICE, stream=stream)
     e1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -538,7 +549,9 @@ def bench_full_tick(args):
         "data": "synthetic",
         "config": {"workload": "batch=%d robots, one serialised free_gait_msgs/RobotState (%d B on average, %s) per robot and tick, "
                                "trot states: unpack -> leg state machine -> balance solve -> swing branch" %
-                               (B, nbytes // B, "ragged layouts" if args.ragged else "one layout"),
+                               (B, nbytes // B, "ragged layouts" if args.ragged else "one layout") +
+                               ("; the balance solve warm-started from the working set the tick keeps (qlamd_tick_batch::working_set), "
+                                "odd ticks on the measured states one control period later" if warm else ""),
                    "messages_ok": int((dev["message_status"] == 0).sum().item()), "solves_ok": int((dev["status"] == 0).sum().item())},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None,

@@ -269,8 +269,9 @@ typedef struct qlamd_placement {
   /* The other half of the hint, for the balance / force-distribution entries with QLAMD_MEM_DEVICE: WARM START.  Each robot's
    * active-set loop starts from the working set in prev_working_set [B] (bit 5 leg + kind of row: kind 0 the minimal normal
    * force, 1..4 the friction pyramid's +t1, -t1, +t2, -t2) instead of the empty one, and its final working set goes to
-   * working_set [B] (0 for a robot whose status is not QLAMD_STATUS_OK); either may be NULL, they must not alias.  Hand a
-   * robot the set it ended with on its previous control step (zeros to start with: a cold start).  At 400 Hz that is this
+   * working_set [B] (0 for a robot whose status is not QLAMD_STATUS_OK); either may be NULL; they may be ONE array, updated in
+   * place (a robot's set is read and written by its own lanes only).  Hand a robot the set it ended with on its previous
+   * control step (zeros to start with: a cold start).  At 400 Hz that is this
    * step's final set for 96 % of the robots of the bench batches: the rows are installed as equalities, slots whose
    * multiplier comes out negative are dropped, and the method of the reference continues from there -- a set that no longer
    * fits (other stance legs, other loads) costs passes, never the answer: the minimiser is unique, efforts and forces agree
@@ -684,6 +685,11 @@ typedef struct qlamd_tick_batch {
   int32_t *message_status;              /* [B]     QLAMD_WIRE_* */
   /* in/out, optional */
   void *command;                        /* qlamd_tick_command_bytes(B) bytes or NULL: the command in force per robot */
+  uint32_t *working_set;                /* [B] or NULL: warm start of the balance solve (qlamd_placement::working_set): each
+                                           robot's final working set of its previous tick in, this tick's out; zeros to start
+                                           with.  One more piece of state the controller keeps between ticks -- the reference
+                                           keeps none because OOQP starts every solve from scratch; efforts agree with the
+                                           cold start's to 1e-7 */
 } qlamd_tick_batch;
 
 size_t qlamd_tick_command_bytes(int64_t batch);

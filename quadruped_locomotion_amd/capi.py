@@ -95,7 +95,8 @@ TICK_FIELDS = (("messages", np.uint8), ("offsets", np.int64), ("joint_position",
                ("base_linear_velocity", np.float64), ("base_angular_velocity", np.float64), ("contact", np.uint8),
                ("limb_state", np.int8), ("store_flag", np.uint8), ("stored_joint_position", np.float64), ("leg_mode", np.uint8), ("support", np.uint8),
                ("pid_error_last", np.float64), ("pid_error_integral", np.float64), ("joint_effort", np.float64),
-               ("leg_state_code", np.int8), ("status", np.int32), ("message_status", np.int32), ("command", np.uint8))
+               ("leg_state_code", np.int8), ("status", np.int32), ("message_status", np.int32), ("command", np.uint8),
+               ("working_set", np.uint32))
 
 
 class TickBatch(C.Structure):

@@ -679,7 +679,7 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
   uint32_t *ws = pl ? pl->working_set : nullptr;
   const bool warm = prev_ws || ws;
   if (warm && memory != QLAMD_MEM_DEVICE) return QLAMD_ERR_INVALID_ARGUMENT; // (a host-buffer call is bound by its copies)
-  if (warm && prev_ws == ws) return QLAMD_ERR_INVALID_ARGUMENT;              // read and written by one launch
+  // (prev_ws == ws is fine: a robot's set is read and written by its own 16 lanes only -- updated in place)
   const bool placed = order || iterations || next_order || warm;
   // the one-lane kernels of qlamd_set_robots_per_wave know no placement (a lane is a robot there: nothing is shared)
   if (placed && pick_rpw(ctx, batch) != 4) return QLAMD_ERR_INVALID_ARGUMENT;

@@ -128,6 +128,7 @@ struct TickSwingArgs {
   SwingBranchPtrs b;
   double period;
 };
+template <bool kWarm>
 __global__ __launch_bounds__(64, 2) void tick_solve_kernel(const DeviceParams *__restrict__ Pp, const coop::CoopPtrs cp, int64_t B,
                                                            double *__restrict__ effort, int32_t *__restrict__ status,
                                                            unsigned nbal, const TickSwingArgs sw) {
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(64, 2) void tick_solve_kernel(const DeviceParams *_
     int64_t i = (int64_t)blockIdx.x * 4 + row;
     const bool live = i < B;
     if (!live) i = B - 1;
-    coop::coop_robot<false, 64>(*Pp, cp, i, live, tab, rows + row * coop::kCoopLdsDoubles, nrm, effort, nullptr, status);
+    coop::coop_robot<false, 64, kWarm>(*Pp, cp, i, live, tab, rows + row * coop::kCoopLdsDoubles, nrm, effort, nullptr, status);
   } else {
     swing_branch_block(*Pp, sw.SP, sw.pid, sw.s, sw.b, sw.period, B, effort, (int64_t)(blockIdx.x - nbal), tab);
   }
@@ -995,6 +996,7 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
     const int i_out[4] = {sg.add(io->joint_effort, B * 96, true, true), sg.add(io->leg_state_code, B * 4, false, true),
                           sg.add(io->status, B * 4, false, true), sg.add(io->message_status, B * 4, false, true)};
     const int i_cmd = sg.add(io->command, cmd_bytes, true, true);
+    const int i_ws = sg.add(io->working_set, B * 4, true, true);
     const int rc = sg.upload(ctx, st);
     if (rc != QLAMD_OK) return rc;
     d.offsets = sg.dev<const int64_t>(i_off);
@@ -1010,6 +1012,7 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
     d.joint_effort = sg.dev<double>(i_out[0]); d.leg_state_code = sg.dev<int8_t>(i_out[1]);
     d.status = sg.dev<int32_t>(i_out[2]); d.message_status = sg.dev<int32_t>(i_out[3]);
     d.command = sg.dev<char>(i_cmd);
+    d.working_set = sg.dev<uint32_t>(i_ws);
   }
   // context scratch: the leg state codes when the caller does not want them, and the command block when the caller
   // keeps none (then no command outlives the call: the flags are cleared first)
@@ -1067,18 +1070,28 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
     ta.s = SwingPtrs{d.joint_position, d.joint_velocity, d.joint_velocity_oldest, D(kCmdFootP), D(kCmdFootV), nullptr, d.support};
     ta.b = SwingBranchPtrs{d.base_orientation, D(kCmdJoint), d.leg_mode, d.pid_error_last, d.pid_error_integral, live};
     ta.period = period;
+    // (working_set: the robot's final working set of its previous tick in, this tick's out -- in place: a robot's set is read
+    // and written by its own 16 lanes only)
     const coop::CoopPtrs cp{d.joint_position, d.base_position, d.base_orientation, d.base_linear_velocity,
                             d.base_angular_velocity, D(kCmdPos), D(kCmdQuat), D(kCmdLin), D(kCmdAng), d.support,
-                            nullptr, nullptr, live, 1};
+                            nullptr, nullptr, live, 1, nullptr, d.working_set, d.working_set};
     const unsigned nbal = (unsigned)((batch + 3) / 4), nsw = (unsigned)((4 * batch + 63) / 64);
-    hipLaunchKernelGGL(tick_solve_kernel, dim3(nbal + nsw), dim3(64), 0, st, ctx->d_params, cp, batch, d.joint_effort, d.status,
-                       nbal, ta);
+    if (d.working_set)
+      hipLaunchKernelGGL(tick_solve_kernel<true>, dim3(nbal + nsw), dim3(64), 0, st, ctx->d_params, cp, batch, d.joint_effort,
+                         d.status, nbal, ta);
+    else
+      hipLaunchKernelGGL(tick_solve_kernel<false>, dim3(nbal + nsw), dim3(64), 0, st, ctx->d_params, cp, batch, d.joint_effort,
+                         d.status, nbal, ta);
     if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   } else {
     // two launches (large batches; the one-lane balance kernels of qlamd_set_robots_per_wave, cross-checks)
     qlamd_state_batch sb{d.joint_position, d.base_position, d.base_orientation, d.base_linear_velocity, d.base_angular_velocity,
                          D(kCmdPos), D(kCmdQuat), D(kCmdLin), D(kCmdAng), d.support, nullptr};
-    rc = balance_impl(ctx, &sb, nullptr, live, 1, batch, d.joint_effort, nullptr, d.status, QLAMD_MEM_DEVICE, stream);
+    qlamd_placement wp;
+    memset(&wp, 0, sizeof(wp));
+    wp.prev_working_set = wp.working_set = d.working_set; // in place
+    const bool warm = d.working_set && pick_rpw(ctx, batch) == 4; // (the one-lane kernels of the cross-check start cold)
+    rc = balance_impl(ctx, &sb, nullptr, live, 1, batch, d.joint_effort, nullptr, d.status, QLAMD_MEM_DEVICE, stream, warm ? &wp : nullptr);
     if (rc != QLAMD_OK) return rc;
     const qlamd_swing_batch sw{d.joint_position, d.joint_velocity, d.joint_velocity_oldest, D(kCmdFootP), D(kCmdFootV), d.support, nullptr};
     const qlamd_swing_branch_extra ex{d.base_orientation, D(kCmdJoint), d.leg_mode, d.pid_error_last, d.pid_error_integral};

@@ -97,9 +97,13 @@ def test_warm_start_arguments(gpu):
     tau = torch.zeros(B, 12, dtype=torch.float64, device="cuda:0")
     status = torch.zeros(B, dtype=torch.int32, device="cuda:0")
     ws = torch.zeros(B, dtype=torch.int32, device="cuda:0")
-    with pytest.raises(capi.QlamdError) as e:   # read and written by one launch
-        ctx.balance_solve_placed_device(d, tau, None, status, prev_working_set=ws, working_set=ws)
-    assert e.value.code == capi.ERR_INVALID_ARGUMENT
+    # one array for both: updated in place (a robot's set is read and written by its own lanes only)
+    ws2 = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    ctx.balance_solve_placed_device(d, tau, None, status, working_set=ws2)
+    ctx.balance_solve_placed_device(d, tau, None, status, prev_working_set=ws, working_set=ws)
+    ctx.balance_solve_placed_device(d, tau, None, status, prev_working_set=ws, working_set=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(ws, ws2) and (status == 0).all()
     # host memory: refused (a host-buffer call is bound by its copies)
     sb, keep = capi.StateBatch(), []
     for key, field, k in capi.FIELD_OF_KEY:

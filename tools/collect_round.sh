@@ -29,7 +29,8 @@ b static_b4096_warm --method warm --steps 200 --warmup 20 --no-cpu-baseline --no
 python3 tools/rocpd_kernels.py $(find $OUT/fc_raw -name "*_results.db" | head -1) $OUT/kernel_stats_trot_b8192_force_collective.csv > /dev/null 2>&1
 rm -rf $OUT/fc_raw
 b pose_sqp_b4096 --workload pose_sqp --steps 200 --warmup 20
-b full_tick_b4096 --workload full_tick --steps 100
+b full_tick_b4096 --workload full_tick --steps 100 --method plain
+b full_tick_warm_b4096 --workload full_tick --steps 100 --method warm
 b full_tick_ragged_b4096 --workload full_tick --ragged --steps 100
 b full_tick_b65536 --workload full_tick --batch 65536 --steps 50
 b wholebody_static_b4096 --workload wholebody --gait static --steps 100
