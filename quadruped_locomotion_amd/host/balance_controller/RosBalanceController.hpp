@@ -169,10 +169,15 @@ class RosBalanceController {
     qlamd_tick_batch io{msg, off, hw_.joint_position_read, qd_queue_[0].data(), qd_queue_[10].data(), hw_.position,
                         hw_.orientation, hw_.linear_velocity, hw_.angular_velocity, contact_, limb_state_, store_flag_,
                         stored_joint_position_.data(), leg_mode_, support_, pid_error_last_.data(), pid_error_integral_.data(),
-                        hw_.joint_effort_write, leg_state_code_, &status, &message_status, command_.data()};
+                        hw_.joint_effort_write, leg_state_code_, &status, &message_status, command_.data(),
+                        warm_start_ ? &working_set_ : nullptr};
     if (qlamd_full_tick_batch(ctx_->get(), &sp, &pid, &io, period, 1, 1, QLAMD_MEM_HOST, nullptr) != QLAMD_OK) return false;
     return message_status == QLAMD_WIRE_OK && status == QLAMD_STATUS_OK;
   }
+  // An addition of the mirror: the balance solve of tick() starts from the working set of the tick before (kept here like the
+  // plugin's other state; qlamd_tick_batch::working_set) instead of from scratch, as OOQP does in the reference.  Efforts agree
+  // to the solver's accuracy; off by default.
+  void setWarmStart(bool on) { warm_start_ = on; working_set_ = 0u; }
   const int8_t *legStateCodes() const { return leg_state_code_; }
   const int8_t *limbStates() const { return limb_state_; }
 
@@ -211,6 +216,8 @@ class RosBalanceController {
       pid_error_integral_{};
   std::array<std::array<double, 12>, 11> qd_queue_{};
   std::vector<uint8_t> command_; // opaque command block of qlamd_full_tick_batch (batch 1)
+  uint32_t working_set_ = 0u;    // final working set of the last tick's force QP (setWarmStart)
+  bool warm_start_ = false;
   double phase_[4] = {0, 0, 0, 0};
   uint8_t support_leg_[4] = {1, 1, 1, 1}, contact_[4] = {1, 1, 1, 1}, store_flag_[4] = {0, 0, 0, 0}, support_[4] = {1, 1, 1, 1};
   uint8_t leg_mode_[4] = {0, 0, 0, 0};

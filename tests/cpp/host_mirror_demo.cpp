@@ -194,6 +194,18 @@ int main(int argc, char **argv) {
     }
     std::sort(us1.begin() + 50, us1.end());
     std::printf("tick1_latency_us %.1f %.1f\n", us1[50 + 125], us1[50 + 225]);
+    // the same ticks with the working set kept from tick to tick (setWarmStart: the second tick starts from the first one's set)
+    double effort2[12] = {0};
+    balance_controller::RobotStateHandleData hw2 = hw;
+    hw2.joint_effort_write = effort2;
+    balance_controller::RosBalanceController warm;
+    if (!warm.init(hw2, params, 0)) return 22;
+    warm.setWarmStart(true);
+    warm.footContactsCallback(touching);
+    if (!warm.tick(msg.data(), msg.size(), 0.0025)) return 23;
+    if (!warm.tick(msg.data(), msg.size(), 0.0025)) return 24;
+    std::printf("tick_warm_effort"); for (int i = 0; i < 12; ++i) std::printf(" %.17g", effort2[i]); std::printf("\n");
+    if (!one.tick(msg.data(), msg.size(), 0.0025)) return 25; // (its PID state has moved on: compare the support legs)
   }
 
   // ---- 2. pose optimisation ---------------------------------------------------------------------

@@ -143,6 +143,8 @@ def test_mirror_full_tick_matches_oracle(oracle, tmp_path):
     # the whole tick (message -> 12 efforts, host buffers, batch 1) fits the reference's 400 Hz loop many times over
     # the one-call tick (qlamd_full_tick_batch) gives the same efforts as the four-call tick
     assert np.array_equal(out["tick1_effort"], out["tick_effort"])
+    # ... and with the working set kept between ticks (setWarmStart) the support legs' efforts agree to the solver's accuracy
+    assert np.abs(out["tick_warm_effort"][3:] - out["tick_effort"][3:]).max() < 1e-7
     print("one-call tick latency: median %.1f us, p90 %.1f us" % tuple(out["tick1_latency_us"]))
     med, p90 = out["tick_latency_us"]
     print("full tick latency: median %.1f us, p90 %.1f us" % (med, p90))
