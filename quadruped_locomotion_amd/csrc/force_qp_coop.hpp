@@ -32,7 +32,7 @@ namespace coop {
 // (144 and not more: with the model table and the normals table a wavefront then needs 13 056 bytes of LDS, and twelve
 // wavefronts -- three per SIMD -- fit a compute unit's 160 KB.)
 constexpr int kCoopLdsDoubles = 12 * 12;
-constexpr int kDropSlot = 48, kZeroSlot = 60;
+constexpr int kDropSlot = 48, kZeroSlot = 60, kWarmSlot = 61; // (kWarmSlot: the update count of a warm start, an int)
 // rows of the wavefront's table of constraint normals ([row kind][lane]) the QP uses: 5, and 3 more with kTorque
 constexpr int kForceQpNrmRows = 5, kForceQpNrmRowsTorque = 8;
 struct ForceQp {
@@ -498,6 +498,10 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
       update_only();
     }
     npj = 0.0;
+    // (parked in the robot's LDS block until the loop is over: one register less across it -- the 168-register form spills
+    // otherwise)
+    if (lr == 0) reinterpret_cast<int *>(lds_row + kWarmSlot)[0] = warm_updates;
+    warm_updates = 0;
   }
   {
     // lanes that are not here (rows that have left with kStatusNotPd) count as finished: ballots never see them
@@ -677,6 +681,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     x = lds_row[lr];
     const int2 a = reinterpret_cast<const int2 *>(lds_row + 16)[lr], b = reinterpret_cast<const int2 *>(lds_row + 32)[lr];
     used = (unsigned)a.x; idk = a.y; q = b.x & 255; status = b.y;
+    if constexpr (kWarm) warm_updates = reinterpret_cast<const int *>(lds_row + kWarmSlot)[0];
     iters_out = (b.x >> 8) + warm_updates; // what this robot cost: the installs and drops of a warm start count as passes
   }
   if constexpr (kWarm) { // the final working set as a bit mask: the OR over the slot lanes of a row
