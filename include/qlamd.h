@@ -55,6 +55,11 @@ extern "C" {
 #define QLAMD_STATUS_NO_COMMAND 4     /* whole tick only: no well-formed command message has reached this robot yet;
                                          nothing of the robot was read or written (the reference's update() runs on
                                          the last command baseCommandCallback stored, ros_balance_controller.cpp:761) */
+#define QLAMD_STATUS_WARM_REJECTED 6     /* warm start only (qlamd_placement::prev_working_set): the set handed in was so far from
+                                         this robot's state that the answer reached from it failed the final check (every row
+                                         holds, every multiplier non-negative, to 1e-6); outputs as for any failed solve, the
+                                         robot's working_set comes back 0, so its next step starts cold.  Never seen with a
+                                         robot's own previous set (2 M soaked control steps) */
 #define QLAMD_STATUS_DEPENDENT_EQUALITY 5 /* qlamd_qp_solve_batch with p = 2 only: the second equality column is all-zero
                                          or linearly dependent on the first and was left out; x is the solution of the
                                          problem without it.  (solve_quadprog ignores add_constraint's result there,
@@ -274,8 +279,10 @@ typedef struct qlamd_placement {
    * control step (zeros to start with: a cold start).  At 400 Hz that is this
    * step's final set for 96 % of the robots of the bench batches: the rows are installed as equalities, slots whose
    * multiplier comes out negative are dropped, and the method of the reference continues from there -- a set that no longer
-   * fits (other stance legs, other loads) costs passes, never the answer: the minimiser is unique, efforts and forces agree
-   * with the cold start's to the solver's accuracy (1e-8), statuses are the same.  What does change: `iterations` counts the
+   * fits (other stance legs, other loads) costs passes, not the answer: the minimiser is unique, efforts and forces agree
+   * with the cold start's to the solver's accuracy (1e-8), statuses are the same.  A mask that is no working set at all (more
+   * than three rows of one leg) is ignored; an answer that fails the final check (possible only from a set unrelated to the
+   * robot's state) is reported as QLAMD_STATUS_WARM_REJECTED, never returned.  What does change: `iterations` counts the
    * rows installed and dropped by the warm start plus the passes still needed, no longer QuadProg++'s `iter`
    * (solve_quadprog has no warm start, QuadProg++.cc:216-233) -- still what the robot cost, so still the placement hint. */
   const uint32_t *prev_working_set;
@@ -295,7 +302,10 @@ int qlamd_force_distribution_placed_batch(qlamd_context *ctx, const double *join
  * calls only (a host-memory call that finds a placement pending returns QLAMD_ERR_INVALID_ARGUMENT and clears it).
  * robot_order / iterations index the call's problems; with prev_iterations / next_robot_order the placement for the
  * caller's next call is made by qlamd_placement_from_iterations' launches behind the solve, on its stream.
- * placement = NULL withdraws a pending one.  (qlamd_balance_solve_batch and the other entries ignore it.) */
+ * placement = NULL withdraws a pending one.  (qlamd_balance_solve_batch and the other entries ignore it.)
+ * Warm start: qlamd_wholebody_solve_batch also takes prev_working_set / working_set this way, with TWO words per robot
+ * ([B][2] uint32 = 64 bits, low word first: bit 11 leg + kind, kinds 0..4 as for the balance step, 5 + 2k / 6 + 2k the upper /
+ * lower torque bound of the leg's joint k); the two dense entries start cold and refuse them (QLAMD_ERR_INVALID_ARGUMENT). */
 int qlamd_place_next_call(qlamd_context *ctx, const qlamd_placement *placement);
 
 /* The placement on its own: iterations [B] in (any counts: only their order matters; negative counts count as 0, counts

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_PKG, "libqlamd.so")
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_LOADED, ERR_OUT_OF_MEMORY, ERR_BUSY, ERR_NEEDS_RESERVE = -1, -2, -3, -4, -5, -6, -7
 STATUS_OK, STATUS_INFEASIBLE, STATUS_NOT_PD, STATUS_MAX_ITER = 0, 1, 2, 3
+STATUS_WARM_REJECTED = 6
 MEM_DEVICE, MEM_HOST = 0, 1
 
 EXPORTS = (

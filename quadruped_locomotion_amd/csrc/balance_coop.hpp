@@ -316,7 +316,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   Q.warm = warm_set; Q.stance = stance;
   double x;
   int qp_iters;
-  unsigned final_set = 0u;
+  unsigned long long final_set = 0ull;
   const int status = force_qp_coop<false, kWarm>(Q, lds_row, lds_nrm, x, qp_iters, &final_set);
   if (status == kStatusNotPd) {
     if (lr == 0 && robot_live) {
@@ -352,7 +352,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     if (lr == 0 && robot_live) {
       status_out[i] = status;
       if (s.iterations) s.iterations[i] = qp_iters;
-      if constexpr (kWarm) { if (s.working_set) s.working_set[i] = final_set; }
+      if constexpr (kWarm) { if (s.working_set) s.working_set[i] = status == kStatusOk ? (uint32_t)final_set : 0u; }
     }
   }
   QL_STAMP(9);

@@ -198,6 +198,9 @@ int placement_launch(qlamd_context *ctx, const int32_t *d_iterations, int64_t ba
 struct PlacePtrs {
   const int32_t *order;
   int32_t *iterations;
+  // warm start (the whole-body step only: 64 bits per problem, i.e. [B][2] words of qlamd_placement's uint32 arrays)
+  const unsigned long long *prev_working_set;
+  unsigned long long *working_set;
 };
 #ifdef __HIPCC__
 // problem index of slot `slot` (row slot % 4 of wavefront slot / 4); live = the slot holds a problem (an order entry
@@ -217,7 +220,7 @@ __device__ __forceinline__ int64_t placed_index(const PlacePtrs &pp, int64_t slo
 // Returns QLAMD_OK and fills pp / *next (next->next_robot_order != NULL when a following placement was asked for), or
 // QLAMD_ERR_INVALID_ARGUMENT for a host-memory call (the placement's arrays are device arrays).
 inline int take_placement(qlamd_context *ctx, int memory, int64_t batch, PlacePtrs *pp, qlamd_placement *next) {
-  *pp = PlacePtrs{nullptr, nullptr};
+  *pp = PlacePtrs{nullptr, nullptr, nullptr, nullptr};
   memset(next, 0, sizeof(*next));
   if (!ctx->has_next_placement) return QLAMD_OK;
   const qlamd_placement pl = ctx->next_placement;
@@ -225,6 +228,8 @@ inline int take_placement(qlamd_context *ctx, int memory, int64_t batch, PlacePt
   if (memory != QLAMD_MEM_DEVICE || batch > INT32_MAX) return QLAMD_ERR_INVALID_ARGUMENT;
   pp->order = pl.robot_order;
   pp->iterations = pl.iterations;
+  pp->prev_working_set = reinterpret_cast<const unsigned long long *>(pl.prev_working_set);
+  pp->working_set = reinterpret_cast<unsigned long long *>(pl.working_set);
   *next = pl;
   return QLAMD_OK;
 }

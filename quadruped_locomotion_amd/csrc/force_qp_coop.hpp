@@ -32,9 +32,13 @@ namespace coop {
 // (144 and not more: with the model table and the normals table a wavefront then needs 13 056 bytes of LDS, and twelve
 // wavefronts -- three per SIMD -- fit a compute unit's 160 KB.)
 constexpr int kCoopLdsDoubles = 12 * 12;
+constexpr int kMaxRefinePasses = 8; // of a warm start whose set did not fit (force_qp_coop's refinement)
 constexpr int kDropSlot = 48, kZeroSlot = 60, kWarmSlot = 61; // (kWarmSlot: the update count of a warm start, an int)
 // rows of the wavefront's table of constraint normals ([row kind][lane]) the QP uses: 5, and 3 more with kTorque
 constexpr int kForceQpNrmRows = 5, kForceQpNrmRowsTorque = 8;
+template <class T>
+constexpr T one_v = T(1);
+constexpr int kStatusWarmRejected = 6; // QLAMD_STATUS_WARM_REJECTED: a warm start whose answer did not check out
 struct ForceQp {
   double Gm[12];                 // my row of G
   double g0;                     // my entry of g0
@@ -47,9 +51,10 @@ struct ForceQp {
   // kTorque only.  tau = tau0 - J_leg' f:  J[c][k] and J[k][c] of my leg (0 unless on && comp)
   double jrow[3], jcol[3];
   double tq_up, tq_lo;           // tau_max - tau0_c, tau_max + tau0_c
-  // kWarm only: the working set to start from (bit 5 leg + kind, as written to `ws_out` by an earlier solve) and the
-  // stance legs as a bit mask (rows of other legs are left out of it)
-  unsigned warm, stance;
+  // kWarm only: the working set to start from (bit kKinds leg + kind, kKinds = 5 or, with kTorque, 11; as written to `ws_out`
+  // by an earlier solve) and the stance legs as a bit mask (rows of other legs are left out of it)
+  unsigned long long warm;
+  unsigned stance;
 };
 
 // My row of G and my entry of g0 for the objective  |A f - F|^2_S + w_reg |f|^2  (A = [1 ... ; [r_leg]x ...], the
@@ -119,8 +124,7 @@ __device__ __forceinline__ void force_qp_objective(const double S[6], double w_r
 // unconstrained minimiser, QuadProg++.cc:216-233): iteration counts no longer match the reference's one for one, torques do.
 template <bool kTorque, bool kWarm = false>
 __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, double *lds_nrm, double &x, int &iters_out,
-                                             unsigned *ws_out = nullptr) {
-  static_assert(!(kTorque && kWarm), "the warm start knows the balance step's five row kinds only");
+                                             unsigned long long *ws_out = nullptr) {
   using mask_t = std::conditional_t<kTorque, unsigned long long, unsigned>;
   constexpr int kKinds = kTorque ? 11 : 5;
   const int lr = threadIdx.x & 15, leg = lr >> 2, c = lr & 3;
@@ -438,15 +442,45 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
   int warm_updates = 0; // rank-one updates of the warm start (kWarm)
   if constexpr (kWarm) {
     // ---- warm start: install the previous working set (rows of legs that still support), then drop negative multipliers
-    unsigned wm = Q.warm & (((Q.stance & 1u) ? 0x1Fu : 0u) | ((Q.stance & 2u) ? 0x3E0u : 0u) | ((Q.stance & 4u) ? 0x7C00u : 0u) |
-                            ((Q.stance & 8u) ? 0xF8000u : 0u));
+    constexpr mask_t kLegRows = (one_v<mask_t> << kKinds) - 1;
+    mask_t wm = (mask_t)Q.warm & (((Q.stance & 1u) ? kLegRows : 0) | ((Q.stance & 2u) ? kLegRows << kKinds : 0) |
+                                  ((Q.stance & 4u) ? kLegRows << (2 * kKinds) : 0) | ((Q.stance & 8u) ? kLegRows << (3 * kKinds) : 0));
+    // a working set holds at most three rows of a leg (every row touches the three variables of ONE leg: a fourth depends on
+    // the others); a mask that claims more is not one, and the robot starts cold
+    {
+      bool sane = true;
+#pragma unroll
+      for (int l = 0; l < 4; l++) {
+        const mask_t rows = (wm >> (kKinds * l)) & kLegRows;
+        int n = 0;
+        if constexpr (kTorque) n = __popcll((unsigned long long)rows);
+        else n = __popc((unsigned)rows);
+        sane = sane && n <= 3;
+      }
+      wm = sane ? wm : (mask_t)0;
+    }
     for (;;) {
-      const bool has = wm != 0u;
+      const bool has = wm != 0;
       if (__builtin_amdgcn_ballot_w64(has) == 0ull) break;
-      const int p = has ? __ffs(wm) - 1 : 0;
-      wm &= wm - 1u;
-      const int pleg = id_leg(p), kind = p - 5 * pleg;
-      const double np_tab = lds_nrm[64 * kind + ((int)threadIdx.x & 63)];
+      int p = 0;
+      if constexpr (kTorque) p = has ? __ffsll((long long)wm) - 1 : 0;
+      else p = has ? __ffs((int)wm) - 1 : 0;
+      wm &= wm - 1;
+      const int pleg = kTorque ? ((p * 47) >> 9) : id_leg(p), kind = p - kKinds * pleg;
+      // the row's normal on my lane and its offset: n'x - b >= 0 with b = f_min (kind 0), 0 (friction), and for the torque
+      // bounds of joint k (kinds 5 + 2k upper, 6 + 2k lower) n = +-J[:,k], b = -(tau_max -+ tau0_k) -- held by the joint's lane
+      int tab_kind = kind;
+      double sign = 1.0, b_p = sel(kind == 0, f_min, 0.0);
+      if constexpr (kTorque) {
+        const int kj = (kind - 5) >> 1;
+        const bool tq = kind >= 5, lower = tq && ((kind - 5) & 1) != 0;
+        tab_kind = tq ? 5 + kj : kind;
+        sign = lower ? -1.0 : 1.0;
+        const int src = 4 * pleg + (tq ? kj : 0);
+        const double bu = __shfl(Q.tq_up, src, 16), bl = __shfl(Q.tq_lo, src, 16);
+        b_p = tq ? -(lower ? bl : bu) : b_p;
+      }
+      const double np_tab = sign * lds_nrm[64 * tab_kind + ((int)threadIdx.x & 63)];
       npj = (has && pleg == leg) ? np_tab : 0.0;
       // directions as in a pass; z'n_p of a row without a candidate is 0: biased to 1, its step is 0
       double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
@@ -457,7 +491,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
       });
       const double zw = (za[0] + za[1]) + za[2], rw = (ra[0] + ra[1]) + ra[2];
       const double znw = row_sum(zw * npj);
-      const double s_p = row_sum(npj * x) - sel(kind == 0, f_min, 0.0); // slack of the row at x
+      const double s_p = row_sum(npj * x) - b_p; // slack of the row at x
       // a row that depends on the rows installed before it is left out: z'n_p is then rounding noise, which with the entries
       // of H reaching 1 / w_reg = 1e4 means up to 1e-10, while an independent row has z'n_p >= |n|^2 / trace(G) ~ 1e-3
       const bool ok = has && znw > 1e-6;
@@ -685,12 +719,15 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     iters_out = (b.x >> 8) + warm_updates; // what this robot cost: the installs and drops of a warm start count as passes
   }
   if constexpr (kWarm) { // the final working set as a bit mask: the OR over the slot lanes of a row
-    unsigned w = ((used >> lr) & 1u) ? (1u << idk) : 0u;
-    w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x128, 0xF, 0xF, true);
-    w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x124, 0xF, 0xF, true);
-    w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x122, 0xF, 0xF, true);
-    w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x121, 0xF, 0xF, true);
-    if (ws_out) *ws_out = status == kStatusOk ? w : 0u;
+    const mask_t mine = ((used >> lr) & 1u) ? (one_v<mask_t> << idk) : 0;
+    unsigned lo = (unsigned)mine, hi = 0u;
+    if constexpr (kTorque) hi = (unsigned)((unsigned long long)mine >> 32);
+    static_for<4>([&](auto K) {
+      constexpr int ctrl = K == 0 ? 0x128 : K == 1 ? 0x124 : K == 2 ? 0x122 : 0x121;
+      lo |= (unsigned)__builtin_amdgcn_mov_dpp((int)lo, ctrl, 0xF, 0xF, true);
+      if constexpr (kTorque) hi |= (unsigned)__builtin_amdgcn_mov_dpp((int)hi, ctrl, 0xF, 0xF, true);
+    });
+    if (ws_out) *ws_out = status == kStatusOk ? ((unsigned long long)hi << 32 | lo) : 0ull;
   }
 
   QL_STAMP(7);
@@ -737,9 +774,40 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
       double dx = 0.0;
       static_for<12>([&](auto K) { constexpr int k = K; fmac_bc<k, k == 0>(dx, rho, NsT[k]); });
       x += dx;
+      if constexpr (kWarm) {
+        // A pass shrinks the error by the operators' relative drift.  A set that fitted leaves a first correction of the
+        // order of the drift itself (<= 4e-5 over 6.3 M cold steps): one pass, as for a cold start.  A set that did not can
+        // leave x far from the optimum of its final set; such a robot passes again until the correction is below 1e-4.
+        const double moved = -row_min(-(__builtin_fabs(corr) + __builtin_fabs(dx)));
+        passes += (warm_updates > 0 && pass + 1 == passes && passes < kMaxRefinePasses && moved > 1e-4) ? 1 : 0;
+      }
     }
   }
 
+  if constexpr (kWarm) {
+    // A warm start is taken on trust only as far as its answer checks out: at the final x every row must hold and every
+    // multiplier of the final set, u = N* (G x + g0), must be non-negative (to 1e-6 N: the efforts' own tolerance).  The
+    // method guarantees both in exact arithmetic; a set that has nothing to do with this robot's state (a reset robot, a
+    // caller's bug) can cost so many installs and drops that the explicit operators drift out of it.  Such a robot is
+    // reported (QLAMD_STATUS_WARM_REJECTED: outputs as for any failed solve, working set 0, so that its next step starts
+    // cold) rather than solved a second time here: a retry inside the kernel keeps the whole problem live across the loop,
+    // which the 168-register form pays for with spills (measured: 88-556 bytes of scratch in three arrangements).
+    if (__builtin_amdgcn_ballot_w64(status == kStatusOk && warm_updates > 0) != 0ull) {
+      double s_min, s_fric;
+      slacks(x, s_min, s_fric);
+      double worst = vmin(s_fric, sel(c == 0, s_min, s_fric));
+      if constexpr (kTorque) worst = sel(comp, vmin(worst, vmin(s_up, s_lo)), worst);
+      const double wmin = row_min(sel(on, worst, 0.0));
+      double grad = g0;
+      static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(grad, x, Gm[j]); });
+      double ua[3] = {0.0, 0.0, 0.0};
+      static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(ua[j % 3], grad, Ns[j]); });
+      const bool myslot2 = ((used >> lr) & 1u) != 0u;
+      const double umin = row_min(sel(myslot2, (ua[0] + ua[1]) + ua[2], 0.0));
+      const bool accept = wmin > -1e-6 && umin > -1e-6;
+      status = (status == kStatusOk && warm_updates > 0 && !accept) ? kStatusWarmRejected : status;
+    }
+  }
   return status;
 }
 

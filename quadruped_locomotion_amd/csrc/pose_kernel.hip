@@ -605,6 +605,7 @@ int qlamd_qp_solve_batch(qlamd_context *ctx, int n, int p, int m, const double *
   PlacePtrs pp;
   qlamd_placement pl;
   { const int rc = take_placement(ctx, memory, batch, &pp, &pl); if (rc != QLAMD_OK) return rc; }
+  if (pp.prev_working_set || pp.working_set) return QLAMD_ERR_INVALID_ARGUMENT; // (the dense entries start cold)
   const size_t B = (size_t)batch;
   const double *dG = G, *dg0 = g0, *dCE = CE, *dce0 = ce0, *dCI = CI, *dci0 = ci0;
   double *dx = x, *dobj = objective;
@@ -665,6 +666,7 @@ int qlamd_weighted_lsq_qp_batch(qlamd_context *ctx, int n, int k, int p, int m, 
   PlacePtrs pp;
   qlamd_placement pl;
   { const int rc = take_placement(ctx, memory, batch, &pp, &pl); if (rc != QLAMD_OK) return rc; }
+  if (pp.prev_working_set || pp.working_set) return QLAMD_ERR_INVALID_ARGUMENT; // (the dense entries start cold)
   const size_t B = (size_t)batch;
   const double *dA = A, *dS = S, *db = b, *dW = W, *dC = p ? C : nullptr, *dc = p ? c : nullptr, *dD = m ? D : nullptr,
                *dd = m ? d : nullptr, *df = m ? f : nullptr;

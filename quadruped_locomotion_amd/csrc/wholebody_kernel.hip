@@ -307,7 +307,8 @@ __global__ __launch_bounds__(64) void wholebody_dynamics_leg_kernel(const Device
 // bound of each joint torque), every one of them local to a leg: the QP runs on the quad layout the dynamics was
 // computed in (lane 4 leg + c: body c of the leg = force component c = joint c), force_qp_coop.hpp with its torque rows
 // -- no exchange through LDS, no general dense solver.
-template <bool kPerLeg>
+// kWarm: the QP starts from the working set handed in through qlamd_place_next_call (force_qp_coop.hpp; 44 rows: 64 bits).
+template <bool kPerLeg, bool kWarm = false>
 __global__ __launch_bounds__(64, 2) void wholebody_solve_kernel(const DeviceParams *__restrict__ Pp, const coop::WbParamsDev W,
                                                              const WbPtrs s, int64_t B, double *__restrict__ tau_out,
                                                              double *__restrict__ grf_out, int32_t *__restrict__ status_out,
@@ -330,6 +331,8 @@ __global__ __launch_bounds__(64, 2) void wholebody_solve_kernel(const DevicePara
   for (int k = 0; k < 6; k++) ades[k] = s.a_des[6 * i + k];
   const double qdd_raw = (s.qdd ? s.qdd : s.qd)[12 * i + jq];
   const uint32_t sm = *reinterpret_cast<const uint32_t *>(s.stance + 4 * i);
+  unsigned long long warm_set = 0ull;
+  if constexpr (kWarm) warm_set = pp.prev_working_set ? pp.prev_working_set[i] : 0ull;
   double nWl[3] = {0.0, 0.0, 1.0};
   if (kPerLeg) { nWl[0] = s.normals[12 * i + 3 * leg]; nWl[1] = s.normals[12 * i + 3 * leg + 1]; nWl[2] = s.normals[12 * i + 3 * leg + 2]; }
   ts.commit(tab);
@@ -393,9 +396,11 @@ __global__ __launch_bounds__(64, 2) void wholebody_solve_kernel(const DevicePara
   Q.on = on; Q.comp = comp; Q.nS = nS; Q.refine_passes = P.refine_passes;
   Q.tq_up = W.tau_max - tau0; Q.tq_lo = W.tau_max + tau0;
   double x = 0.0;
-  Q.warm = 0u; Q.stance = 0u;
+  Q.warm = 0ull; Q.stance = stance;
+  if constexpr (kWarm) Q.warm = warm_set;
   int qp_iters;
-  const int st = force_qp_coop<true>(Q, rows + kCoopLdsDoubles * row, nrm, x, qp_iters);
+  unsigned long long final_set = 0ull;
+  const int st = force_qp_coop<true, kWarm>(Q, rows + kCoopLdsDoubles * row, nrm, x, qp_iters, &final_set);
 
   // ---- joint efforts: tau = tau0 - J_leg' f on the stance legs, tau0 elsewhere
   const bool ok = st == kStatusOk;
@@ -409,6 +414,7 @@ __global__ __launch_bounds__(64, 2) void wholebody_solve_kernel(const DevicePara
   if (lr == 0 && live) {
     status_out[i] = st;
     if (pp.iterations) pp.iterations[i] = st == kStatusNotPd ? 0 : qp_iters;
+    if constexpr (kWarm) { if (pp.working_set) pp.working_set[i] = st == kStatusOk ? final_set : 0ull; }
   }
 }
 
@@ -545,10 +551,19 @@ int qlamd_wholebody_solve_batch(qlamd_context *ctx, const qlamd_wholebody_params
   }
   const coop::WbParamsDev W = wb_params_of(ctx, params->torque_weight, params->torque_limit, params->gravity);
   const unsigned grid = (unsigned)((batch + 3) / 4);
-  if (s.normals)
-    hipLaunchKernelGGL(wholebody_solve_kernel<true>, dim3(grid), dim3(64), 0, st, ctx->d_params, W, s, batch, dtau, dgrf, dst, pp);
-  else
-    hipLaunchKernelGGL(wholebody_solve_kernel<false>, dim3(grid), dim3(64), 0, st, ctx->d_params, W, s, batch, dtau, dgrf, dst, pp);
+  const bool warm = pp.prev_working_set || pp.working_set;
+#define QL_LAUNCH_WB(PERLEG)                                                                                                   \
+  do {                                                                                                                         \
+    if (warm)                                                                                                                  \
+      hipLaunchKernelGGL((wholebody_solve_kernel<PERLEG, true>), dim3(grid), dim3(64), 0, st, ctx->d_params, W, s, batch, dtau, \
+                         dgrf, dst, pp);                                                                                       \
+    else                                                                                                                       \
+      hipLaunchKernelGGL((wholebody_solve_kernel<PERLEG, false>), dim3(grid), dim3(64), 0, st, ctx->d_params, W, s, batch,     \
+                         dtau, dgrf, dst, pp);                                                                                 \
+  } while (0)
+  if (s.normals) QL_LAUNCH_WB(true);
+  else QL_LAUNCH_WB(false);
+#undef QL_LAUNCH_WB
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   { const int rc = finish_placement(ctx, pl, batch, st); if (rc != QLAMD_OK) return rc; }
   if (memory == QLAMD_MEM_HOST) return sg.finish(st);

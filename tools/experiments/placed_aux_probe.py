@@ -61,6 +61,18 @@ def main():
                 ctx.place_next_call(order=order, iterations=it)
                 entry(cap)
             res.append("%s %.2f" % (pname, timed(placed, args.reps)))
+        if name.startswith("wholebody"):
+            # warm start: the working set kept from call to call (64 bits per robot, in place)
+            ws = torch.zeros(B, 2, dtype=torch.int32, device="cuda:0")
+            import ctypes as C2
+
+            def warm(cap):
+                pl = capi.Placement(None, it.data_ptr(), None, None, 0, ws.data_ptr(), ws.data_ptr())
+                assert capi.lib().qlamd_place_next_call(ctx._h, C2.byref(pl)) == 0
+                entry(cap)
+            warm(torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            res.append("warm start (its own previous set) %.2f" % timed(warm, args.reps))
         print("%-42s %5d problems (iterations mean %.1f max %d) | %s" % (name, B, itn.mean(), itn.max(), " | ".join(res)), flush=True)
 
 
