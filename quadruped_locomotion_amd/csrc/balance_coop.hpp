@@ -42,10 +42,56 @@ struct CoopPtrs {
   uint32_t *working_set;
 };
 
+// Support legs first.  The QP's variables are the contact forces of the legs that support; with the legs of a robot laid
+// out in the row in the order [support legs ascending, then the others] a robot on two legs (a trot) is a 6-variable problem
+// in rows 0 and 1 -- force_qp_coop<..., kLegs = 2>: every broadcast product, every rank-one update and the inversion of G
+// half as long -- and a robot on four legs is laid out as always.  slot_legs(m): the leg behind each of the four slots for
+// the support mask m, two bits per slot (0xE4 = identity).
+__host__ __device__ constexpr unsigned slot_legs_of(unsigned m) {
+  unsigned perm = 0, k = 0;
+  for (unsigned l = 0; l < 4; l++)
+    if ((m >> l) & 1u) perm |= l << (2 * k++);
+  for (unsigned l = 0; l < 4; l++)
+    if (!((m >> l) & 1u)) perm |= l << (2 * k++);
+  return perm;
+}
+__host__ __device__ constexpr unsigned long long slot_legs_table(int half) {
+  unsigned long long t = 0;
+  for (int m = 0; m < 8; m++) t |= (unsigned long long)slot_legs_of(8 * half + m) << (8 * m);
+  return t;
+}
+__device__ __forceinline__ unsigned slot_legs(unsigned m) {
+  constexpr unsigned long long lo = slot_legs_table(0), hi = slot_legs_table(1);
+  return (unsigned)(((m & 8u) ? hi : lo) >> (8 * (m & 7u))) & 0xFFu;
+}
+// a working set (kKinds bits per leg) between the caller's leg order and the row's slot order
+template <int kKinds, class mask_t>
+__device__ __forceinline__ mask_t working_set_to_slots(mask_t by_leg, unsigned perm) {
+  constexpr mask_t rows = ((mask_t)1 << kKinds) - 1;
+  mask_t out = 0;
+#pragma unroll
+  for (int sl = 0; sl < 4; sl++) out |= ((by_leg >> (kKinds * ((perm >> (2 * sl)) & 3u))) & rows) << (kKinds * sl);
+  return out;
+}
+template <int kKinds, class mask_t>
+__device__ __forceinline__ mask_t working_set_to_legs(mask_t by_slot, unsigned perm) {
+  constexpr mask_t rows = ((mask_t)1 << kKinds) - 1;
+  mask_t out = 0;
+#pragma unroll
+  for (int sl = 0; sl < 4; sl++) out |= ((by_slot >> (kKinds * sl)) & rows) << (kKinds * ((perm >> (2 * sl)) & 3u));
+  return out;
+}
+// my value of a per-lane quantity laid out by leg, fetched from the lane of the leg behind my slot (same component)
+__device__ __forceinline__ double from_leg_lane(double v, int aleg) {
+  const int addr = (((int)threadIdx.x & 48) | (4 * aleg) | ((int)threadIdx.x & 3)) << 2;
+  return __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, __double2hiint(v)),
+                          __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)));
+}
+
 // One robot per 16-lane row.  lds_tab: 256-double model table; lds_row: this robot's private
 // LDS block of kCoopLdsDoubles doubles (N* export for the refinement, row export for drops); lds_nrm: the wavefront's
 // table of constraint normals, kCoopNrmDoubles doubles ([row kind][lane]).
-constexpr int kCoopNrmDoubles = 11 * 64; // 5 row kinds + parked Jacobian row (3) and gravity torque (3)
+constexpr int kCoopNrmDoubles = 12 * 64; // 5 row kinds + parked Jacobian row (3), gravity torque (3), output index and slot order
 
 template <bool kPerLeg, int kBlock = 64, bool kWarm = false>
 __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs &s, int64_t irobot, bool robot_live_in,
@@ -54,7 +100,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
                                            double *__restrict__ grf_out, int32_t *__restrict__ status_out) {
   bool robot_live = robot_live_in;
   const int lr = threadIdx.x & 15;   // lane in row
-  const int leg = lr >> 2, c = lr & 3;
+  const int leg = lr >> 2, c = lr & 3; // leg: my SLOT in the row (the leg behind it: aleg, below)
   const bool comp = c < 3;           // carries a variable / matrix row
   const int myidx = 3 * leg + c;     // valid when comp
   const double eps = 2.220446049250313e-16;
@@ -88,7 +134,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     }
   }
   const uint32_t sm = *reinterpret_cast<const uint32_t *>(s.stance + 4 * i);
-  const double qj = s.q[12 * i + (comp ? myidx : 0)];
+  double qj = s.q[12 * i + (comp ? myidx : 0)];
   const uint8_t alive = s.live ? s.live[i] : (uint8_t)1;
   unsigned warm_set = 0u;
   if constexpr (kWarm) warm_set = s.prev_working_set ? s.prev_working_set[i] : 0u;
@@ -105,7 +151,18 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
                                         ((sm & 0xFF0000u) ? 4u : 0u) | ((sm & 0xFF000000u) ? 8u : 0u))
                                      : 0u;
   const int nS = __popc(stance);
-  const bool on = ((stance >> leg) & 1u) != 0; // my leg supports
+  // support legs first: the leg behind my slot, and what was loaded by leg goes to the lane of its slot
+  const unsigned perm = slot_legs(stance);
+  const int aleg = (int)((perm >> (2 * leg)) & 3u);
+  // (where my results go and the slot order are not needed before the very end: parked like the Jacobian row)
+  reinterpret_cast<int2 *>(lds_nrm + 64 * 11)[(int)threadIdx.x & 63] = make_int2(3 * aleg + c, (int)perm);
+  const bool on = leg < nS; // my slot's leg supports
+  const unsigned stance_slots = (1u << nS) - 1u;
+  const bool permuted = __builtin_amdgcn_ballot_w64(perm != 0xE4u) != 0ull; // (scalar: some row of the wavefront is)
+  if (permuted) {
+    qj = from_leg_lane(qj, aleg);
+    if (kPerLeg) { nWl[0] = from_leg_lane(nWl[0], aleg); nWl[1] = from_leg_lane(nWl[1], aleg); nWl[2] = from_leg_lane(nWl[2], aleg); }
+  }
 #pragma unroll
   for (int j = 0; j < kTabLoads; j++) {
     const int idx = (int)threadIdx.x + kBlock * j;
@@ -195,7 +252,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   QL_STAMP(2);
   // ---------------------------------------------------------------- leg kinematics, 4 lanes per leg
   // lane c holds row c of the cumulative rotation and component c of every position
-  const CoopTab tab{lds_tab + kTabPerLeg * leg};
+  const CoopTab tab{lds_tab + kTabPerLeg * aleg};
   double sj, cj;
   sincos_reduced(qj, sj, cj);
   double Rc[3] = {c == 0 ? 1.0 : 0.0, c == 1 ? 1.0 : 0.0, c == 2 ? 1.0 : 0.0};
@@ -300,7 +357,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   QL_STAMP(4);
   // ---------------------------------------------------------------- G row, g0
   double Gm[12], g0;
-  force_qp_objective(P.S, P.w_reg, foot, stance, comp && on, b, nullptr, 0.0, Gm, g0);
+  force_qp_objective(P.S, P.w_reg, foot, stance_slots, comp && on, b, nullptr, 0.0, Gm, g0);
 
   QL_STAMP(5);
   // ---------------------------------------------------------------- the force QP (force_qp_coop.hpp)
@@ -313,18 +370,28 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   Q.myn = myn; Q.myt1 = myt1; Q.myt2 = myt2;
   Q.mu = mu; Q.f_min = f_min;
   Q.on = on; Q.comp = comp; Q.nS = nS; Q.refine_passes = P.refine_passes;
-  Q.warm = warm_set; Q.stance = stance;
+  Q.warm = 0ull; Q.stance = stance_slots;
+  if constexpr (kWarm) Q.warm = permuted ? working_set_to_slots<5, unsigned>(warm_set, perm) : warm_set;
   double x;
   int qp_iters;
   unsigned long long final_set = 0ull;
-  const int status = force_qp_coop<false, kWarm>(Q, lds_row, lds_nrm, x, qp_iters, &final_set);
+  // (wave-uniform: rows without a robot have no support leg)
+  const bool two_legs = __builtin_amdgcn_ballot_w64(nS > 2) == 0ull;
+  int status;
+  if (two_legs) status = force_qp_coop<false, kWarm, 2>(Q, lds_row, lds_nrm, x, qp_iters, &final_set);
+  else status = force_qp_coop<false, kWarm, 4>(Q, lds_row, lds_nrm, x, qp_iters, &final_set);
+  const int2 parked = reinterpret_cast<const int2 *>(lds_nrm + 64 * 11)[(int)threadIdx.x & 63];
+  const int aidx = parked.x;
+  if constexpr (kWarm) {
+    if (permuted) final_set = working_set_to_legs<5, unsigned>((unsigned)final_set, (unsigned)parked.y);
+  }
   if (status == kStatusNotPd) {
     if (lr == 0 && robot_live) {
       status_out[i] = kStatusNotPd;
       if (s.iterations) s.iterations[i] = 0;
       if constexpr (kWarm) { if (s.working_set) s.working_set[i] = 0u; }
     }
-    if (comp && robot_live && !P.keep_on_failure && (on || !s.support_only)) { tau_out[12 * i + myidx] = 0.0; if (grf_out) grf_out[12 * i + myidx] = 0.0; }
+    if (comp && robot_live && !P.keep_on_failure && (on || !s.support_only)) { tau_out[12 * i + aidx] = 0.0; if (grf_out) grf_out[12 * i + aidx] = 0.0; }
     return;
   }
 
@@ -346,8 +413,8 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     t = t > P.tau_max ? P.tau_max : t;
     t = t < -P.tau_max ? -P.tau_max : t;
     if (comp && robot_live && !(P.keep_on_failure && status != kStatusOk) && (on || !s.support_only)) {
-      tau_out[12 * i + myidx] = live ? t : 0.0;
-      if (grf_out) grf_out[12 * i + myidx] = live ? x : 0.0;
+      tau_out[12 * i + aidx] = live ? t : 0.0;
+      if (grf_out) grf_out[12 * i + aidx] = live ? x : 0.0;
     }
     if (lr == 0 && robot_live) {
       status_out[i] = status;

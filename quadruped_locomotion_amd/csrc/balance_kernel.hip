@@ -164,49 +164,66 @@ __device__ __forceinline__ int place_bin(int v) { // bin 0 = hardest (the clamp 
   const int h = v < 0 ? 0 : (v >= kPlaceBins ? kPlaceBins - 1 : v);
   return kPlaceBins - 1 - h;
 }
+// The launches of their own also know a robot's CLASS when the caller's support flags are at hand (`support`: [B][4] bytes
+// read as one word per robot; NULL: one class): robots on more than two legs first, then the robots on at most two --
+// whose wavefronts then take the 6-variable form of the QP (balance_coop.hpp, "support legs first": a wavefront takes it
+// only when all four of its robots can).  Key = class * kPlaceBins + bin; sorted placement only (placing the hardest
+// robots one per wavefront mixes the classes by design).
+constexpr int kPlaceKeys = 2 * kPlaceBins;
+__device__ __forceinline__ int place_key(int v, const uint32_t *__restrict__ support, int64_t i) {
+  int key = place_bin(v);
+  if (support) {
+    const uint32_t w = support[i];
+    const int n = ((w & 0xFFu) ? 1 : 0) + ((w & 0xFF00u) ? 1 : 0) + ((w & 0xFF0000u) ? 1 : 0) + ((w & 0xFF000000u) ? 1 : 0);
+    key += n <= 2 ? kPlaceBins : 0;
+  }
+  return key;
+}
 __global__ __launch_bounds__(kPlaceThreads) void placement_hist_kernel(const int32_t *__restrict__ iters, int64_t B, int64_t per_block,
+                                                                      const uint32_t *__restrict__ support,
                                                                       uint32_t *__restrict__ blockhist) {
-  __shared__ uint32_t h[kPlaceBins];
-  if (threadIdx.x < kPlaceBins) h[threadIdx.x] = 0;
+  __shared__ uint32_t h[kPlaceKeys];
+  if (threadIdx.x < kPlaceKeys) h[threadIdx.x] = 0;
   __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * per_block, hi = lo + per_block < B ? lo + per_block : B;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += kPlaceThreads) atomicAdd(&h[place_bin(iters[i])], 1u);
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kPlaceThreads) atomicAdd(&h[place_key(iters[i], support, i)], 1u);
   __syncthreads();
-  if (threadIdx.x < kPlaceBins) blockhist[(int64_t)blockIdx.x * kPlaceBins + threadIdx.x] = h[threadIdx.x];
+  if (threadIdx.x < kPlaceKeys) blockhist[(int64_t)blockIdx.x * kPlaceKeys + threadIdx.x] = h[threadIdx.x];
 }
 template <int G>
 __global__ __launch_bounds__(kPlaceThreads) void placement_kernel(const int32_t *__restrict__ iters, int64_t B, int throughput,
+                                                                 const uint32_t *__restrict__ support,
                                                                  const uint32_t *__restrict__ blockhist, int32_t *__restrict__ order) {
-  constexpr int kN = kPlaceBins * G * kPlaceWaves, kPer = (kN + kPlaceThreads - 1) / kPlaceThreads; // counters, counters per lane in the scan
+  constexpr int kN = kPlaceKeys * G * kPlaceWaves, kPer = (kN + kPlaceThreads - 1) / kPlaceThreads; // counters, counters per lane in the scan
   __shared__ uint32_t cnt[kN];
   __shared__ uint32_t wtot[kPlaceWaves];
-  __shared__ uint32_t bin_base[kPlaceBins];
+  __shared__ uint32_t bin_base[kPlaceKeys];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t first = (int64_t)blockIdx.x * (kPlaceThreads * G);
   int v[G];
 #pragma unroll
   for (int g = 0; g < G; g++) { // all loads in flight before the first atomic
     const int64_t i = first + g * kPlaceThreads + t;
-    v[g] = i < B ? place_bin(iters[i]) : -1;
+    v[g] = i < B ? place_key(iters[i], support, i) : -1;
   }
 #pragma unroll
   for (int k = 0; k < kPer; k++)
     if (t + k * kPlaceThreads < kN) cnt[t + k * kPlaceThreads] = 0;
-  __shared__ uint32_t tot[kPlaceBins], before[kPlaceBins];
+  __shared__ uint32_t tot[kPlaceKeys], before[kPlaceKeys];
   if (gridDim.x > 1) {
     // several workgroups: robots of the harder bins anywhere, and of my bin in the workgroups before mine
-    if (t < kPlaceBins) { tot[t] = 0; before[t] = 0; }
+    if (t < kPlaceKeys) { tot[t] = 0; before[t] = 0; }
     __syncthreads();
-    for (unsigned e = t; e < gridDim.x * kPlaceBins; e += kPlaceThreads) {
-      const unsigned blk = e / kPlaceBins, b = e - blk * kPlaceBins;
+    for (unsigned e = t; e < gridDim.x * kPlaceKeys; e += kPlaceThreads) {
+      const unsigned blk = e / kPlaceKeys, b = e - blk * kPlaceKeys;
       const uint32_t c = blockhist[e];
       atomicAdd(&tot[b], c);
       if (blk < blockIdx.x) atomicAdd(&before[b], c);
     }
     __syncthreads();
-    if (t < kPlaceBins) {
+    if (t < kPlaceKeys) {
       uint32_t harder = 0;
-      for (int b = 0; b < kPlaceBins; b++) harder += b < t ? tot[b] : 0u;
+      for (int b = 0; b < kPlaceKeys; b++) harder += b < t ? tot[b] : 0u;
       bin_base[t] = harder + before[t];
     }
   }
@@ -265,8 +282,9 @@ __global__ __launch_bounds__(kPlaceThreads) void placement_kernel(const int32_t 
 // scan is done -- in registers (13 000 instructions of unrolled code), as bytes in LDS (16 us at 4096 robots: sub-word LDS
 // stores) or as words of four rounds (14.6 us, and 16 KB of LDS per workgroup cost every placed launch 0.3 us).
 constexpr int kShadowLdsBytes = (4 * kTabPerLeg + 4 * coop::kCoopLdsDoubles + coop::kCoopNrmDoubles) * 8;
-constexpr int kShadowMaxRounds = kShadowLdsBytes / (kPlaceBins * 4);
+constexpr int kShadowMaxRounds = 136;                                // (the figure include/qlamd.h documents: 8704 robots)
 constexpr int64_t kShadowMaxRobots = 64 * (int64_t)kShadowMaxRounds;
+static_assert(kShadowMaxRounds * kPlaceBins * 4 <= kShadowLdsBytes, "the shadow wavefront's counters live in the solve's LDS");
 constexpr int kShadowChunk = 32;
 typedef __attribute__((address_space(3))) uint32_t lds_u32; // (a generic pointer would turn the atomics into flat ones)
 template <bool kThroughput>
@@ -559,9 +577,9 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
     ctx->base_I[5] = I[5] + bm * (cc - c[2] * c[2]);
   }
   ctx->d_params = nullptr;
-  // (the placement scratch for batches up to 1 M robots comes with the context: 24 KB, and no placement call of a
+  // (the placement scratch for batches up to 1 M robots comes with the context: 48 KB, and no placement call of a
   // sensible size ever has to allocate inside a stream capture)
-  const size_t place_bytes = (size_t)256 * kPlaceBins * sizeof(uint32_t);
+  const size_t place_bytes = (size_t)256 * kPlaceKeys * sizeof(uint32_t);
   if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&ctx->d_params, sizeof(DeviceParams)) != hipSuccess ||
       hipMemcpy(ctx->d_params, &ctx->params, sizeof(DeviceParams), hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc(&ctx->place_ws, place_bytes) != hipSuccess) {
@@ -624,16 +642,19 @@ int qlamd_set_option(qlamd_context *ctx, int option, int value) {
 // live: device pointer [B] or NULL (whole tick, QLAMD_MEM_DEVICE only): robots with 0 are left alone
 namespace {
 // qlamd_placement_from_iterations on device pointers (the caller holds the context's guard)
-int launch_placement(qlamd_context *ctx, const int32_t *d_it, int64_t batch, int throughput, int32_t *d_ord, hipStream_t st) {
+// d_support: the robots' support flags ([B][4] bytes, device) or NULL -- the class of the sorted placement (place_key)
+int launch_placement(qlamd_context *ctx, const int32_t *d_it, int64_t batch, int throughput, int32_t *d_ord, hipStream_t st,
+                     const uint8_t *d_support = nullptr) {
+  const uint32_t *sup = throughput ? reinterpret_cast<const uint32_t *>(d_support) : nullptr;
   if (batch <= kPlaceRounds * kPlaceThreads)
-    hipLaunchKernelGGL(placement_kernel<kPlaceRounds>, dim3(1), dim3(kPlaceThreads), 0, st, d_it, batch, throughput, nullptr, d_ord);
+    hipLaunchKernelGGL(placement_kernel<kPlaceRounds>, dim3(1), dim3(kPlaceThreads), 0, st, d_it, batch, throughput, sup, nullptr, d_ord);
   else {
     // several workgroups (the LDS atomics of one compute unit serve about one robot per cycle: 4096 robots per workgroup
     // keep a launch at 3-4 us whatever the batch): their counts per bin go through the context's placement scratch
     // (sized for 1 M robots when the context is created; growing it is an allocation, which a stream capture cannot take)
     const int64_t per_block = (int64_t)kPlaceRounds * kPlaceThreads;
     const unsigned nb = (unsigned)((batch + per_block - 1) / per_block);
-    const size_t need = (size_t)nb * kPlaceBins * sizeof(uint32_t);
+    const size_t need = (size_t)nb * kPlaceKeys * sizeof(uint32_t);
     if (ctx->place_ws_bytes < need) {
       if (CallGuard::capturing(st)) return QLAMD_ERR_NEEDS_RESERVE;
       if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
@@ -643,8 +664,8 @@ int launch_placement(qlamd_context *ctx, const int32_t *d_it, int64_t batch, int
       if (hipMalloc(&ctx->place_ws, need) != hipSuccess) return QLAMD_ERR_OUT_OF_MEMORY;
       ctx->place_ws_bytes = need;
     }
-    hipLaunchKernelGGL(placement_hist_kernel, dim3(nb), dim3(kPlaceThreads), 0, st, d_it, batch, per_block, (uint32_t *)ctx->place_ws);
-    hipLaunchKernelGGL(placement_kernel<kPlaceRounds>, dim3(nb), dim3(kPlaceThreads), 0, st, d_it, batch, throughput,
+    hipLaunchKernelGGL(placement_hist_kernel, dim3(nb), dim3(kPlaceThreads), 0, st, d_it, batch, per_block, sup, (uint32_t *)ctx->place_ws);
+    hipLaunchKernelGGL(placement_kernel<kPlaceRounds>, dim3(nb), dim3(kPlaceThreads), 0, st, d_it, batch, throughput, sup,
                        (const uint32_t *)ctx->place_ws, d_ord);
   }
   return hipGetLastError() == hipSuccess ? QLAMD_OK : QLAMD_ERR_HIP;
@@ -822,7 +843,7 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
   }
   if (e != hipSuccess) return QLAMD_ERR_HIP;
   if (next_order && memory == QLAMD_MEM_DEVICE && !s.next_order) { // too many robots for the shadow wavefront: launches of their own
-    const int rc = launch_placement(ctx, prev_iterations, batch, throughput_policy(pl->policy, batch) ? 1 : 0, next_order, st);
+    const int rc = launch_placement(ctx, prev_iterations, batch, throughput_policy(pl->policy, batch) ? 1 : 0, next_order, st, s.stance);
     if (rc != QLAMD_OK) return rc;
   }
 

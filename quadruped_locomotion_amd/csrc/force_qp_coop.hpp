@@ -122,29 +122,33 @@ __device__ __forceinline__ void force_qp_objective(const double S[6], double w_r
 // method runs as always, so a set that no longer fits costs passes, not the answer (the minimiser is unique).  The passes a
 // robot then still needs are its `iters_out`.  QuadProg++ has no such entry (solve_quadprog always starts from the
 // unconstrained minimiser, QuadProg++.cc:216-233): iteration counts no longer match the reference's one for one, torques do.
-template <bool kTorque, bool kWarm = false>
+template <bool kTorque, bool kWarm = false, int kLegs = 4>
 __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, double *lds_nrm, double &x, int &iters_out,
                                              unsigned long long *ws_out = nullptr) {
   using mask_t = std::conditional_t<kTorque, unsigned long long, unsigned>;
   constexpr int kKinds = kTorque ? 11 : 5;
+  // kLegs: the legs that can support, in rows 0 .. kLegs-1 of the 16-lane row (the callers put the support legs first: a
+  // robot on two legs is a 6-variable problem, and every product below is half as long); kV variables, at most kV slots
+  static_assert(kLegs == 2 || kLegs == 4, "legs in front of the row");
+  constexpr int kV = 3 * kLegs;
   const int lr = threadIdx.x & 15, leg = lr >> 2, c = lr & 3;
-  const bool comp = Q.comp, on = Q.on, row_on = comp && on;
+  const bool comp = Q.comp && leg < kLegs, on = Q.on, row_on = comp && on;
   const int myidx = 3 * leg + c, nS = Q.nS;
   const double eps = 2.220446049250313e-16;
   const double inf = INFINITY;
   const double mu = Q.mu, f_min = Q.f_min, g0 = Q.g0;
   const double myn = Q.myn, myt1 = Q.myt1, myt2 = Q.myt2;
   const double *nb = Q.nb, *t1 = Q.t1, *t2 = Q.t2, *Gm = Q.Gm;
-  double H[12];
+  double H[kV];
   double c1 = 0.0, c2 = 0.0;
   {
 #pragma unroll
-    for (int j = 0; j < 12; j++) H[j] = Gm[j];
+    for (int j = 0; j < kV; j++) H[j] = Gm[j];
     // trace(G) over the stance block
     {
       double diag = 0.0;
 #pragma unroll
-      for (int j = 0; j < 12; j++) diag = (j == myidx) ? Gm[j] : diag;
+      for (int j = 0; j < kV; j++) diag = (j == myidx) ? Gm[j] : diag;
       c1 = row_sum(sel(row_on, diag, 0.0));
     }
     // in-place Gauss-Jordan inversion, row per lane; pivot k = L_kk^2 of the Cholesky factor.
@@ -156,7 +160,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     // updated first, so that its reciprocal (hardware seed + one Newton step, 2e-15: the final refinement works on
     // G itself, not on this inverse) is under way while the other ten columns are still being updated.
     double d = bcv<0>(H[0]);
-    static_for<12>([&](auto K) {
+    static_for<kV>([&](auto K) {
       constexpr int k = K;
       bad = bad || !(d > 0.0);
       const double p = rcp_nr1(d);
@@ -164,13 +168,13 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
       my_pivot = piv ? d : my_pivot;
       const double f = piv ? (1.0 - p) : H[k] * p;
       const double nf = -f;
-      if constexpr (k < 11) {
+      if constexpr (k < kV - 1) {
         fmac_bc<lane_of(k), true>(H[k + 1], H[k + 1], nf);
         d = bcv<k + 1>(H[k + 1]);
       }
-      static_for<12>([&](auto J) {
+      static_for<kV>([&](auto J) {
         constexpr int j = J;
-        if constexpr (j != k && j != k + 1) fmac_bc<lane_of(k), (k == 11 && j == 0)>(H[j], H[j], nf);
+        if constexpr (j != k && j != k + 1) fmac_bc<lane_of(k), (k == kV - 1 && j == 0)>(H[j], H[j], nf);
       });
       H[k] = piv ? p : nf;
     });
@@ -187,7 +191,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
   {
     const double ng0 = -g0;
     double xa[3] = {0.0, 0.0, 0.0};
-    static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(xa[j % 3], ng0, H[j]); });
+    static_for<kV>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(xa[j % 3], ng0, H[j]); });
     x = (xa[0] + xa[1]) + xa[2];
   }
 
@@ -218,9 +222,9 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
   // feasibility test |psi| <= tol (:246), which is only evaluated when the chosen slack is above -tol (psi <= the
   // most negative slack, so the test cannot pass otherwise).  Component c of the chosen row's normal comes from a
   // table in LDS ([row kind][lane], written once before the loop), read in the same shadow.
-  double Ns[12];
+  double Ns[kV];
 #pragma unroll
-  for (int j = 0; j < 12; j++) Ns[j] = 0.0;
+  for (int j = 0; j < kV; j++) Ns[j] = 0.0;
   double u = 0.0;            // multiplier of slot lr (free lanes: never read)
   int idk = 0;               // constraint id of slot lr
   unsigned used = 0;         // bit k set <=> slot lane k holds an active constraint
@@ -346,11 +350,11 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     }
     key = umax_dpp(key, std::integral_constant<int, 0x124>{});
     if constexpr (kUpd) {
-      static_for<2>([&](auto J) { constexpr int j = J + 6; fmac_bc<lane_of(j)>(H[j], vec, hc); fmac_bc<lane_of(j)>(Ns[j], vec, nc); });
+      static_for<2>([&](auto J) { constexpr int j = J + 6; if constexpr (j < kV) { fmac_bc<lane_of(j)>(H[j], vec, hc); fmac_bc<lane_of(j)>(Ns[j], vec, nc); } });
     }
     key = umax_dpp(key, std::integral_constant<int, 0x122>{});
     if constexpr (kUpd) {
-      static_for<2>([&](auto J) { constexpr int j = J + 8; fmac_bc<lane_of(j)>(H[j], vec, hc); fmac_bc<lane_of(j)>(Ns[j], vec, nc); });
+      static_for<2>([&](auto J) { constexpr int j = J + 8; if constexpr (j < kV) { fmac_bc<lane_of(j)>(H[j], vec, hc); fmac_bc<lane_of(j)>(Ns[j], vec, nc); } });
     }
     key = umax_dpp(key, std::integral_constant<int, 0x121>{});
     // the chosen row: lane and kind from the low bits, its slack from its lane, its normal from the table
@@ -368,7 +372,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     double np_tab = lds_nrm[64 * tab_kind + ((int)threadIdx.x & 63)];
     if constexpr (kTorque) np_tab = ((key & 3u) == 3u) ? -np_tab : np_tab;
     if constexpr (kUpd) {
-      static_for<2>([&](auto J) { constexpr int j = J + 10; fmac_bc<lane_of(j)>(H[j], vec, hc); fmac_bc<lane_of(j)>(Ns[j], vec, nc); });
+      static_for<2>([&](auto J) { constexpr int j = J + 10; if constexpr (j < kV) { fmac_bc<lane_of(j)>(H[j], vec, hc); fmac_bc<lane_of(j)>(Ns[j], vec, nc); } });
     }
     const double np_new = sel((wl >> 2) == leg, np_tab, 0.0);
     const bool any = (int)key < 0;                       // a violated row that may enter
@@ -404,7 +408,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     if (newly_m != 0ull) latch(__builtin_amdgcn_inverse_ballot_w64(newly_m));
   };
   const auto update_only = [&]() {
-    static_for<12>([&](auto J) {
+    static_for<kV>([&](auto J) {
       constexpr int j = J;
       fmac_bc<lane_of(j), j == 0>(H[j], vec, hc);
       fmac_bc<lane_of(j)>(Ns[j], vec, nc);
@@ -416,7 +420,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
   const auto drop_vectors = [&](int lpos) {
     if (lr == lpos) {
 #pragma unroll
-      for (int j = 0; j < 12; j++) lds_row[kDropSlot + j] = Ns[j];
+      for (int j = 0; j < kV; j++) lds_row[kDropSlot + j] = Ns[j];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
@@ -424,12 +428,12 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     const int drop_id = __shfl(idk, lpos, 16);
     // (three partial sums each: a single accumulator makes twelve dependent broadcast-FMAs, 8.5 cycles apiece, of each product)
     double ga[3] = {0.0, 0.0, 0.0};
-    static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(ga[j % 3], nt_me, Gm[j]); });
+    static_for<kV>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(ga[j % 3], nt_me, Gm[j]); });
     const double Gn = (ga[0] + ga[1]) + ga[2];
     const double einv = rcp_nr1(row_sum(fma(nt_me, Gn, zb)));
     drop_einv = einv;
     double ca[3] = {0.0, 0.0, 0.0};
-    static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(ca[j % 3], Gn, Ns[j]); });
+    static_for<kV>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(ca[j % 3], Gn, Ns[j]); });
     const double coef = (ca[0] + ca[1]) + ca[2];
     vec = nt_me;
     hc = nt_me * einv;
@@ -484,7 +488,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
       npj = (has && pleg == leg) ? np_tab : 0.0;
       // directions as in a pass; z'n_p of a row without a candidate is 0: biased to 1, its step is 0
       double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
-      static_for<12>([&](auto J) {
+      static_for<kV>([&](auto J) {
         constexpr int j = J;
         fmac_bc<lane_of(j), j == 0>(za[j % 3], npj, H[j]);
         fmac_bc<lane_of(j)>(ra[j % 3], npj, Ns[j]);
@@ -598,15 +602,23 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
   };
   // ---- directions of a pass: z = H n_p (lane i), r = N* n_p (slot lane k; 0 on free lanes, whose rows are 0), z'n_p
   // three partial sums per product (z and r alternate: consecutive dependent FMAs are 6 instructions apart)
+  // one accumulator per product: z and r alternate, so consecutive dependent FMAs are two instructions apart, which at the
+  // issue rate of a lone wavefront (one instruction per ~4.5-5.5 cycles) covers the 8.4 cycles of a dependent v_fma_f64;
+  // the three partial sums per product of rounds 2-4 cost four more moves and four more adds per pass for nothing
+#ifndef QLAMD_DIRS_ACC
+#define QLAMD_DIRS_ACC 3
+#endif
   const auto general_dirs = [&]() {
+    constexpr int kAcc = QLAMD_DIRS_ACC;
     double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
-    static_for<12>([&](auto J) {
+    static_for<kV>([&](auto J) {
       constexpr int j = J;
-      fmac_bc<lane_of(j), j == 0>(za[j % 3], npj, H[j]);
-      fmac_bc<lane_of(j)>(ra[j % 3], npj, Ns[j]);
+      fmac_bc<lane_of(j), j == 0>(za[j % kAcc], npj, H[j]);
+      fmac_bc<lane_of(j)>(ra[j % kAcc], npj, Ns[j]);
     });
-    z = (za[0] + za[1]) + za[2];
-    r = (ra[0] + ra[1]) + ra[2];
+    if constexpr (kAcc == 1) { z = za[0]; r = ra[0]; }
+    else if constexpr (kAcc == 2) { z = za[0] + za[1]; r = ra[0] + ra[1]; }
+    else { z = (za[0] + za[1]) + za[2]; r = (ra[0] + ra[1]) + ra[2]; }
     zn = row_sum(fma(z, npj, zb));
   };
   // ---- step lengths, QuadProg++.cc:304-331; returns whether the pass is a full step that adds the candidate
@@ -736,15 +748,15 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
   // the same: it is refined like any other)
   if (status == kStatusOk && (q > 0 || (kWarm && warm_updates > 0))) {
     // export N* through LDS once: lane (leg,c) needs column myidx of N*
-    if (lr < 12) {
+    if (lr < kV) {
 #pragma unroll
-      for (int j = 0; j < 12; j++) lds_row[12 * lr + j] = Ns[j];
+      for (int j = 0; j < kV; j++) lds_row[12 * lr + j] = Ns[j];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0xC07F);
-    double NsT[12]; // N*[k][myidx], k = 0..11
+    double NsT[kV]; // N*[k][myidx], k = 0 .. kV-1
 #pragma unroll
-    for (int k = 0; k < 12; k++) NsT[k] = comp ? lds_row[12 * k + myidx] : 0.0;
+    for (int k = 0; k < kV; k++) NsT[k] = comp ? lds_row[12 * k + myidx] : 0.0;
     // the row behind my slot: leg, kind, and the lane that watches it
     const int lg = kTorque ? ((idk * 47) >> 9) : id_leg(idk), tt = idk - kKinds * lg;
     const bool myslot = (used >> lr) & 1u;
@@ -757,9 +769,9 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     for (int pass = 0; pass < passes; pass++) {
       // (1) reduced gradient: x -= H (G x + g0)
       double grad = g0;
-      static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(grad, x, Gm[j]); });
+      static_for<kV>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(grad, x, Gm[j]); });
       double corr = 0.0;
-      static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(corr, grad, H[j]); });
+      static_for<kV>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(corr, grad, H[j]); });
       x -= corr;
       // (2) constraint residuals rho_k = b_k - n_k'x on slot lanes; x += N*' rho
       double s_min, s_fric;
@@ -772,7 +784,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
       }
       const double rho = sel(myslot, -res, 0.0);
       double dx = 0.0;
-      static_for<12>([&](auto K) { constexpr int k = K; fmac_bc<k, k == 0>(dx, rho, NsT[k]); });
+      static_for<kV>([&](auto K) { constexpr int k = K; fmac_bc<k, k == 0>(dx, rho, NsT[k]); });
       x += dx;
       if constexpr (kWarm) {
         // A pass shrinks the error by the operators' relative drift.  A set that fitted leaves a first correction of the
@@ -799,9 +811,9 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
       if constexpr (kTorque) worst = sel(comp, vmin(worst, vmin(s_up, s_lo)), worst);
       const double wmin = row_min(sel(on, worst, 0.0));
       double grad = g0;
-      static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(grad, x, Gm[j]); });
+      static_for<kV>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(grad, x, Gm[j]); });
       double ua[3] = {0.0, 0.0, 0.0};
-      static_for<12>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(ua[j % 3], grad, Ns[j]); });
+      static_for<kV>([&](auto J) { constexpr int j = J; fmac_bc<lane_of(j), j == 0>(ua[j % 3], grad, Ns[j]); });
       const bool myslot2 = ((used >> lr) & 1u) != 0u;
       const double umin = row_min(sel(myslot2, (ua[0] + ua[1]) + ua[2], 0.0));
       const bool accept = wmin > -1e-6 && umin > -1e-6;

@@ -46,10 +46,14 @@ def placed(gpu, d, B, order, fill=np.nan):
     return tau.cpu().numpy(), grf.cpu().numpy(), status.cpu().numpy(), iters.cpu().numpy()
 
 
-def reference_placement(iters, throughput):
-    """The documented placement (include/qlamd.h), restated: stable sort by iteration count (clipped to 23), hardest first."""
+def reference_placement(iters, throughput, support=None):
+    """The documented placement (include/qlamd.h), restated: stable sort by iteration count (clipped to 23), hardest first;
+    `support` ([B][4], sorted placement by launches of their own only): robots on more than two legs before the others."""
     B = len(iters)
-    rank_to_robot = np.argsort(-np.clip(iters, 0, 23), kind="stable")
+    key = -np.clip(iters, 0, 23)
+    if support is not None and throughput:
+        key = key + 24 * (np.asarray(support).astype(bool).sum(1) <= 2)
+    rank_to_robot = np.argsort(key, kind="stable")
     if throughput:
         return rank_to_robot.astype(np.int32)
     W = (B + 3) // 4
@@ -198,6 +202,10 @@ def test_next_placement_made_inside_the_solve_equals_the_placement_entry(gpu, B)
     d_prev = torch.from_numpy(prev).to("cuda:0")
     for policy in (capi.PLACEMENT_LATENCY, capi.PLACEMENT_THROUGHPUT, capi.PLACEMENT_AUTO):
         want = ctx.placement_from_iterations(prev, policy=policy)
+        if B > 8704:  # launches of their own: a sorted placement also sorts by class (robots on at most two legs last)
+            thr = policy == capi.PLACEMENT_THROUGHPUT or (policy == capi.PLACEMENT_AUTO and B >= 16384)
+            assert np.array_equal(want, reference_placement(prev, thr))
+            want = reference_placement(prev, thr, support=s["stance"])
         tau = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
         grf = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
         status = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
