@@ -256,7 +256,12 @@ int qlamd_force_distribution_batch(qlamd_context *ctx, const double *joint_posit
  *                               where the launch lasts as long as its slowest wavefront
  *   QLAMD_PLACEMENT_THROUGHPUT  robots sorted by iteration count, hardest first, four neighbours per wavefront: the union
  *                               of four similar sequences is the shortest there is; for batches that fill every SIMD
- *                               several times over
+ *                               several times over.  When the placement is made by launches behind the solve (beyond 8704
+ *                               robots) the robots on more than two support legs come first and the others after them,
+ *                               each group sorted by count: a wavefront whose four robots all stand on at most two legs
+ *                               solves 6-variable QPs (the support legs sit in front of the row: every product of a pass
+ *                               and the inversion of G half as long; 9-11 % on batches of such robots), and a sorted
+ *                               placement that ignores the class would mix them
  *   QLAMD_PLACEMENT_AUTO        by batch size (latency below 16 384 robots)
  * A placement computed from stale or wrong hints costs time, never correctness.  Not available with
  * qlamd_set_robots_per_wave(16 | 64) (QLAMD_ERR_INVALID_ARGUMENT): one lane is one robot there and nothing is shared.

@@ -602,23 +602,17 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
   };
   // ---- directions of a pass: z = H n_p (lane i), r = N* n_p (slot lane k; 0 on free lanes, whose rows are 0), z'n_p
   // three partial sums per product (z and r alternate: consecutive dependent FMAs are 6 instructions apart)
-  // one accumulator per product: z and r alternate, so consecutive dependent FMAs are two instructions apart, which at the
-  // issue rate of a lone wavefront (one instruction per ~4.5-5.5 cycles) covers the 8.4 cycles of a dependent v_fma_f64;
-  // the three partial sums per product of rounds 2-4 cost four more moves and four more adds per pass for nothing
-#ifndef QLAMD_DIRS_ACC
-#define QLAMD_DIRS_ACC 3
-#endif
+  // (one or two accumulators per product instead of three -- four moves and adds fewer, the compiler fills the dependent
+  // pairs with s_nop -- measured the same to 0.1 us on one box: profiles/r5/ab_dirs_accumulators.txt)
   const auto general_dirs = [&]() {
-    constexpr int kAcc = QLAMD_DIRS_ACC;
     double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
     static_for<kV>([&](auto J) {
       constexpr int j = J;
-      fmac_bc<lane_of(j), j == 0>(za[j % kAcc], npj, H[j]);
-      fmac_bc<lane_of(j)>(ra[j % kAcc], npj, Ns[j]);
+      fmac_bc<lane_of(j), j == 0>(za[j % 3], npj, H[j]);
+      fmac_bc<lane_of(j)>(ra[j % 3], npj, Ns[j]);
     });
-    if constexpr (kAcc == 1) { z = za[0]; r = ra[0]; }
-    else if constexpr (kAcc == 2) { z = za[0] + za[1]; r = ra[0] + ra[1]; }
-    else { z = (za[0] + za[1]) + za[2]; r = (ra[0] + ra[1]) + ra[2]; }
+    z = (za[0] + za[1]) + za[2];
+    r = (ra[0] + ra[1]) + ra[2];
     zn = row_sum(fma(z, npj, zb));
   };
   // ---- step lengths, QuadProg++.cc:304-331; returns whether the pass is a full step that adds the candidate
