@@ -677,14 +677,17 @@ def main():
             ds.append(capi.to_device(synth.next_tick_states(state, 0.0025), dev))
         d = ds[0]
         placed, warm = method == "placed", method == "warm"
-        orders = [torch.arange(B, dtype=torch.int32, device=dev) for _ in range(2)] if placed else None
+        orders = [torch.arange(B, dtype=torch.int32, device=dev) for _ in range(2)] if (placed or warm) else None
         its = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)] if (placed or warm) else None
         wss = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)] if warm else None
 
         def solve(k, out, st):
             if warm:
-                # every robot's active-set loop starts from its final working set of the step before (include/qlamd.h)
-                ctx.balance_solve_placed_device(ds[k % len(ds)], out, None, status, iterations=its[k & 1],
+                # the placed loop, and every robot's active-set loop starts from its final working set of the step before
+                # (include/qlamd.h: both halves of the hint a 400 Hz caller has)
+                ctx.balance_solve_placed_device(ds[k % len(ds)], out, None, status, order=orders[k & 1], iterations=its[k & 1],
+                                                prev_iterations=its[(k - 1) & 1], next_order=orders[(k + 1) & 1],
+                                                policy=capi.PLACEMENT_AUTO,
                                                 prev_working_set=wss[(k - 1) & 1], working_set=wss[k & 1], stream=st)
             elif placed:
                 ctx.balance_solve_placed_device(ds[k % len(ds)], out, None, status, order=orders[k & 1], iterations=its[k & 1],
@@ -886,8 +889,8 @@ def main():
         """roofline and valu_issue objects of one preset from its kernel time and the committed PMC record."""
         kernel_ms, Bp, placed, warm = res["kernel_ms"], res["batch"], res["method"] == "placed", res["method"] == "warm"
         # placed: + robot_order in, iterations out, prev_iterations in, next_robot_order out (4 B each);
-        # warm: + iterations out, previous working set in, working set out
-        algo_bytes = (ALGO_BYTES_PER_STEP + (16 if placed else 12 if warm else 0)) * Bp
+        # warm: the placed loop's four + previous working set in, working set out
+        algo_bytes = (ALGO_BYTES_PER_STEP + (16 if placed else 24 if warm else 0)) * Bp
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         wl = ("static-%s" % errors if gait == "static" else "trot") + ("+placed" if placed else "+warm" if warm else "")
         rec, prov = pmc_record("balance_coop_kernel", Bp, wl)
@@ -1069,14 +1072,14 @@ def main():
                        "method_note": ("every step is ONE launch of qlamd_balance_solve_placed_batch: it solves all robots in the "
                                        "placement (which four robots share a wavefront) that the previous step's launch made from "
                                        "the iteration counts of the step before it, writes its own counts, and makes the next "
-                                       "step's placement with one extra wavefront -- hints, placement and solve all inside the timed "
+                                       "step's placement with extra wavefronts of its own -- hints, placement and solve all inside the timed "
                                        "region; results bit for bit those of the plain entry (tests/test_placement_gpu.py); "
                                        "`unplaced` = the same steps through qlamd_balance_solve_batch (robot s in slot s), the "
                                        "headline of rounds 1-4; `also[\"...-warm\"]` = the same robots with every active-set loop "
                                        "started from its final working set of the step before") if method == "placed" else
-                                      ("qlamd_balance_solve_placed_batch with prev_working_set / working_set: every robot's "
-                                       "active-set loop starts from its final working set of the step before; odd steps run on the "
-                                       "states one control period (2.5 ms) later than even steps") if method == "warm" else
+                                      ("the placed loop of qlamd_balance_solve_placed_batch with prev_working_set / working_set as "
+                                       "well: every robot's active-set loop starts from its final working set of the step before; odd "
+                                       "steps run on the states one control period (2.5 ms) later than even steps") if method == "warm" else
                                       "qlamd_balance_solve_batch: robot s in slot s of the launch",
                        "iterations": res.get("iterations"),
                        "tracking_error": list(synth.tracking_error(args.gait, args.errors)),

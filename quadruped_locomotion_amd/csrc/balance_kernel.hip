@@ -19,12 +19,15 @@ struct StatePtrs {
                         // others, runs beside this kernel on another stream)
   const int32_t *order; // [B] or NULL: slot s of the launch (row s % 4 of wavefront s / 4) takes robot order[s]
   int32_t *iterations;  // [B] or NULL: outer iterations of each robot's QP
-  // the placement of the NEXT launch, made by one extra wavefront in the shadow of this one (placement_wave below)
+  // the placement of the NEXT launch, made by extra wavefronts in the shadow of this one (placement_wave below)
   const int32_t *prev_iterations; // [B]: the counts it is made from (the previous launch's `iterations`)
   int32_t *next_order;            // [B] or NULL: where it goes
   int place_throughput;           // policy: 0 latency, 1 throughput
   const uint32_t *prev_working_set; // [B] or NULL: warm start (kWarm instantiations)
   uint32_t *working_set;            // [B] or NULL
+  int shadow_blocks, shadow_chunk;  // workgroups in front of the launch that make next_order, and the robots each of them takes
+  uint32_t *place_hist;             // [shadow_blocks][kPlaceKeys]: their counts per key, for each other (the context's scratch)
+  uint32_t *place_sync;             // two words, zero when the context is created: arrivals, generation (their barrier)
 };
 
 __device__ __forceinline__ void load_robot(const StatePtrs &s, int64_t i, RobotIn &in) {
@@ -268,13 +271,18 @@ __global__ __launch_bounds__(kPlaceThreads) void placement_kernel(const int32_t 
   }
 }
 
-// The same placement by ONE wavefront, for the extra workgroup a placed launch carries when the caller asks for the next
-// launch's placement (qlamd_placement::next_robot_order): it runs in the shadow of the solve -- a launch of a few thousand
-// robots lasts 13-24 us, this wavefront 13 us at 4096 robots and 22 at 8192 -- instead of as a launch of its own between two
-// control steps (6-9 us).  Rounds of 64 robots; counters [bin][round] in the workgroup's LDS (the solve's 13 056 bytes: up
-// to kShadowMaxRobots robots).  Pass 1 counts (LDS atomics without a return value), an exclusive scan in (bin, round)
-// order turns the counters into first ranks, pass 2 takes each robot's rank as the return value of one more atomic on its
-// counter (lanes that meet on a counter are served in lane order: rank order = index order within a count).
+// The same placement inside a placed launch, for the extra workgroups it carries when the caller asks for the next launch's
+// placement (qlamd_placement::next_robot_order): they run in the shadow of the solve -- a launch of a few thousand robots
+// lasts 9-24 us, one of these wavefronts a few us for its 1024 robots -- instead of as launches of their own between two
+// control steps (6-9 us).  One wavefront (= workgroup) per `chunk` robots, the first workgroups of the grid:
+// rounds of 64 robots; counters [key][round] in the workgroup's LDS (the solve's 13.5 KB).  Pass 1 counts (LDS atomics
+// without a return value), an exclusive scan in (key, round) order turns the counters into first ranks within the chunk,
+// pass 2 takes each robot's rank as the return value of one more atomic on its counter (lanes that meet on a counter are
+// served in lane order: rank order = index order within a key).  With several chunks a wavefront needs the others' counts
+// per key between the scan and pass 2: each leaves its own in the context's scratch and they meet at a barrier in global
+// memory (arrivals + generation, agent scope; the workgroups in front of a grid are dispatched first and all at once, so
+// they can wait for each other; the barrier resets itself, so a hipGraph can replay the launch).  Keys: the iteration
+// count's bin, and with a sorted placement also the robot's class (place_key: robots on more than two legs first).
 // A lone wavefront issues one instruction per ~5.5 cycles and waits out every memory round trip, so the loop bodies are
 // counted in instructions (32-bit index arithmetic, the division by 3 as a multiplication, one clamp per count),
 // kShadowChunk rounds have their loads in flight together, and the last, ragged rounds are the only ones that check
@@ -282,10 +290,15 @@ __global__ __launch_bounds__(kPlaceThreads) void placement_kernel(const int32_t 
 // scan is done -- in registers (13 000 instructions of unrolled code), as bytes in LDS (16 us at 4096 robots: sub-word LDS
 // stores) or as words of four rounds (14.6 us, and 16 KB of LDS per workgroup cost every placed launch 0.3 us).
 constexpr int kShadowLdsBytes = (4 * kTabPerLeg + 4 * coop::kCoopLdsDoubles + coop::kCoopNrmDoubles) * 8;
-constexpr int kShadowMaxRounds = 136;                                // (the figure include/qlamd.h documents: 8704 robots)
-constexpr int64_t kShadowMaxRobots = 64 * (int64_t)kShadowMaxRounds;
-static_assert(kShadowMaxRounds * kPlaceBins * 4 <= kShadowLdsBytes, "the shadow wavefront's counters live in the solve's LDS");
-constexpr int kShadowChunk = 32;
+// robots per shadow wavefront: 1024 below the throughput form's batches (4096 robots: 4 wavefronts, 6 us -- shorter than the
+// shortest solve, a warm-started calm batch's 9.5 us), 4096 from there (65 536 robots: 16 wavefronts, 13 us of a 70 us
+// launch; with 64 of them every one reads 64 x 48 counts and the launch is 3-5 us longer)
+#ifndef QLAMD_SHADOW_CHUNK_SMALL
+#define QLAMD_SHADOW_CHUNK_SMALL 1024
+#endif
+constexpr int kShadowChunkSmall = QLAMD_SHADOW_CHUNK_SMALL, kShadowChunkLarge = 4096, kShadowMaxBlocks = 256;
+static_assert((kShadowChunkLarge / 64) * kPlaceKeys * 4 + kPlaceKeys * 4 <= kShadowLdsBytes, "the shadow wavefront's counters live in the solve's LDS");
+constexpr int kShadowChunk = 16; // rounds whose loads are in flight together: a chunk's 1024 robots
 typedef __attribute__((address_space(3))) uint32_t lds_u32; // (a generic pointer would turn the atomics into flat ones)
 template <bool kThroughput>
 __device__ __forceinline__ uint32_t place_slot(uint32_t rk, uint32_t B, uint32_t W) {
@@ -293,72 +306,131 @@ __device__ __forceinline__ uint32_t place_slot(uint32_t rk, uint32_t B, uint32_t
   const uint32_t e = B - 1u - rk, q = __umulhi(e, 0xAAAAAAABu) >> 1; // e / 3
   return rk < W ? 4u * rk : 4u * q + 1u + (e - 3u * q);
 }
+// sidx of S: my chunk; support: the robots' support flags when the keys carry the class (sorted placement), else NULL
 __device__ __forceinline__ void placement_wave(const int32_t *__restrict__ iters, int64_t B64, int throughput,
-                                               int32_t *__restrict__ order, lds_u32 *cnt) {
+                                               int32_t *__restrict__ order, lds_u32 *cnt, uint32_t sidx, uint32_t S,
+                                               uint32_t chunk, const uint32_t *__restrict__ support, uint32_t *__restrict__ ghist,
+                                               uint32_t *__restrict__ gsync) {
   const uint32_t lane = threadIdx.x & 63u, B = (uint32_t)B64, W = (B + 3u) >> 2;
-  const uint32_t R = (B + 63u) >> 6, full = B >> 6, N = kPlaceBins * R; // rounds, rounds without a missing robot, counters
-  for (uint32_t k = lane; k < N; k += 64) cnt[k] = 0;
+  const uint32_t lo = sidx * chunk;
+  const uint32_t n = lo >= B ? 0u : (B - lo < chunk ? B - lo : chunk); // my robots
+  const uint32_t R = (n + 63u) >> 6, full = n >> 6;      // rounds, rounds without a missing robot
+  const bool classes = throughput && support != nullptr;
+  const uint32_t nkeys = classes ? kPlaceKeys : kPlaceBins, N = nkeys * R; // counters
+  lds_u32 *adj = cnt + N;                                // what turns a rank within the chunk into the rank of the batch, per key
+  for (uint32_t k = lane; k < N + nkeys; k += 64) cnt[k] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  const auto counter = [&](int v, uint32_t r) -> lds_u32 * { return cnt + (uint32_t)place_bin(v) * R + r; };
-  // ---- pass 1: count
-  for (uint32_t r0 = 0; r0 < R; r0 += kShadowChunk) {
-    if (r0 + kShadowChunk <= full) {
-      int v[kShadowChunk];
-#pragma unroll
-      for (int k = 0; k < kShadowChunk; k++) v[k] = iters[(r0 + k) * 64u + lane];
-#pragma unroll
-      for (int k = 0; k < kShadowChunk; k++)
-        (void)__hip_atomic_fetch_add(counter(v[k], r0 + k), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
-      for (uint32_t r = r0; r < R && r < r0 + kShadowChunk; r++) {
-        const uint32_t i = r * 64u + lane;
-        if (i < B) (void)__hip_atomic_fetch_add(counter(iters[i], r), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const auto run = [&](auto Classes, auto Thr) {
+    constexpr bool kClasses = decltype(Classes)::value, kThr = decltype(Thr)::value;
+    const auto key_of = [&](int v, uint32_t w) -> uint32_t {
+      uint32_t key = (uint32_t)place_bin(v);
+      if constexpr (kClasses) {
+        const int legs = ((w & 0xFFu) ? 1 : 0) + ((w & 0xFF00u) ? 1 : 0) + ((w & 0xFF0000u) ? 1 : 0) + ((w & 0xFF000000u) ? 1 : 0);
+        key += legs <= 2 ? (uint32_t)kPlaceBins : 0u;
       }
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  // ---- exclusive scan in (bin, round) order: `per` consecutive counters per lane
-  {
-    const uint32_t per = (N + 63u) >> 6, k0 = lane * per, k1 = k0 + per < N ? k0 + per : N;
-    uint32_t mine = 0;
-    for (uint32_t k = k0; k < k1; k++) mine += cnt[k];
-    uint32_t incl = mine;
+      return key;
+    };
+    // one pass over my robots: kPass 1 counts, kPass 2 ranks and stores
+    const auto pass = [&](auto Pass) {
+      constexpr int kPass = decltype(Pass)::value;
+      for (uint32_t r0 = 0; r0 < R; r0 += kShadowChunk) {
+        if (r0 + kShadowChunk <= full) {
+          int v[kShadowChunk];
+          uint32_t w[kShadowChunk], rk[kShadowChunk];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = __shfl_up(incl, d, 64);
-      incl += lane >= (uint32_t)d ? o : 0u;
-    }
-    uint32_t run = incl - mine;
-    for (uint32_t k = k0; k < k1; k++) { const uint32_t c = cnt[k]; cnt[k] = run; run += c; }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  // ---- pass 2: a robot's rank is what one more atomic on its counter returns
-  const auto pass2 = [&](auto Thr) {
-    constexpr bool kThr = decltype(Thr)::value;
-    for (uint32_t r0 = 0; r0 < R; r0 += kShadowChunk) {
-      if (r0 + kShadowChunk <= full) {
-        int v[kShadowChunk];
-        uint32_t rk[kShadowChunk];
+          for (int k = 0; k < kShadowChunk; k++) {
+            v[k] = iters[lo + (r0 + k) * 64u + lane];
+            w[k] = kClasses ? support[lo + (r0 + k) * 64u + lane] : 0u;
+          }
 #pragma unroll
-        for (int k = 0; k < kShadowChunk; k++) v[k] = iters[(r0 + k) * 64u + lane];
+          for (int k = 0; k < kShadowChunk; k++) {
+            const uint32_t key = key_of(v[k], w[k]);
+            w[k] = key;
+            lds_u32 *c = cnt + key * R + (r0 + k);
+            if constexpr (kPass == 1) (void)__hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else rk[k] = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          if constexpr (kPass == 2) {
 #pragma unroll
-        for (int k = 0; k < kShadowChunk; k++)
-          rk[k] = __hip_atomic_fetch_add(counter(v[k], r0 + k), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-        for (int k = 0; k < kShadowChunk; k++) order[place_slot<kThr>(rk[k], B, W)] = (int32_t)((r0 + k) * 64u + lane);
-      } else {
-        for (uint32_t r = r0; r < R && r < r0 + kShadowChunk; r++) {
-          const uint32_t i = r * 64u + lane;
-          if (i < B) {
-            const uint32_t rk = __hip_atomic_fetch_add(counter(iters[i], r), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            order[place_slot<kThr>(rk, B, W)] = (int32_t)i;
+            for (int k = 0; k < kShadowChunk; k++)
+              order[place_slot<kThr>(rk[k] + adj[w[k]], B, W)] = (int32_t)(lo + (r0 + k) * 64u + lane);
+          }
+        } else {
+          for (uint32_t r = r0; r < R && r < r0 + kShadowChunk; r++) {
+            const uint32_t i = r * 64u + lane;
+            if (i < n) {
+              const uint32_t key = key_of(iters[lo + i], kClasses ? support[lo + i] : 0u);
+              lds_u32 *c = cnt + key * R + r;
+              if constexpr (kPass == 1) (void)__hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              else {
+                const uint32_t rk = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                order[place_slot<kThr>(rk + adj[key], B, W)] = (int32_t)(lo + i);
+              }
+            }
           }
         }
       }
+    };
+    pass(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- exclusive scan in (key, round) order: `per` consecutive counters per lane
+    {
+      const uint32_t per = (N + 63u) >> 6, k0 = lane * per, k1 = k0 + per < N ? k0 + per : N;
+      uint32_t mine = 0;
+      for (uint32_t k = k0; k < k1; k++) mine += cnt[k];
+      uint32_t incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        incl += lane >= (uint32_t)d ? o : 0u;
+      }
+      uint32_t running = incl - mine;
+      for (uint32_t k = k0; k < k1; k++) { const uint32_t c = cnt[k]; cnt[k] = running; running += c; }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (S > 1) {
+      // ---- the other chunks: lane k < nkeys owns key k.  My count of it goes to the scratch, the barrier, then
+      //      rank of the batch = robots of harder keys anywhere + robots of my key in the chunks before mine + rank in my chunk
+      const uint32_t start = (lane < nkeys && R > 0) ? cnt[lane * R] : 0u;
+      const uint32_t next = (lane + 1u < nkeys && R > 0) ? cnt[(lane + 1u) * R] : n;
+      if (lane < nkeys) __hip_atomic_store(ghist + sidx * kPlaceKeys + lane, R > 0 ? next - start : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (lane == 0) {
+        const uint32_t gen = __hip_atomic_load(gsync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t arrived = __hip_atomic_fetch_add(gsync, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == S - 1u) {
+          __hip_atomic_store(gsync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          (void)__hip_atomic_fetch_add(gsync + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          // (bounded, a second or two: a wait that cannot end -- a launch cut short -- must not hang the device; the
+          // placement it then writes is wrong, which costs the next launch time, never a result)
+          for (unsigned spin = 0; spin < (1u << 24) && __hip_atomic_load(gsync + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen; spin++)
+            __builtin_amdgcn_s_sleep(4);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      uint32_t total = 0, before = 0;
+      if (lane < nkeys) {
+        for (uint32_t b = 0; b < S; b++) {
+          const uint32_t h = __hip_atomic_load(ghist + b * kPlaceKeys + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          total += h;
+          before += b < sidx ? h : 0u;
+        }
+      }
+      uint32_t incl = total;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        incl += lane >= (uint32_t)d ? o : 0u;
+      }
+      if (lane < nkeys) adj[lane] = (incl - total) + before - start;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    pass(std::integral_constant<int, 2>{});
   };
-  if (throughput) pass2(std::true_type{});
-  else pass2(std::false_type{});
+  if (classes) run(std::true_type{}, std::true_type{});
+  else if (throughput) run(std::false_type{}, std::true_type{});
+  else run(std::false_type{}, std::false_type{});
 }
 
 // Latency form: 16 lanes per robot, 4 robots per wavefront (balance_coop.hpp), kCoopWaves wavefronts per workgroup.
@@ -383,18 +455,25 @@ template <bool kPerLeg, int kMinWaves, bool kPlaced = false, bool kWarm = false>
 __global__ __launch_bounds__(64 * kCoopWaves, kMinWaves) void balance_coop_kernel(const DeviceParams *__restrict__ Pp, const StatePtrs s,
                                                                       int64_t B, double *__restrict__ tau,
                                                                       double *__restrict__ grf, int32_t *__restrict__ status) {
-  constexpr bool kShadow = kPlaced && kMinWaves == 2; // (batches of the three-wavefront form are beyond kShadowMaxRobots)
   __shared__ double lds[4 * kTabPerLeg + 4 * kCoopWaves * coop::kCoopLdsDoubles + kCoopWaves * coop::kCoopNrmDoubles];
-  static_assert(sizeof(lds) >= kShadowLdsBytes || kCoopWaves != 1, "the shadow wavefront's counters live in the solve's LDS");
+  static_assert(sizeof(lds) >= kShadowLdsBytes || kCoopWaves != 1, "the shadow wavefronts' counters live in the solve's LDS");
   double *tab = lds, *rows = lds + 4 * kTabPerLeg, *nrm = rows + 4 * kCoopWaves * coop::kCoopLdsDoubles;
   const DeviceParams &P = *Pp;
   const int row = threadIdx.x >> 4, wave = threadIdx.x >> 6;
   unsigned block = blockIdx.x;
-  if constexpr (kShadow) {
-    // the first workgroup of a launch that also places the next one (it starts first and has the whole launch to finish in)
-    if (s.next_order) {
-      if (block == 0) { placement_wave(s.prev_iterations, B, s.place_throughput, s.next_order, (lds_u32 *)lds); return; }
-      block -= 1;
+  if constexpr (kPlaced) {
+    // the first workgroups of a launch that also places the next one (they start first and have the whole launch to finish in)
+    if (s.shadow_blocks) {
+      if (block < (unsigned)s.shadow_blocks) {
+        placement_wave(s.prev_iterations, B, s.place_throughput, s.next_order, (lds_u32 *)lds, block, (uint32_t)s.shadow_blocks,
+                       (uint32_t)s.shadow_chunk, s.place_throughput ? reinterpret_cast<const uint32_t *>(s.stance) : nullptr, s.place_hist, s.place_sync);
+        return;
+      }
+      block -= (unsigned)s.shadow_blocks;
+      // the wavefronts that solve go first wherever one of them shares a SIMD with a shadow wavefront (which has the whole
+      // launch to finish in): without it the placed loop of 4096 robots is 0.4 us longer with four shadow wavefronts than
+      // with one (profiles/r5/ab_shadow_blocks.txt)
+      __builtin_amdgcn_s_setprio(3);
     }
   }
   int64_t i = (int64_t)block * (4 * kCoopWaves) + row;
@@ -555,6 +634,7 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
   ctx->tick_ws_bytes = 0;
   ctx->place_ws = nullptr;
   ctx->place_ws_bytes = 0;
+  ctx->place_sync = nullptr;
   ctx->has_next_placement = false;
   ctx->on_failure = QLAMD_ON_FAILURE_ZERO;
   ctx->dynamics_form = QLAMD_DYNAMICS_AUTO;
@@ -582,8 +662,11 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
   const size_t place_bytes = (size_t)256 * kPlaceKeys * sizeof(uint32_t);
   if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&ctx->d_params, sizeof(DeviceParams)) != hipSuccess ||
       hipMemcpy(ctx->d_params, &ctx->params, sizeof(DeviceParams), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMalloc(&ctx->place_ws, place_bytes) != hipSuccess) {
+      hipMalloc(&ctx->place_ws, place_bytes) != hipSuccess || hipMalloc(&ctx->place_sync, 256) != hipSuccess ||
+      hipMemset(ctx->place_sync, 0, 256) != hipSuccess) {
     if (ctx->d_params) (void)hipFree(ctx->d_params);
+    if (ctx->place_ws) (void)hipFree(ctx->place_ws);
+    if (ctx->place_sync) (void)hipFree(ctx->place_sync);
     delete ctx;
     return QLAMD_ERR_HIP;
   }
@@ -600,6 +683,7 @@ void qlamd_context_destroy(qlamd_context *ctx) {
   if (ctx->wire_tpl) (void)hipFree(ctx->wire_tpl);
   if (ctx->tick_ws) (void)hipFree(ctx->tick_ws);
   if (ctx->place_ws) (void)hipFree(ctx->place_ws);
+  if (ctx->place_sync) (void)hipFree(ctx->place_sync);
   if (ctx->d_params) (void)hipFree(ctx->d_params);
   if (ctx->done_event) (void)hipEventDestroy(ctx->done_event);
   delete ctx;
@@ -806,19 +890,24 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
                   in->surface_normal, wrench, live, support_only, order, iterations, nullptr, nullptr, 0};
     s.prev_working_set = prev_ws;
     s.working_set = ws;
-    // the next launch's placement: by one more wavefront of this launch when its counters fit the workgroup's LDS
-    static_assert(kShadowMaxRobots < QLAMD_THROUGHPUT_BATCH, "the shadow wavefront exists in the two-wavefront form only");
-    if (next_order && batch <= kShadowMaxRobots) {
+    // the next launch's placement: by extra wavefronts in front of this launch
+    const int chunk = batch >= QLAMD_THROUGHPUT_BATCH ? kShadowChunkLarge : kShadowChunkSmall;
+    const int64_t shadows = (batch + chunk - 1) / chunk;
+    if (next_order && shadows <= kShadowMaxBlocks && pick_rpw(ctx, batch) == 4) {
       s.prev_iterations = prev_iterations;
       s.next_order = next_order;
       s.place_throughput = throughput_policy(pl->policy, batch) ? 1 : 0;
+      s.shadow_blocks = (int)shadows;
+      s.shadow_chunk = chunk;
+      s.place_hist = (uint32_t *)ctx->place_ws;
+      s.place_sync = (uint32_t *)ctx->place_sync;
     }
   }
 
   hipError_t e;
   switch (pick_rpw(ctx, batch)) {
     case 4: {
-      const unsigned grid = (unsigned)((batch + 4 * kCoopWaves - 1) / (4 * kCoopWaves)) + (s.next_order ? 1u : 0u);
+      const unsigned grid = (unsigned)((batch + 4 * kCoopWaves - 1) / (4 * kCoopWaves)) + (unsigned)s.shadow_blocks;
 #define QL_LAUNCH_COOP(PERLEG, WAVES)                                                                                        \
   do {                                                                                                                       \
     if (warm)                                                                                                                \
@@ -842,7 +931,7 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
     default: e = launch_balance<64>(ctx, s, batch, d_tau, d_grf, d_status, st); break;
   }
   if (e != hipSuccess) return QLAMD_ERR_HIP;
-  if (next_order && memory == QLAMD_MEM_DEVICE && !s.next_order) { // too many robots for the shadow wavefront: launches of their own
+  if (next_order && memory == QLAMD_MEM_DEVICE && !s.shadow_blocks) { // more robots than the shadow wavefronts take: launches of their own
     const int rc = launch_placement(ctx, prev_iterations, batch, throughput_policy(pl->policy, batch) ? 1 : 0, next_order, st, s.stance);
     if (rc != QLAMD_OK) return rc;
   }

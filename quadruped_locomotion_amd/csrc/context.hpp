@@ -27,6 +27,7 @@ struct qlamd_context {
   size_t tick_ws_bytes;
   void *place_ws;      // per-workgroup bin counts of qlamd_placement_from_iterations beyond 4096 robots
   size_t place_ws_bytes;
+  void *place_sync;    // two words, zero from the start: the barrier of a placed launch's shadow wavefronts (balance_kernel.hip)
   qlamd_placement next_placement; // qlamd_place_next_call: taken (and cleared) by the next QP entry that knows placements
   bool has_next_placement;
   uint32_t *wire_tpl;  // two layout templates of robot_state_unpack_kernel (read one, write the other), or NULL

@@ -189,10 +189,11 @@ def test_force_distribution_placed_equals_the_plain_entry(gpu):
     assert (it.cpu().numpy() >= 0).all()
 
 
-@pytest.mark.parametrize("B", [4096, 4099, 8192, 8704, 8705, 16385, 70])
+@pytest.mark.parametrize("B", [4096, 4099, 8192, 8704, 8705, 16383, 16385, 70, 65536, 262145, 1048577])
 def test_next_placement_made_inside_the_solve_equals_the_placement_entry(gpu, B):
-    """prev_iterations -> next_robot_order: by one extra wavefront of the solve's own launch up to 8704 robots, by launches of
-    their own beyond -- the same placement as qlamd_placement_from_iterations either way, and the solve's results untouched."""
+    """prev_iterations -> next_robot_order: by extra wavefronts of the solve's own launch (one per 1024 robots, per 4096 from 16 384 robots up, up to
+    1 M robots: several of them meet at a barrier in global memory), by launches of their own beyond -- the documented placement
+    either way, the same from launch to launch (the barrier resets itself), and the solve's results untouched."""
     capi, ctx, torch = gpu
     s = synth.make_states(B, "trot")
     d = capi.to_device(s)
@@ -201,11 +202,11 @@ def test_next_placement_made_inside_the_solve_equals_the_placement_entry(gpu, B)
     prev = rng.integers(0, 30, size=B).astype(np.int32)
     d_prev = torch.from_numpy(prev).to("cuda:0")
     for policy in (capi.PLACEMENT_LATENCY, capi.PLACEMENT_THROUGHPUT, capi.PLACEMENT_AUTO):
-        want = ctx.placement_from_iterations(prev, policy=policy)
-        if B > 8704:  # launches of their own: a sorted placement also sorts by class (robots on at most two legs last)
-            thr = policy == capi.PLACEMENT_THROUGHPUT or (policy == capi.PLACEMENT_AUTO and B >= 16384)
-            assert np.array_equal(want, reference_placement(prev, thr))
-            want = reference_placement(prev, thr, support=s["stance"])
+        # the entry on its own knows the counts only; the placed solve also knows who stands on how many legs, and a sorted
+        # placement made there sorts by class first (robots on at most two legs last)
+        thr = policy == capi.PLACEMENT_THROUGHPUT or (policy == capi.PLACEMENT_AUTO and B >= 16384)
+        assert np.array_equal(ctx.placement_from_iterations(prev, policy=policy), reference_placement(prev, thr))
+        want = reference_placement(prev, thr, support=s["stance"])
         tau = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
         grf = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
         status = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
