@@ -240,10 +240,11 @@ int qlamd_force_distribution_batch(qlamd_context *ctx, const double *joint_posit
  *                     selected; 0 for a robot without a stance leg or with status QLAMD_STATUS_NOT_PD).
  *   prev_iterations   [B] in and
  *   next_robot_order  [B] out, both or neither: the placement (by `policy`) that follows from the counts in prev_iterations
- *                     -- the `iterations` of the caller's previous call -- for the caller's next call.  Up to 8704 robots
- *                     it is made by one extra wavefront inside the solve's own launch, in its shadow: no launch, no time
- *                     between two control steps; beyond that by qlamd_placement_from_iterations' launches behind the solve.
- *                     Must not alias robot_order / iterations (two buffers of each, used in turn).
+ *                     -- the `iterations` of the caller's previous call -- for the caller's next call.  Up to 1 M robots
+ *                     it is made by extra wavefronts inside the solve's own launch, in its shadow (one per 1024 robots,
+ *                     per 4096 from 16 384 robots up; several of them meet at a barrier in global memory): no launch, no
+ *                     time between two control steps; beyond that by qlamd_placement_from_iterations' launches behind the
+ *                     solve.  Must not alias robot_order / iterations (two buffers of each, used in turn).
  * The hint is free for a caller that runs at 400 Hz (balance_controller_manager.cpp:48): the iteration counts of the last
  * control steps predict this one's (same count for 94 % of the robots of the bench batches one period later, rank
  * correlation 0.99: tools/experiments/placement_model.py).  The loop of such a caller, with two buffers of each kind:
@@ -256,8 +257,9 @@ int qlamd_force_distribution_batch(qlamd_context *ctx, const double *joint_posit
  *                               where the launch lasts as long as its slowest wavefront
  *   QLAMD_PLACEMENT_THROUGHPUT  robots sorted by iteration count, hardest first, four neighbours per wavefront: the union
  *                               of four similar sequences is the shortest there is; for batches that fill every SIMD
- *                               several times over.  When the placement is made by launches behind the solve (beyond 8704
- *                               robots) the robots on more than two support legs come first and the others after them,
+ *                               several times over.  When the placement is made by a placed balance / force-distribution
+ *                               call (next_robot_order: the call knows the support flags; qlamd_placement_from_iterations
+ *                               does not) the robots on more than two support legs come first and the others after them,
  *                               each group sorted by count: a wavefront whose four robots all stand on at most two legs
  *                               solves 6-variable QPs (the support legs sit in front of the row: every product of a pass
  *                               and the inversion of G half as long; 9-11 % on batches of such robots), and a sorted
