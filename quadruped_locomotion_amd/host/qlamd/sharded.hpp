@@ -77,6 +77,8 @@ class ShardedBalanceSolver {
     int gather_every = 1;  // control steps per all-gather (G): the efforts of G steps travel with one collective
     bool placed = true;    // qlamd_balance_solve_placed_batch with the caller's loop of qlamd.h (placement of the next
                            // step made in the shadow of this one) instead of the plain entry
+    bool warm = false;     // with `placed`: every robot's active-set loop starts from the working set it ended with on the
+                           // step before (qlamd_placement::prev_working_set / working_set, one array updated in place)
   };
   ShardedBalanceSolver() = default;
   ShardedBalanceSolver(const ShardedBalanceSolver &) = delete;
@@ -108,6 +110,9 @@ class ShardedBalanceSolver {
                                             nullptr) != QLAMD_OK)
           return fail("qlamd_placement_from_iterations");
       }
+      if (opt.placed && opt.warm && b == 0 &&
+          (hipMalloc((void **)&working_set_, B * 4) != hipSuccess || hipMemset(working_set_, 0, B * 4) != hipSuccess))
+        return fail("hipMalloc");
       if (hipEventCreateWithFlags(&solved_[b], hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&gathered_[b], hipEventDisableTiming) != hipSuccess)
         return fail("hipEventCreate");
@@ -135,7 +140,7 @@ class ShardedBalanceSolver {
     int rc;
     if (opt_.placed) {
       const int k = (int)(step_ & 1);
-      const qlamd_placement pl{order_[k], iters_[k], iters_[k ^ 1], order_[k ^ 1], QLAMD_PLACEMENT_AUTO};
+      const qlamd_placement pl{order_[k], iters_[k], iters_[k ^ 1], order_[k ^ 1], QLAMD_PLACEMENT_AUTO, working_set_, working_set_};
       rc = qlamd_balance_solve_placed_batch(ctx_, &in, shard_.count, &pl, out, nullptr, status_, QLAMD_MEM_DEVICE, s_solve_);
     } else {
       rc = qlamd_balance_solve_batch(ctx_, &in, shard_.count, out, nullptr, status_, QLAMD_MEM_DEVICE, s_solve_);
@@ -185,6 +190,7 @@ class ShardedBalanceSolver {
       tau_[b] = all_[b] = nullptr; order_[b] = iters_[b] = nullptr; solved_[b] = gathered_[b] = nullptr;
     }
     if (status_) { (void)hipFree(status_); status_ = nullptr; }
+    if (working_set_) { (void)hipFree(working_set_); working_set_ = nullptr; }
     if (s_solve_) { (void)hipStreamDestroy(s_solve_); s_solve_ = nullptr; }
     if (s_gather_) { (void)hipStreamDestroy(s_gather_); s_gather_ = nullptr; }
     if (ctx_) { qlamd_context_destroy(ctx_); ctx_ = nullptr; }
@@ -211,6 +217,7 @@ class ShardedBalanceSolver {
   bool have_comm_ = false;
   double *tau_[2] = {nullptr, nullptr}, *all_[2] = {nullptr, nullptr};
   int32_t *order_[2] = {nullptr, nullptr}, *iters_[2] = {nullptr, nullptr}, *status_ = nullptr;
+  uint32_t *working_set_ = nullptr;
   hipStream_t s_solve_ = nullptr, s_gather_ = nullptr;
   hipEvent_t solved_[2] = {nullptr, nullptr}, gathered_[2] = {nullptr, nullptr};
   bool pending_[2] = {false, false};

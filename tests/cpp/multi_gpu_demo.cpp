@@ -3,7 +3,7 @@
 // efforts of all shards collected on every rank with ONE RCCL all-gather per control step or per G steps), without torch:
 // qlamd.h, the HIP runtime and rccl.h only.
 //
-//   multi_gpu_demo --states FILE --robots N [--rank R --ranks W --id-file F] [--steps K] [--out FILE] [--gather-every G] [--plain]
+//   multi_gpu_demo --states FILE --robots N [--rank R --ranks W --id-file F] [--steps K] [--out FILE] [--gather-every G] [--plain | --warm]
 //   multi_gpu_demo --selftest-sharding                       (no GPU: prints the shard of every rank for a few batch sizes)
 //   multi_gpu_demo --selftest-rendezvous --rank R --ranks W --id-file F
 //                                                            (no GPU, no RCCL call: the ranks exchange a 128-byte id through
@@ -12,7 +12,8 @@
 // --states: the global batch as written by tests/test_multi_gpu_cpp.py -- ten float64 arrays [N][k] one after the other
 //   in the order of qlamd_state_batch (k = 12 3 4 3 3 3 4 3 3) followed by support_leg [N][4] uint8.
 // Rank r solves robots shard_of(r, W, N) on device LOCAL_RANK (default r) and owns row block r of the gathered array.
-// --plain: qlamd_balance_solve_batch instead of the placed loop (qlamd_balance_solve_placed_batch, include/qlamd.h).
+// --plain: qlamd_balance_solve_batch instead of the placed loop (qlamd_balance_solve_placed_batch, include/qlamd.h);
+// --warm: the placed loop with every robot's working set carried from step to step (warm start).
 // Exit codes: 0 ok, 2 usage, 3 no device, 4 a library call failed.
 #include <cstdlib>
 #include <string>
@@ -86,6 +87,7 @@ int main(int argc, char **argv) {
     else if (a == "--steps") steps = std::atoi(next());
     else if (a == "--gather-every") opt.gather_every = std::atoi(next());
     else if (a == "--plain") opt.placed = false;
+    else if (a == "--warm") opt.warm = true;
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
   }
   if (rendezvous_only) {
@@ -191,7 +193,7 @@ int main(int argc, char **argv) {
   for (int32_t v : hs) failed += v != QLAMD_STATUS_OK;
   std::printf("rank %d of %d device %d robots %lld+%lld steps %d gather_every %d %s : %.1f us/step with the all-gather, %.1f without, "
               "%lld robots with status != ok\n",
-              rank, ranks, device, (long long)sh.first, (long long)B, steps, G, opt.placed ? "placed" : "plain",
+              rank, ranks, device, (long long)sh.first, (long long)B, steps, G, opt.placed ? (opt.warm ? "placed+warm" : "placed") : "plain",
               1e3 * ms[1] / steps, 1e3 * ms[0] / steps, (long long)failed);
   solver.destroy();
   return 0;

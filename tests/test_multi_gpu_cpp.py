@@ -129,3 +129,9 @@ def test_one_rank_pipeline_equals_the_python_path(gpu, tmp_path, gather_every):
     torch.cuda.synchronize()
     assert (status.cpu().numpy() == 0).all()
     assert np.array_equal(got, tau.cpu().numpy())  # bit for bit: same library, same kernel, gathered through RCCL
+    # the placed loop with the working sets carried from step to step: the same minimisers to the solver's accuracy
+    p = run("--states", states, "--robots", str(B), "--ranks", "1", "--rank", "0", "--steps", "10",
+            "--gather-every", str(gather_every), "--out", out, "--warm")
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "0 robots with status != ok" in p.stdout and "placed+warm" in p.stdout
+    assert np.abs(np.fromfile(out, dtype=np.float64).reshape(B, 12) - got).max() < 1e-7
