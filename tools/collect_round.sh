@@ -43,6 +43,10 @@ b full_tick_b16384 --workload full_tick --batch 16384 --steps 50
 ( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/aux_raw -o aux -- python3 $GRAFT_REPO_ROOT/tools/aux_kernels.py > /dev/null 2>&1 )
 python3 tools/rocpd_kernels.py $(find $OUT/aux_raw -name "*_results.db" | head -1) $OUT/kernel_stats_aux_entries_b4096.csv > /dev/null 2>&1
 rm -rf $OUT/aux_raw
+# the same solvers on device-resident inputs (the dense QP, the weighted LSQ entry, the whole-body step: plain, placed, warm)
+( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/auxd_raw -o auxd -- python3 $GRAFT_REPO_ROOT/tools/experiments/placed_aux_probe.py > /dev/null 2>&1 )
+python3 tools/rocpd_kernels.py $(find $OUT/auxd_raw -name "*_results.db" | head -1) $OUT/kernel_stats_aux_device_resident_b4096.csv > /dev/null 2>&1
+rm -rf $OUT/auxd_raw
 python3 tools/tail_probe.py 2>&1 | grep -v amdgpu > $OUT/single_wavefront_latency.txt
 python3 tools/latency_b1.py 2>&1 | grep -v amdgpu > $OUT/host_buffer_latency.txt
 python3 tools/write_bw.py 2>&1 | grep -v amdgpu > $OUT/write_bandwidth.txt
@@ -63,6 +67,7 @@ python3 tools/experiments/variant_bench.py 2>&1 | grep -v amdgpu > $OUT/variant_
 python3 tools/experiments/placed_probe.py --grid 2>&1 | grep -v amdgpu > $OUT/placed_probe.txt
 python3 tools/experiments/placed_aux_probe.py 2>&1 | grep -v amdgpu > $OUT/placed_aux_probe.txt
 python3 tools/experiments/warm_probe.py 2>&1 | grep -v amdgpu > $OUT/warm_probe.txt
+python3 tools/experiments/two_leg_probe.py quadruped_locomotion_amd/libqlamd.so 2>&1 | grep -v amdgpu > $OUT/two_leg_probe_final.txt
 ( ./tools/ubench/launch_head; ./tools/ubench/launch_head_preload ) > $OUT/launch_head.txt 2>&1
 [ -f scratch_bin/libqlamd_stamps.so ] && ( python3 tools/stamp_probe_tick_blocks.py; python3 tools/stamp_probe_tick_blocks.py --ragged ) 2>&1 | grep -v amdgpu > $OUT/tick_block_stamps.txt
 python3 - > $OUT/multi_gpu_cpp_one_rank.txt 2>&1 <<'PY'
@@ -76,7 +81,7 @@ for B in (8192, 65536):
     st = os.path.join(d, "s%d.bin" % B)
     T.write_states(st, synth.make_states(B, "trot"))
     for every in (1, 8):
-        for extra in ((), ("--plain",)):
+        for extra in ((), ("--plain",), ("--warm",)):
             p = T.run("--states", st, "--robots", str(B), "--ranks", "1", "--rank", "0", "--steps", "200", "--gather-every", str(every), *extra)
             print(p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr.strip())
 PY
