@@ -741,7 +741,10 @@ def main():
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=side):
+                # (thread_local: the process group's watchdog thread polls its events with hipEventQuery while this thread
+                # captures; under the default "global" mode that query invalidates the capture -- seen once in five rounds,
+                # profiles/r5/bench_trot_b8192_force_collective.err of the first r5 collection)
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local" if collective else "global"):
                     cap = torch.cuda.current_stream().cuda_stream
                     # The gathers go to a second captured stream: gather k (reads tau[k & 1]) overlaps solve k+1 (writes
                     # the other buffer); solve k+2 waits for gather k before it reuses the buffer.  (With a single rank

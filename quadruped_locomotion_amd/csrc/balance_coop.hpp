@@ -118,33 +118,33 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     const int idx = (int)threadIdx.x + kBlock * j;
     tabv[j] = P.legtab[idx < 4 * kTabPerLeg ? idx : 4 * kTabPerLeg - 1];
   }
-  const int64_t i = irobot;
+  const int64_t i_in = irobot; // (below the QP the index comes back from LDS as `i`: one value less across the loop)
   double quat[4], dquat[4], pos[3], linvel[3], angvel[3], dpos[3], dlinvel[3], dangvel[3];
   {
-    const double2 *a2 = reinterpret_cast<const double2 *>(s.quat + 4 * i);
-    const double2 *b2 = reinterpret_cast<const double2 *>(s.dquat + 4 * i);
+    const double2 *a2 = reinterpret_cast<const double2 *>(s.quat + 4 * i_in);
+    const double2 *b2 = reinterpret_cast<const double2 *>(s.dquat + 4 * i_in);
     double2 v = a2[0]; quat[0] = v.x; quat[1] = v.y;
     v = a2[1]; quat[2] = v.x; quat[3] = v.y;
     v = b2[0]; dquat[0] = v.x; dquat[1] = v.y;
     v = b2[1]; dquat[2] = v.x; dquat[3] = v.y;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      pos[k] = s.pos[3 * i + k]; linvel[k] = s.linvel[3 * i + k]; angvel[k] = s.angvel[3 * i + k];
-      dpos[k] = s.dpos[3 * i + k]; dlinvel[k] = s.dlinvel[3 * i + k]; dangvel[k] = s.dangvel[3 * i + k];
+      pos[k] = s.pos[3 * i_in + k]; linvel[k] = s.linvel[3 * i_in + k]; angvel[k] = s.angvel[3 * i_in + k];
+      dpos[k] = s.dpos[3 * i_in + k]; dlinvel[k] = s.dlinvel[3 * i_in + k]; dangvel[k] = s.dangvel[3 * i_in + k];
     }
   }
-  const uint32_t sm = *reinterpret_cast<const uint32_t *>(s.stance + 4 * i);
-  double qj = s.q[12 * i + (comp ? myidx : 0)];
-  const uint8_t alive = s.live ? s.live[i] : (uint8_t)1;
+  const uint32_t sm = *reinterpret_cast<const uint32_t *>(s.stance + 4 * i_in);
+  double qj = s.q[12 * i_in + (comp ? myidx : 0)];
+  const uint8_t alive = s.live ? s.live[i_in] : (uint8_t)1;
   unsigned warm_set = 0u;
-  if constexpr (kWarm) warm_set = s.prev_working_set ? s.prev_working_set[i] : 0u;
+  if constexpr (kWarm) warm_set = s.prev_working_set ? s.prev_working_set[i_in] : 0u;
   double wr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; // externally supplied (F_B, T_B), if any: issued with the rest
   if (s.wrench) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) wr[k] = s.wrench[6 * i + k];
+    for (int k = 0; k < 6; k++) wr[k] = s.wrench[6 * i_in + k];
   }
   double nWl[3] = {0.0, 0.0, 1.0}; // caller-supplied surface normal of my leg (world frame), if any
-  if (kPerLeg) { nWl[0] = s.normals[12 * i + 3 * leg]; nWl[1] = s.normals[12 * i + 3 * leg + 1]; nWl[2] = s.normals[12 * i + 3 * leg + 2]; }
+  if (kPerLeg) { nWl[0] = s.normals[12 * i_in + 3 * leg]; nWl[1] = s.normals[12 * i_in + 3 * leg + 1]; nWl[2] = s.normals[12 * i_in + 3 * leg + 2]; }
   // (all loads above are in flight before the first of them is consumed)
   robot_live = robot_live && alive != 0;
   const unsigned stance = robot_live ? (((sm & 0xFFu) ? 1u : 0u) | ((sm & 0xFF00u) ? 2u : 0u) |
@@ -154,8 +154,9 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   // support legs first: the leg behind my slot, and what was loaded by leg goes to the lane of its slot
   const unsigned perm = slot_legs(stance);
   const int aleg = (int)((perm >> (2 * leg)) & 3u);
-  // (where my results go and the slot order are not needed before the very end: parked like the Jacobian row)
-  reinterpret_cast<int2 *>(lds_nrm + 64 * 11)[(int)threadIdx.x & 63] = make_int2(3 * aleg + c, (int)perm);
+  // (which robot I am, where my results go and the slot order are not needed before the very end: parked like the Jacobian
+  // row; a batch has fewer than 2^31 robots -- 300 bytes of state each)
+  reinterpret_cast<int2 *>(lds_nrm + 64 * 11)[(int)threadIdx.x & 63] = make_int2((int)i_in, (3 * aleg + c) | ((int)perm << 8));
   const bool on = leg < nS; // my slot's leg supports
   const unsigned stance_slots = (1u << nS) - 1u;
   const bool permuted = __builtin_amdgcn_ballot_w64(perm != 0xE4u) != 0ull; // (scalar: some row of the wavefront is)
@@ -332,6 +333,9 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     lds_nrm[64 * (5 + k) + ((int)threadIdx.x & 63)] = Jrow[k];
     lds_nrm[64 * (8 + k) + ((int)threadIdx.x & 63)] = Gq[k];
   }
+  // (the stores stay HERE: left to itself the compiler sinks them, and the kinematics behind them, below the QP -- their
+  // inputs then live across the active-set loop, which the 168-register form pays for with spills)
+  asm volatile("" ::: "memory");
 
   QL_STAMP(3);
   // ---------------------------------------------------------------- friction pyramid of my leg
@@ -355,35 +359,42 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   const double mu = P.mu, f_min = P.f_min;
 
   QL_STAMP(4);
-  // ---------------------------------------------------------------- G row, g0
-  double Gm[12], g0;
-  force_qp_objective(P.S, P.w_reg, foot, stance_slots, comp && on, b, nullptr, 0.0, Gm, g0);
-
   QL_STAMP(5);
-  // ---------------------------------------------------------------- the force QP (force_qp_coop.hpp)
-  ForceQp Q;
-#pragma unroll
-  for (int j = 0; j < 12; j++) Q.Gm[j] = Gm[j];
-  Q.g0 = g0;
-#pragma unroll
-  for (int k = 0; k < 3; k++) { Q.nb[k] = nb[k]; Q.t1[k] = t1[k]; Q.t2[k] = t2[k]; }
-  Q.myn = myn; Q.myt1 = myt1; Q.myt2 = myt2;
-  Q.mu = mu; Q.f_min = f_min;
-  Q.on = on; Q.comp = comp; Q.nS = nS; Q.refine_passes = P.refine_passes;
-  Q.warm = 0ull; Q.stance = stance_slots;
-  if constexpr (kWarm) Q.warm = permuted ? working_set_to_slots<5, unsigned>(warm_set, perm) : warm_set;
+  // ---------------------------------------------------------------- G row, g0 and the force QP (force_qp_coop.hpp)
   double x;
   int qp_iters;
   unsigned long long final_set = 0ull;
   // (wave-uniform: rows without a robot have no support leg)
   const bool two_legs = __builtin_amdgcn_ballot_w64(nS > 2) == 0ull;
-  int status;
-  if (two_legs) status = force_qp_coop<false, kWarm, 2>(Q, lds_row, lds_nrm, x, qp_iters, &final_set);
-  else status = force_qp_coop<false, kWarm, 4>(Q, lds_row, lds_nrm, x, qp_iters, &final_set);
+  // Two regions one after the other, the small form first, behind flags the compiler cannot see through: as an if / else
+  // the two come out in the order "12 variables, then 6" with the inputs of the second live across the first -- whose loop
+  // is the one that needs every register of the 168-register form (88 bytes of scratch per lane, and 17 % on a million
+  // robots).  This way the inputs of the large form are live across the small one, which has 48 registers to spare -- and
+  // they are few: each region assembles its own row of G and g0 from the foot position and the wrench.
+  int status = kStatusOk;
+  const auto solve = [&](auto Legs) {
+    ForceQp Q;
+    force_qp_objective(P.S, P.w_reg, foot, stance_slots, comp && on, b, nullptr, 0.0, Q.Gm, Q.g0);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { Q.nb[k] = nb[k]; Q.t1[k] = t1[k]; Q.t2[k] = t2[k]; }
+    Q.myn = myn; Q.myt1 = myt1; Q.myt2 = myt2;
+    Q.mu = mu; Q.f_min = f_min;
+    Q.on = on; Q.comp = comp; Q.nS = nS; Q.refine_passes = P.refine_passes;
+    Q.warm = 0ull; Q.stance = stance_slots;
+    if constexpr (kWarm) Q.warm = permuted ? working_set_to_slots<5, unsigned>(warm_set, perm) : warm_set;
+    status = force_qp_coop<false, kWarm, decltype(Legs)::value>(Q, lds_row, lds_nrm, x, qp_iters, &final_set);
+  };
+  int small_form = __builtin_amdgcn_readfirstlane(two_legs ? 1 : 0);
+  asm volatile("" : "+s"(small_form));
+  if (small_form != 0) solve(std::integral_constant<int, 2>{});
+  int large_form = __builtin_amdgcn_readfirstlane(1 - small_form);
+  asm volatile("" : "+s"(large_form));
+  if (large_form != 0) solve(std::integral_constant<int, 4>{});
   const int2 parked = reinterpret_cast<const int2 *>(lds_nrm + 64 * 11)[(int)threadIdx.x & 63];
-  const int aidx = parked.x;
+  const int64_t i = parked.x;
+  const int aidx = parked.y & 15;
   if constexpr (kWarm) {
-    if (permuted) final_set = working_set_to_legs<5, unsigned>((unsigned)final_set, (unsigned)parked.y);
+    if (permuted) final_set = working_set_to_legs<5, unsigned>((unsigned)final_set, (unsigned)parked.y >> 8);
   }
   if (status == kStatusNotPd) {
     if (lr == 0 && robot_live) {

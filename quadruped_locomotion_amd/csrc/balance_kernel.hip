@@ -290,13 +290,12 @@ __global__ __launch_bounds__(kPlaceThreads) void placement_kernel(const int32_t 
 // scan is done -- in registers (13 000 instructions of unrolled code), as bytes in LDS (16 us at 4096 robots: sub-word LDS
 // stores) or as words of four rounds (14.6 us, and 16 KB of LDS per workgroup cost every placed launch 0.3 us).
 constexpr int kShadowLdsBytes = (4 * kTabPerLeg + 4 * coop::kCoopLdsDoubles + coop::kCoopNrmDoubles) * 8;
-// robots per shadow wavefront: 1024 below the throughput form's batches (4096 robots: 4 wavefronts, 6 us -- shorter than the
-// shortest solve, a warm-started calm batch's 9.5 us), 4096 from there (65 536 robots: 16 wavefronts, 13 us of a 70 us
-// launch; with 64 of them every one reads 64 x 48 counts and the launch is 3-5 us longer)
-#ifndef QLAMD_SHADOW_CHUNK_SMALL
-#define QLAMD_SHADOW_CHUNK_SMALL 1024
-#endif
-constexpr int kShadowChunkSmall = QLAMD_SHADOW_CHUNK_SMALL, kShadowChunkLarge = 4096, kShadowMaxBlocks = 256;
+// robots per shadow wavefront.  Below the throughput form's batches: 1024 with a warm start (4096 robots: 4 wavefronts, 6 us
+// -- shorter than the shortest solve, a warm-started calm batch's 9.5 us), 2048 without (8 us against the 13.4 us of a calm
+// batch solved cold: every shadow wavefront shares a SIMD with a wavefront that solves, and two of them cost the placed
+// loop of 4096 robots 0.3 us less than four: profiles/r5/ab_shadow_blocks.txt).  4096 from there (65 536 robots: 16
+// wavefronts, 13 us of a 70 us launch; with 64 of them every one reads 64 x 48 counts and the launch is 3-5 us longer).
+constexpr int kShadowChunkWarm = 1024, kShadowChunkCold = 2048, kShadowChunkLarge = 4096, kShadowMaxBlocks = 256;
 static_assert((kShadowChunkLarge / 64) * kPlaceKeys * 4 + kPlaceKeys * 4 <= kShadowLdsBytes, "the shadow wavefront's counters live in the solve's LDS");
 constexpr int kShadowChunk = 16; // rounds whose loads are in flight together: a chunk's 1024 robots
 typedef __attribute__((address_space(3))) uint32_t lds_u32; // (a generic pointer would turn the atomics into flat ones)
@@ -891,7 +890,7 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
     s.prev_working_set = prev_ws;
     s.working_set = ws;
     // the next launch's placement: by extra wavefronts in front of this launch
-    const int chunk = batch >= QLAMD_THROUGHPUT_BATCH ? kShadowChunkLarge : kShadowChunkSmall;
+    const int chunk = batch >= QLAMD_THROUGHPUT_BATCH ? kShadowChunkLarge : (warm ? kShadowChunkWarm : kShadowChunkCold);
     const int64_t shadows = (batch + chunk - 1) / chunk;
     if (next_order && shadows <= kShadowMaxBlocks && pick_rpw(ctx, batch) == 4) {
       s.prev_iterations = prev_iterations;
