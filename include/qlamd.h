@@ -184,10 +184,15 @@ int qlamd_set_robots_per_wave(qlamd_context *ctx, int robots_per_wave);
  *   QLAMD_OPT_REFINE_PASSES  refinement passes of the lane-cooperative force QP on its final working set (default 1)
  *   QLAMD_OPT_DYNAMICS_FORM  layout of qlamd_wholebody_dynamics_batch's kernel: QLAMD_DYNAMICS_AUTO (default) picks by batch
  *                          size; _LEG = one lane per leg, 16 robots per wavefront (throughput: large batches); _ROW = 16
- *                          lanes per robot (latency: small batches).  Same results to rounding. */
+ *                          lanes per robot (latency: small batches).  Same results to rounding.
+ *   QLAMD_OPT_PLACEMENT_WAIT  how long the wavefronts that make qlamd_placement::next_robot_order inside a placed launch wait
+ *                          for each other before they give up, in polls of about 0.1 us (default 2^24: one to two seconds;
+ *                          0: not at all).  They normally meet within microseconds; a launch that gives up leaves the identity
+ *                          order in next_robot_order -- a valid placement: the next launch is slower, no result changes. */
 #define QLAMD_OPT_ON_FAILURE 1
 #define QLAMD_OPT_REFINE_PASSES 2
 #define QLAMD_OPT_DYNAMICS_FORM 5
+#define QLAMD_OPT_PLACEMENT_WAIT 6
 #define QLAMD_ON_FAILURE_ZERO 0
 #define QLAMD_ON_FAILURE_KEEP 1
 #define QLAMD_DYNAMICS_AUTO 0

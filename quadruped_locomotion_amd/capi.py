@@ -865,7 +865,7 @@ def wholebody_dynamics_device(ctx, dstate, M, h, Jc, gravity=9.81, stream=None):
         raise QlamdError(rc, "qlamd_wholebody_dynamics_batch")
 
 
-OPT_ON_FAILURE, OPT_REFINE_PASSES, OPT_DYNAMICS_FORM = 1, 2, 5
+OPT_ON_FAILURE, OPT_REFINE_PASSES, OPT_DYNAMICS_FORM, OPT_PLACEMENT_WAIT = 1, 2, 5, 6
 DYNAMICS_AUTO, DYNAMICS_LEG, DYNAMICS_ROW = 0, 1, 2
 ON_FAILURE_ZERO, ON_FAILURE_KEEP = 0, 1
 PLACEMENT_AUTO, PLACEMENT_LATENCY, PLACEMENT_THROUGHPUT = 0, 1, 2

@@ -93,7 +93,9 @@ __device__ __forceinline__ double from_leg_lane(double v, int aleg) {
 // table of constraint normals, kCoopNrmDoubles doubles ([row kind][lane]).
 constexpr int kCoopNrmDoubles = 12 * 64; // 5 row kinds + parked Jacobian row (3), gravity torque (3), output index and slot order
 
-template <bool kPerLeg, int kBlock = 64, bool kWarm = false>
+// kParkInputs (the 168-register form): what only the assembly of G and g0 reads -- the foot position and the wrench -- waits in
+// LDS instead of in registers while the first of the two forms of the QP runs (see `solve` below)
+template <bool kPerLeg, int kBlock = 64, bool kWarm = false, bool kParkInputs = false>
 __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs &s, int64_t irobot, bool robot_live_in,
                                            double *lds_tab, double *lds_row, double *lds_nrm,
                                            double *__restrict__ tau_out,
@@ -333,9 +335,16 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
     lds_nrm[64 * (5 + k) + ((int)threadIdx.x & 63)] = Jrow[k];
     lds_nrm[64 * (8 + k) + ((int)threadIdx.x & 63)] = Gq[k];
   }
-  // (the stores stay HERE: left to itself the compiler sinks them, and the kinematics behind them, below the QP -- their
-  // inputs then live across the active-set loop, which the 168-register form pays for with spills)
   asm volatile("" ::: "memory");
+  // The model table is dead from here on (one wavefront per workgroup: nobody else reads it): its place takes what only the
+  // assembly of G and g0 reads -- my foot position component, the wrench of my row (replicated: every lane of the row writes the
+  // same six values) -- so that it does not sit in registers across the first of the two regions below.
+  static_assert(!kParkInputs || kBlock == 64, "the parked inputs take the model table's place: one wavefront per workgroup");
+  if constexpr (kParkInputs) {
+    lds_tab[(int)threadIdx.x & 63] = foot;
+#pragma unroll
+    for (int k = 0; k < 6; k++) lds_tab[64 + 6 * (((int)threadIdx.x & 63) >> 4) + k] = b[k];
+  }
 
   QL_STAMP(3);
   // ---------------------------------------------------------------- friction pyramid of my leg
@@ -374,7 +383,16 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   int status = kStatusOk;
   const auto solve = [&](auto Legs) {
     ForceQp Q;
-    force_qp_objective(P.S, P.w_reg, foot, stance_slots, comp && on, b, nullptr, 0.0, Q.Gm, Q.g0);
+    if constexpr (kParkInputs) {
+      asm volatile("" ::: "memory");
+      const double foot_l = lds_tab[(int)threadIdx.x & 63];
+      double b_l[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) b_l[k] = lds_tab[64 + 6 * (((int)threadIdx.x & 63) >> 4) + k];
+      force_qp_objective(P.S, P.w_reg, foot_l, stance_slots, comp && on, b_l, nullptr, 0.0, Q.Gm, Q.g0);
+    } else {
+      force_qp_objective(P.S, P.w_reg, foot, stance_slots, comp && on, b, nullptr, 0.0, Q.Gm, Q.g0);
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) { Q.nb[k] = nb[k]; Q.t1[k] = t1[k]; Q.t2[k] = t2[k]; }
     Q.myn = myn; Q.myt1 = myt1; Q.myt2 = myt2;

@@ -27,7 +27,8 @@ struct StatePtrs {
   uint32_t *working_set;            // [B] or NULL
   int shadow_blocks, shadow_chunk;  // workgroups in front of the launch that make next_order, and the robots each of them takes
   uint32_t *place_hist;             // [shadow_blocks][kPlaceKeys]: their counts per key, for each other (the context's scratch)
-  uint32_t *place_sync;             // two words, zero when the context is created: arrivals, generation (their barrier)
+  uint32_t *place_sync;             // two words, zero when the context is created: arrivals, state (their barrier)
+  uint32_t place_wait;              // polls they wait for each other before they give up (QLAMD_OPT_PLACEMENT_WAIT)
 };
 
 __device__ __forceinline__ void load_robot(const StatePtrs &s, int64_t i, RobotIn &in) {
@@ -309,7 +310,7 @@ __device__ __forceinline__ uint32_t place_slot(uint32_t rk, uint32_t B, uint32_t
 __device__ __forceinline__ void placement_wave(const int32_t *__restrict__ iters, int64_t B64, int throughput,
                                                int32_t *__restrict__ order, lds_u32 *cnt, uint32_t sidx, uint32_t S,
                                                uint32_t chunk, const uint32_t *__restrict__ support, uint32_t *__restrict__ ghist,
-                                               uint32_t *__restrict__ gsync) {
+                                               uint32_t *__restrict__ gsync, uint32_t max_polls) {
   const uint32_t lane = threadIdx.x & 63u, B = (uint32_t)B64, W = (B + 3u) >> 2;
   const uint32_t lo = sidx * chunk;
   const uint32_t n = lo >= B ? 0u : (B - lo < chunk ? B - lo : chunk); // my robots
@@ -394,20 +395,48 @@ __device__ __forceinline__ void placement_wave(const int32_t *__restrict__ iters
       const uint32_t next = (lane + 1u < nkeys && R > 0) ? cnt[(lane + 1u) * R] : n;
       if (lane < nkeys) __hip_atomic_store(ghist + sidx * kPlaceKeys + lane, R > 0 ? next - start : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      // The barrier: arrivals in gsync[0], its state in gsync[1].  A launch finds the state at an even value g and leaves it at
+      // g + 2 (everybody arrived: the last one says so) or at g + 4 (somebody gave up waiting -- g + 1, odd -- and the last one
+      // to arrive closed the launch).  Both transitions away from g are compare-and-swaps, so a launch has ONE outcome, and
+      // every wavefront can tell which whenever it looks (odd: given up; g + 2: complete; g + 4: given up and closed).  The
+      // waiting is bounded (a second or two: a device shared with something that keeps these wavefronts from running together
+      // must not hang), and a launch that gives up writes the identity order -- a valid placement, which costs the next launch
+      // time, never a result.
+      int gave_up = 0;
       if (lane == 0) {
-        const uint32_t gen = __hip_atomic_load(gsync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t g = __hip_atomic_load(gsync + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t arrived = __hip_atomic_fetch_add(gsync, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived == S - 1u) {
-          __hip_atomic_store(gsync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          (void)__hip_atomic_fetch_add(gsync + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = arrived == S - 1u;
+        if (last) __hip_atomic_store(gsync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g & 1u) { // somebody gave up before I got here
+          gave_up = 1;
+          if (last) __hip_atomic_store(gsync + 1, g + 3u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (last) {
+          uint32_t now = g;
+          if (!__hip_atomic_compare_exchange_strong(gsync + 1, &now, g + 2u, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_store(gsync + 1, g + 4u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            gave_up = 1;
+          }
         } else {
-          // (bounded, a second or two: a wait that cannot end -- a launch cut short -- must not hang the device; the
-          // placement it then writes is wrong, which costs the next launch time, never a result)
-          for (unsigned spin = 0; spin < (1u << 24) && __hip_atomic_load(gsync + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen; spin++)
+          uint32_t now = g;
+          for (unsigned spin = 0;; spin++) {
+            now = __hip_atomic_load(gsync + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (now != g) break;
+            if (spin >= max_polls) {
+              if (__hip_atomic_compare_exchange_strong(gsync + 1, &now, g + 1u, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) now = g + 1u;
+              break; // (lost the exchange: `now` holds what the winner wrote)
+            }
             __builtin_amdgcn_s_sleep(4);
+          }
+          gave_up = now != g + 2u ? 1 : 0;
         }
       }
+      gave_up = __builtin_amdgcn_readfirstlane(gave_up);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (gave_up) {
+        for (uint32_t i = lane; i < n; i += 64) order[lo + i] = (int32_t)(lo + i);
+        return;
+      }
       uint32_t total = 0, before = 0;
       if (lane < nkeys) {
         for (uint32_t b = 0; b < S; b++) {
@@ -465,7 +494,8 @@ __global__ __launch_bounds__(64 * kCoopWaves, kMinWaves) void balance_coop_kerne
     if (s.shadow_blocks) {
       if (block < (unsigned)s.shadow_blocks) {
         placement_wave(s.prev_iterations, B, s.place_throughput, s.next_order, (lds_u32 *)lds, block, (uint32_t)s.shadow_blocks,
-                       (uint32_t)s.shadow_chunk, s.place_throughput ? reinterpret_cast<const uint32_t *>(s.stance) : nullptr, s.place_hist, s.place_sync);
+                       (uint32_t)s.shadow_chunk, s.place_throughput ? reinterpret_cast<const uint32_t *>(s.stance) : nullptr, s.place_hist, s.place_sync,
+                       s.place_wait);
         return;
       }
       block -= (unsigned)s.shadow_blocks;
@@ -492,7 +522,9 @@ __global__ __launch_bounds__(64 * kCoopWaves, kMinWaves) void balance_coop_kerne
 #pragma unroll 1
   for (int rep = 0; rep < 2; rep++) // second pass runs with a warm instruction cache
 #endif
-  coop::coop_robot<kPerLeg, 64 * kCoopWaves, kWarm>(P, cp, i, live, tab, rows + row * coop::kCoopLdsDoubles, nrm + wave * coop::kCoopNrmDoubles, tau, grf,
+  // (inputs parked in LDS across the first form of the QP: the 168-register form solving cold -- no scratch then, 1-2 % on 65 536
+  // to a million robots; the warm-started kernel is 3 % faster with them in registers and 20 bytes of scratch around the loop)
+  coop::coop_robot<kPerLeg, 64 * kCoopWaves, kWarm, kMinWaves == 3 && !kWarm>(P, cp, i, live, tab, rows + row * coop::kCoopLdsDoubles, nrm + wave * coop::kCoopNrmDoubles, tau, grf,
                             status);
 }
 
@@ -634,6 +666,7 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
   ctx->place_ws = nullptr;
   ctx->place_ws_bytes = 0;
   ctx->place_sync = nullptr;
+  ctx->placement_wait = 1u << 24;
   ctx->has_next_placement = false;
   ctx->on_failure = QLAMD_ON_FAILURE_ZERO;
   ctx->dynamics_form = QLAMD_DYNAMICS_AUTO;
@@ -710,6 +743,10 @@ int qlamd_set_option(qlamd_context *ctx, int option, int value) {
     case QLAMD_OPT_DYNAMICS_FORM:
       if (value < QLAMD_DYNAMICS_AUTO || value > QLAMD_DYNAMICS_ROW) return QLAMD_ERR_INVALID_ARGUMENT;
       ctx->dynamics_form = (int)value;
+      return QLAMD_OK;
+    case QLAMD_OPT_PLACEMENT_WAIT:
+      if (value < 0) return QLAMD_ERR_INVALID_ARGUMENT;
+      ctx->placement_wait = (unsigned)value;
       return QLAMD_OK;
     default: return QLAMD_ERR_INVALID_ARGUMENT;
   }
@@ -900,6 +937,7 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
       s.shadow_chunk = chunk;
       s.place_hist = (uint32_t *)ctx->place_ws;
       s.place_sync = (uint32_t *)ctx->place_sync;
+      s.place_wait = ctx->placement_wait;
     }
   }
 

@@ -54,8 +54,9 @@ def test_no_dpp_hazard_in_the_library(tu, tmp_path):
     if tu == "balance_kernel.hip":
         # the hot kernel: two wavefronts per SIMD for the latency form (at most 256 registers, nothing spilled to scratch
         # memory), three for the throughput form that large batches take (at most 168 registers; since it carries the QP in
-        # two forms -- 12 variables, and 6 for wavefronts whose robots stand on two legs -- two or three values that are live
-        # across the first form go to scratch around it: never inside a loop)
+        # two forms -- 12 variables, and 6 for wavefronts whose robots stand on two legs -- the inputs of the second form wait
+        # in LDS while the first runs; in the warm-started kernel two or three values go to scratch around it instead, never
+        # inside a loop)
         md = kernel_isa.meta(path)
         hot = {k: v for k, v in md.items() if "balance_coop_kernel" in k}
         assert len(hot) == 9   # per-leg normals / latency form / throughput form, each plain, placed and placed + warm start
@@ -63,7 +64,8 @@ def test_no_dpp_hazard_in_the_library(tu, tmp_path):
         for name, m in hot.items():
             three = "ELi3E" in name
             assert m["vgpr"] + m.get("agpr", 0) <= (168 if three else 256), (name, m)
-            assert m.get("scratch", 0) <= (48 if three else 0), (name, m)
+            warm = name.endswith("ELb1ELb1EEEvPKN5qlamd12DeviceParamsENS_9StatePtrsElPdS6_Pi")
+            assert m.get("scratch", 0) <= (48 if (three and warm) else 0), (name, m)
             in_loop = False
             for line in code[name]:
                 if line.startswith(".LBB"):

@@ -240,6 +240,50 @@ def test_next_placement_made_inside_the_solve_equals_the_placement_entry(gpu, B)
         assert rc == capi.ERR_INVALID_ARGUMENT
 
 
+@pytest.mark.parametrize("B", [8192, 65536])
+def test_shadow_wavefronts_that_give_up_leave_the_identity_order(gpu, B):
+    """QLAMD_OPT_PLACEMENT_WAIT = 0: the wavefronts that make the next placement do not wait for each other at all, so all but
+    the last to arrive give up -- the launch has ONE outcome (a compare-and-swap on the barrier's state): every wavefront
+    writes the identity order, a valid placement; the solve's results are untouched, and the launches after it (waiting
+    again) make the documented placement: the barrier is left in order."""
+    capi, ctx2, torch = gpu
+    ctx = capi.Context(device=0)
+    try:
+        s = synth.make_states(B, "trot")
+        d = capi.to_device(s)
+        t0, g0, s0 = plain((capi, ctx, torch), d, B)
+        rng = np.random.default_rng(B + 1)
+        prev = rng.integers(0, 30, size=B).astype(np.int32)
+        d_prev = torch.from_numpy(prev).to("cuda:0")
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def launch():
+            tau = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+            status = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+            iters = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+            nxt = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+            ctx.balance_solve_placed_device(d, tau, None, status, iterations=iters, prev_iterations=d_prev, next_order=nxt,
+                                            policy=capi.PLACEMENT_LATENCY, stream=stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(tau.cpu().numpy(), t0) and np.array_equal(status.cpu().numpy(), s0)
+            return nxt.cpu().numpy()
+
+        want = reference_placement(prev, False)
+        assert np.array_equal(launch(), want)
+        ctx.set_option(capi.OPT_PLACEMENT_WAIT, 0)
+        for _ in range(3):
+            got = launch()
+            # (with luck every wavefront arrives before the first one polls twice: then the placement is simply made)
+            assert np.array_equal(got, np.arange(B, dtype=np.int32)) or np.array_equal(got, want)
+        ctx.set_option(capi.OPT_PLACEMENT_WAIT, 1 << 24)
+        for _ in range(3):
+            assert np.array_equal(launch(), want)
+        with pytest.raises(capi.QlamdError):
+            ctx.set_option(capi.OPT_PLACEMENT_WAIT, -1)
+    finally:
+        ctx.close()
+
+
 def _force_qps(torch, B):
     """The golden force QPs (n = 12, m = 20) tiled to B problems, on the device, in both forms the library takes."""
     import os
