@@ -93,6 +93,44 @@ def test_warm_start_reaches_the_cold_start_s_answer(gpu, oracle, gait, errors, B
     assert np.array_equal(s2, so) and np.abs(t2 - to).max() < TAU_TOL and np.abs(g2 - go).max() < 1e-6
 
 
+def test_the_callers_loop_at_the_baseline_batch(gpu, oracle):
+    """BASELINE configs[3]'s global batch on one GPU, as a caller would run it: 65 536 trot robots, five control steps of the
+    placed + warm-started loop (the 168-register form of the kernel, both forms of the QP, the sorted placement by class made
+    by sixteen shadow wavefronts, working sets updated in place), odd steps on the states one control period later -- every
+    step's efforts and statuses against the oracle's for the states it ran on."""
+    capi, ctx, torch = gpu
+    B = 65536
+    a = synth.make_states(B, "trot")
+    b = synth.next_tick_states(a, 0.0025)
+    states, devs = [a, b], [capi.to_device(a), capi.to_device(b)]
+    want = [oracle.balance_batch(s, nthreads=16) for s in states]
+    order = [torch.arange(B, dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    iters = [torch.zeros(B, dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    ws = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for k in range(5):
+        tau = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+        status = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+        ctx.balance_solve_placed_device(devs[k & 1], tau, None, status, order=order[k & 1], iterations=iters[k & 1],
+                                        prev_iterations=iters[(k - 1) & 1], next_order=order[(k + 1) & 1],
+                                        policy=capi.PLACEMENT_AUTO, prev_working_set=ws, working_set=ws, stream=stream)
+        torch.cuda.synchronize()
+        t0, _, s0 = want[k & 1]
+        st = status.cpu().numpy()
+        assert np.array_equal(st, s0), (k, int((st != s0).sum()))
+        ok = s0 == 0
+        assert np.abs(tau.cpu().numpy()[ok] - t0[ok]).max() < TAU_TOL, k
+        nxt = order[(k + 1) & 1].cpu().numpy()
+        assert np.array_equal(np.sort(nxt), np.arange(B)), k    # a permutation, whatever the hints were
+        if k >= 2:  # made from real counts: robots on more than two legs first, each class hardest first
+            legs = states[k & 1]["stance"].astype(bool).sum(1)
+            cls = (legs[nxt] <= 2).astype(int)
+            assert (np.diff(cls) >= 0).all(), k
+            cnt = np.clip(iters[(k - 1) & 1].cpu().numpy(), 0, 23)[nxt]
+            for c in (0, 1):
+                assert (np.diff(cnt[cls == c]) <= 0).all(), (k, c)
+
+
 def test_warm_start_arguments(gpu):
     capi, ctx, torch = gpu
     B = 64
