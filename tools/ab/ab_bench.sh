@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B on one GPU box: bench the library in the tree ("new") against scratch_bin/libqlamd_base.so ("base"),
-# alternating, so that box-to-box clock differences cancel.  Usage (inside gpurun): bash tools/ab_bench.sh
+# alternating, so that box-to-box clock differences cancel.  Usage (inside gpurun): bash tools/ab/ab_bench.sh
 cd "${GRAFT_REPO_ROOT:-.}"
 cp quadruped_locomotion_amd/libqlamd.so /tmp/libqlamd_new.so
 run() { python bench.py --steps 200 --warmup 20 --no-cpu-baseline "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('%8.2f us/step %8.1f M/s' % (d['ms_per_step']*1e3, d['value']/1e6))"; }

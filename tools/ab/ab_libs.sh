@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B/C... on one GPU box: the same bench lines through several builds of the library, alternating, so that box-to-box
-# clock differences cancel.  Usage (inside gpurun): bash tools/ab_libs.sh [-r REPS] lib1.so lib2.so ...
+# clock differences cancel.  Usage (inside gpurun): bash tools/ab/ab_libs.sh [-r REPS] lib1.so lib2.so ...
 cd "${GRAFT_REPO_ROOT:-.}"
 reps=3
 if [ "$1" = "-r" ]; then reps=$2; shift 2; fi
