@@ -1001,7 +1001,7 @@ def main():
                 r, args.gait, args.errors,
                 note="odd steps run on the states one control period (2.5 ms) later than even steps: every placement in use was "
                      "made from the iteration counts of OTHER states, as for a caller at 400 Hz")
-        WARM_NOTE = ("warm start: every robot's active-set loop starts from its final working set of the step before "
+        WARM_NOTE = ("the placed loop with a warm start: every robot's active-set loop starts from its final working set of the step before "
                      "(qlamd_placement::prev_working_set), odd steps on the states one control period (2.5 ms) later than even "
                      "steps, so that the set always comes from OTHER states; efforts within 1e-7 of the cold start's "
                      "(tests/test_warm_start_gpu.py), iteration counts no longer QuadProg++'s")
@@ -1114,6 +1114,11 @@ def main():
             line["scale_point"] = scale_point
         if also is not None:
             line["also"] = also
+            wk = "%s-warm" % ("static-%s" % args.errors if args.gait == "static" else "trot")
+            if method == "placed" and wk in also:
+                # the line's own workload through the placed AND warm-started loop, beside `unplaced`: the three ways a caller
+                # can step the same robots (`value`: every QP solved from the empty working set, as the reference's solvers do)
+                line["warm_started"] = also[wk]
         if cpu is not None:
             line["cpu_baseline"] = cpu
 

@@ -60,6 +60,7 @@ def check_round5(d):
     assert w["method"] == "warm" and "working set" in w["note"] and w["ms_per_step"] < d["unplaced"]["ms_per_step"]
     assert d["also"]["trot_b8192"]["warm"]["all_status_ok"] is True and d["also"]["trot_b65536"]["warm"]["ms_per_step"] > 0
     assert d["scale_point"]["warm"]["value"] > 0
+    assert d["warm_started"] == w   # the line's own workload by the three ways a caller can step it: value, unplaced, warm_started
     sp = d["scale_point"]
     assert sp["robots_per_gpu"] == 8192 and sp["gait"] == "trot" and sp["n_gpus"] == d["n_gpus"]
     assert sp["value"] > 0 and sp["without_gather"] > 0 and "efficiency" in sp["definition"]
