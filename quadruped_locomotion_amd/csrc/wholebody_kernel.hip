@@ -336,11 +336,22 @@ __global__ __launch_bounds__(64, 2) void wholebody_solve_kernel(const DevicePara
   double nWl[3] = {0.0, 0.0, 1.0};
   if (kPerLeg) { nWl[0] = s.normals[12 * i + 3 * leg]; nWl[1] = s.normals[12 * i + 3 * leg + 1]; nWl[2] = s.normals[12 * i + 3 * leg + 2]; }
   ts.commit(tab);
-  const unsigned stance = live ? (((sm & 0xFFu) ? 1u : 0u) | ((sm & 0xFF00u) ? 2u : 0u) | ((sm & 0xFF0000u) ? 4u : 0u) |
-                                  ((sm & 0xFF000000u) ? 8u : 0u))
-                               : 0u;
-  const int nS = __popc(stance);
-  const bool comp = c < 3, on = ((stance >> leg) & 1u) != 0u, row_on = comp && on;
+  const unsigned stance_legs = live ? (((sm & 0xFFu) ? 1u : 0u) | ((sm & 0xFF00u) ? 2u : 0u) | ((sm & 0xFF0000u) ? 4u : 0u) |
+                                       ((sm & 0xFF000000u) ? 8u : 0u))
+                                    : 0u;
+  const int nS = __popc(stance_legs);
+  // support legs first (balance_coop.hpp): `leg` is my SLOT in the row, aleg the leg behind it; what was loaded by leg moves
+  // to the lane of its slot
+  const unsigned perm = slot_legs(stance_legs);
+  const int aleg = (int)((perm >> (2 * leg)) & 3u);
+  const unsigned stance = (1u << nS) - 1u;
+  const bool permuted = __builtin_amdgcn_ballot_w64(perm != 0xE4u) != 0ull;
+  double qdd_l = qdd_raw;
+  if (permuted) {
+    in.qj = from_leg_lane(in.qj, aleg); in.qdj = from_leg_lane(in.qdj, aleg); qdd_l = from_leg_lane(qdd_l, aleg);
+    if (kPerLeg) { nWl[0] = from_leg_lane(nWl[0], aleg); nWl[1] = from_leg_lane(nWl[1], aleg); nWl[2] = from_leg_lane(nWl[2], aleg); }
+  }
+  const bool comp = c < 3, on = leg < nS, row_on = comp && on;
 
   // ---- dynamics on the quad lanes
   double Rm[9], gB[3], vB[3];
@@ -351,11 +362,11 @@ __global__ __launch_bounds__(64, 2) void wholebody_solve_kernel(const DevicePara
   double sj, cj;
   sincos_reduced(in.qj, sj, cj);
   WbLink L;
-  wb_link(CoopTab{tab + kTabPerLeg * leg}, c, sj, cj, L);
+  wb_link(CoopTab{tab + kTabPerLeg * aleg}, c, sj, cj, L);
   const double V0[6] = {in.angvel[0], in.angvel[1], in.angvel[2], vB[0], vB[1], vB[2]};
   const double A0[6] = {ades[3], ades[4], ades[5], ades[0] - gB[0], ades[1] - gB[1], ades[2] - gB[2]};
   double tau0, gb[6];
-  wb_inverse_dynamics(W, L, c, V0, A0, comp ? in.qdj : 0.0, (comp && s.qdd) ? qdd_raw : 0.0, tau0, gb);
+  wb_inverse_dynamics(W, L, c, V0, A0, comp ? in.qdj : 0.0, (comp && s.qdd) ? qdd_l : 0.0, tau0, gb);
   tau0 = comp ? tau0 : 0.0;
 
   ForceQp Q;
@@ -397,10 +408,21 @@ __global__ __launch_bounds__(64, 2) void wholebody_solve_kernel(const DevicePara
   Q.tq_up = W.tau_max - tau0; Q.tq_lo = W.tau_max + tau0;
   double x = 0.0;
   Q.warm = 0ull; Q.stance = stance;
-  if constexpr (kWarm) Q.warm = warm_set;
+  if constexpr (kWarm) Q.warm = permuted ? working_set_to_slots<11, unsigned long long>(warm_set, perm) : warm_set;
   int qp_iters;
   unsigned long long final_set = 0ull;
-  const int st = force_qp_coop<true, kWarm>(Q, rows + kCoopLdsDoubles * row, nrm, x, qp_iters, &final_set);
+  // the two forms of the QP as two regions behind opaque flags, the 6-variable one first (balance_coop.hpp)
+  const bool two_legs = __builtin_amdgcn_ballot_w64(nS > 2) == 0ull;
+  int st = kStatusOk;
+  int small_form = __builtin_amdgcn_readfirstlane(two_legs ? 1 : 0);
+  asm volatile("" : "+s"(small_form));
+  if (small_form != 0) st = force_qp_coop<true, kWarm, 2>(Q, rows + kCoopLdsDoubles * row, nrm, x, qp_iters, &final_set);
+  int large_form = __builtin_amdgcn_readfirstlane(1 - small_form);
+  asm volatile("" : "+s"(large_form));
+  if (large_form != 0) st = force_qp_coop<true, kWarm, 4>(Q, rows + kCoopLdsDoubles * row, nrm, x, qp_iters, &final_set);
+  if constexpr (kWarm) {
+    if (permuted) final_set = working_set_to_legs<11, unsigned long long>(final_set, perm);
+  }
 
   // ---- joint efforts: tau = tau0 - J_leg' f on the stance legs, tau0 elsewhere
   const bool ok = st == kStatusOk;
@@ -408,8 +430,8 @@ __global__ __launch_bounds__(64, 2) void wholebody_solve_kernel(const DevicePara
   const double tq = tau0 - (Q.jcol[0] * quad_bc<0>(f) + Q.jcol[1] * quad_bc<1>(f) + Q.jcol[2] * quad_bc<2>(f));
   // a failed robot: zeros, or (QLAMD_ON_FAILURE_KEEP) its entries stay as the caller left them
   if (comp && live && !(P.keep_on_failure && !ok)) {
-    tau_out[12 * i + 3 * leg + c] = ok ? tq : 0.0;
-    if (grf_out) grf_out[12 * i + 3 * leg + c] = f;
+    tau_out[12 * i + 3 * aleg + c] = ok ? tq : 0.0;
+    if (grf_out) grf_out[12 * i + 3 * aleg + c] = f;
   }
   if (lr == 0 && live) {
     status_out[i] = st;

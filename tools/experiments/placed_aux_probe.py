@@ -47,6 +47,12 @@ def main():
     for gait in ("trot", "static"):
         wb = capi.to_device(synth.make_wholebody_states(B, gait))
         entries.append(("wholebody_solve_kernel %s" % gait, lambda cap, wb=wb: capi.wholebody_solve_device(ctx, wb, tau, grf, st, stream=cap)))
+    # the trot batch with its robots in double support put on their diagonal pair: every wavefront takes the 6-variable form
+    import numpy as np
+    two = synth.make_wholebody_states(B, "trot")
+    two["stance"][two["stance"].sum(1) == 4] = np.array([1, 0, 1, 0], dtype=np.uint8)
+    wb2 = capi.to_device(two)
+    entries.append(("wholebody_solve_kernel trot, all on two legs", lambda cap, wb=wb2: capi.wholebody_solve_device(ctx, wb, tau, grf, st, stream=cap)))
     for name, entry in entries:
         it = torch.zeros(B, dtype=torch.int32, device="cuda:0")
         ctx.place_next_call(iterations=it)
