@@ -67,7 +67,10 @@ def reference_placement(iters, throughput, support=None):
 @pytest.mark.parametrize("gait,errors,B", [("static", "survey", 4096), ("trot", None, 4099), ("trot", None, 16385), ("static", "calm", 7)])
 def test_results_are_bit_equal_under_any_placement(gpu, oracle, gait, errors, B):
     """Identity, a random permutation, the reversed order and both placements of the library, at batch sizes that leave
-    the last wavefront ragged and on both forms of the kernel (two / three wavefronts per SIMD from 16 384 robots)."""
+    the last wavefront ragged and on both forms of the kernel (two / three wavefronts per SIMD from 16 384 robots).
+    (Also the test of the ghost rows, ADVICE r4: a robot that has finished rides along while the other rows of its wavefront
+    run on -- for one pass next to easy companions, for twenty next to a hard one; if its operators were touched after it
+    latched, its refinement, and so its result, would depend on who it sits with.)"""
     capi, ctx, torch = gpu
     s = synth.make_states(B, gait, errors=errors)
     d = capi.to_device(s)
