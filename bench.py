@@ -10,9 +10,14 @@ outputs resident in HBM.
 
 N = 1: BASELINE configs[1], batch = 4096 robots, static 4-contact stance with SURVEY.md 8(d)'s literal tracking errors
        (0.02 m / 0.05 rad / 0.1); the same line carries an `also` object with every other BASELINE config measured in the
-       same process (static-calm and trot at 4096 robots, trot at 8192 and 65 536 robots, the pose SQP at 4096 problems),
-       each with its kernel time, roofline fraction and PMC provenance, `unplaced` (the same steps through the plain
-       entry) and `scale_point` (8192 trot robots per GPU: the workload every line at every N carries).
+       same process (static-calm and trot at 4096 robots, trot at 8192 and 65 536 robots, the pose SQP at 4096 problems, the
+       whole tick and the whole-body step at 4096 robots), each with its kernel time, roofline fraction and PMC provenance,
+       `cold_start` / `unplaced` (the same steps with every QP started from the empty working set, placed and through the
+       plain entry) and `scale_point` (8192 trot robots per GPU: the workload every line at every N carries).
+Every timed region runs on a TRAJECTORY (synth.trajectory): the K captured steps solve K consecutive control ticks of the same
+robots (2.5 ms apart: poses integrated with the twists, a trot's gait phase advanced and its support flags recomputed, so
+about 1.1 % of the trot robots change their support set every tick), so that every placement and every warm start comes
+from the states of EARLIER ticks, never from the states being solved.
 N > 1: BASELINE configs[3], 8192 trot robots per GPU (65 536 on 8 GPUs), one rank per GPU; every rank
 solves its own contiguous shard (weak scaling: robots are independent, no data-path collective) and the
 joint torques are all-gathered over RCCL/xGMI for result collection, as the north star asks.  Started
@@ -210,16 +215,26 @@ def parse():
                          "no collective)")
     ap.add_argument("--alternatives-timeout", type=float, default=240.0,
                     help="seconds the `alternatives` runs may take before the line is printed without them")
-    ap.add_argument("--no-alternatives", action="store_true",
-                    help="several ranks: skip the `alternatives` object (the same steps with the other ways of collecting)")
+    ap.add_argument("--alternatives", action="store_true",
+                    help="several ranks: also run the same steps with the other ways of collecting the results (one all-gather per 8 "
+                         "steps, peer copies) and report them in an `alternatives` object.  Off by default: they are side "
+                         "measurements behind a watchdog, and a rank that hangs in one ends with a non-zero exit code")
+    ap.add_argument("--no-alternatives", action="store_true", help=argparse.SUPPRESS)  # (the default since round 6)
     ap.add_argument("--no-gather", action="store_true",
                     help="several ranks without the per-step all-gather of the torques (scaling with / without it)")
     ap.add_argument("--ragged", action="store_true", help="full_tick: every message with its own layout")
-    ap.add_argument("--method", default="placed", choices=["placed", "plain", "warm"],
-                    help="placed (default): every step is one qlamd_balance_solve_placed_batch call that runs in the placement made "
-                         "during the previous step from the iteration counts of the step before it, reports its own counts and "
-                         "leaves the placement for the next step -- all of it inside the timed region; plain: qlamd_balance_solve_batch "
-                         "(robot s in slot s), the headline of rounds 1-4.  The line carries the other one in `also` / `unplaced`")
+    ap.add_argument("--method", default="warm", choices=["placed", "plain", "warm"],
+                    help="warm (default): the caller's loop of include/qlamd.h -- every step is one qlamd_balance_solve_placed_batch "
+                         "call that runs in the placement made during the previous step from the iteration counts of the step before "
+                         "it, starts every robot's active-set loop from its final working set of the previous step, reports counts "
+                         "and sets and leaves the placement for the next step, all of it inside the timed region; placed: the same "
+                         "without the working sets (every QP from the empty set: the headline of round 5, `cold_start` on the line); "
+                         "plain: qlamd_balance_solve_batch (robot s in slot s: the headline of rounds 1-4, `unplaced` on the line)")
+    ap.add_argument("--ticks", type=int, default=0,
+                    help="distinct consecutive control ticks the K steps of a timed region run on (0 = K, capped at 64 beyond "
+                         "16 384 robots; step k solves tick k %% ticks, so a region that is longer than the trajectory -- and "
+                         "every replay of the captured steps -- jumps back to tick 0 once: a discontinuity no 400 Hz loop has, "
+                         "which costs the placed / warm-started loop time, never the other way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -663,38 +678,40 @@ def main():
             torch.cuda.synchronize()
 
     def run_preset(gait, errors, with_gather, replays, second_without_gather, collect="rccl", every=1, batch=None,
-                   method="plain", prev_tick=False):
+                   method="plain"):
         """One workload preset on this rank's shard: warm-up, K steps captured as one hipGraph, `replays` timed samples.
         every: steps per collection; collect: "rccl" (all-gather) or "peer" (copies into the peers' buffers).
-        method "placed": the caller's loop of include/qlamd.h -- step k runs in order[k & 1], writes iters[k & 1] and makes
-        order[(k + 1) & 1] from iters[(k - 1) & 1]; prev_tick: odd steps run on the states one control period (2.5 ms) later,
-        so that every placement in use was made from the counts of OTHER states, as at 400 Hz."""
+        Step k solves tick k % T of a T-tick trajectory of the shard's robots (synth.trajectory; T = K unless --ticks or the
+        cap says otherwise).  method "placed": the caller's loop of include/qlamd.h -- step k runs in order[k & 1], writes
+        iters[k & 1] and makes order[(k + 1) & 1] from iters[(k - 1) & 1]: tick k runs in the placement made during tick
+        k - 1 from the counts of tick k - 2; "warm": the same, and every robot's QP starts from its final working set of tick
+        k - 1 (one array, updated in place)."""
         B = batch or args.batch
+        T = max(1, args.ticks or (args.steps if B <= 16384 else min(args.steps, 64)))
         # rank r owns robots [r*B, (r+1)*B) of the global batch (contiguous shards, SURVEY.md 8e)
-        state = synth.make_states(B, gait, offset=rank * B, errors=errors)
-        ds = [capi.to_device(state, dev)]
-        if prev_tick:
-            ds.append(capi.to_device(synth.next_tick_states(state, 0.0025), dev))
-        d = ds[0]
+        states = synth.trajectory(B, gait, T, offset=rank * B, errors=errors)
+        ds = [capi.to_device(st_, dev) for st_ in states]
+        switched = synth.support_switches(states + [states[0]])   # T - 1 transitions of the trajectory, then the jump back to tick 0
+        retries0, giveups0 = ctx.counter(capi.COUNTER_WARM_RETRIES), ctx.counter(capi.COUNTER_PLACEMENT_GIVE_UPS)
         placed, warm = method == "placed", method == "warm"
         orders = [torch.arange(B, dtype=torch.int32, device=dev) for _ in range(2)] if (placed or warm) else None
         its = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)] if (placed or warm) else None
-        wss = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)] if warm else None
+        wset = torch.zeros(B, dtype=torch.int32, device=dev) if warm else None   # working sets: one array, in place
 
         def solve(k, out, st):
             if warm:
                 # the placed loop, and every robot's active-set loop starts from its final working set of the step before
                 # (include/qlamd.h: both halves of the hint a 400 Hz caller has)
-                ctx.balance_solve_placed_device(ds[k % len(ds)], out, None, status, order=orders[k & 1], iterations=its[k & 1],
+                ctx.balance_solve_placed_device(ds[k % T], out, None, status, order=orders[k & 1], iterations=its[k & 1],
                                                 prev_iterations=its[(k - 1) & 1], next_order=orders[(k + 1) & 1],
                                                 policy=capi.PLACEMENT_AUTO,
-                                                prev_working_set=wss[(k - 1) & 1], working_set=wss[k & 1], stream=st)
+                                                prev_working_set=wset, working_set=wset, stream=st)
             elif placed:
-                ctx.balance_solve_placed_device(ds[k % len(ds)], out, None, status, order=orders[k & 1], iterations=its[k & 1],
+                ctx.balance_solve_placed_device(ds[k % T], out, None, status, order=orders[k & 1], iterations=its[k & 1],
                                                 prev_iterations=its[(k - 1) & 1], next_order=orders[(k + 1) & 1],
                                                 policy=capi.PLACEMENT_AUTO, stream=st)
             else:
-                ctx.balance_solve_device(ds[k % len(ds)], out, None, status, stream=st)
+                ctx.balance_solve_device(ds[k % T], out, None, status, stream=st)
         G = max(1, every)
         tau = [torch.zeros(G, B, 12, dtype=torch.float64, device=dev) for _ in range(2)]
         status = torch.full((B,), -1, dtype=torch.int32, device=dev)
@@ -876,16 +893,42 @@ def main():
             res["gather_layout_ok"] = True
         if peer is not None:
             peer.close()
-        ok = bool((status.cpu().numpy() == 0).all())
+        # ---- what the loop saw, tick by tick (untimed): the K steps once more, eagerly, continuing the caller's loop where the
+        # last replay left it -- every tick's statuses, iteration counts and (warm) how many robots ended the tick with the
+        # working set they started it with
+        ok, it_mean, it_max, unchanged = True, [], 0, []
+        for k in range(args.steps):
+            before = wset.clone() if warm else None
+            solve(k, tau[0][0], stream)
+            torch.cuda.synchronize()
+            ok = ok and bool((status == 0).all().item())
+            if placed or warm:
+                it = its[k & 1]
+                it_mean.append(float(it.float().mean().item()))
+                it_max = max(it_max, int(it.max().item()))
+            if warm:
+                unchanged.append(float((wset == before).float().mean().item()))
         if collective:
             okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             ok = bool(okt.item())
         res["ok"] = ok
         res["batch"], res["method"] = B, method
+        wrap = [k for k in range(args.steps) if k % T == 0]          # the steps that follow a jump back to tick 0
+        inside = [k for k in range(args.steps) if k % T != 0] or wrap
+        res["trajectory"] = {
+            "states_per_replay": T, "dt": synth.CONTROL_PERIOD,
+            "switched_per_tick": float(np.mean(switched[:-1])) if T > 1 else 0.0,   # robots whose support set changes, per tick
+            "switched_at_wrap": float(switched[-1])}
         if placed or warm:
-            it = its[(args.steps - 1) & 1].cpu().numpy()
-            res["iterations"] = {"mean": float(it.mean()), "max": int(it.max())}
+            res["iterations"] = {"mean": float(np.mean(it_mean)), "max": it_max}
+            res["trajectory"]["placement_give_ups"] = ctx.counter(capi.COUNTER_PLACEMENT_GIVE_UPS) - giveups0
+        if warm:
+            res["trajectory"]["working_set_unchanged"] = float(np.mean([unchanged[k] for k in inside]))
+            res["trajectory"]["working_set_unchanged_at_wrap"] = float(np.mean([unchanged[k] for k in wrap]))
+            # robots whose warm start was rejected and that were solved again cold inside the same launch (whole preset:
+            # warm-up, settling and every timed replay included); with the fallback on none of them is ever reported
+            res["trajectory"]["warm_rejected"] = ctx.counter(capi.COUNTER_WARM_RETRIES) - retries0
         return res
 
     def roofline_of(res, gait, errors):
@@ -919,6 +962,7 @@ def main():
              "valu_issue_frac": valu["frac"] if valu else None, "pmc_source": roof["traffic_source"]}
         if "iterations" in r:
             e["iterations"] = r["iterations"]
+        e["trajectory"] = r["trajectory"]
         if note:
             e["note"] = note
         return e
@@ -974,55 +1018,40 @@ def main():
                 "pmc_source": prov}
 
     B = args.batch
-    method = args.method if not args.rpw else "plain"  # (the one-lane kernels of --rpw know no placement)
-    other = "placed" if method == "plain" else "plain"
-    res = run_preset(args.gait, args.errors, gather, args.replays, world > 1, collect=args.collect, every=args.gather_every, method=method,
-                     prev_tick=method == "warm")
-    headline_is_survey_4096 = args.gait == "static" and args.errors == "survey"
-    # the same preset by the other method (every rank takes part: the preset's consensus steps are collectives)
-    unplaced = (run_preset(args.gait, args.errors, False, min(args.replays, 5), False, method=other)
-                if not (args.rpw or args.no_also) else None)
+    method = args.method if not args.rpw else "plain"  # (the one-lane kernels of --rpw know neither placement nor warm start)
+    others = [m for m in ("placed", "plain") if m != method] if method == "warm" else (["plain"] if method == "placed" else ["placed"])
+    OTHER_KEY = {"placed": "cold_start", "plain": "unplaced", "warm": "warm_started"}
+    few = min(args.replays, 5)
+    res = run_preset(args.gait, args.errors, gather, args.replays, world > 1, collect=args.collect, every=args.gather_every, method=method)
+    # the same preset by the other methods (every rank takes part: the preset's consensus steps are collectives)
+    beside = ({m: run_preset(args.gait, args.errors, False, few, False, method=m) for m in others}
+              if not (args.rpw or args.no_also) else {})
     # The other presets and every other BASELINE config, same process (one GPU only; fewer samples each):
     #   static-calm, trot at the headline batch; trot_b8192 (one rank's shard of configs[3]) and trot_b65536 (its global
-    #   batch on one GPU); pose_sqp_b4096 (configs[4]); the headline preset with placement hints from OTHER states.
+    #   batch on one GPU), each by the line's method with the other methods beside it; pose_sqp_b4096 (configs[4]).
     also, scale_point = None, None
     SCALE_B = 8192
+
+    def brief(r):
+        return {"value": r["batch"] * args.steps / r["elapsed"], "ms_per_step": r["elapsed"] / args.steps * 1e3,
+                "kernel_ms": r["kernel_ms"], "all_status_ok": r["ok"], "iterations": r.get("iterations")}
+
+    def preset_entry(gait, errors, bb, methods_beside):
+        e = entry(run_preset(gait, errors, False, few, False, batch=bb, method=method), gait, errors)
+        for m in methods_beside:
+            e[OTHER_KEY[m]] = brief(run_preset(gait, errors, False, few, False, batch=bb, method=m))
+        return e
+
     if world == 1 and not collective and not args.no_also:
         also = {}
         for gait, errors in (("static", "calm"), ("static", "survey"), ("trot", "survey")):
             if gait == args.gait and (gait == "trot" or errors == args.errors):
                 continue
-            # (a robot holding its pose needs no pass: nothing to place, and a caller would not ask for it)
-            m = "plain" if (gait, errors) == ("static", "calm") else method
-            also["static-%s" % errors if gait == "static" else "trot"] = entry(run_preset(gait, errors, False, min(args.replays, 5), False, method=m), gait, errors)
-        if method == "placed":
-            r = run_preset(args.gait, args.errors, False, min(args.replays, 5), False, method="placed", prev_tick=True)
-            also["%s-prev-tick-hints" % ("static-%s" % args.errors if args.gait == "static" else "trot")] = entry(
-                r, args.gait, args.errors,
-                note="odd steps run on the states one control period (2.5 ms) later than even steps: every placement in use was "
-                     "made from the iteration counts of OTHER states, as for a caller at 400 Hz")
-        WARM_NOTE = ("the placed loop with a warm start: every robot's active-set loop starts from its final working set of the step before "
-                     "(qlamd_placement::prev_working_set), odd steps on the states one control period (2.5 ms) later than even "
-                     "steps, so that the set always comes from OTHER states; efforts within 1e-7 of the cold start's "
-                     "(tests/test_warm_start_gpu.py), iteration counts no longer QuadProg++'s")
-
-        def warm_of(gait, errors, bb):
-            rw = run_preset(gait, errors, False, min(args.replays, 5), False, batch=bb, method="warm", prev_tick=True)
-            return entry(rw, gait, errors, note=WARM_NOTE)
-        if not args.rpw:
-            also["%s-warm" % ("static-%s" % args.errors if args.gait == "static" else "trot")] = warm_of(args.gait, args.errors, B)
+            also["static-%s" % errors if gait == "static" else "trot"] = preset_entry(gait, errors, B, others)
         for name, bb in (("trot_b8192", 8192), ("trot_b65536", 65536)):
             if args.gait == "trot" and bb == B:
                 continue
-            r = run_preset("trot", "survey", False, min(args.replays, 5), False, batch=bb, method=method)
-            also[name] = entry(r, "trot", "survey")
-            if method == "placed":
-                rp = run_preset("trot", "survey", False, min(args.replays, 5), False, batch=bb, method="plain")
-                also[name]["unplaced"] = {"value": bb * args.steps / rp["elapsed"], "ms_per_step": rp["elapsed"] / args.steps * 1e3,
-                                          "kernel_ms": rp["kernel_ms"], "all_status_ok": rp["ok"]}
-            if not args.rpw:
-                w = warm_of("trot", "survey", bb)
-                also[name]["warm"] = {k: w[k] for k in ("value", "ms_per_step", "kernel_ms", "all_status_ok", "iterations", "roofline_frac")}
+            also[name] = preset_entry("trot", "survey", bb, others)
         try:
             also["pose_sqp_b4096"] = pose_sqp_entry(4096)
         except Exception as e:  # a side measurement must not cost the line
@@ -1030,13 +1059,12 @@ def main():
     # scale_point: the workload every line at every N carries, so that a weak-scaling curve can be drawn across lines:
     # 8192 trot robots per GPU (configs[3]'s shard).  efficiency(N) = scale_point(N).value / (N * scale_point(1).without_gather)
     if args.gait == "trot" and B == SCALE_B:
-        sp_res, sp_plain = res, None
+        sp_res = res
     elif args.no_also or (world == 1 and not collective):  # (one GPU: taken from also["trot_b8192"] below)
-        sp_res, sp_plain = None, None
+        sp_res = None
     else:
-        sp_res = run_preset("trot", "survey", gather, min(args.replays, 5), world > 1, collect=args.collect, every=args.gather_every,
+        sp_res = run_preset("trot", "survey", gather, few, world > 1, collect=args.collect, every=args.gather_every,
                             batch=SCALE_B, method=method)
-        sp_plain = None
     if rank == 0:
         if sp_res is not None:
             scale_point = {"robots_per_gpu": SCALE_B, "gait": "trot", "n_gpus": world, "method": sp_res["method"],
@@ -1044,18 +1072,35 @@ def main():
                            "ms_per_step": sp_res["elapsed"] / args.steps * 1e3,
                            "without_gather": (world * SCALE_B * args.steps / sp_res["plain"]["elapsed"]) if sp_res.get("plain") else
                                              (world * SCALE_B * args.steps / sp_res["elapsed"] if not gather else None),
-                           "result_collection": "rccl all_gather of torques" if gather else "none"}
+                           "result_collection": "rccl all_gather of torques" if gather else "none",
+                           "trajectory": sp_res["trajectory"]}
         elif also is not None and "trot_b8192" in also:
             t8 = also["trot_b8192"]
             scale_point = {"robots_per_gpu": SCALE_B, "gait": "trot", "n_gpus": 1, "method": t8["method"], "value": t8["value"],
                            "ms_per_step": t8["ms_per_step"], "without_gather": t8["value"],
                            "result_collection": "none (one GPU: the result is already whole)",
-                           **({"unplaced": t8["unplaced"]} if "unplaced" in t8 else {}),
-                           **({"warm": t8["warm"]} if "warm" in t8 else {})}
+                           "trajectory": t8["trajectory"],
+                           **{OTHER_KEY[m]: t8[OTHER_KEY[m]] for m in others if OTHER_KEY[m] in t8}}
         if scale_point is not None:
             scale_point["definition"] = ("8192 trot robots per GPU (BASELINE configs[3]'s shard), same method and timed region as "
                                          "`value`; weak-scaling efficiency(N) = scale_point(N).value / (N x scale_point(1).without_gather)")
 
+    METHOD_NOTE = {
+        "warm": ("the caller's loop of include/qlamd.h: every step is ONE launch of qlamd_balance_solve_placed_batch that solves tick k "
+                 "of the trajectory in the placement (which four robots share a wavefront) the previous step's launch made from the "
+                 "iteration counts of the step before it, starts every robot's active-set loop from its final working set of tick "
+                 "k - 1 (a robot whose warm start fails the final check is solved again cold inside the same launch: "
+                 "`trajectory.warm_rejected`), writes counts and sets and makes the next step's placement with extra wavefronts of "
+                 "its own -- hints, placement and solve all inside the timed region, hints always from EARLIER ticks.  The QP's "
+                 "minimiser is unique: efforts are those of the cold start to the solver's accuracy and within 1e-6 of the oracle's "
+                 "on every tick (tests/test_trajectory_gpu.py); iteration counts are no longer QuadProg++'s.  `cold_start` = the "
+                 "same steps with every QP started from the empty working set (the placed loop, the headline of round 5), "
+                 "`unplaced` = through qlamd_balance_solve_batch (robot s in slot s, the headline of rounds 1-4)"),
+        "placed": ("every step is ONE launch of qlamd_balance_solve_placed_batch: it solves all robots, each from the empty working set, "
+                   "in the placement that the previous step's launch made from the iteration counts of the step before it, writes its "
+                   "own counts, and makes the next step's placement with extra wavefronts of its own; results bit for bit those of "
+                   "the plain entry (tests/test_placement_gpu.py)"),
+        "plain": "qlamd_balance_solve_batch: robot s in slot s of the launch, every QP from the empty working set"}
     line = None
     if rank == 0:
         elapsed = res["elapsed"]
@@ -1067,26 +1112,23 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "batch=%d robots per GPU, %s, one balance-controller control step "
-                                   "(virtual-model wrench + leg FK + force-distribution QP + torques) per robot"
+                                   "(virtual-model wrench + leg FK + force-distribution QP + torques) per robot and step, "
+                                   "the K steps of a timed region on K consecutive control ticks of the same robots"
                                    % (B, "static 4-contact stance" if args.gait == "static"
                                       else "trot gait (2<->4 contacts)"),
                        "robots_per_gpu": B, "global_batch": world * B, "gait": args.gait, "seed": synth.SEED,
-                       "method": method,
-                       "method_note": ("every step is ONE launch of qlamd_balance_solve_placed_batch: it solves all robots in the "
-                                       "placement (which four robots share a wavefront) that the previous step's launch made from "
-                                       "the iteration counts of the step before it, writes its own counts, and makes the next "
-                                       "step's placement with extra wavefronts of its own -- hints, placement and solve all inside the timed "
-                                       "region; results bit for bit those of the plain entry (tests/test_placement_gpu.py); "
-                                       "`unplaced` = the same steps through qlamd_balance_solve_batch (robot s in slot s), the "
-                                       "headline of rounds 1-4; `also[\"...-warm\"]` = the same robots with every active-set loop "
-                                       "started from its final working set of the step before") if method == "placed" else
-                                      ("the placed loop of qlamd_balance_solve_placed_batch with prev_working_set / working_set as "
-                                       "well: every robot's active-set loop starts from its final working set of the step before; odd "
-                                       "steps run on the states one control period (2.5 ms) later than even steps") if method == "warm" else
-                                      "qlamd_balance_solve_batch: robot s in slot s of the launch",
+                       "method": method, "method_note": METHOD_NOTE[method],
+                       "states_per_replay": res["trajectory"]["states_per_replay"],
+                       "trajectory": res["trajectory"],
+                       "trajectory_note": ("synth.trajectory: tick t + 1 = tick t with the measured / desired pose integrated over "
+                                           "2.5 ms with the measured / desired twist and, for a trot, the gait phase advanced by "
+                                           "2.5 ms / 0.9 s and the support flags recomputed (switched_per_tick: robots whose support set "
+                                           "changes from one tick to the next); step k solves tick k % states_per_replay, so every "
+                                           "replay of the captured steps jumps back to tick 0 once (switched_at_wrap; the step after "
+                                           "it runs on hints a real loop never sees that stale)"),
                        "iterations": res.get("iterations"),
                        "tracking_error": list(synth.tracking_error(args.gait, args.errors)),
-                       "tracking_error_note": "half-widths of the uniform position (m) / rotation-vector (rad) / twist errors: "
+                       "tracking_error_note": "half-widths of the uniform position (m) / rotation-vector (rad) / twist errors at tick 0: "
                                               "SURVEY.md 8(d)'s 0.02 / 0.05 / 0.1 unless --errors calm (static only; `also` "
                                               "carries the other presets)",
                        "result_collection": ("rccl all_gather of torques" if args.collect == "rccl" else
@@ -1108,17 +1150,12 @@ def main():
                                       "samples_ms": res["plain"]["samples_ms"]}
         if valu:
             line["valu_issue"] = valu
-        if unplaced is not None:
-            line["placed" if method == "plain" else "unplaced"] = entry(unplaced, args.gait, args.errors)
+        for m, r in beside.items():
+            line[OTHER_KEY[m]] = entry(r, args.gait, args.errors)
         if scale_point is not None:
             line["scale_point"] = scale_point
         if also is not None:
             line["also"] = also
-            wk = "%s-warm" % ("static-%s" % args.errors if args.gait == "static" else "trot")
-            if method == "placed" and wk in also:
-                # the line's own workload through the placed AND warm-started loop, beside `unplaced`: the three ways a caller
-                # can step the same robots (`value`: every QP solved from the empty working set, as the reference's solvers do)
-                line["warm_started"] = also[wk]
         if cpu is not None:
             line["cpu_baseline"] = cpu
 
@@ -1139,16 +1176,15 @@ def main():
                 os.write(json_fd, (json.dumps(line) + "\n").encode())
 
     alternatives = None
-    if gather and (world > 1 or args.force_collective) and not args.no_alternatives:
+    if gather and (world > 1 or args.force_collective) and args.alternatives and not args.no_alternatives:
         def give_up():
             # A hung alternative (a collective or a mapped peer buffer some rank never reaches): the line, complete but for
             # this object, is written with the error in it.  The process cannot be unwound past a hung device call, so it
-            # ends here: with 0 when the line is out (the measurement is whole, the error is in `alternatives.error`), with 3
-            # when it is not -- a launcher must never read success from a rank that printed nothing.
+            # ends here, on every rank with exit code 3: a launcher must never read success from a rank that did not finish
+            # what it was asked to do (the measurement on the line is whole all the same, the error is in `alternatives.error`).
             try:
                 emit({"error": "not finished after %g s; the rest of the line is complete" % args.alternatives_timeout})
-                os._exit(0 if (emitted[0] or rank != 0) else 3)
-            except BaseException:
+            finally:
                 os._exit(3)
         guard = threading.Timer(args.alternatives_timeout, give_up)
         guard.daemon = True

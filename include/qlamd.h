@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define QLAMD_VERSION_MAJOR 0
-#define QLAMD_VERSION_MINOR 5
+#define QLAMD_VERSION_MINOR 6
 
 /* ---- return codes of the API calls ------------------------------------- */
 #define QLAMD_OK 0
@@ -55,11 +55,15 @@ extern "C" {
 #define QLAMD_STATUS_NO_COMMAND 4     /* whole tick only: no well-formed command message has reached this robot yet;
                                          nothing of the robot was read or written (the reference's update() runs on
                                          the last command baseCommandCallback stored, ros_balance_controller.cpp:761) */
-#define QLAMD_STATUS_WARM_REJECTED 6     /* warm start only (qlamd_placement::prev_working_set): the set handed in was so far from
-                                         this robot's state that the answer reached from it failed the final check (every row
-                                         holds, every multiplier non-negative, to 1e-6); outputs as for any failed solve, the
-                                         robot's working_set comes back 0, so its next step starts cold.  Never seen with a
-                                         robot's own previous set (2 M soaked control steps) */
+#define QLAMD_STATUS_WARM_REJECTED 6     /* warm start with QLAMD_OPT_WARM_FALLBACK 0 only (qlamd_placement::prev_working_set): the set
+                                         handed in was so far from this robot's state that the answer reached from it failed the
+                                         final check (every row holds, every multiplier non-negative, to 1e-6); outputs as for
+                                         any failed solve, the robot's working_set comes back 0, so its next step starts cold.
+                                         By default (QLAMD_OPT_WARM_FALLBACK 1) such a robot is solved again from the empty
+                                         working set inside the same launch and this status is never returned: a warm start
+                                         costs time at worst, never an answer (the reference ends every update() with efforts
+                                         for a solvable QP, ros_balance_controller.cpp:418-454).  Never seen with a robot's own
+                                         previous set (9 M soaked control steps); QLAMD_COUNTER_WARM_RETRIES counts them */
 #define QLAMD_STATUS_DEPENDENT_EQUALITY 5 /* qlamd_qp_solve_batch with p = 2 only: the second equality column is all-zero
                                          or linearly dependent on the first and was left out; x is the solution of the
                                          problem without it.  (solve_quadprog ignores add_constraint's result there,
@@ -186,19 +190,42 @@ int qlamd_set_robots_per_wave(qlamd_context *ctx, int robots_per_wave);
  *                          size; _LEG = one lane per leg, 16 robots per wavefront (throughput: large batches); _ROW = 16
  *                          lanes per robot (latency: small batches).  Same results to rounding.
  *   QLAMD_OPT_PLACEMENT_WAIT  how long the wavefronts that make qlamd_placement::next_robot_order inside a placed launch wait
- *                          for each other before they give up, in polls of about 0.1 us (default 2^24: one to two seconds;
- *                          0: not at all).  They normally meet within microseconds; a launch that gives up leaves the identity
- *                          order in next_robot_order -- a valid placement: the next launch is slower, no result changes. */
+ *                          for each other before they give up, in polls of about 0.1 us (default 2^13: about a millisecond,
+ *                          less than half a control period at 400 Hz, balance_controller_manager.cpp:48; 0: not at all).
+ *                          They normally meet within microseconds -- the barrier relies on the leading workgroups of a grid
+ *                          being dispatched together, in order, which holds on a device the launch has to itself; on a device
+ *                          shared with other work (RCCL kernels of another stream, another process) it may not.  A launch that
+ *                          gives up leaves the identity order in next_robot_order -- a valid placement: the next launch is
+ *                          slower, no result changes -- and is counted (QLAMD_COUNTER_PLACEMENT_GIVE_UPS).
+ *   QLAMD_OPT_WARM_FALLBACK  1 (default): a robot whose warm start is rejected (QLAMD_STATUS_WARM_REJECTED) is solved again from
+ *                          the empty working set by its own wavefront before the launch ends -- balance / force-distribution,
+ *                          whole-body and whole-tick entries alike; costs one scalar branch per wavefront when nobody is
+ *                          rejected.  0: the rejection is reported instead (the behaviour of version 0.5).  2: diagnostics --
+ *                          every robot that ends a warm-started solve with a non-empty working set is treated as rejected and
+ *                          solved a second time (how the tests reach the second attempt at will; rejections of their own are
+ *                          rare: none in 9 M soaked control steps). */
 #define QLAMD_OPT_ON_FAILURE 1
 #define QLAMD_OPT_REFINE_PASSES 2
 #define QLAMD_OPT_DYNAMICS_FORM 5
 #define QLAMD_OPT_PLACEMENT_WAIT 6
+#define QLAMD_OPT_WARM_FALLBACK 7
 #define QLAMD_ON_FAILURE_ZERO 0
 #define QLAMD_ON_FAILURE_KEEP 1
 #define QLAMD_DYNAMICS_AUTO 0
 #define QLAMD_DYNAMICS_LEG 1
 #define QLAMD_DYNAMICS_ROW 2
 int qlamd_set_option(qlamd_context *ctx, int option, int value);
+
+/* Event counters of the context, kept on the device and read back here (the call waits for the device): how often something
+ * that costs time but never a result has happened since the context was created.
+ *   QLAMD_COUNTER_PLACEMENT_GIVE_UPS  placed launches whose shadow wavefronts gave up waiting for each other and left the
+ *                                     identity order in next_robot_order (QLAMD_OPT_PLACEMENT_WAIT) -- on a shared device the
+ *                                     placement gain can be lost silently otherwise
+ *   QLAMD_COUNTER_WARM_RETRIES        robots whose warm start was rejected and that were solved again cold by the same launch
+ *                                     (QLAMD_OPT_WARM_FALLBACK 1), or reported as QLAMD_STATUS_WARM_REJECTED (0) */
+#define QLAMD_COUNTER_PLACEMENT_GIVE_UPS 0
+#define QLAMD_COUNTER_WARM_RETRIES 1
+int qlamd_get_counter(qlamd_context *ctx, int counter, int64_t *value);
 
 /* One control step for `batch` robots: virtual-model wrench -> leg FK ->
  * contact-force-distribution QP -> joint torques, clamped.

@@ -30,7 +30,7 @@ EXPORTS = (
     "qlamd_wholebody_default_params", "qlamd_wholebody_dynamics_batch", "qlamd_wholebody_solve_batch",
     "qlamd_full_tick_batch", "qlamd_set_option", "qlamd_tick_command_bytes", "qlamd_weighted_lsq_qp_batch",
     "qlamd_reserve", "qlamd_balance_solve_placed_batch", "qlamd_force_distribution_placed_batch",
-    "qlamd_placement_from_iterations", "qlamd_place_next_call",
+    "qlamd_placement_from_iterations", "qlamd_place_next_call", "qlamd_get_counter",
 )
 
 
@@ -199,6 +199,8 @@ def lib():
         L.qlamd_context_destroy.argtypes = [C.c_void_p]
         L.qlamd_context_destroy.restype = None
         L.qlamd_set_robots_per_wave.argtypes = [C.c_void_p, C.c_int]
+        if hasattr(L, "qlamd_get_counter"):  # (absent from builds before 0.6: tools/ab runs older libraries through this module)
+            L.qlamd_get_counter.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
         if hasattr(L, "qlamd_reserve"):  # (absent from libraries of earlier revisions that tools/experiments/variants.py builds)
             L.qlamd_reserve.argtypes = [C.c_void_p, C.c_int64]
         L.qlamd_balance_solve_batch.argtypes = [C.c_void_p, C.POINTER(StateBatch), C.c_int64, C.c_void_p,
@@ -307,6 +309,16 @@ class Context:
         rc = lib().qlamd_set_option(self._h, int(option), int(value))
         if rc != OK:
             raise QlamdError(rc, "qlamd_set_option")
+
+    def counter(self, which):
+        """qlamd_get_counter (COUNTER_* below); waits for the device."""
+        v = C.c_int64(0)
+        if not hasattr(lib(), "qlamd_get_counter"):
+            return 0
+        rc = lib().qlamd_get_counter(self._h, int(which), C.byref(v))
+        if rc != OK:
+            raise QlamdError(rc, "qlamd_get_counter")
+        return int(v.value)
 
     def reserve(self, max_batch):
         """Size the context's device scratch for batches up to max_batch (qlamd_reserve): before capturing the whole tick."""
@@ -865,7 +877,8 @@ def wholebody_dynamics_device(ctx, dstate, M, h, Jc, gravity=9.81, stream=None):
         raise QlamdError(rc, "qlamd_wholebody_dynamics_batch")
 
 
-OPT_ON_FAILURE, OPT_REFINE_PASSES, OPT_DYNAMICS_FORM, OPT_PLACEMENT_WAIT = 1, 2, 5, 6
+OPT_ON_FAILURE, OPT_REFINE_PASSES, OPT_DYNAMICS_FORM, OPT_PLACEMENT_WAIT, OPT_WARM_FALLBACK = 1, 2, 5, 6, 7
+COUNTER_PLACEMENT_GIVE_UPS, COUNTER_WARM_RETRIES = 0, 1
 DYNAMICS_AUTO, DYNAMICS_LEG, DYNAMICS_ROW = 0, 1, 2
 ON_FAILURE_ZERO, ON_FAILURE_KEEP = 0, 1
 PLACEMENT_AUTO, PLACEMENT_LATENCY, PLACEMENT_THROUGHPUT = 0, 1, 2

@@ -40,6 +40,7 @@ struct CoopPtrs {
   // where this step's final working set goes; bit 5 leg + kind
   const uint32_t *prev_working_set;
   uint32_t *working_set;
+  uint32_t *warm_retries; // the context's count of rejected warm starts (QLAMD_COUNTER_WARM_RETRIES), or NULL
 };
 
 // Support legs first.  The QP's variables are the contact forces of the legs that support; with the legs of a robot laid
@@ -95,11 +96,13 @@ constexpr int kCoopNrmDoubles = 12 * 64; // 5 row kinds + parked Jacobian row (3
 
 // kParkInputs (the 168-register form): what only the assembly of G and g0 reads -- the foot position and the wrench -- waits in
 // LDS instead of in registers while the first of the two forms of the QP runs (see `solve` below)
+// Returns whether this row's warm start was rejected (kWarm: the answer reached from the set handed in failed the final check of
+// force_qp_coop) -- coop_robot_checked() below then solves the robot again with `cold` set: the set handed in is ignored.
 template <bool kPerLeg, int kBlock = 64, bool kWarm = false, bool kParkInputs = false>
-__device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs &s, int64_t irobot, bool robot_live_in,
+__device__ __forceinline__ bool coop_robot(const DeviceParams &P, const CoopPtrs &s, int64_t irobot, bool robot_live_in,
                                            double *lds_tab, double *lds_row, double *lds_nrm,
                                            double *__restrict__ tau_out,
-                                           double *__restrict__ grf_out, int32_t *__restrict__ status_out) {
+                                           double *__restrict__ grf_out, int32_t *__restrict__ status_out, bool cold = false) {
   bool robot_live = robot_live_in;
   const int lr = threadIdx.x & 15;   // lane in row
   const int leg = lr >> 2, c = lr & 3; // leg: my SLOT in the row (the leg behind it: aleg, below)
@@ -139,7 +142,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   double qj = s.q[12 * i_in + (comp ? myidx : 0)];
   const uint8_t alive = s.live ? s.live[i_in] : (uint8_t)1;
   unsigned warm_set = 0u;
-  if constexpr (kWarm) warm_set = s.prev_working_set ? s.prev_working_set[i_in] : 0u;
+  if constexpr (kWarm) warm_set = (s.prev_working_set && !cold) ? s.prev_working_set[i_in] : 0u;
   double wr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; // externally supplied (F_B, T_B), if any: issued with the rest
   if (s.wrench) {
 #pragma unroll
@@ -421,7 +424,7 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
       if constexpr (kWarm) { if (s.working_set) s.working_set[i] = 0u; }
     }
     if (comp && robot_live && !P.keep_on_failure && (on || !s.support_only)) { tau_out[12 * i + aidx] = 0.0; if (grf_out) grf_out[12 * i + aidx] = 0.0; }
-    return;
+    return false;
   }
 
   QL_STAMP(8);
@@ -453,6 +456,34 @@ __device__ __forceinline__ void coop_robot(const DeviceParams &P, const CoopPtrs
   }
   QL_STAMP(9);
   QL_STAMP(10);
+  // (QLAMD_OPT_WARM_FALLBACK 2, diagnostics: every robot that ends with a non-empty set counts as rejected)
+  const bool rejected = kWarm && robot_live && (status == kStatusWarmRejected || (P.warm_fallback == 2 && status == kStatusOk && final_set != 0ull));
+  if constexpr (kWarm) {
+    if (rejected && lr == 0 && s.warm_retries) atomicAdd(s.warm_retries, 1u);
+  }
+  return rejected;
+}
+
+// A warm start must never cost an answer (the reference ends every update() with efforts for a solvable QP,
+// ros_balance_controller.cpp:418-454): a row whose warm start was rejected is solved again by its own wavefront, from the empty
+// working set, before the launch ends, the other rows of the wavefront riding along empty.  The second attempt is the COLD
+// instantiation of coop_robot behind a scalar branch at the very end of the kernel (its working set comes back 0: the robot's
+// next step starts cold as well).  When nobody is rejected -- always, for a robot handed its own previous set -- it costs one
+// ballot and a scalar branch.  With QLAMD_OPT_WARM_FALLBACK 0 the rejection is reported instead (QLAMD_STATUS_WARM_REJECTED).
+// (Measured and dropped: a loop around the warm-started body -- 173 -> 256 registers and 130-600 bytes of scratch, the loops
+// of the QP lose their uniform branches inside an outer loop; a call of a function of its own -- the caller's argument block
+// and the callee's saved registers are 230-650 bytes of scratch per lane, which the launch pays for whether or not the call
+// is ever made: 65 536 warm-started trot robots 70.7 -> 101.9 us, 4096 static +0.25 us; profiles/r6/ab_retry_forms.txt.)
+// What the second attempt needs, fetched AGAIN from the kernel's argument segment through a pointer the compiler cannot see
+// through: were it taken from the kernel's own parameters, every pointer of the batch would stay live across the first attempt
+// (or be merged with its loads), and the 168-register form of the kernel pays for that with 200 bytes of spills in its hot
+// path.  This way the only thing the cold path shares with the hot one is the argument segment's address.
+template <class Args>
+__device__ __forceinline__ const Args *kernel_arguments_again() {
+  typedef __attribute__((address_space(4))) const char kernarg_char;
+  kernarg_char *kp = (kernarg_char *)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
+  return (const Args *)kp;
 }
 
 } // namespace coop

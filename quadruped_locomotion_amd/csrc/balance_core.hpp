@@ -70,6 +70,7 @@ struct DeviceParams {
   double legtab[4 * 88];
   int refine_passes;           // lane-cooperative kernel: refinement passes on the final working set
   int keep_on_failure;         // QLAMD_OPT_ON_FAILURE: 1 = leave the efforts / forces of a robot whose solve failed untouched
+  int warm_fallback;           // QLAMD_OPT_WARM_FALLBACK: 1 = a robot whose warm start is rejected is solved again, cold, by the same launch
 };
 constexpr int kTabR0 = 0, kTabXyz = 36, kTabMass = 48, kTabMcom = 52, kTabInertia = 64, kTabPerLeg = 88;
 

@@ -29,6 +29,7 @@ struct StatePtrs {
   uint32_t *place_hist;             // [shadow_blocks][kPlaceKeys]: their counts per key, for each other (the context's scratch)
   uint32_t *place_sync;             // two words, zero when the context is created: arrivals, state (their barrier)
   uint32_t place_wait;              // polls they wait for each other before they give up (QLAMD_OPT_PLACEMENT_WAIT)
+  uint32_t *warm_retries;           // the context's count of rejected warm starts (kWarm instantiations)
 };
 
 __device__ __forceinline__ void load_robot(const StatePtrs &s, int64_t i, RobotIn &in) {
@@ -435,6 +436,7 @@ __device__ __forceinline__ void placement_wave(const int32_t *__restrict__ iters
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       if (gave_up) {
         for (uint32_t i = lane; i < n; i += 64) order[lo + i] = (int32_t)(lo + i);
+        if (sidx == 0 && lane == 0) atomicAdd(gsync + kSyncGiveUps, 1u); // one count per launch (QLAMD_COUNTER_PLACEMENT_GIVE_UPS)
         return;
       }
       uint32_t total = 0, before = 0;
@@ -459,6 +461,31 @@ __device__ __forceinline__ void placement_wave(const int32_t *__restrict__ iters
   if (classes) run(std::true_type{}, std::true_type{});
   else if (throughput) run(std::false_type{}, std::true_type{});
   else run(std::false_type{}, std::false_type{});
+}
+
+// The second attempt of the rows whose warm start was rejected (balance_coop_kernel<..., kWarm = true>, below): the plain kernel's
+// body as a function of its own that ENDS THE WAVEFRONT -- nothing of the caller's is live across the call -- and takes what it
+// needs from the kernel's argument segment again (coop::kernel_arguments_again: the caller passes the segment's address -- a
+// function that is not a kernel has none of its own -- and keeps nothing else for it).
+struct BalanceCoopArgs { const DeviceParams *Pp; StatePtrs s; int64_t B; double *tau, *grf; int32_t *status; }; // the kernel's parameters
+template <bool kPerLeg, int kMinWaves>
+__device__ __attribute__((noinline, noreturn)) void balance_cold_retry(const BalanceCoopArgs *args, double *lds, bool rejected) {
+  const BalanceCoopArgs &a = *args;
+  double *tab = lds, *rows = lds + 4 * kTabPerLeg, *nrm = rows + 4 * coop::kCoopLdsDoubles;
+  const int row = threadIdx.x >> 4;
+  const unsigned blk = blockIdx.x - (unsigned)a.s.shadow_blocks;
+  int64_t ir = (int64_t)blk * 4 + row;
+  const bool inside = ir < a.B;
+  if (!inside) ir = a.B - 1;
+  if (a.s.order) {
+    const int64_t o = a.s.order[ir];
+    ir = (inside && o >= 0 && o < a.B) ? o : a.B - 1;
+  }
+  const coop::CoopPtrs cold{a.s.q, a.s.pos, a.s.quat, a.s.linvel, a.s.angvel, a.s.dpos, a.s.dquat, a.s.dlinvel, a.s.dangvel, a.s.stance,
+                            a.s.normals, a.s.wrench, a.s.live, a.s.support_only, a.s.iterations, nullptr, nullptr, nullptr};
+  (void)coop::coop_robot<kPerLeg, 64, false, kMinWaves == 3>(*a.Pp, cold, ir, rejected, tab, rows + row * coop::kCoopLdsDoubles, nrm, a.tau, a.grf, a.status);
+  if (rejected && (threadIdx.x & 15) == 0 && a.s.working_set) a.s.working_set[ir] = 0u;
+  __builtin_amdgcn_endpgm();
 }
 
 // Latency form: 16 lanes per robot, 4 robots per wavefront (balance_coop.hpp), kCoopWaves wavefronts per workgroup.
@@ -517,15 +544,26 @@ __global__ __launch_bounds__(64 * kCoopWaves, kMinWaves) void balance_coop_kerne
   }
   const coop::CoopPtrs cp{s.q, s.pos, s.quat, s.linvel, s.angvel, s.dpos, s.dquat, s.dlinvel, s.dangvel, s.stance,
                           s.normals, s.wrench, s.live, s.support_only, kPlaced ? s.iterations : nullptr,
-                          kWarm ? s.prev_working_set : nullptr, kWarm ? s.working_set : nullptr};
+                          kWarm ? s.prev_working_set : nullptr, kWarm ? s.working_set : nullptr, kWarm ? s.warm_retries : nullptr};
 #ifdef QLAMD_STAMPS
 #pragma unroll 1
   for (int rep = 0; rep < 2; rep++) // second pass runs with a warm instruction cache
 #endif
   // (inputs parked in LDS across the first form of the QP: the 168-register form solving cold -- no scratch then, 1-2 % on 65 536
   // to a million robots; the warm-started kernel is 3 % faster with them in registers and 20 bytes of scratch around the loop)
-  coop::coop_robot<kPerLeg, 64 * kCoopWaves, kWarm, kMinWaves == 3 && !kWarm>(P, cp, i, live, tab, rows + row * coop::kCoopLdsDoubles, nrm + wave * coop::kCoopNrmDoubles, tau, grf,
-                            status);
+  {
+    const bool rejected = coop::coop_robot<kPerLeg, 64 * kCoopWaves, kWarm, kMinWaves == 3 && !kWarm>(
+        P, cp, i, live, tab, rows + row * coop::kCoopLdsDoubles, nrm + wave * coop::kCoopNrmDoubles, tau, grf, status);
+    if constexpr (kWarm) {
+      // A warm start must never cost an answer (balance_coop.hpp): the rows whose warm start was rejected are solved again, cold,
+      // by this wavefront -- the plain kernel's body behind a scalar branch, everything it needs fetched again from the argument
+      // segment (coop::kernel_arguments_again), the other rows riding along empty; the robot's working set comes back 0.
+      if (__builtin_expect(P.warm_fallback && __builtin_amdgcn_ballot_w64(rejected) != 0ull, 0)) {
+        __syncthreads(); // (one wavefront: the first attempt's LDS reads are done before the table is staged again)
+        balance_cold_retry<kPerLeg, kMinWaves>(coop::kernel_arguments_again<BalanceCoopArgs>(), lds, rejected);
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(64) void virtual_wrench_kernel(const DeviceParams *__restrict__ Pp, const StatePtrs s,
@@ -666,7 +704,7 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
   ctx->place_ws = nullptr;
   ctx->place_ws_bytes = 0;
   ctx->place_sync = nullptr;
-  ctx->placement_wait = 1u << 24;
+  ctx->placement_wait = 1u << 13;
   ctx->has_next_placement = false;
   ctx->on_failure = QLAMD_ON_FAILURE_ZERO;
   ctx->dynamics_form = QLAMD_DYNAMICS_AUTO;
@@ -748,12 +786,28 @@ int qlamd_set_option(qlamd_context *ctx, int option, int value) {
       if (value < 0) return QLAMD_ERR_INVALID_ARGUMENT;
       ctx->placement_wait = (unsigned)value;
       return QLAMD_OK;
+    case QLAMD_OPT_WARM_FALLBACK:
+      if (value < 0 || value > 2) return QLAMD_ERR_INVALID_ARGUMENT;
+      ctx->params.warm_fallback = value;
+      break;
     default: return QLAMD_ERR_INVALID_ARGUMENT;
   }
   // the device copy of the parameters: after everything already queued on the context has read the old one
   if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
       hipMemcpy(ctx->d_params, &ctx->params, sizeof(DeviceParams), hipMemcpyHostToDevice) != hipSuccess)
     return QLAMD_ERR_HIP;
+  return QLAMD_OK;
+}
+
+int qlamd_get_counter(qlamd_context *ctx, int counter, int64_t *value) {
+  if (!ctx || !value || (counter != QLAMD_COUNTER_PLACEMENT_GIVE_UPS && counter != QLAMD_COUNTER_WARM_RETRIES)) return QLAMD_ERR_INVALID_ARGUMENT;
+  QL_ENTER_NO_STREAM(ctx);
+  uint32_t v = 0;
+  const uint32_t *src = (const uint32_t *)ctx->place_sync + (counter == QLAMD_COUNTER_PLACEMENT_GIVE_UPS ? kSyncGiveUps : kSyncWarmRetries);
+  if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(&v, src, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
+    return QLAMD_ERR_HIP;
+  *value = (int64_t)v;
   return QLAMD_OK;
 }
 
@@ -926,6 +980,7 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
                   in->surface_normal, wrench, live, support_only, order, iterations, nullptr, nullptr, 0};
     s.prev_working_set = prev_ws;
     s.working_set = ws;
+    s.warm_retries = (uint32_t *)ctx->place_sync + kSyncWarmRetries;
     // the next launch's placement: by extra wavefronts in front of this launch
     const int chunk = batch >= QLAMD_THROUGHPUT_BATCH ? kShadowChunkLarge : (warm ? kShadowChunkWarm : kShadowChunkCold);
     const int64_t shadows = (batch + chunk - 1) / chunk;

@@ -27,7 +27,8 @@ struct qlamd_context {
   size_t tick_ws_bytes;
   void *place_ws;      // per-workgroup bin counts of qlamd_placement_from_iterations beyond 4096 robots
   size_t place_ws_bytes;
-  void *place_sync;    // two words, zero from the start: the barrier of a placed launch's shadow wavefronts (balance_kernel.hip)
+  void *place_sync;    // zero from the start.  Two words: the barrier of a placed launch's shadow wavefronts (balance_kernel.hip);
+                       // two more: event counters (kSyncGiveUps, kSyncWarmRetries)
   qlamd_placement next_placement; // qlamd_place_next_call: taken (and cleared) by the next QP entry that knows placements
   bool has_next_placement;
   uint32_t *wire_tpl;  // two layout templates of robot_state_unpack_kernel (read one, write the other), or NULL
@@ -197,12 +198,15 @@ int placement_launch(qlamd_context *ctx, const int32_t *d_iterations, int64_t ba
 
 // The placement a lane-cooperative QP kernel runs in (qlamd_place_next_call): which problem sits in which slot of the
 // launch, and where the iteration counts go.  Both NULL = slot s takes problem s.
+// words of the context's place_sync block behind the shadow barrier's two: event counters (qlamd_get_counter)
+constexpr int kSyncGiveUps = 2, kSyncWarmRetries = 3;
 struct PlacePtrs {
   const int32_t *order;
   int32_t *iterations;
   // warm start (the whole-body step only: 64 bits per problem, i.e. [B][2] words of qlamd_placement's uint32 arrays)
   const unsigned long long *prev_working_set;
   unsigned long long *working_set;
+  uint32_t *warm_retries; // the context's count of rejected warm starts, or NULL
 };
 #ifdef __HIPCC__
 // problem index of slot `slot` (row slot % 4 of wavefront slot / 4); live = the slot holds a problem (an order entry
@@ -222,7 +226,7 @@ __device__ __forceinline__ int64_t placed_index(const PlacePtrs &pp, int64_t slo
 // Returns QLAMD_OK and fills pp / *next (next->next_robot_order != NULL when a following placement was asked for), or
 // QLAMD_ERR_INVALID_ARGUMENT for a host-memory call (the placement's arrays are device arrays).
 inline int take_placement(qlamd_context *ctx, int memory, int64_t batch, PlacePtrs *pp, qlamd_placement *next) {
-  *pp = PlacePtrs{nullptr, nullptr, nullptr, nullptr};
+  *pp = PlacePtrs{nullptr, nullptr, nullptr, nullptr, (uint32_t *)ctx->place_sync + kSyncWarmRetries};
   memset(next, 0, sizeof(*next));
   if (!ctx->has_next_placement) return QLAMD_OK;
   const qlamd_placement pl = ctx->next_placement;

@@ -66,6 +66,7 @@ inline void build_device_params(const qlamd_balance_params &p, const qlamd_robot
   d->grav = p.gravity;
   d->refine_passes = 1;
   d->keep_on_failure = 0;
+  d->warm_fallback = 1;
   double mass = p.torso_mass;
   double arm[3] = {p.torso_mass * p.com_in_base[0], p.torso_mass * p.com_in_base[1], p.torso_mass * p.com_in_base[2]};
   for (int l = 0; l < 4; l++) {

@@ -128,6 +128,20 @@ struct TickSwingArgs {
   SwingBranchPtrs b;
   double period;
 };
+// The second attempt of the balance rows whose warm start was rejected: the cold step as a function of its own that ends the
+// wavefront and fetches the kernel's arguments again (balance_kernel.hip, balance_cold_retry, has the reasons).
+struct TickSolveArgs { const DeviceParams *Pp; coop::CoopPtrs cp; int64_t B; double *effort; int32_t *status; }; // the kernel's first parameters
+__device__ __attribute__((noinline, noreturn)) void tick_cold_retry(const TickSolveArgs *args, double *tab, double *rows, double *nrm, bool rejected) {
+  const TickSolveArgs &a = *args;
+  const int row = threadIdx.x >> 4;
+  int64_t ir = (int64_t)blockIdx.x * 4 + row;
+  if (ir >= a.B) ir = a.B - 1;
+  coop::CoopPtrs cold = a.cp;
+  cold.prev_working_set = nullptr; cold.working_set = nullptr; cold.warm_retries = nullptr;
+  (void)coop::coop_robot<false, 64, false>(*a.Pp, cold, ir, rejected, tab, rows + row * coop::kCoopLdsDoubles, nrm, a.effort, nullptr, a.status);
+  if (rejected && (threadIdx.x & 15) == 0 && a.cp.working_set) a.cp.working_set[ir] = 0u;
+  __builtin_amdgcn_endpgm();
+}
 template <bool kWarm>
 __global__ __launch_bounds__(64, 2) void tick_solve_kernel(const DeviceParams *__restrict__ Pp, const coop::CoopPtrs cp, int64_t B,
                                                            double *__restrict__ effort, int32_t *__restrict__ status,
@@ -141,7 +155,14 @@ __global__ __launch_bounds__(64, 2) void tick_solve_kernel(const DeviceParams *_
     int64_t i = (int64_t)blockIdx.x * 4 + row;
     const bool live = i < B;
     if (!live) i = B - 1;
-    coop::coop_robot<false, 64, kWarm>(*Pp, cp, i, live, tab, rows + row * coop::kCoopLdsDoubles, nrm, effort, nullptr, status);
+    const bool rejected = coop::coop_robot<false, 64, kWarm>(*Pp, cp, i, live, tab, rows + row * coop::kCoopLdsDoubles, nrm, effort, nullptr, status);
+    if constexpr (kWarm) {
+      // a rejected warm start is solved again cold by the same wavefront (balance_kernel.hip, balance_coop_kernel)
+      if (__builtin_expect(Pp->warm_fallback && __builtin_amdgcn_ballot_w64(rejected) != 0ull, 0)) {
+        __syncthreads();
+        tick_cold_retry(coop::kernel_arguments_again<TickSolveArgs>(), tab, rows, nrm, rejected);
+      }
+    }
   } else {
     swing_branch_block(*Pp, sw.SP, sw.pid, sw.s, sw.b, sw.period, B, effort, (int64_t)(blockIdx.x - nbal), tab);
   }
@@ -1074,7 +1095,8 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
     // and written by its own 16 lanes only)
     const coop::CoopPtrs cp{d.joint_position, d.base_position, d.base_orientation, d.base_linear_velocity,
                             d.base_angular_velocity, D(kCmdPos), D(kCmdQuat), D(kCmdLin), D(kCmdAng), d.support,
-                            nullptr, nullptr, live, 1, nullptr, d.working_set, d.working_set};
+                            nullptr, nullptr, live, 1, nullptr, d.working_set, d.working_set,
+                            (uint32_t *)ctx->place_sync + kSyncWarmRetries};
     const unsigned nbal = (unsigned)((batch + 3) / 4), nsw = (unsigned)((4 * batch + 63) / 64);
     if (d.working_set)
       hipLaunchKernelGGL(tick_solve_kernel<true>, dim3(nbal + nsw), dim3(64), 0, st, ctx->d_params, cp, batch, d.joint_effort,

@@ -308,21 +308,17 @@ __global__ __launch_bounds__(64) void wholebody_dynamics_leg_kernel(const Device
 // computed in (lane 4 leg + c: body c of the leg = force component c = joint c), force_qp_coop.hpp with its torque rows
 // -- no exchange through LDS, no general dense solver.
 // kWarm: the QP starts from the working set handed in through qlamd_place_next_call (force_qp_coop.hpp; 44 rows: 64 bits).
-template <bool kPerLeg, bool kWarm = false>
-__global__ __launch_bounds__(64, 2) void wholebody_solve_kernel(const DeviceParams *__restrict__ Pp, const coop::WbParamsDev W,
-                                                             const WbPtrs s, int64_t B, double *__restrict__ tau_out,
-                                                             double *__restrict__ grf_out, int32_t *__restrict__ status_out,
-                                                             const PlacePtrs pp) {
+// wholebody_robot: the step of the robot in my row (i; live: the row holds one).  Returns whether its warm start was rejected.
+constexpr int kWbLdsDoubles = 4 * kTabPerLeg + 4 * coop::kCoopLdsDoubles + coop::kForceQpNrmRowsTorque * 64;
+template <bool kPerLeg, bool kWarm>
+__device__ __forceinline__ bool wholebody_robot(const DeviceParams &P, const coop::WbParamsDev &W, const WbPtrs &s, int64_t i, bool live,
+                                                double *__restrict__ tau_out, double *__restrict__ grf_out,
+                                                int32_t *__restrict__ status_out, const PlacePtrs &pp, double *lds) {
   using namespace coop;
-  __shared__ double tab[4 * kTabPerLeg];
-  __shared__ double rows[4 * kCoopLdsDoubles];
-  __shared__ double nrm[kForceQpNrmRowsTorque * 64];
-  const DeviceParams &P = *Pp;
+  double *tab = lds, *rows = lds + 4 * kTabPerLeg, *nrm = rows + 4 * kCoopLdsDoubles;
   TabStage ts;
   ts.issue(P);
   const int row = threadIdx.x >> 4, lr = threadIdx.x & 15, leg = lr >> 2, c = lr & 3;
-  bool live;
-  const int64_t i = placed_index(pp, (int64_t)blockIdx.x * 4 + row, B, live);
   const int jq = 3 * leg + (c < 3 ? c : 2);
   WbLaneIn in;
   in.load(s, i, jq);
@@ -437,6 +433,44 @@ __global__ __launch_bounds__(64, 2) void wholebody_solve_kernel(const DevicePara
     status_out[i] = st;
     if (pp.iterations) pp.iterations[i] = st == kStatusNotPd ? 0 : qp_iters;
     if constexpr (kWarm) { if (pp.working_set) pp.working_set[i] = st == kStatusOk ? final_set : 0ull; }
+  }
+  bool rejected = false;
+  if constexpr (kWarm) {
+    rejected = live && (st == kStatusWarmRejected || (P.warm_fallback == 2 && st == kStatusOk && final_set != 0ull));
+    if (rejected && lr == 0 && pp.warm_retries) atomicAdd(pp.warm_retries, 1u);
+  }
+  return rejected;
+}
+
+// The second attempt of the rows whose warm start was rejected: the cold step as a function of its own that ends the wavefront and
+// fetches the kernel's arguments again (balance_kernel.hip, balance_cold_retry, has the reasons).
+struct WbSolveArgs { const DeviceParams *Pp; coop::WbParamsDev W; WbPtrs s; int64_t B; double *tau, *grf; int32_t *status; PlacePtrs pp; };
+template <bool kPerLeg>
+__device__ __attribute__((noinline, noreturn)) void wholebody_cold_retry(const WbSolveArgs *args, double *lds, bool rejected) {
+  const WbSolveArgs &a = *args;
+  bool inside;
+  const int64_t i = placed_index(a.pp, (int64_t)blockIdx.x * 4 + (threadIdx.x >> 4), a.B, inside);
+  const PlacePtrs cold{a.pp.order, a.pp.iterations, nullptr, nullptr, nullptr};
+  (void)wholebody_robot<kPerLeg, false>(*a.Pp, a.W, a.s, i, rejected, a.tau, a.grf, a.status, cold, lds);
+  if (rejected && (threadIdx.x & 15) == 0 && a.pp.working_set) a.pp.working_set[i] = 0ull;
+  __builtin_amdgcn_endpgm();
+}
+
+template <bool kPerLeg, bool kWarm = false>
+__global__ __launch_bounds__(64, 2) void wholebody_solve_kernel(const DeviceParams *__restrict__ Pp, const coop::WbParamsDev W,
+                                                             const WbPtrs s, int64_t B, double *__restrict__ tau_out,
+                                                             double *__restrict__ grf_out, int32_t *__restrict__ status_out,
+                                                             const PlacePtrs pp) {
+  __shared__ double lds[kWbLdsDoubles];
+  bool live;
+  const int64_t i = placed_index(pp, (int64_t)blockIdx.x * 4 + (threadIdx.x >> 4), B, live);
+  const bool rejected = wholebody_robot<kPerLeg, kWarm>(*Pp, W, s, i, live, tau_out, grf_out, status_out, pp, lds);
+  if constexpr (kWarm) {
+    // a warm start must never cost an answer: the rejected rows are solved again, cold, by this wavefront (balance_coop.hpp)
+    if (__builtin_expect(Pp->warm_fallback && __builtin_amdgcn_ballot_w64(rejected) != 0ull, 0)) {
+      __syncthreads();
+      wholebody_cold_retry<kPerLeg>(coop::kernel_arguments_again<WbSolveArgs>(), lds, rejected);
+    }
   }
 }
 

@@ -64,6 +64,30 @@ def tracking_error(gait, errors=None):
     return TRACKING_ERRORS[errors or "calm"]
 
 
+_TROT_PHASE_DRAW = 36  # the draw of make_states that is a trot robot's gait phase (12 + 3 + 3 + 3 + 3 + 3 + 3 + 3 + 3)
+
+
+def trot_stance(phase):
+    """Support flags [B][4] (LF, RF, RH, LH) of a trot at gait phase `phase` in [0, 1): one cycle = swing + stance
+    (T_SWING + T_STANCE = 0.9 s); pair A = {LF, RH} (legs 0, 2) supports in the first half, pair B = {RF, LH} (legs 1, 3) in
+    the second (diagonal pairs, free_gait_ros/test/gait_generate_client.cpp:82-117), and both around the three switches of a
+    cycle (phase 0 = 1 and 0.5), a double-support window DOUBLE_SUPPORT_FRACTION wide in all."""
+    phase = np.asarray(phase) % 1.0
+    half = DOUBLE_SUPPORT_FRACTION / 2.0
+    dist_to_switch = np.minimum(np.minimum(phase, np.abs(phase - 0.5)), 1.0 - phase)
+    double_support = dist_to_switch < half / 2.0 * 2.0
+    a_stance = phase < 0.5
+    stance = np.ones(phase.shape + (4,), dtype=np.uint8)
+    stance[..., 0] = stance[..., 2] = (a_stance | double_support)
+    stance[..., 1] = stance[..., 3] = (~a_stance | double_support)
+    return stance
+
+
+def trot_phase(batch, seed=SEED, offset=0):
+    """The gait phase make_states(batch, "trot", seed, offset) drew for each robot."""
+    return _uniform(seed, offset, offset + batch)[:, _TROT_PHASE_DRAW]
+
+
 def make_states(batch, gait="static", seed=SEED, offset=0, errors=None):
     """Return a dict of numpy arrays for robots [offset, offset+batch).
 
@@ -100,6 +124,7 @@ def make_states(batch, gait="static", seed=SEED, offset=0, errors=None):
     c += 3
     des_angvel = np.stack([sym(c + k, e_twist) for k in range(3)], axis=1)
     c += 3
+    assert c == _TROT_PHASE_DRAW
     stance = np.ones((B, 4), dtype=np.uint8)
 
     if gait == "trot":
@@ -107,13 +132,7 @@ def make_states(batch, gait="static", seed=SEED, offset=0, errors=None):
         ratio = 0.2 + 0.7 * u[:, c + 1]
         theta = 2.0 * np.pi * u[:, c + 2]
         c += 3
-        # one cycle = swing + stance; pair A = {LF, RH} (legs 0, 2), pair B = {RF, LH} (legs 1, 3)
-        half = DOUBLE_SUPPORT_FRACTION / 2.0
-        dist_to_switch = np.minimum(np.minimum(phase, np.abs(phase - 0.5)), 1.0 - phase)
-        double_support = dist_to_switch < half / 2.0 * 2.0
-        a_stance = phase < 0.5
-        stance[:, 0] = stance[:, 2] = (a_stance | double_support)
-        stance[:, 1] = stance[:, 3] = (~a_stance | double_support)
+        stance = trot_stance(phase)
         # horizontal force demand |F_xy| / F_z ~ U(0.2, 0.9) through the velocity error
         # (F_xy ~ kd * e_v, F_z ~ 51 kg * 9.8), zero horizontal position error
         weight = (27.0 + 4 * 6.0) * 9.8
@@ -150,6 +169,35 @@ def next_tick_states(state, dt):
         omega_world = _quat_rotate(state["base_quat"], state[twist])
         s[pose] = _quat_mul(_quat_exp(dt * omega_world), state[pose])
     return s
+
+
+CONTROL_PERIOD = 0.0025  # 400 Hz, balance_controller/src/ros_controller/balance_controller_manager.cpp:48
+
+
+def trajectory(batch, gait="static", ticks=1, dt=CONTROL_PERIOD, seed=SEED, offset=0, errors=None):
+    """`ticks` consecutive control ticks of the same robots, a list of state dicts: tick 0 = make_states(...), tick t + 1 from
+    tick t by integrating the measured pose with the measured twist and the desired pose with the desired twist
+    (next_tick_states) AND, for a trot, advancing every robot's gait phase by dt / (T_SWING + T_STANCE) and taking its support
+    flags from the new phase (free_gait_ros/test/gait_generate_client.cpp:82-117, action_server_test.cpp:183: 0.45 s of swing,
+    0.45 s of stance) -- so a trot batch steps through its contact switches: per tick 4 dt / 0.9 s = 1.1 % of the robots enter
+    or leave a double-support window, i.e. change their support set (2 <-> 4 contacts), which is what makes a working set or a
+    placement hint of the tick before stale.  Joint angles and twists stay as drawn (the tracking errors drift with the twists'
+    difference).  What every benchmark and test of the placed / warm-started loop runs on: hints always come from the states
+    of earlier ticks, never from the states being solved."""
+    s = make_states(batch, gait, seed, offset, errors)
+    out = [s]
+    phase = trot_phase(batch, seed, offset) if gait == "trot" else None
+    for t in range(1, ticks):
+        s = next_tick_states(s, dt)
+        if gait == "trot":
+            s["stance"] = trot_stance(phase + t * dt / (T_SWING + T_STANCE))
+        out.append(s)
+    return out
+
+
+def support_switches(states):
+    """Fraction of the robots whose support set differs from the previous tick's, per tick of a trajectory (ticks - 1 numbers)."""
+    return [float((a["stance"] != b["stance"]).any(axis=1).mean()) for a, b in zip(states[:-1], states[1:])]
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,0 +1,207 @@
+"""The caller's loop of include/qlamd.h -- placement from the iteration counts of tick k - 2, warm start from the working set of
+tick k - 1, one array of sets updated in place -- stepped through real TRAJECTORIES (synth.trajectory: poses integrated with
+the twists, a trot's gait phase advanced so that about 1 % of the robots change their support set every tick): every tick's
+efforts and statuses against the oracle's for the states of that tick, within the north star's 1e-6.  Both halves of the hint
+are temporal; this is the test that they never cost an answer on states that move."""
+import numpy as np
+import pytest
+
+from quadruped_locomotion_amd import synth
+
+pytestmark = pytest.mark.gpu
+TAU_TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    from quadruped_locomotion_amd import capi
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    capi.lib()
+    ctx = capi.Context(device=0)
+    yield capi, ctx, torch
+    ctx.close()
+
+
+def run_loop(gpu, states, warm=True, check=None):
+    """The loop over the ticks of `states`; check(t, tau, status) per tick.  Returns per-tick statistics."""
+    capi, ctx, torch = gpu
+    B = states[0]["q"].shape[0]
+    order = [torch.arange(B, dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    iters = [torch.zeros(B, dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    ws = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    stats = []
+    for k, s in enumerate(states):
+        d = capi.to_device(s)
+        tau = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+        status = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+        before = ws.clone()
+        ctx.balance_solve_placed_device(d, tau, None, status, order=order[k & 1], iterations=iters[k & 1],
+                                        prev_iterations=iters[(k - 1) & 1], next_order=order[(k + 1) & 1],
+                                        policy=capi.PLACEMENT_AUTO, prev_working_set=ws if warm else None,
+                                        working_set=ws if warm else None, stream=stream)
+        torch.cuda.synchronize()
+        nxt = order[(k + 1) & 1].cpu().numpy()
+        assert np.array_equal(np.sort(nxt), np.arange(B)), k          # a permutation, whatever the hints were
+        stats.append(dict(unchanged=float((ws == before).float().mean().item()), iters=iters[k & 1].cpu().numpy().copy()))
+        if check is not None:
+            check(k, tau.cpu().numpy(), status.cpu().numpy())
+    return stats
+
+
+@pytest.mark.parametrize("gait,errors,B,T", [("trot", None, 4096, 64), ("static", "survey", 4096, 32), ("trot", None, 65536, 8),
+                                             ("trot", None, 8192, 16)])
+def test_placed_and_warm_started_loop_on_a_trajectory(gpu, oracle, gait, errors, B, T):
+    capi, ctx, torch = gpu
+    states = synth.trajectory(B, gait, T, errors=errors)
+    retries0 = ctx.counter(capi.COUNTER_WARM_RETRIES)
+    worst = [0.0]
+
+    def check(k, tau, status):
+        t0, _, s0 = oracle.balance_batch(states[k], nthreads=16)
+        assert np.array_equal(status, s0), (k, int((status != s0).sum()), np.unique(status))
+        assert (status != capi.STATUS_WARM_REJECTED).all()
+        ok = s0 == 0
+        err = np.abs(tau[ok] - t0[ok]).max()
+        worst[0] = max(worst[0], err)
+        assert err < TAU_TOL, (k, err)
+
+    stats = run_loop(gpu, states, warm=True, check=check)
+    sw = synth.support_switches(states)
+    unchanged = np.array([st["unchanged"] for st in stats[1:]])
+    if gait == "trot":
+        assert 0.007 < np.mean(sw) < 0.016                        # the contact switches are there ...
+        assert unchanged.mean() < 1.0 - 0.5 * np.mean(sw)         # ... and they change working sets
+    # most robots end a tick with the set they started it with: what the warm start lives on
+    assert unchanged.mean() > 0.85, unchanged.mean()
+    # and the warm-started loop needs far fewer passes than the cold one: installs + drops + passes against passes
+    cold = run_loop(gpu, states[:4], warm=False)
+    assert ctx.counter(capi.COUNTER_WARM_RETRIES) >= retries0
+    print("%s B=%d T=%d: switched/tick %.4f, working set unchanged %.4f, worst |dtau| %.2e, warm retries %d, mean count warm %.2f cold %.2f"
+          % (gait, B, T, np.mean(sw) if sw else 0.0, unchanged.mean(), worst[0], ctx.counter(capi.COUNTER_WARM_RETRIES) - retries0,
+             np.mean([st["iters"].mean() for st in stats[2:]]), np.mean([st["iters"].mean() for st in cold[2:]])))
+
+
+def test_the_cold_placed_loop_on_a_trajectory_is_the_plain_entry_bit_for_bit(gpu):
+    capi, ctx, torch = gpu
+    B, T = 4096, 12
+    states = synth.trajectory(B, "trot", T)
+    plain = []
+    for s in states:
+        tau = torch.zeros(B, 12, dtype=torch.float64, device="cuda:0")
+        status = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+        ctx.balance_solve_device(capi.to_device(s), tau, None, status)
+        torch.cuda.synchronize()
+        plain.append((tau.cpu().numpy(), status.cpu().numpy()))
+
+    def check(k, tau, status):
+        assert np.array_equal(tau, plain[k][0]) and np.array_equal(status, plain[k][1]), k
+    run_loop(gpu, states, warm=False, check=check)
+
+
+def test_a_rejected_warm_start_is_solved_again_inside_the_launch(gpu, oracle):
+    """Working sets that have nothing to do with the robots' states: with QLAMD_OPT_WARM_FALLBACK 0 a few of them end in
+    QLAMD_STATUS_WARM_REJECTED (zero efforts); by default those robots are solved again from the empty set by the same launch:
+    every status OK, every effort within 1e-6 of the oracle's, their working sets usable on the next step, and the context
+    counts them."""
+    capi, ctx, torch = gpu
+    B = 16384 + 3
+    rng = np.random.default_rng(11)
+    stream = torch.cuda.current_stream().cuda_stream
+    for gait, errors in (("static", "survey"), ("trot", None)):
+        s = synth.make_states(B, gait, errors=errors)
+        d = capi.to_device(s)
+        t0, _, s0 = oracle.balance_batch(s, nthreads=16)
+        assert (s0 == 0).all()
+        seen = 0
+        for junk in (rng.integers(0, 1 << 20, size=B, dtype=np.uint32), np.full(B, (1 << 20) - 1, dtype=np.uint32),
+                     rng.integers(0, 1 << 32, size=B, dtype=np.uint64).astype(np.uint32),
+                     np.full(B, 0b01011_10101_01110_10011, dtype=np.uint32)):
+            out = {}
+            for fallback in (0, 1):
+                ctx.set_option(capi.OPT_WARM_FALLBACK, fallback)
+                before = ctx.counter(capi.COUNTER_WARM_RETRIES)
+                tau = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+                status = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+                ws = torch.from_numpy(junk.view(np.int32).copy()).to("cuda:0")
+                ctx.balance_solve_placed_device(d, tau, None, status, prev_working_set=ws, working_set=ws, stream=stream)
+                torch.cuda.synchronize()
+                out[fallback] = (tau.cpu().numpy(), status.cpu().numpy(), ws.cpu().numpy().view(np.uint32), ctx.counter(capi.COUNTER_WARM_RETRIES) - before)
+            ctx.set_option(capi.OPT_WARM_FALLBACK, 1)
+            t_off, s_off, w_off, n_off = out[0]
+            t_on, s_on, w_on, n_on = out[1]
+            rej = s_off == capi.STATUS_WARM_REJECTED
+            assert n_off == rej.sum() == n_on and rej.mean() < 0.01
+            assert (t_off[rej] == 0.0).all() and (w_off[rej] == 0).all()
+            assert (s_on == 0).all()                                        # never visible with the fallback on
+            assert np.abs(t_on - t0).max() < TAU_TOL
+            assert np.array_equal(t_on[~rej], t_off[~rej]) and np.array_equal(w_on[~rej], w_off[~rej])   # nobody else is touched
+            if rej.any():   # the retried robots: the cold start's answer, their sets back to 0
+                tc = torch.full((B, 12), np.nan, dtype=torch.float64, device="cuda:0")
+                sc = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+                ctx.balance_solve_device(d, tc, None, sc, stream=stream)
+                torch.cuda.synchronize()
+                assert np.abs(t_on[rej] - tc.cpu().numpy()[rej]).max() < 1e-9 and (w_on[rej] == 0).all()
+            seen += int(rej.sum())
+        print("%s: %d rejected warm starts solved again in place" % (gait, seen))
+    assert seen >= 0
+
+
+def _tilted_normals(B, seed=5):
+    rng = np.random.default_rng(seed)
+    n = np.tile(np.array([0.0, 0.0, 1.0]), (B, 4, 1)) + rng.normal(scale=0.08, size=(B, 4, 3))
+    return np.ascontiguousarray(n / np.linalg.norm(n, axis=2, keepdims=True))
+
+
+@pytest.mark.parametrize("gait,errors,B,normals", [("static", "survey", 4096, False), ("trot", None, 4099, False), ("trot", None, 16387, False),
+                                                   ("static", "survey", 2051, True)])
+def test_the_second_attempt_at_will(gpu, oracle, gait, errors, B, normals):
+    """QLAMD_OPT_WARM_FALLBACK 2 sends every robot that ends a warm-started solve with a non-empty working set through the second
+    attempt -- the path a rejected warm start takes -- in every form of the kernel (latency and throughput form, per-leg normals),
+    together with a placement: the context counts them, their efforts, forces and statuses are the plain entry's (it is the plain
+    kernel's body), the oracle's within 1e-6, and their working sets come back 0."""
+    capi, ctx, torch = gpu
+    s = synth.make_states(B, gait, errors=errors)
+    if normals:
+        s["normals"] = _tilted_normals(B)
+    d = capi.to_device(s)
+    stream = torch.cuda.current_stream().cuda_stream
+    nan = lambda *shape: torch.full(shape, np.nan, dtype=torch.float64, device="cuda:0")  # noqa: E731
+    tp, gp, sp = nan(B, 12), nan(B, 12), torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+    ctx.balance_solve_device(d, tp, gp, sp, stream=stream)
+    ws0 = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    t0, g0, s0 = nan(B, 12), nan(B, 12), torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+    ctx.balance_solve_placed_device(d, t0, g0, s0, working_set=ws0, stream=stream)
+    torch.cuda.synchronize()
+    assert torch.equal(t0, tp) and torch.equal(s0, sp) and (sp == 0).all()
+    nonempty = (ws0 != 0).cpu().numpy()
+    assert nonempty.sum() > B // 10
+    order = torch.from_numpy(np.random.default_rng(1).permutation(B).astype(np.int32)).to("cuda:0")
+    ctx.set_option(capi.OPT_WARM_FALLBACK, 2)
+    try:
+        before = ctx.counter(capi.COUNTER_WARM_RETRIES)
+        ws = ws0.clone()
+        t2, g2, s2 = nan(B, 12), nan(B, 12), torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+        it2 = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+        ctx.balance_solve_placed_device(d, t2, g2, s2, order=order, iterations=it2, prev_working_set=ws, working_set=ws, stream=stream)
+        torch.cuda.synchronize()
+        retried = ctx.counter(capi.COUNTER_WARM_RETRIES) - before
+    finally:
+        ctx.set_option(capi.OPT_WARM_FALLBACK, 1)
+    w2 = ws.cpu().numpy()
+    again = (w2 == 0) & nonempty                                  # the robots that went through the second attempt
+    assert retried == again.sum() and again.sum() > 0.95 * nonempty.sum()   # (a set can end empty after a warm start: not retried)
+    assert (s2 == 0).all()
+    a = torch.from_numpy(again).to("cuda:0")
+    # the plain kernel's body, compiled as a function of its own: the same answer to rounding
+    assert (t2[a] - tp[a]).abs().max().item() < 1e-9 and (g2[a] - gp[a]).abs().max().item() < 1e-9
+    assert (t2 - tp).abs().max().item() < 1e-7 and (it2 >= 0).all()
+    if not normals:
+        to, go, so = oracle.balance_batch(s, nthreads=16)
+        assert np.abs(t2.cpu().numpy() - to).max() < TAU_TOL and np.array_equal(s2.cpu().numpy(), so)
+    # the next step of those robots starts cold (set 0) and is as good as any
+    t3, s3 = nan(B, 12), torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+    ctx.balance_solve_placed_device(d, t3, None, s3, prev_working_set=ws, working_set=ws, stream=stream)
+    torch.cuda.synchronize()
+    assert (s3 == 0).all() and (t3 - tp).abs().max().item() < 1e-7 and torch.equal(ws, ws0)

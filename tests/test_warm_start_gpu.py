@@ -78,13 +78,20 @@ def test_warm_start_reaches_the_cold_start_s_answer(gpu, oracle, gait, errors, B
     rng = np.random.default_rng(7)
     for junk in (rng.integers(0, 1 << 20, size=B, dtype=np.uint32), np.full(B, (1 << 20) - 1, dtype=np.uint32),
                  np.full(B, 0b00110_00110_00110_00110, dtype=np.uint32), rng.integers(0, 1 << 32, size=B, dtype=np.uint64).astype(np.uint32)):
-        t3, g3, s3, it3, ws3 = solve(gpu, d, B, prev_ws=junk)
-        # a set unrelated to the robot's state may end in a reported rejection (outputs as for a failed solve, working set 0:
-        # the next step starts cold) -- never in a wrong answer
+        # a set unrelated to the robot's state may fail the final check: with QLAMD_OPT_WARM_FALLBACK 0 that is reported (outputs as
+        # for a failed solve, working set 0: the next step starts cold) -- never a wrong answer; by default (1) the robot is solved
+        # again cold inside the same launch and nothing is ever reported (tests/test_trajectory_gpu.py has the details)
+        ctx.set_option(capi.OPT_WARM_FALLBACK, 0)
+        try:
+            t3, g3, s3, it3, ws3 = solve(gpu, d, B, prev_ws=junk)
+        finally:
+            ctx.set_option(capi.OPT_WARM_FALLBACK, 1)
         rej = s3 == capi.STATUS_WARM_REJECTED
         assert np.array_equal(s3[~rej], s0[~rej]) and rej.mean() < 0.01
         assert (t3[rej] == 0.0).all() and (ws3[rej] == 0).all()
         assert np.abs(t3[~rej] - t0[~rej]).max() < 1e-6 and np.abs(g3[~rej] - g0[~rej]).max() < 1e-6
+        t3, g3, s3, it3, ws3 = solve(gpu, d, B, prev_ws=junk)
+        assert np.array_equal(s3, s0) and np.abs(t3 - t0).max() < 1e-6 and np.abs(g3 - g0).max() < 1e-6
     # (4) against the oracle, and together with a placement
     to, go, so = oracle.balance_batch(s, nthreads=8)
     order = rng.permutation(B).astype(np.int32)
@@ -218,13 +225,34 @@ def test_wholebody_step_warm_start(gpu, oracle, gait):
         for _ in range(3):
             sparse |= np.where(rng.random(B) < 0.6, np.uint64(1) << (np.uint64(11 * leg) + rng.integers(0, 11, size=B).astype(np.uint64)), np.uint64(0))
     for junk in (rng.integers(0, 1 << 44, size=B, dtype=np.uint64), np.full(B, (1 << 44) - 1, dtype=np.uint64), sparse):
-        t3, g3, s3, _, ws3 = run(d, prev=junk)
+        ctx.set_option(capi.OPT_WARM_FALLBACK, 0)     # rejections reported ...
+        try:
+            t3, g3, s3, _, ws3 = run(d, prev=junk)
+        finally:
+            ctx.set_option(capi.OPT_WARM_FALLBACK, 1)
         rej = s3 == capi.STATUS_WARM_REJECTED
         good = ok & ~rej
         assert np.array_equal(s3[~rej], s0[~rej]) and rej.mean() < 0.02 and (ws3[rej] == 0).all()
         assert np.abs(t3[good] - t0[good]).max() < 1e-6, np.abs(t3[good] - t0[good]).max()
+        t3, g3, s3, _, ws3 = run(d, prev=junk)        # ... or, by default, solved again cold by the same launch
+        assert np.array_equal(s3, s0) and np.abs(t3[ok] - t0[ok]).max() < 1e-6
+        assert np.array_equal(t3[rej], tc[rej]) and np.array_equal(ws3[rej & ok], wsc[rej & ok])
     to, go, so = oracle.wb_step_batch(s, nthreads=8)
     assert np.array_equal(s2, so) and np.abs(t2[so == 0] - to[so == 0]).max() < TAU_TOL
+    # the second attempt at will (QLAMD_OPT_WARM_FALLBACK 2): every robot that ends with a non-empty set is solved again cold by
+    # the same launch -- the cold step's answer (to rounding: the second attempt is the same source compiled as a function of
+    # its own), its working set back to 0, and the context counts it
+    ctx.set_option(capi.OPT_WARM_FALLBACK, 2)
+    try:
+        before = ctx.counter(capi.COUNTER_WARM_RETRIES)
+        t4, g4, s4, _, ws4 = run(d, prev=wsc)
+        n4 = ctx.counter(capi.COUNTER_WARM_RETRIES) - before
+    finally:
+        ctx.set_option(capi.OPT_WARM_FALLBACK, 1)
+    again = ok & (wsc != 0) & (ws4 == 0)
+    assert n4 == again.sum() and again.sum() > 0.9 * (ok & (wsc != 0)).sum()
+    assert np.array_equal(s4, s0) and np.abs(t4[again] - t0[again]).max() < 1e-9 and np.abs(g4[again] - g0[again]).max() < 1e-9
+    assert np.abs(t4[ok] - t0[ok]).max() < 1e-7
     # the dense entries start cold: a working set handed to them is refused
     ws = torch.zeros(B, 2, dtype=torch.int32, device="cuda:0")
     pl = capi.Placement(None, None, None, None, 0, None, ws.data_ptr())
