@@ -231,10 +231,10 @@ def parse():
                          "without the working sets (every QP from the empty set: the headline of round 5, `cold_start` on the line); "
                          "plain: qlamd_balance_solve_batch (robot s in slot s: the headline of rounds 1-4, `unplaced` on the line)")
     ap.add_argument("--ticks", type=int, default=0,
-                    help="distinct consecutive control ticks the K steps of a timed region run on (0 = K, capped at 64 beyond "
-                         "16 384 robots; step k solves tick k %% ticks, so a region that is longer than the trajectory -- and "
-                         "every replay of the captured steps -- jumps back to tick 0 once: a discontinuity no 400 Hz loop has, "
-                         "which costs the placed / warm-started loop time, never the other way)")
+                    help="length T of the trajectory, in control ticks (0 = 200, or 64 beyond 16 384 robots, rounded down to a "
+                         "multiple of K).  Step k of the loop solves tick k %% T; a timed region is K steps and consecutive regions "
+                         "continue the trajectory, so the jump back to tick 0 -- a discontinuity no 400 Hz loop has, which costs the "
+                         "placed / warm-started loop time, never the other way -- falls into one region in T / K")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -677,21 +677,31 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    trajectories = {}   # (gait, errors, batch, ticks, rank) -> (device-resident states of every tick, support switches per tick)
+
     def run_preset(gait, errors, with_gather, replays, second_without_gather, collect="rccl", every=1, batch=None,
                    method="plain"):
         """One workload preset on this rank's shard: warm-up, K steps captured as one hipGraph, `replays` timed samples.
         every: steps per collection; collect: "rccl" (all-gather) or "peer" (copies into the peers' buffers).
-        Step k solves tick k % T of a T-tick trajectory of the shard's robots (synth.trajectory; T = K unless --ticks or the
-        cap says otherwise).  method "placed": the caller's loop of include/qlamd.h -- step k runs in order[k & 1], writes
+        Step k of the loop solves tick k % T of a T-tick trajectory of the shard's robots (synth.trajectory).  method "placed": the caller's loop of include/qlamd.h -- step k runs in order[k & 1], writes
         iters[k & 1] and makes order[(k + 1) & 1] from iters[(k - 1) & 1]: tick k runs in the placement made during tick
         k - 1 from the counts of tick k - 2; "warm": the same, and every robot's QP starts from its final working set of tick
         k - 1 (one array, updated in place)."""
         B = batch or args.batch
-        T = max(1, args.ticks or (args.steps if B <= 16384 else min(args.steps, 64)))
+        K = args.steps
+        # The trajectory: T consecutive ticks, 200 by default (a tenth of that beyond 16 384 robots: 20 MB a tick at 65 536), a
+        # multiple of K when it is longer than a timed region.  A timed region is exactly K steps; consecutive regions -- and the
+        # untimed replays between them -- CONTINUE the trajectory (NG = T / K captured graphs of K steps each, replayed in turn),
+        # so the jump back to tick 0, which no 400 Hz loop has, falls into one region in NG, not into every one.
+        cap = 200 if B <= 16384 else 64
+        T = max(1, args.ticks) if args.ticks else (cap if K >= cap else K * max(1, cap // K))
+        NG = max(1, -(-T // K)) if K > 0 else 1
         # rank r owns robots [r*B, (r+1)*B) of the global batch (contiguous shards, SURVEY.md 8e)
-        states = synth.trajectory(B, gait, T, offset=rank * B, errors=errors)
-        ds = [capi.to_device(st_, dev) for st_ in states]
-        switched = synth.support_switches(states + [states[0]])   # T - 1 transitions of the trajectory, then the jump back to tick 0
+        key = (gait, errors, B, T, rank)
+        if key not in trajectories:
+            states = synth.trajectory(B, gait, T, offset=rank * B, errors=errors)
+            trajectories[key] = ([capi.to_device(st_, dev) for st_ in states], synth.support_switches(states + [states[0]]))
+        ds, switched = trajectories[key]   # (switched: T - 1 transitions of the trajectory, then the jump back to tick 0)
         retries0, giveups0 = ctx.counter(capi.COUNTER_WARM_RETRIES), ctx.counter(capi.COUNTER_PLACEMENT_GIVE_UPS)
         placed, warm = method == "placed", method == "warm"
         orders = [torch.arange(B, dtype=torch.int32, device=dev) for _ in range(2)] if (placed or warm) else None
@@ -728,11 +738,14 @@ def main():
                 return None
             return dist.all_gather_into_tensor(gathered[buf].view(world * G * B, 12), tau[buf].view(G * B, 12), async_op=True)
 
+        eager_k = [0]   # steps launched eagerly so far: the loop goes on where it is (ticks eager_k % T)
+
         def step(k, wg, events=None):
             buf = (k // G) & 1
             if events is not None:
                 events[0].record()
-            solve(k, tau[buf][k % G], stream)
+            solve(eager_k[0], tau[buf][k % G], stream)
+            eager_k[0] += 1
             if events is not None:
                 events[1].record()
             if wg and collect_now(k):
@@ -753,7 +766,8 @@ def main():
         # hipGraph (solves on one stream, gathers on a second one) and replayed: a step is a few tens of microseconds,
         # comparable to one eager launch from Python.  If capture fails the steps are launched eagerly, the all-gather
         # of step k then overlapping the solve of step k+1.
-        def capture(wg):
+        def capture(wg, g):
+            """steps g K .. g K + K - 1 of the loop (ticks (g K + j) % T) as one graph"""
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -774,7 +788,7 @@ def main():
                         buf = (k // G) & 1
                         if overlap and k % G == 0 and gathered_ev[buf] is not None:
                             side.wait_event(gathered_ev[buf])
-                        solve(k, tau[buf][k % G], cap)
+                        solve(g * K + k, tau[buf][k % G], cap)
                         if not (wg and collect_now(k)):
                             continue
                         if overlap:  # RCCL collectives and peer copies are capturable; they replay from the graph
@@ -797,87 +811,99 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             return graph, overlap
 
-        def build_graph(wg):
-            graph, overlap = None, False
+        def build_graphs(wg):
+            graphs, overlap = None, False
             if not args.no_graph:
                 try:
-                    graph, overlap = capture(wg)
+                    graphs = []
+                    for g in range(NG):
+                        gr, overlap = capture(wg, g)
+                        graphs.append(gr)
                 except Exception as e:  # pragma: no cover - fall back to eager launches
                     sys.stderr.write("hipGraph capture failed (%s); eager launches\n" % e)
-                    graph = None
+                    graphs = None
                 if collective:
                     # every rank must take the same path, or the collectives would not match up
-                    okflag = torch.tensor([1 if graph is not None else 0], dtype=torch.int32, device=dev)
+                    okflag = torch.tensor([1 if graphs is not None else 0], dtype=torch.int32, device=dev)
                     dist.all_reduce(okflag, op=dist.ReduceOp.MIN)
                     if int(okflag.item()) == 0:
-                        graph = None
-                if graph is not None:
-                    graph.replay()  # one untimed replay (instantiation / upload)
-                    fence()
-                    # ... and untimed replays until the clocks have settled (every rank the same number: no host clock involved
-                    # in the count once it is agreed on)
-                    t_one = time.perf_counter()
-                    graph.replay()
-                    fence()
-                    t_one = max(time.perf_counter() - t_one, 1e-5)
-                    n_settle = int(min(2000, max(0.0, args.settle_ms * 1e-3) / t_one))
-                    if collective:
-                        nt = torch.tensor([n_settle], dtype=torch.int32, device=dev)
-                        dist.all_reduce(nt, op=dist.ReduceOp.MAX)
-                        n_settle = int(nt.item())
-                    for _ in range(n_settle):
-                        graph.replay()
-                    fence()
-            return graph, overlap
-
-        def sample(graph, wg):
-            """One timed region: exactly K steps between barrier + synchronize on both sides.  Returns (wall seconds,
-            mean solve-kernel ms from HIP events on the launch stream)."""
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev, pending = [], []
-            fence()
-            t0 = time.perf_counter()
-            if graph is not None:
-                graph.replay()  # nothing else inside the timed region: the event pair is taken on a replay of its own below
-            else:
-                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-                for k in range(args.steps):
-                    w = step(k, wg, ev[k])
-                    if w is not None:
-                        pending.append(w)
-                        if len(pending) > 1:
-                            pending.pop(0).wait()
-                for w in pending:
-                    w.wait()
-            fence()
-            elapsed = time.perf_counter() - t0
-            if graph is not None:
-                # HIP events around an untimed replay: K kernels back to back, so this average includes the
-                # kernel-to-kernel boundary (an upper bound of the pure kernel duration; the rocprofv3 summary under
-                # profiles/ has the exact figure)
-                e0.record()
-                graph.replay()
-                e1.record()
-                fence()
-                kernel_ms = e0.elapsed_time(e1) / args.steps
-            else:
-                kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-            return elapsed, kernel_ms
+                        graphs = None
+            return graphs, overlap
 
         def measure(wg):
-            graph, overlap = build_graph(wg)
+            graphs, overlap = build_graphs(wg)
+            turn = [0]
+
+            def replay():   # the next K steps of the loop
+                graphs[turn[0] % NG].replay()
+                turn[0] += 1
+
+            if graphs is not None:
+                for _ in range(NG):
+                    replay()  # one untimed replay of each (instantiation / upload)
+                fence()
+                # ... and untimed replays until the clocks have settled (every rank the same number: no host clock involved
+                # in the count once it is agreed on)
+                t_one = time.perf_counter()
+                replay()
+                fence()
+                t_one = max(time.perf_counter() - t_one, 1e-5)
+                n_settle = int(min(2000, max(0.0, args.settle_ms * 1e-3) / t_one))
+                n_settle += (-(turn[0] + n_settle)) % NG      # the first timed region starts at tick 0
+                if collective:
+                    nt = torch.tensor([n_settle], dtype=torch.int32, device=dev)
+                    dist.all_reduce(nt, op=dist.ReduceOp.MAX)
+                    n_settle = int(nt.item())
+                for _ in range(n_settle):
+                    replay()
+                fence()
+
+            def sample():
+                """One timed region: exactly K steps between barrier + synchronize on both sides.  Returns (wall seconds,
+                mean solve-kernel ms from HIP events on the launch stream)."""
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev, pending = [], []
+                fence()
+                t0 = time.perf_counter()
+                if graphs is not None:
+                    replay()  # nothing else inside the timed region: the event pair is taken on a replay of its own below
+                else:
+                    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+                    for k in range(args.steps):
+                        w = step(k, wg, ev[k])
+                        if w is not None:
+                            pending.append(w)
+                            if len(pending) > 1:
+                                pending.pop(0).wait()
+                    for w in pending:
+                        w.wait()
+                fence()
+                elapsed = time.perf_counter() - t0
+                if graphs is not None:
+                    # HIP events around an untimed replay (the NEXT K steps of the loop): K kernels back to back, so this average
+                    # includes the kernel-to-kernel boundary (an upper bound of the pure kernel duration; the rocprofv3 summary
+                    # under profiles/ has the exact figure)
+                    e0.record()
+                    replay()
+                    e1.record()
+                    fence()
+                    kernel_ms = e0.elapsed_time(e1) / args.steps
+                else:
+                    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+                return elapsed, kernel_ms
+
             n = max(1, replays)
             el = np.zeros(n)
             km = np.zeros(n)
             for r in range(n):
-                el[r], km[r] = sample(graph, wg)
+                el[r], km[r] = sample()
             if collective:  # a sample lasts as long as its slowest rank
                 t = torch.from_numpy(el).to(dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 el = t.cpu().numpy()
             pick = int(np.argsort(el)[n // 2])  # the median sample is the timed region reported
             return dict(elapsed=float(el[pick]), kernel_ms=float(np.median(km)), samples_ms=[float(x * 1e3) for x in el],
-                        graph=graph is not None, overlap=overlap)
+                        graph=graphs is not None, overlap=overlap)
 
         res = measure(with_gather)
         if peer is not None:
@@ -897,7 +923,7 @@ def main():
         # last replay left it -- every tick's statuses, iteration counts and (warm) how many robots ended the tick with the
         # working set they started it with
         ok, it_mean, it_max, unchanged = True, [], 0, []
-        for k in range(args.steps):
+        for k in range(T):
             before = wset.clone() if warm else None
             solve(k, tau[0][0], stream)
             torch.cuda.synchronize()
@@ -914,10 +940,9 @@ def main():
             ok = bool(okt.item())
         res["ok"] = ok
         res["batch"], res["method"] = B, method
-        wrap = [k for k in range(args.steps) if k % T == 0]          # the steps that follow a jump back to tick 0
-        inside = [k for k in range(args.steps) if k % T != 0] or wrap
+        wrap, inside = [0], list(range(1, T)) or [0]                  # tick 0 follows the jump back from tick T - 1
         res["trajectory"] = {
-            "states_per_replay": T, "dt": synth.CONTROL_PERIOD,
+            "states_per_replay": K, "ticks": T, "regions": NG, "dt": synth.CONTROL_PERIOD,
             "switched_per_tick": float(np.mean(switched[:-1])) if T > 1 else 0.0,   # robots whose support set changes, per tick
             "switched_at_wrap": float(switched[-1])}
         if placed or warm:
@@ -967,6 +992,58 @@ def main():
             e["note"] = note
         return e
 
+    def time_captured(step_fn, eager_steps, regions=1):
+        """`eager_steps` untimed eager steps, then the loop's steps captured as `regions` hipGraphs of K steps each (step_fn(k, stream)
+        with k running on from graph to graph) and replayed in turn: 50 ms of untimed replays, five timed samples of exactly K steps
+        between synchronisations (median), the kernel time from HIP events around one more replay."""
+        for k in range(eager_steps):
+            step_fn(k, stream)
+        torch.cuda.synchronize()
+        graphs = []
+        for g in range(regions):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    cap = torch.cuda.current_stream().cuda_stream
+                    for k in range(args.steps):
+                        step_fn(g * args.steps + k, cap)
+            torch.cuda.current_stream().wait_stream(side)
+            graphs.append(graph)
+        turn = [0]
+
+        def replay():
+            graphs[turn[0] % regions].replay()
+            turn[0] += 1
+        for _ in range(regions):
+            replay()
+        torch.cuda.synchronize()
+        t_end = time.perf_counter() + 0.05
+        while time.perf_counter() < t_end or turn[0] % regions:
+            replay()
+        torch.cuda.synchronize()
+        el = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            replay()
+            torch.cuda.synchronize()
+            el.append(time.perf_counter() - t0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return float(np.median(el)), e0.elapsed_time(e1) / args.steps
+
+    def ticks_for(cap):
+        """(T, regions) of a side measurement: about `cap` ticks, a multiple of K"""
+        K = args.steps
+        if args.ticks:
+            return max(1, args.ticks), max(1, -(-args.ticks // K))
+        return (K, 1) if K >= cap else (K * max(1, cap // K), max(1, cap // K))
+
     def pose_sqp_entry(batch):
         """BASELINE configs[4] inside the headline line: batch pose optimisations, exactly 5 SQP iterations each, the K calls
         captured and timed like every other preset."""
@@ -976,38 +1053,8 @@ def main():
         dp = {k: torch.from_numpy(v).to(dev) for k, v in pb.items()}
         out = (torch.zeros(batch, 7, dtype=torch.float64, device=dev), torch.zeros(batch, dtype=torch.int32, device=dev),
                torch.zeros(batch, dtype=torch.int32, device=dev))
-        for _ in range(max(2, min(args.warmup, 5))):
-            capi.pose_sqp(ctx, dp, prm, memory=capi.MEM_DEVICE, out=out, stream=stream)
-        torch.cuda.synchronize()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                cap = torch.cuda.current_stream().cuda_stream
-                for _ in range(args.steps):
-                    capi.pose_sqp(ctx, dp, prm, memory=capi.MEM_DEVICE, out=out, stream=cap)
-        torch.cuda.current_stream().wait_stream(side)
-        graph.replay()
-        torch.cuda.synchronize()
-        t_end = time.perf_counter() + 0.05
-        while time.perf_counter() < t_end:
-            graph.replay()
-        torch.cuda.synchronize()
-        el = []
-        for _ in range(5):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            graph.replay()
-            torch.cuda.synchronize()
-            el.append(time.perf_counter() - t0)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        graph.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        kernel_ms = e0.elapsed_time(e1) / args.steps
-        elapsed = float(np.median(el))
+        elapsed, kernel_ms = time_captured(lambda k, st_: capi.pose_sqp(ctx, dp, prm, memory=capi.MEM_DEVICE, out=out, stream=st_),
+                                           max(2, min(args.warmup, 5)))
         rec, prov = pmc_record("pose_sqp_coop_kernel", batch, "pose_sqp")
         frac = 424.0 * batch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS  # 46 doubles in + 7 out per solve
         return {"value": batch * args.steps / elapsed, "unit": "pose-SQP solves/s", "ms_per_step": elapsed / args.steps * 1e3,
@@ -1016,6 +1063,109 @@ def main():
                 "traffic": int(rec["fetch_bytes"] + rec["write_bytes"]) if rec and "fetch_bytes" in rec and "write_bytes" in rec else None,
                 "valu_issue_frac": (rec["valu_insts"] * 4.0 / (N_SIMD * kernel_ms * 1e-3 * SHADER_CLOCK_HZ)) if rec and rec.get("valu_insts") else None,
                 "pmc_source": prov}
+
+    def full_tick_entry(batch):
+        """The plugin's whole tick (rows a1 + f1 + f2: ros_balance_controller.cpp:198-718) on a trot trajectory: per robot and tick
+        one serialised /desired_robot_state message (one publisher's layout; desired base state and support flags of the
+        trajectory's tick) -> leg state machine -> balance solve -> swing branch -> 12 efforts, qlamd_full_tick_batch, the
+        controller's state carried from tick to tick; cold, and with the working set the tick keeps (`warm`)."""
+        T, regions = ticks_for(60)
+        states = synth.trajectory(batch, "trot", T)
+        rng = np.random.default_rng(11)
+        from quadruped_locomotion_amd import wire
+        mt = synth.MessageTemplate([wire.MODE_NAMES[k] for k in rng.integers(0, len(wire.MODE_NAMES), 4)])
+        fixed = {k: rng.normal(size=(batch, n)) for k, n in mt.DOUBLES}
+        fixed["phase"] = rng.random((batch, 4))
+        shared_in = dict(joint_position=states[0]["q"], joint_velocity=rng.normal(scale=0.3, size=(batch, 12)),
+                         joint_velocity_oldest=rng.normal(scale=0.3, size=(batch, 12)),
+                         base_linear_velocity=np.ascontiguousarray(states[0]["base_linvel"]),
+                         base_angular_velocity=np.ascontiguousarray(states[0]["base_angvel"]),
+                         contact=rng.integers(0, 2, (batch, 4)).astype(np.uint8))
+        shared_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in shared_in.items()}
+        per_tick, nbytes = [], 0
+        for s_ in states:
+            f = dict(fixed, des_pos=s_["des_pos"], des_quat=s_["des_quat"], des_linvel=s_["des_linvel"], des_angvel=s_["des_angvel"],
+                     support_leg=s_["stance"])
+            blob, off = mt.pack(f)
+            nbytes = int(off[-1])
+            per_tick.append(dict(shared_in, messages=torch.from_numpy(blob).to(dev), offsets=torch.from_numpy(off).to(dev),
+                                 base_position=torch.from_numpy(s_["base_pos"]).to(dev),
+                                 base_orientation=torch.from_numpy(s_["base_quat"]).to(dev)))
+        out = {}
+        for warm in (False, True):
+            keep = dict(limb_state=np.zeros((batch, 4), np.int8), store_flag=np.zeros((batch, 4), np.uint8),
+                        stored_joint_position=np.zeros((batch, 12)), leg_mode=np.zeros((batch, 4), np.uint8),
+                        support=np.ones((batch, 4), np.uint8), pid_error_last=np.zeros((batch, 12)), pid_error_integral=np.zeros((batch, 12)),
+                        joint_effort=np.zeros((batch, 12)), leg_state_code=np.zeros((batch, 4), np.int8), status=np.full(batch, -1, np.int32),
+                        message_status=np.full(batch, -1, np.int32), command=np.zeros(capi.tick_command_bytes(batch), np.uint8))
+            if warm:
+                keep["working_set"] = np.zeros(batch, np.uint32)
+            keep = {k: torch.from_numpy(v).to(dev) for k, v in keep.items()}
+            ios = [dict(pt, **keep) for pt in per_tick]
+            tctx = capi.Context(device=local_rank)
+            tctx.reserve(batch)
+            elapsed, tick_ms = time_captured(lambda k, st_: capi.full_tick(tctx, ios[k % T], 0.0025, memory=capi.MEM_DEVICE, stream=st_),
+                                             max(2, min(args.warmup, 5)), regions)
+            ok_all = True
+            for k in range(T):   # every tick's statuses, untimed
+                capi.full_tick(tctx, ios[k % T], 0.0025, memory=capi.MEM_DEVICE, stream=stream)
+                torch.cuda.synchronize()
+                ok_all = ok_all and bool(((keep["status"] == 0) | (keep["status"] == 4)).all().item()) and bool((keep["message_status"] == 0).all().item())
+            # algorithmic bytes per robot: its message + measured state (q, qd, qd_oldest 288, base pose / twist 104, contact 4) +
+            # persistent state read and written (2 x (4 + 4 + 96 + 4 + 4 + 96 + 96)) + efforts 96 + codes / statuses 12
+            algo = nbytes + (288 + 104 + 4 + 2 * 304 + 96 + 12) * batch
+            out["warm" if warm else "cold"] = {
+                "value": batch * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3, "kernel_ms": tick_ms,
+                "all_status_ok": ok_all, "roofline_frac": algo / (tick_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "warm_rejected": tctx.counter(capi.COUNTER_WARM_RETRIES)}
+            tctx.close()
+        e = dict(out["warm"], unit="ticks/s", batch=batch, message_bytes=nbytes // batch, states_per_replay=args.steps, ticks=T,
+                 method="qlamd_full_tick_batch (unpack + leg state machine, then balance blocks + swing-branch blocks: two launches per "
+                        "tick), the balance solve warm-started from the working set the tick keeps (qlamd_tick_batch::working_set)",
+                 cold_start=out["cold"], switched_per_tick=float(np.mean(synth.support_switches(states))) if T > 1 else 0.0)
+        e["kernel_ms_note"] = "both launches of a tick (HIP events around K captured ticks)"
+        return e
+
+    def wholebody_entry(batch):
+        """SURVEY 8 row f4 (what the north star describes and the reference lacks): one whole-body control step per robot --
+        18-DoF inverse dynamics -> force / torque QP -> 12 joint efforts -- on a trot trajectory (joints moved by their rates),
+        placed and warm-started through qlamd_place_next_call (64-bit working sets, updated in place), and cold."""
+        T, regions = ticks_for(200)
+        states = synth.wholebody_trajectory(batch, "trot", T)
+        dsw = [capi.to_device(s_, dev) for s_ in states]
+        tau, grf = torch.zeros(batch, 12, dtype=torch.float64, device=dev), torch.zeros(batch, 12, dtype=torch.float64, device=dev)
+        st_w = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+        out = {}
+        import ctypes as C
+        for warm in (False, True):
+            wctx = capi.Context(device=local_rank)
+            orders = [torch.arange(batch, dtype=torch.int32, device=dev) for _ in range(2)]
+            its = [torch.zeros(batch, dtype=torch.int32, device=dev) for _ in range(2)]
+            wsets = torch.zeros(batch, 2, dtype=torch.int32, device=dev)
+
+            def step(k, st_, wctx=wctx, orders=orders, its=its, wsets=wsets, warm=warm):
+                pl = capi.Placement(orders[k & 1].data_ptr(), its[k & 1].data_ptr(), its[(k - 1) & 1].data_ptr(), orders[(k + 1) & 1].data_ptr(),
+                                    capi.PLACEMENT_AUTO, wsets.data_ptr() if warm else None, wsets.data_ptr() if warm else None)
+                rc = capi.lib().qlamd_place_next_call(wctx._h, C.byref(pl))
+                if rc != 0:
+                    raise capi.QlamdError(rc, "qlamd_place_next_call")
+                capi.wholebody_solve_device(wctx, dsw[k % T], tau, grf, st_w, stream=st_)
+            elapsed, kernel_ms = time_captured(step, max(2, min(args.warmup, 5)), regions)
+            ok_all = True
+            for k in range(T):
+                step(k, stream)
+                torch.cuda.synchronize()
+                ok_all = ok_all and bool((st_w == 0).all().item())
+            out["warm" if warm else "cold"] = {
+                "value": batch * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3, "kernel_ms": kernel_ms,
+                "all_status_ok": ok_all, "roofline_frac": (272 + 52 + 196) * batch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "warm_rejected": wctx.counter(capi.COUNTER_WARM_RETRIES)}
+            wctx.close()
+        return dict(out["warm"], unit="whole-body control steps/s", batch=batch, states_per_replay=args.steps, ticks=T,
+                    method="qlamd_wholebody_solve_batch (18-DoF inverse dynamics -> force / torque QP with friction-cone and torque-limit rows "
+                           "-> 12 efforts), placed and warm-started through qlamd_place_next_call",
+                    cold_start=out["cold"], switched_per_tick=float(np.mean(synth.support_switches(states))) if T > 1 else 0.0,
+                    kernel_ms_note="solve launch + the placement's launches behind it (HIP events around K captured steps)")
 
     B = args.batch
     method = args.method if not args.rpw else "plain"  # (the one-lane kernels of --rpw know neither placement nor warm start)
@@ -1052,10 +1202,11 @@ def main():
             if args.gait == "trot" and bb == B:
                 continue
             also[name] = preset_entry("trot", "survey", bb, others)
-        try:
-            also["pose_sqp_b4096"] = pose_sqp_entry(4096)
-        except Exception as e:  # a side measurement must not cost the line
-            also["pose_sqp_b4096"] = {"error": repr(e)[:200]}
+        for name, fn in (("pose_sqp_b4096", pose_sqp_entry), ("full_tick_b4096", full_tick_entry), ("wholebody_trot_b4096", wholebody_entry)):
+            try:
+                also[name] = fn(4096)
+            except Exception as e:  # a side measurement must not cost the line
+                also[name] = {"error": repr(e)[:300]}
     # scale_point: the workload every line at every N carries, so that a weak-scaling curve can be drawn across lines:
     # 8192 trot robots per GPU (configs[3]'s shard).  efficiency(N) = scale_point(N).value / (N * scale_point(1).without_gather)
     if args.gait == "trot" and B == SCALE_B:
@@ -1118,14 +1269,15 @@ def main():
                                       else "trot gait (2<->4 contacts)"),
                        "robots_per_gpu": B, "global_batch": world * B, "gait": args.gait, "seed": synth.SEED,
                        "method": method, "method_note": METHOD_NOTE[method],
-                       "states_per_replay": res["trajectory"]["states_per_replay"],
+                       "states_per_replay": res["trajectory"]["states_per_replay"],   # K states solved per timed region, all different
                        "trajectory": res["trajectory"],
                        "trajectory_note": ("synth.trajectory: tick t + 1 = tick t with the measured / desired pose integrated over "
                                            "2.5 ms with the measured / desired twist and, for a trot, the gait phase advanced by "
                                            "2.5 ms / 0.9 s and the support flags recomputed (switched_per_tick: robots whose support set "
-                                           "changes from one tick to the next); step k solves tick k % states_per_replay, so every "
-                                           "replay of the captured steps jumps back to tick 0 once (switched_at_wrap; the step after "
-                                           "it runs on hints a real loop never sees that stale)"),
+                                           "changes from one tick to the next); step k of the loop solves tick k % ticks; a timed region is "
+                                           "K steps (states_per_replay), consecutive regions continue the trajectory (`regions` captured "
+                                           "graphs replayed in turn), so the jump back to tick 0 (switched_at_wrap; the steps after it run "
+                                           "on hints a real loop never sees that stale) falls into one region in `regions`"),
                        "iterations": res.get("iterations"),
                        "tracking_error": list(synth.tracking_error(args.gait, args.errors)),
                        "tracking_error_note": "half-widths of the uniform position (m) / rotation-vector (rad) / twist errors at tick 0: "

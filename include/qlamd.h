@@ -312,9 +312,11 @@ typedef struct qlamd_placement {
   int policy;                       /* QLAMD_PLACEMENT_*, for next_robot_order */
   /* The other half of the hint, for the balance / force-distribution entries with QLAMD_MEM_DEVICE: WARM START.  Each robot's
    * active-set loop starts from the working set in prev_working_set [B] (bit 5 leg + kind of row: kind 0 the minimal normal
-   * force, 1..4 the friction pyramid's +t1, -t1, +t2, -t2) instead of the empty one, and its final working set goes to
-   * working_set [B] (0 for a robot whose status is not QLAMD_STATUS_OK); either may be NULL; they may be ONE array, updated in
-   * place (a robot's set is read and written by its own lanes only).  Hand a robot the set it ended with on its previous
+   * force, 1..4 the friction pyramid's +t1, -t1, +t2, -t2; bits 20..23: the support legs the set was reached with, written by
+   * the library, 0 = not recorded) instead of the empty one, and its final working set goes to working_set [B] (0 for a robot
+   * whose status is not QLAMD_STATUS_OK); either may be NULL; they may be ONE array, updated in place (a robot's set is read
+   * and written by its own lanes only).  A robot whose support legs are not the recorded ones any more -- a trot entering or
+   * leaving double support -- starts cold: a stale set costs such a robot more than it saves.  Hand a robot the set it ended with on its previous
    * control step (zeros to start with: a cold start).  At 400 Hz that is this
    * step's final set for 96 % of the robots of the bench batches: the rows are installed as equalities, slots whose
    * multiplier comes out negative are dropped, and the method of the reference continues from there -- a set that no longer
@@ -344,7 +346,8 @@ int qlamd_force_distribution_placed_batch(qlamd_context *ctx, const double *join
  * placement = NULL withdraws a pending one.  (qlamd_balance_solve_batch and the other entries ignore it.)
  * Warm start: qlamd_wholebody_solve_batch also takes prev_working_set / working_set this way, with TWO words per robot
  * ([B][2] uint32 = 64 bits, low word first: bit 11 leg + kind, kinds 0..4 as for the balance step, 5 + 2k / 6 + 2k the upper /
- * lower torque bound of the leg's joint k); the two dense entries start cold and refuse them (QLAMD_ERR_INVALID_ARGUMENT). */
+ * lower torque bound of the leg's joint k; bits 44..47: the support legs the set was reached with); the two dense entries start
+ * cold and refuse them (QLAMD_ERR_INVALID_ARGUMENT). */
 int qlamd_place_next_call(qlamd_context *ctx, const qlamd_placement *placement);
 
 /* The placement on its own: iterations [B] in (any counts: only their order matters; negative counts count as 0, counts

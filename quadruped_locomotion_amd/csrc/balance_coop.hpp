@@ -98,7 +98,8 @@ constexpr int kCoopNrmDoubles = 12 * 64; // 5 row kinds + parked Jacobian row (3
 // LDS instead of in registers while the first of the two forms of the QP runs (see `solve` below)
 // Returns whether this row's warm start was rejected (kWarm: the answer reached from the set handed in failed the final check of
 // force_qp_coop) -- coop_robot_checked() below then solves the robot again with `cold` set: the set handed in is ignored.
-template <bool kPerLeg, int kBlock = 64, bool kWarm = false, bool kParkInputs = false>
+// kThroughput (the 168-register form of the kernels): a warm start installs its rows one after the other, not by rounds
+template <bool kPerLeg, int kBlock = 64, bool kWarm = false, bool kParkInputs = false, bool kThroughput = false>
 __device__ __forceinline__ bool coop_robot(const DeviceParams &P, const CoopPtrs &s, int64_t irobot, bool robot_live_in,
                                            double *lds_tab, double *lds_row, double *lds_nrm,
                                            double *__restrict__ tau_out,
@@ -156,12 +157,20 @@ __device__ __forceinline__ bool coop_robot(const DeviceParams &P, const CoopPtrs
                                         ((sm & 0xFF0000u) ? 4u : 0u) | ((sm & 0xFF000000u) ? 8u : 0u))
                                      : 0u;
   const int nS = __popc(stance);
+  if constexpr (kWarm) {
+    // A working set remembers the support legs it was reached with (bits 20..23; 0: not recorded).  A robot that has changed
+    // them since -- a trot entering or leaving double support -- starts cold: on the bench's trot trajectory such a robot
+    // needs 11.2 installs / drops / passes from its stale set against 9.5 passes from the empty one (2 -> 4 legs), 6.0 against
+    // 3.4 (4 -> 2): profiles/r6/trajectory_stats.txt
+    const unsigned from = (warm_set >> 20) & 0xFu;
+    warm_set = (from != 0u && from != stance) ? 0u : (warm_set & 0xFFFFFu);
+  }
   // support legs first: the leg behind my slot, and what was loaded by leg goes to the lane of its slot
   const unsigned perm = slot_legs(stance);
   const int aleg = (int)((perm >> (2 * leg)) & 3u);
   // (which robot I am, where my results go and the slot order are not needed before the very end: parked like the Jacobian
   // row; a batch has fewer than 2^31 robots -- 300 bytes of state each)
-  reinterpret_cast<int2 *>(lds_nrm + 64 * 11)[(int)threadIdx.x & 63] = make_int2((int)i_in, (3 * aleg + c) | ((int)perm << 8));
+  reinterpret_cast<int2 *>(lds_nrm + 64 * 11)[(int)threadIdx.x & 63] = make_int2((int)i_in, (3 * aleg + c) | ((int)perm << 8) | ((int)stance << 16));
   const bool on = leg < nS; // my slot's leg supports
   const unsigned stance_slots = (1u << nS) - 1u;
   const bool permuted = __builtin_amdgcn_ballot_w64(perm != 0xE4u) != 0ull; // (scalar: some row of the wavefront is)
@@ -403,7 +412,7 @@ __device__ __forceinline__ bool coop_robot(const DeviceParams &P, const CoopPtrs
     Q.on = on; Q.comp = comp; Q.nS = nS; Q.refine_passes = P.refine_passes;
     Q.warm = 0ull; Q.stance = stance_slots;
     if constexpr (kWarm) Q.warm = permuted ? working_set_to_slots<5, unsigned>(warm_set, perm) : warm_set;
-    status = force_qp_coop<false, kWarm, decltype(Legs)::value>(Q, lds_row, lds_nrm, x, qp_iters, &final_set);
+    status = force_qp_coop<false, kWarm, decltype(Legs)::value, !kThroughput>(Q, lds_row, lds_nrm, x, qp_iters, &final_set);
   };
   int small_form = __builtin_amdgcn_readfirstlane(two_legs ? 1 : 0);
   asm volatile("" : "+s"(small_form));
@@ -415,7 +424,7 @@ __device__ __forceinline__ bool coop_robot(const DeviceParams &P, const CoopPtrs
   const int64_t i = parked.x;
   const int aidx = parked.y & 15;
   if constexpr (kWarm) {
-    if (permuted) final_set = working_set_to_legs<5, unsigned>((unsigned)final_set, (unsigned)parked.y >> 8);
+    if (permuted) final_set = working_set_to_legs<5, unsigned>((unsigned)final_set, ((unsigned)parked.y >> 8) & 0xFFu);
   }
   if (status == kStatusNotPd) {
     if (lr == 0 && robot_live) {
@@ -451,7 +460,9 @@ __device__ __forceinline__ bool coop_robot(const DeviceParams &P, const CoopPtrs
     if (lr == 0 && robot_live) {
       status_out[i] = status;
       if (s.iterations) s.iterations[i] = qp_iters;
-      if constexpr (kWarm) { if (s.working_set) s.working_set[i] = status == kStatusOk ? (uint32_t)final_set : 0u; }
+      if constexpr (kWarm) { // (with the support legs it was reached with: bits 20..23)
+        if (s.working_set) s.working_set[i] = status == kStatusOk ? ((uint32_t)final_set | (((uint32_t)parked.y >> 16 & 0xFu) << 20)) : 0u;
+      }
     }
   }
   QL_STAMP(9);

@@ -122,7 +122,7 @@ __device__ __forceinline__ void force_qp_objective(const double S[6], double w_r
 // method runs as always, so a set that no longer fits costs passes, not the answer (the minimiser is unique).  The passes a
 // robot then still needs are its `iters_out`.  QuadProg++ has no such entry (solve_quadprog always starts from the
 // unconstrained minimiser, QuadProg++.cc:216-233): iteration counts no longer match the reference's one for one, torques do.
-template <bool kTorque, bool kWarm = false, int kLegs = 4>
+template <bool kTorque, bool kWarm = false, int kLegs = 4, bool kRounds = true>
 __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, double *lds_nrm, double &x, int &iters_out,
                                              unsigned long long *ws_out = nullptr) {
   using mask_t = std::conditional_t<kTorque, unsigned long long, unsigned>;
@@ -463,59 +463,163 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
       }
       wm = sane ? wm : (mask_t)0;
     }
-    for (;;) {
-      const bool has = wm != 0;
-      if (__builtin_amdgcn_ballot_w64(has) == 0ull) break;
-      int p = 0;
-      if constexpr (kTorque) p = has ? __ffsll((long long)wm) - 1 : 0;
-      else p = has ? __ffs((int)wm) - 1 : 0;
-      wm &= wm - 1;
-      const int pleg = kTorque ? ((p * 47) >> 9) : id_leg(p), kind = p - kKinds * pleg;
-      // the row's normal on my lane and its offset: n'x - b >= 0 with b = f_min (kind 0), 0 (friction), and for the torque
-      // bounds of joint k (kinds 5 + 2k upper, 6 + 2k lower) n = +-J[:,k], b = -(tau_max -+ tau0_k) -- held by the joint's lane
-      int tab_kind = kind;
-      double sign = 1.0, b_p = sel(kind == 0, f_min, 0.0);
-      if constexpr (kTorque) {
-        const int kj = (kind - 5) >> 1;
-        const bool tq = kind >= 5, lower = tq && ((kind - 5) & 1) != 0;
-        tab_kind = tq ? 5 + kj : kind;
-        sign = lower ? -1.0 : 1.0;
-        const int src = 4 * pleg + (tq ? kj : 0);
-        const double bu = __shfl(Q.tq_up, src, 16), bl = __shfl(Q.tq_lo, src, 16);
-        b_p = tq ? -(lower ? bl : bu) : b_p;
+    // Which form: by rounds when some robot of the wavefront brings many rows (a round of four rows is 0.95 us whatever it
+    // holds, a row on its own 0.40 us: the static bench batch -- 8 rows on average, up to 12 -- 15.5 -> 14.85 us by rounds, its
+    // trot batches -- one to three rows on two legs -- 22.2 -> 23.2 us: profiles/r6/ab_install_forms.txt), row by row otherwise
+    // and always in the throughput form of the kernels (!kRounds).  Wavefront-uniform: one scalar branch.
+    bool by_rounds = false;
+    if constexpr (kRounds) {
+      int nrows;
+      if constexpr (kTorque) nrows = __popcll((unsigned long long)wm);
+      else nrows = __popc((unsigned)wm);
+      by_rounds = __builtin_amdgcn_ballot_w64(nrows >= (kLegs == 4 ? 6 : 4)) != 0ull;
+    }
+    if (by_rounds) {
+      // Installed a ROUND at a time: the next row of every leg together.  Every row touches the variables of one leg, so the
+      // directions of up to four rows -- z_m = H n_m, r_m = N* n_m -- are ONE broadcast sweep (column j of H and N* goes to the
+      // accumulators of leg j / 3: 24 broadcast-FMAs for all of them, what a single row used to take), and the rows then go in one
+      // after the other inside a straight block: d_k = n_k'z_k from a quad sum, the full step onto row k, the rank-one update, and the
+      // directions of the legs still to come corrected by one broadcast-FMA each (z_m -= z_k (n_m'z_k) / d_k: the quad sum that gave
+      // d_k on leg k's lanes gave n_m'z_k on leg m's) instead of being swept again.  A lone wavefront pays for dependent chains:
+      // round 5 installed a row in 0.40 us (LDS fetch of the normal -> sweep -> two row sums -> reciprocal -> update, 960 cycles:
+      // profiles/r6/warm_install_probe.txt), twelve rows in 4.8 us; a round of four is 0.7 us and three rounds are the most there are.
+      // A leg without a row in a round rides along with a zero normal and divisors biased to 1, like a ghost row of the loop.
+      unsigned mine = (unsigned)((wm >> (kKinds * leg)) & kLegRows); // the rows of my leg still to install (lanes of a leg agree)
+      for (;;) {
+        if (__builtin_amdgcn_ballot_w64(mine != 0u) == 0ull) break;
+        const bool have = mine != 0u;
+        const int kind = have ? __ffs((int)mine) - 1 : 0;
+        mine &= mine - 1u;
+        // component c of my leg's row and its offset: n'x - b >= 0 with b = f_min (kind 0), 0 (friction), and for the torque bounds
+        // of joint k (kinds 5 + 2k upper, 6 + 2k lower) n = +-J[:,k], b = -(tau_max -+ tau0_k) -- held by the joint's lane
+        double nv, bp;
+        {
+          const double fr = sel(kind == 1, myt1, sel(kind == 2, -myt1, sel(kind == 3, myt2, -myt2)));
+          nv = sel(kind == 0, myn, fma(mu, myn, fr));
+          bp = sel(kind == 0, f_min, 0.0);
+          if constexpr (kTorque) {
+            const bool tq = kind >= 5, lower = tq && ((kind - 5) & 1) != 0;
+            const int kj = (kind - 5) >> 1;
+            const double jn = pick3(Q.jrow, kj);
+            nv = sel(tq, sel(lower, -jn, jn), nv);
+            const double bu = sel(kj == 0, quad_bc<0>(Q.tq_up), sel(kj == 1, quad_bc<1>(Q.tq_up), quad_bc<2>(Q.tq_up)));
+            const double bl = sel(kj == 0, quad_bc<0>(Q.tq_lo), sel(kj == 1, quad_bc<1>(Q.tq_lo), quad_bc<2>(Q.tq_lo)));
+            bp = sel(tq, -sel(lower, bl, bu), bp);
+          }
+        }
+        npj = sel(have && comp, nv, 0.0);
+        // which row every leg brings, for all lanes of the robot: (kind + 1) in four bits per leg, OR-ed over the row
+        unsigned kinds = (have && c == 0) ? (unsigned)(kind + 1) << (4 * leg) : 0u;
+        static_for<4>([&](auto K) {
+          constexpr int ctrl = K == 0 ? 0x128 : K == 1 ? 0x124 : K == 2 ? 0x122 : 0x121;
+          kinds |= (unsigned)__builtin_amdgcn_mov_dpp((int)kinds, ctrl, 0xF, 0xF, true);
+        });
+        double sl = quad_sum(npj * x) - sel(have, bp, 0.0); // slack of my leg's row at x, kept up to date through the round
+        double za[kLegs], ra[kLegs];
+#pragma unroll
+        for (int m = 0; m < kLegs; m++) { za[m] = 0.0; ra[m] = 0.0; }
+        static_for<kV>([&](auto J) {
+          constexpr int j = J;
+          fmac_bc<lane_of(j), j == 0>(za[j / 3], npj, H[j]);
+          fmac_bc<lane_of(j)>(ra[j / 3], npj, Ns[j]);
+        });
+        static_for<kLegs>([&](auto K) {
+          constexpr int k = K;
+          const int kk = (int)((kinds >> (4 * k)) & 15u) - 1; // leg k's row of this round (-1: none)
+          const double qk = quad_sum(npj * za[k]);            // on the lanes of leg m: n_m'z_k
+          const double dk = bc<4 * k>(qk);
+          // a row that depends on the rows installed before it is left out: z'n_p is then rounding noise, which with the entries
+          // of H reaching 1 / w_reg = 1e4 means up to 1e-10, while an independent row has z'n_p >= |n|^2 / trace(G) ~ 1e-3
+          const bool ok = kk >= 0 && dk > 1e-6;
+          const double zi = rcp_nr(sel(ok, dk, 1.0));
+          const double tw = sel(ok, -bc<4 * k>(sl) * zi, 0.0);
+          x = fma(tw, za[k], x);
+          u = fma(-tw, ra[k], u);
+          sl = fma(tw, qk, sl);
+          const int newlane = __ffs(~used & 0xFFFu) - 1;
+          const bool newslot = ok && lr == newlane;
+          const int pk = kKinds * k + kk;
+          vec = sel(ok, za[k] * zi, 0.0);
+          hc = sel(ok, -za[k], 0.0);
+          const double rk = sel(newslot, -1.0, ra[k]);
+          nc = sel(ok, -rk, 0.0);
+          u = sel(newslot, tw, u);
+          idk = newslot ? pk : idk;
+          used |= ok ? (1u << newlane) : 0u;
+          act_mask |= ok ? (one << pk) : 0;
+          rnorm2 = sel(ok, vmax(rnorm2, dk), rnorm2);
+          q += ok ? 1 : 0;
+          warm_updates += ok ? 1 : 0;
+          // the legs still to come: z_m -= z_k (n_m'z_k) / d_k, r_m -= r_k (n_m'z_k) / d_k (the new slot's own entry: + n_m'z_k / d_k)
+          if constexpr (k + 1 < kLegs) {
+            const double cm = sel(ok, -qk * zi, 0.0);
+            static_for<kLegs - 1 - k>([&](auto M) {
+              constexpr int m = k + 1 + M;
+              fmac_bc<4 * m, M == 0>(za[m], cm, za[k]);
+              fmac_bc<4 * m>(ra[m], cm, rk);
+            });
+          }
+          update_only();
+        });
       }
-      const double np_tab = sign * lds_nrm[64 * tab_kind + ((int)threadIdx.x & 63)];
-      npj = (has && pleg == leg) ? np_tab : 0.0;
-      // directions as in a pass; z'n_p of a row without a candidate is 0: biased to 1, its step is 0
-      double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
-      static_for<kV>([&](auto J) {
-        constexpr int j = J;
-        fmac_bc<lane_of(j), j == 0>(za[j % 3], npj, H[j]);
-        fmac_bc<lane_of(j)>(ra[j % 3], npj, Ns[j]);
-      });
-      const double zw = (za[0] + za[1]) + za[2], rw = (ra[0] + ra[1]) + ra[2];
-      const double znw = row_sum(zw * npj);
-      const double s_p = row_sum(npj * x) - b_p; // slack of the row at x
-      // a row that depends on the rows installed before it is left out: z'n_p is then rounding noise, which with the entries
-      // of H reaching 1 / w_reg = 1e4 means up to 1e-10, while an independent row has z'n_p >= |n|^2 / trace(G) ~ 1e-3
-      const bool ok = has && znw > 1e-6;
-      const double zi = rcp_nr(sel(ok, znw, 1.0));
-      const double tw = sel(ok, -s_p * zi, 0.0);
-      x = fma(tw, zw, x);
-      u = fma(-tw, rw, u);
-      const int newlane = __ffs(~used & 0xFFFu) - 1;
-      const bool newslot = ok && lr == newlane;
-      vec = sel(ok, zw * zi, 0.0);
-      hc = sel(ok, -zw, 0.0);
-      nc = sel(newslot, 1.0, sel(ok, -rw, 0.0));
-      u = sel(newslot, tw, u);
-      idk = newslot ? p : idk;
-      used |= ok ? (1u << newlane) : 0u;
-      act_mask |= ok ? (one << p) : 0;
-      rnorm2 = sel(ok, vmax(rnorm2, znw), rnorm2);
-      q += ok ? 1 : 0;
-      warm_updates += ok ? 1 : 0;
-      update_only();
+    } else {
+      // One row after the other (the throughput form of the kernels, which has no registers for a round's eight direction
+      // vectors: in 168 registers the round form spills 70 values around the loop, 65 536 warm-started trot robots 70 -> 85 us):
+      // directions as in a pass, a full step onto the row, the rank-one update.
+      for (;;) {
+        const bool has = wm != 0;
+        if (__builtin_amdgcn_ballot_w64(has) == 0ull) break;
+        int p = 0;
+        if constexpr (kTorque) p = has ? __ffsll((long long)wm) - 1 : 0;
+        else p = has ? __ffs((int)wm) - 1 : 0;
+        wm &= wm - 1;
+        const int pleg = kTorque ? ((p * 47) >> 9) : id_leg(p), kind = p - kKinds * pleg;
+        // the row's normal on my lane and its offset: n'x - b >= 0 with b = f_min (kind 0), 0 (friction), and for the torque
+        // bounds of joint k (kinds 5 + 2k upper, 6 + 2k lower) n = +-J[:,k], b = -(tau_max -+ tau0_k) -- held by the joint's lane
+        int tab_kind = kind;
+        double sign = 1.0, b_p = sel(kind == 0, f_min, 0.0);
+        if constexpr (kTorque) {
+          const int kj = (kind - 5) >> 1;
+          const bool tq = kind >= 5, lower = tq && ((kind - 5) & 1) != 0;
+          tab_kind = tq ? 5 + kj : kind;
+          sign = lower ? -1.0 : 1.0;
+          const int src = 4 * pleg + (tq ? kj : 0);
+          const double bu = __shfl(Q.tq_up, src, 16), bl = __shfl(Q.tq_lo, src, 16);
+          b_p = tq ? -(lower ? bl : bu) : b_p;
+        }
+        const double np_tab = sign * lds_nrm[64 * tab_kind + ((int)threadIdx.x & 63)];
+        npj = (has && pleg == leg) ? np_tab : 0.0;
+        // directions as in a pass; z'n_p of a row without a candidate is 0: biased to 1, its step is 0
+        double za[3] = {0.0, 0.0, 0.0}, ra[3] = {0.0, 0.0, 0.0};
+        static_for<kV>([&](auto J) {
+          constexpr int j = J;
+          fmac_bc<lane_of(j), j == 0>(za[j % 3], npj, H[j]);
+          fmac_bc<lane_of(j)>(ra[j % 3], npj, Ns[j]);
+        });
+        const double zw = (za[0] + za[1]) + za[2], rw = (ra[0] + ra[1]) + ra[2];
+        const double znw = row_sum(zw * npj);
+        const double s_p = row_sum(npj * x) - b_p; // slack of the row at x
+        // a row that depends on the rows installed before it is left out: z'n_p is then rounding noise, which with the entries
+        // of H reaching 1 / w_reg = 1e4 means up to 1e-10, while an independent row has z'n_p >= |n|^2 / trace(G) ~ 1e-3
+        const bool ok = has && znw > 1e-6;
+        const double zi = rcp_nr(sel(ok, znw, 1.0));
+        const double tw = sel(ok, -s_p * zi, 0.0);
+        x = fma(tw, zw, x);
+        u = fma(-tw, rw, u);
+        const int newlane = __ffs(~used & 0xFFFu) - 1;
+        const bool newslot = ok && lr == newlane;
+        vec = sel(ok, zw * zi, 0.0);
+        hc = sel(ok, -zw, 0.0);
+        nc = sel(newslot, 1.0, sel(ok, -rw, 0.0));
+        u = sel(newslot, tw, u);
+        idk = newslot ? p : idk;
+        used |= ok ? (1u << newlane) : 0u;
+        act_mask |= ok ? (one << p) : 0;
+        rnorm2 = sel(ok, vmax(rnorm2, znw), rnorm2);
+        q += ok ? 1 : 0;
+        warm_updates += ok ? 1 : 0;
+        update_only();
+      }
     }
     for (;;) { // at most q rounds: every round frees a slot and none is taken
       const bool slot = (used & lanebit) != 0u;

@@ -336,6 +336,10 @@ __device__ __forceinline__ bool wholebody_robot(const DeviceParams &P, const coo
                                        ((sm & 0xFF000000u) ? 8u : 0u))
                                     : 0u;
   const int nS = __popc(stance_legs);
+  if constexpr (kWarm) { // a set remembers the support legs it was reached with (bits 44..47); other legs now: a cold start (balance_coop.hpp)
+    const unsigned from = (unsigned)(warm_set >> 44) & 0xFu;
+    warm_set = (from != 0u && from != stance_legs) ? 0ull : (warm_set & ((1ull << 44) - 1ull));
+  }
   // support legs first (balance_coop.hpp): `leg` is my SLOT in the row, aleg the leg behind it; what was loaded by leg moves
   // to the lane of its slot
   const unsigned perm = slot_legs(stance_legs);
@@ -432,7 +436,7 @@ __device__ __forceinline__ bool wholebody_robot(const DeviceParams &P, const coo
   if (lr == 0 && live) {
     status_out[i] = st;
     if (pp.iterations) pp.iterations[i] = st == kStatusNotPd ? 0 : qp_iters;
-    if constexpr (kWarm) { if (pp.working_set) pp.working_set[i] = st == kStatusOk ? final_set : 0ull; }
+    if constexpr (kWarm) { if (pp.working_set) pp.working_set[i] = st == kStatusOk ? (final_set | ((unsigned long long)stance_legs << 44)) : 0ull; }
   }
   bool rejected = false;
   if constexpr (kWarm) {

@@ -295,3 +295,83 @@ def make_messages(batch, ragged=False, seed=SEED + 21, mode_names=None):
         msgs.append(wire.pack_robot_state(f, wire.random_layout(rng) if ragged else one))
     blob, off = wire.pack_batch(msgs)
     return blob, off, fields
+
+
+class MessageTemplate:
+    """One publisher's layout of free_gait_msgs/RobotState, for packing a whole batch at once: the payload elements of a message sit
+    at fixed byte offsets when every message shares the strings and array counts (wire.pack_robot_state's `layout`), so a batch is
+    the template's bytes tiled B times with the payload written in place (numpy, no per-robot Python).  The offsets are FOUND, not
+    derived: the template message is packed once more per payload element with that element changed, and the bytes that differ
+    are where it lives -- whatever wire.pack_robot_state does (the quaternion's x, y, z, w order included) is what this follows."""
+    DOUBLES = (("des_pos", 3), ("des_quat", 4), ("des_linvel", 3), ("des_angvel", 3), ("joint_command", 12), ("foot_position", 12),
+               ("foot_velocity", 12), ("foot_acceleration", 12), ("surface_normal", 12), ("phase", 4))
+
+    def __init__(self, mode_names, layout=None, seed=SEED + 22):
+        from . import wire
+        self.layout = layout if layout is not None else wire.random_layout(np.random.default_rng(seed))
+        self.mode_names = list(mode_names)
+        base = {k: np.arange(1.0, n + 1.0) * (3.0 + i) for i, (k, n) in enumerate(self.DOUBLES)}
+        base["support_leg"] = np.zeros(4, np.uint8)
+        base["mode_name"] = self.mode_names
+        self.template = np.frombuffer(wire.pack_robot_state(base, self.layout), np.uint8).copy()
+        self.offsets = {}
+        for k, n in self.DOUBLES:
+            offs = []
+            for e in range(n):
+                f = dict(base)
+                v = np.array(base[k], copy=True)
+                v[e] = -v[e] - 0.5
+                f[k] = v
+                m = np.frombuffer(wire.pack_robot_state(f, self.layout), np.uint8)
+                d = np.nonzero(m != self.template)[0]
+                assert len(m) == len(self.template) and len(d) and d.max() - d.min() < 8
+                # the element's 8 bytes: the differing bytes lie inside one aligned-to-the-element window; find its start by
+                # decoding candidates
+                start = None
+                for s0 in range(max(0, d.max() - 7), d.min() + 1):
+                    if np.frombuffer(m[s0:s0 + 8].tobytes(), "<f8")[0] == v[e]:
+                        start = s0
+                        break
+                assert start is not None
+                offs.append(start)
+            self.offsets[k] = np.array(offs)
+        offs = []
+        for e in range(4):
+            f = dict(base)
+            v = np.zeros(4, np.uint8)
+            v[e] = 1
+            f["support_leg"] = v
+            m = np.frombuffer(wire.pack_robot_state(f, self.layout), np.uint8)
+            d = np.nonzero(m != self.template)[0]
+            assert len(d) == 1
+            offs.append(int(d[0]))
+        self.offsets["support_leg"] = np.array(offs)
+
+    def pack(self, fields):
+        """(blob uint8 [B * L], offsets int64 [B + 1]) for the [B][k] arrays of `fields` (the keys of DOUBLES + support_leg)."""
+        B, L = np.asarray(fields["des_pos"]).shape[0], len(self.template)
+        blob = np.tile(self.template, (B, 1))
+        for k, n in self.DOUBLES:
+            v = np.ascontiguousarray(np.asarray(fields[k], dtype="<f8").reshape(B, n))
+            raw = v.view(np.uint8).reshape(B, n, 8)
+            for e in range(n):
+                o = int(self.offsets[k][e])
+                blob[:, o:o + 8] = raw[:, e, :]
+        sup = np.asarray(fields["support_leg"]).reshape(B, 4)
+        for e in range(4):
+            blob[:, int(self.offsets["support_leg"][e])] = (sup[:, e] != 0).astype(np.uint8)
+        return np.ascontiguousarray(blob.reshape(-1)), np.arange(B + 1, dtype=np.int64) * L
+
+
+def wholebody_trajectory(batch, gait="trot", ticks=1, dt=CONTROL_PERIOD, seed=SEED, offset=0):
+    """trajectory() for the whole-body step: the base as there, the joints moved by their own rates, rates and the desired base
+    acceleration as drawn (make_wholebody_states)."""
+    first = make_wholebody_states(batch, gait, seed, offset)
+    base = trajectory(batch, gait, ticks, dt, seed, offset)
+    out = []
+    for t, s in enumerate(base):
+        s = dict(s)
+        s["q"] = np.ascontiguousarray(first["q"] + t * dt * first["qd"])
+        s["qd"], s["a_des"] = first["qd"], first["a_des"]
+        out.append(s)
+    return out

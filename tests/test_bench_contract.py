@@ -1,5 +1,5 @@
 """The one-line JSON contract of bench.py: every key the driver reads, with the types and relations it relies on.
-CPU: the committed line of the last measured run (profiles/r5/bench_static_b4096.json).  GPU: short live runs."""
+CPU: the committed line of the last measured run (profiles/r6/bench_static_b4096.json).  GPU: short live runs."""
 import json
 import os
 import subprocess
@@ -37,38 +37,60 @@ def check(line, want_cpu=True):
     return d
 
 
-ALSO = {"static-calm", "trot", "static-survey-prev-tick-hints", "static-survey-warm", "trot_b8192", "trot_b65536", "pose_sqp_b4096"}
-ALSO_KEYS = ("value", "ms_per_step", "kernel_ms", "roofline_frac", "valu_issue_frac", "all_status_ok")
+ALSO = {"static-calm", "trot", "trot_b8192", "trot_b65536", "pose_sqp_b4096", "full_tick_b4096", "wholebody_trot_b4096"}
+ALSO_KEYS = ("value", "ms_per_step", "kernel_ms", "roofline_frac", "all_status_ok")
+TRAJECTORY_KEYS = ("states_per_replay", "ticks", "regions", "dt", "switched_per_tick", "switched_at_wrap", "placement_give_ups", "working_set_unchanged",
+                   "working_set_unchanged_at_wrap", "warm_rejected")
 
 
-def check_round5(d):
-    """What round 5 added to the default line: the placed loop as the method, the same steps through the plain entry beside
-    it, every BASELINE config in `also`, and the scale point a weak-scaling curve is drawn from."""
-    assert d["config"]["method"] == "placed" and "placement" in d["config"]["method_note"]
-    u = d["unplaced"]
-    assert u["method"] == "plain" and u["all_status_ok"] is True and u["batch"] == 4096 and u["ms_per_step"] > 0
+def check_round6(d, steps):
+    """Round 6: every timed region runs on a trajectory (K consecutive control ticks, contact switches included), the method is the
+    caller's placed + warm-started loop, the same steps with every QP started cold ride along (`cold_start`: the placed loop,
+    round 5's method; `unplaced`: the plain entry, rounds 1-4's), and `also` carries every other BASELINE config plus the whole
+    tick and the whole-body step."""
+    c = d["config"]
+    assert c["method"] == "warm" and "working set" in c["method_note"] and "placement" in c["method_note"]
+    assert c["states_per_replay"] == steps and "consecutive control ticks" in c["workload"]
+    t = c["trajectory"]
+    for k in TRAJECTORY_KEYS:
+        assert k in t, k
+    assert t["states_per_replay"] == steps and t["dt"] == 0.0025 and t["switched_per_tick"] == 0.0      # a static stance switches nothing
+    assert t["ticks"] == max(steps, steps * (200 // steps)) and t["regions"] * steps == t["ticks"]   # regions continue the trajectory
+    assert 0.9 < t["working_set_unchanged"] <= 1.0 and t["warm_rejected"] == 0 and t["placement_give_ups"] == 0
+    for key, m in (("cold_start", "placed"), ("unplaced", "plain")):
+        u = d[key]
+        assert u["method"] == m and u["all_status_ok"] is True and u["batch"] == 4096 and u["ms_per_step"] > 0, key
+        assert u["trajectory"]["states_per_replay"] == steps
+    assert d["ms_per_step"] < d["cold_start"]["ms_per_step"] < d["unplaced"]["ms_per_step"] * 1.02
     assert set(d["also"]) == ALSO
     for name, a in d["also"].items():
+        assert "error" not in a, (name, a)
         for k in ALSO_KEYS:
             assert k in a, (name, k)
         assert a["all_status_ok"] is True and a["value"] > 0 and a["kernel_ms"] > 0 and 0 < a["roofline_frac"] < 1, name
-    assert d["also"]["static-calm"]["tracking_error"] == [0.004, 0.005, 0.01] and d["also"]["static-calm"]["method"] == "plain"
+        if name != "pose_sqp_b4096":
+            assert a["cold_start"]["ms_per_step"] > 0 and a["cold_start"]["all_status_ok"] is True, name
+    for name in ("static-calm", "trot", "trot_b8192", "trot_b65536"):
+        a = d["also"][name]
+        assert a["method"] == "warm" and a["unplaced"]["all_status_ok"] is True and "pmc_source" in a, name
+        assert a["trajectory"]["warm_rejected"] == 0
+        if name != "static-calm":   # a trot steps through its contact switches: about 1.1 % of the robots per tick
+            assert 0.007 < a["trajectory"]["switched_per_tick"] < 0.016, name
+    assert d["also"]["static-calm"]["tracking_error"] == [0.004, 0.005, 0.01]
     assert d["also"]["trot_b8192"]["batch"] == 8192 and d["also"]["trot_b65536"]["batch"] == 65536
-    assert d["also"]["trot_b8192"]["unplaced"]["ms_per_step"] > 0 and d["also"]["trot_b65536"]["unplaced"]["all_status_ok"] is True
-    assert "note" in d["also"]["static-survey-prev-tick-hints"] and d["also"]["static-survey-prev-tick-hints"]["method"] == "placed"
-    w = d["also"]["static-survey-warm"]
-    assert w["method"] == "warm" and "working set" in w["note"] and w["ms_per_step"] < d["unplaced"]["ms_per_step"]
-    assert d["also"]["trot_b8192"]["warm"]["all_status_ok"] is True and d["also"]["trot_b65536"]["warm"]["ms_per_step"] > 0
-    assert d["scale_point"]["warm"]["value"] > 0
-    assert d["warm_started"] == w   # the line's own workload by the three ways a caller can step it: value, unplaced, warm_started
+    assert d["also"]["trot_b65536"]["trajectory"]["ticks"] == (64 if steps >= 64 else steps * (64 // steps))
+    ft, wb = d["also"]["full_tick_b4096"], d["also"]["wholebody_trot_b4096"]
+    assert ft["unit"] == "ticks/s" and ft["message_bytes"] > 3000 and 0.007 < ft["switched_per_tick"] < 0.016
+    assert wb["unit"] == "whole-body control steps/s" and wb["warm_rejected"] == 0
     sp = d["scale_point"]
-    assert sp["robots_per_gpu"] == 8192 and sp["gait"] == "trot" and sp["n_gpus"] == d["n_gpus"]
+    assert sp["robots_per_gpu"] == 8192 and sp["gait"] == "trot" and sp["n_gpus"] == d["n_gpus"] and sp["method"] == "warm"
     assert sp["value"] > 0 and sp["without_gather"] > 0 and "efficiency" in sp["definition"]
     assert abs(sp["value"] - d["also"]["trot_b8192"]["value"]) < 1e-6 * sp["value"]
+    assert sp["cold_start"]["ms_per_step"] > 0 and sp["unplaced"]["ms_per_step"] > 0
 
 
 def test_committed_bench_line_follows_the_contract():
-    path = os.path.join(ROOT, "profiles", "r5", "bench_static_b4096.json")
+    path = os.path.join(ROOT, "profiles", "r6", "bench_static_b4096.json")
     d = check(open(path).read().strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["config"]["robots_per_gpu"] == 4096 and d["config"]["all_status_ok"] is True
     # round 2: the input is disclosed, the timed region is a median of samples, PMC numbers carry their source
@@ -80,9 +102,7 @@ def test_committed_bench_line_follows_the_contract():
     assert c["cpu_model"] and c["value"] >= 0.9 * max(c["thread_sweep"].values()) and c["thread_sweep_seconds_each"] >= 1.5
     assert d["roofline"]["traffic"] and "FETCH_SIZE" in d["roofline"]["traffic_rule"]
     assert d["valu_issue"]["frac"] >= 0.25
-    # round 5
-    check_round5(d)
-    assert d["ms_per_step"] < d["unplaced"]["ms_per_step"]   # the placement pays on the headline preset
+    check_round6(d, d["steps"])
 
 
 @pytest.mark.gpu
@@ -101,11 +121,11 @@ def test_live_bench_line_follows_the_contract():
     assert "OMP_PLACES=cores" in c["threads"] and "OMP_PROC_BIND=close" in c["threads"]
 
 
-def _bench(*argv):
+def _bench(*argv, rc=0):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=900,
                          cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.returncode == rc, (out.returncode, out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, "bench.py must print exactly one line (RCCL's shutdown banner included): %r" % lines
     return lines[0]
@@ -117,13 +137,14 @@ def test_live_default_line_is_the_contract_workload_and_carries_the_other_preset
     `also` object with static-calm and trot measured in the same process."""
     d = check(_bench("--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--replays", "3"), want_cpu=False)
     assert d["config"]["gait"] == "static" and d["config"]["tracking_error"] == [0.02, 0.05, 0.1]
-    check_round5(d)
-    for name, a in d["also"].items():
-        assert "pmc_source" in a, name
+    check_round6(d, 20)
     assert d["also"]["static-calm"]["kernel_ms"] < d["roofline"]["kernel_ms"]     # the calm preset is the lighter one
-    # the plain entry as the method: the placed loop rides along instead
-    d = check(_bench("--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--replays", "3", "--method", "plain"), want_cpu=False)
-    assert d["config"]["method"] == "plain" and d["placed"]["method"] == "placed" and d["placed"]["all_status_ok"] is True
+    # the plain entry as the method: the placed loop rides along instead; the placed loop: the plain entry does
+    d = check(_bench("--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--replays", "3", "--method", "plain", "--no-also"), want_cpu=False)
+    assert d["config"]["method"] == "plain" and "cold_start" not in d
+    d = check(_bench("--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--replays", "3", "--method", "placed", "--ticks", "7"), want_cpu=False)
+    assert d["config"]["method"] == "placed" and d["unplaced"]["method"] == "plain" and d["unplaced"]["all_status_ok"] is True
+    assert d["config"]["trajectory"]["ticks"] == 7 and d["config"]["states_per_replay"] == 20
 
 
 @pytest.mark.gpu
@@ -132,7 +153,7 @@ def test_collective_path_with_one_rank():
     hipGraph, gathers on a second captured stream -- exercised with a single rank, then without the gather, then with
     eager launches (what the ranks fall back to when a capture fails)."""
     common = ("--force-collective", "--gait", "trot", "--batch", "8192", "--steps", "20", "--warmup", "3",
-              "--no-cpu-baseline", "--replays", "3", "--no-alternatives")
+              "--no-cpu-baseline", "--replays", "3")
     d = check(_bench(*common, "--overlap-gather"), want_cpu=False)
     c = d["config"]
     assert c["rccl_ranks"] == 1 and d["n_gpus"] == 1 and c["robots_per_gpu"] == 8192 and c["all_status_ok"] is True
@@ -156,23 +177,24 @@ def test_collection_cadence_and_peer_copies_with_one_rank():
     collective) and the `alternatives` object a several-rank line carries, each through the captured two-stream form."""
     common = ("--force-collective", "--overlap-gather", "--gait", "trot", "--batch", "8192", "--steps", "20", "--warmup", "3",
               "--no-cpu-baseline", "--replays", "3")
-    d = check(_bench(*common, "--gather-every", "4", "--no-alternatives"), want_cpu=False)
+    d = check(_bench(*common, "--gather-every", "4"), want_cpu=False)
     c = d["config"]
     assert c["gather_every"] == 4 and c["collect"] == "rccl" and c["gather_layout_ok"] is True and c["all_status_ok"] is True
     assert c["launch"] == "hipGraph of K steps" and "alternatives" not in d
-    d = check(_bench(*common, "--collect", "peer", "--no-alternatives"), want_cpu=False)
+    d = check(_bench(*common, "--collect", "peer"), want_cpu=False)
     c = d["config"]
     assert c["collect"] == "peer" and c["gather_every"] == 1 and c["gather_layout_ok"] is True and c["all_status_ok"] is True
     assert c["result_collection"].startswith("copies of the torque shard") and c["launch"] == "hipGraph of K steps"
-    d = check(_bench(*common), want_cpu=False)  # the default: RCCL every step, the others measured beside it
+    d = check(_bench(*common, "--alternatives"), want_cpu=False)  # RCCL every step, the others measured beside it on request
     assert d["config"]["collect"] == "rccl" and d["config"]["gather_every"] == 1
     alt = d["alternatives"]
     assert set(alt) == {"rccl_every_8", "peer_every_1", "peer_every_8"}
     for name, a in alt.items():
         assert "error" not in a, (name, a)
         assert a["value"] > 0 and a["layout_ok"] is True, (name, a)
-    # alternatives that do not come back in time cost the line their object only (the watchdog prints the line and ends the rank)
-    d = check(_bench(*common, "--alternatives-timeout", "0.05"), want_cpu=False)
+    # alternatives that do not come back in time cost the line their object only: the watchdog prints the line and ends the rank
+    # -- with a non-zero exit code: a launcher must not read success from a rank that did not finish what it was asked to do
+    d = check(_bench(*common, "--alternatives", "--alternatives-timeout", "0.05", rc=3), want_cpu=False)
     assert d["config"]["gather_layout_ok"] is True and d["value"] > 0
     assert "not finished" in d["alternatives"]["error"]
 
@@ -191,7 +213,7 @@ def test_profile_collection_names_exist_in_the_sources():
     kernels = set(re.findall(r"__global__[^;{]*?\bvoid\s+(\w+)\s*\(", text))
     for name, kernel, batch, args in cp.WORKLOADS:
         assert kernel in kernels, kernel
-    idx = json.load(open(os.path.join(ROOT, "profiles", "r5", "pmc_index.json")))
+    idx = json.load(open(os.path.join(ROOT, "profiles", "r6", "pmc_index.json")))
     have = {(r["kernel"], r["batch"], r["workload"]) for r in idx["records"]}
     assert have == {(k, b, n) for n, k, b, _ in cp.WORKLOADS}
     assert all("fetch_bytes" in r and "write_bytes" in r and "valu_insts" in r for r in idx["records"])

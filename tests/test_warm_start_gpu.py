@@ -57,14 +57,16 @@ def test_warm_start_reaches_the_cold_start_s_answer(gpu, oracle, gait, errors, B
     stance_bits = np.zeros(B, dtype=np.uint32)
     for leg in range(4):
         stance_bits |= np.where(s["stance"][:, leg] != 0, np.uint32(0x1F << (5 * leg)), np.uint32(0))
-    assert ((ws0 & ~stance_bits) == 0).all() and (ws0 < (1 << 20)).all()
-    nact = np.array([bin(int(w)).count("1") for w in ws0])
+    rows0 = ws0 & np.uint32(0xFFFFF)                 # bits 20..23: the support legs the set was reached with
+    legs0 = (s["stance"].astype(bool) * (1 << np.arange(4))).sum(axis=1).astype(np.uint32)
+    assert ((rows0 & ~stance_bits) == 0).all() and np.array_equal(ws0 >> 20, legs0)
+    nact = np.array([bin(int(w)).count("1") for w in rows0])
     assert (nact <= 3 * s["stance"].astype(bool).sum(axis=1)).all() and nact.max() >= 4
     # (1) its own final set: nothing left to do but one selection that finds no violated row
     t1, g1, s1, it1, ws1 = solve(gpu, d, B, prev_ws=ws0)
     assert np.array_equal(s1, s0) and np.array_equal(ws1, ws0)
     assert np.abs(t1 - t0).max() < 1e-7 and np.abs(g1 - g0).max() < 1e-7
-    nset = np.array([bin(int(w)).count("1") for w in ws0])
+    nset = nact
     assert ((it1 - nset) <= 1).mean() > 0.99 and (it1 - nset).max() <= 3 and (it1 >= nset).all()   # installs + one selection
     # (2) the set of the state one control period earlier -- what a 400 Hz caller has
     prev = synth.next_tick_states(s, -0.0025)
@@ -96,7 +98,10 @@ def test_warm_start_reaches_the_cold_start_s_answer(gpu, oracle, gait, errors, B
     to, go, so = oracle.balance_batch(s, nthreads=8)
     order = rng.permutation(B).astype(np.int32)
     t4, g4, s4, _, _ = solve(gpu, d, B, prev_ws=ws_prev, order=order)
-    assert np.array_equal(t4, t2) and np.array_equal(s4, s2)      # placement never changes a result
+    # a placement never changes the answer.  (Cold, not a bit of it: tests/test_placement_gpu.py.  Warm-started, the form in which
+    # the previous set is installed -- by rounds of four rows or row by row -- is chosen per wavefront, by the largest set among
+    # its four robots: the same minimiser, rounded along another path.)
+    assert np.abs(t4 - t2).max() < 1e-9 and np.array_equal(s4, s2)
     assert np.array_equal(s2, so) and np.abs(t2 - to).max() < TAU_TOL and np.abs(g2 - go).max() < 1e-6
 
 
@@ -207,12 +212,13 @@ def test_wholebody_step_warm_start(gpu, oracle, gait):
     t0, g0, s0 = tau0.cpu().numpy(), grf0.cpu().numpy(), st0.cpu().numpy()
     tc, gc, sc, itc, wsc = run(d)
     assert np.array_equal(tc, t0) and np.array_equal(sc, s0)      # no set handed in: the cold start, bit for bit
-    assert (wsc < (1 << 44)).all() and (wsc != 0).sum() > (B // 8 if gait == "trot" else 0)   # (a static stance activates next to nothing)
+    rows_c = wsc & np.uint64((1 << 44) - 1)           # bits 44..47: the support legs the set was reached with
+    assert (wsc < (1 << 48)).all() and (rows_c != 0).sum() > (B // 8 if gait == "trot" else 0)   # (a static stance activates next to nothing)
     ok = s0 == 0
     t1, g1, s1, it1, ws1 = run(d, prev=wsc)
     assert np.array_equal(s1, s0) and np.array_equal(ws1[ok], wsc[ok])
     assert np.abs(t1[ok] - t0[ok]).max() < 1e-7 and np.abs(g1[ok] - g0[ok]).max() < 1e-7
-    nset = np.array([bin(int(w)).count("1") for w in wsc])
+    nset = np.array([bin(int(w)).count("1") for w in rows_c])
     assert ((it1 - nset)[ok] <= 1).mean() > 0.98
     earlier = dict(s)
     earlier["q"] = s["q"] - 0.0025 * s["qd"]
@@ -249,8 +255,8 @@ def test_wholebody_step_warm_start(gpu, oracle, gait):
         n4 = ctx.counter(capi.COUNTER_WARM_RETRIES) - before
     finally:
         ctx.set_option(capi.OPT_WARM_FALLBACK, 1)
-    again = ok & (wsc != 0) & (ws4 == 0)
-    assert n4 == again.sum() and again.sum() > 0.9 * (ok & (wsc != 0)).sum()
+    again = ok & (rows_c != 0) & (ws4 == 0)
+    assert n4 == again.sum() and again.sum() > 0.9 * (ok & (rows_c != 0)).sum()
     assert np.array_equal(s4, s0) and np.abs(t4[again] - t0[again]).max() < 1e-9 and np.abs(g4[again] - g0[again]).max() < 1e-9
     assert np.abs(t4[ok] - t0[ok]).max() < 1e-7
     # the dense entries start cold: a working set handed to them is refused

@@ -1,0 +1,55 @@
+"""What the placed + warm-started loop sees on a trot trajectory, by class of robot: iteration counts (installs + drops + passes)
+of the robots whose support set stayed (on two legs, on four), of the ones that entered double support (2 -> 4 legs) and of the
+ones that left it (4 -> 2), next to the counts of a cold start on the same states.  usage: trajectory_stats.py [B] [T] [heuristic]"""
+import sys, os
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import torch
+from quadruped_locomotion_amd import capi, synth
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+heur = sys.argv[3] if len(sys.argv) > 3 else "none"
+ctx = capi.Context()
+states = synth.trajectory(B, "trot", T)
+ws = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+it = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+itc = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+tau = torch.zeros(B, 12, dtype=torch.float64, device="cuda:0")
+st = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+rows = {}
+for t, s in enumerate(states):
+    d = capi.to_device(s)
+    if t > 0 and heur != "none":
+        # guess rows for the legs that have just started to support: the friction rows (kinds 1..4) of a leg that already did
+        prev, cur = states[t - 1]["stance"].astype(bool), s["stance"].astype(bool)
+        w = ws.cpu().numpy().view(np.uint32).copy()
+        new = cur & ~prev
+        for b in np.nonzero(new.any(axis=1))[0]:
+            old_legs = [l for l in range(4) if prev[b, l] and cur[b, l]]
+            if not old_legs:
+                continue
+            src = (int(w[b]) >> (5 * old_legs[0])) & 0x1F
+            if heur == "friction":
+                src &= 0x1E
+            for l in np.nonzero(new[b])[0]:
+                w[b] |= np.uint32(src << (5 * int(l)))
+        ws.copy_(torch.from_numpy(w.view(np.int32)).to("cuda:0"))
+    ctx.balance_solve_placed_device(d, tau, None, st, iterations=itc)                       # cold
+    ctx.balance_solve_placed_device(d, tau, None, st, iterations=it, prev_working_set=ws, working_set=ws)
+    torch.cuda.synchronize()
+    assert (st == 0).all()
+    if t == 0:
+        continue
+    prev, cur = states[t - 1]["stance"].sum(1), s["stance"].sum(1)
+    w_it, c_it = it.cpu().numpy(), itc.cpu().numpy()
+    for name, m in (("stay 2", (prev == 2) & (cur == 2) & (states[t - 1]["stance"] == s["stance"]).all(1)), ("stay 4", (prev == 4) & (cur == 4)),
+                    ("2 -> 4", (prev == 2) & (cur == 4)), ("4 -> 2", (prev == 4) & (cur == 2))):
+        if m.any():
+            rows.setdefault(name, []).append((m.sum(), w_it[m].mean(), w_it[m].max(), c_it[m].mean(), c_it[m].max()))
+print("trot B=%d T=%d heuristic=%s" % (B, T, heur))
+print("%-8s %8s %10s %9s %10s %9s" % ("class", "robots/t", "warm mean", "warm max", "cold mean", "cold max"))
+for name, r in rows.items():
+    r = np.array(r)
+    print("%-8s %8.1f %10.2f %9d %10.2f %9d" % (name, r[:, 0].mean(), (r[:, 1] * r[:, 0]).sum() / r[:, 0].sum(), r[:, 2].max(),
+                                                (r[:, 3] * r[:, 0]).sum() / r[:, 0].sum(), r[:, 4].max()))
