@@ -723,11 +723,15 @@ def main():
             else:
                 ctx.balance_solve_device(ds[k % T], out, None, status, stream=st)
         G = max(1, every)
-        tau = [torch.zeros(G, B, 12, dtype=torch.float64, device=dev) for _ in range(2)]
         status = torch.full((B,), -1, dtype=torch.int32, device=dev)
         peer = PeerBuffers(G * B * 12, rank, world, dev, dist, torch) if (with_gather and collect == "peer") else None
         gathered = ([torch.zeros(world, G, B, 12, dtype=torch.float64, device=dev) for _ in range(2)]
                     if (with_gather and peer is None) else None)
+        # Result collection IN PLACE: a step writes its efforts straight into this rank's block of the gathered buffer and the
+        # all-gather gets that block as its input (sendbuff = recvbuff + rank x count: RCCL's in-place form, which moves nothing
+        # locally).  Out of place, one rank's "gather" was a copy kernel plus two event edges per step (+6.9 us per step, round 5).
+        tau = ([gathered[b_][rank] for b_ in range(2)] if gathered is not None else
+               [torch.zeros(G, B, 12, dtype=torch.float64, device=dev) for _ in range(2)])
 
         def collect_now(k):  # the last step of its group, or the last step of all
             return (k % G == G - 1) or (k == args.steps - 1)
@@ -908,15 +912,24 @@ def main():
         res = measure(with_gather)
         if peer is not None:
             peer.agree_no_failure()
-        res["plain"] = measure(False) if (with_gather and second_without_gather) else None
         if collective and args.steps > 0 and with_gather:
-            # the collected buffer holds every rank's torques in rank order (every rank checks its own slot)
+            # the collected buffer holds every rank's torques in rank order: every rank sends a checksum of the block it computed
+            # and checks every block it received against its sender's (peer copies: its own slot against its own buffer)
             last = ((args.steps - 1) // G) & 1
-            mine = peer.slot_equals(last, rank, tau[last]) if peer is not None else torch.equal(gathered[last][rank], tau[last])
+            torch.cuda.synchronize()
+            if peer is not None:
+                mine = peer.slot_equals(last, rank, tau[last])
+            else:
+                sums = torch.zeros(world, dtype=torch.float64, device=dev)
+                dist.all_gather_into_tensor(sums, tau[last].abs().sum().reshape(1))
+                got = gathered[last].abs().sum(dim=(1, 2, 3))
+                mine = bool(torch.equal(got, sums)) and bool((sums > 0).all().item())
             flag = torch.tensor([1 if mine else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             assert int(flag.item()) == 1, "collected layout"
             res["gather_layout_ok"] = True
+        # (after the check: these steps write over this rank's block of the gathered buffers)
+        res["plain"] = measure(False) if (with_gather and second_without_gather) else None
         if peer is not None:
             peer.close()
         # ---- what the loop saw, tick by tick (untimed): the K steps once more, eagerly, continuing the caller's loop where the

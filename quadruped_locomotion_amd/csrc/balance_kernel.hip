@@ -516,6 +516,7 @@ __global__ __launch_bounds__(64 * kCoopWaves, kMinWaves) void balance_coop_kerne
   const DeviceParams &P = *Pp;
   const int row = threadIdx.x >> 4, wave = threadIdx.x >> 6;
   unsigned block = blockIdx.x;
+  QL_BLOCK_STAMP(0);
   if constexpr (kPlaced) {
     // the first workgroups of a launch that also places the next one (they start first and have the whole launch to finish in)
     if (s.shadow_blocks) {
@@ -554,6 +555,7 @@ __global__ __launch_bounds__(64 * kCoopWaves, kMinWaves) void balance_coop_kerne
   {
     const bool rejected = coop::coop_robot<kPerLeg, 64 * kCoopWaves, kWarm, kMinWaves == 3 && !kWarm, kMinWaves == 3>(
         P, cp, i, live, tab, rows + row * coop::kCoopLdsDoubles, nrm + wave * coop::kCoopNrmDoubles, tau, grf, status);
+    QL_BLOCK_STAMP(3);
     if constexpr (kWarm) {
       // A warm start must never cost an answer (balance_coop.hpp): the rows whose warm start was rejected are solved again, cold,
       // by this wavefront -- the plain kernel's body behind a scalar branch, everything it needs fetched again from the argument
@@ -1197,3 +1199,4 @@ int qlamd_leg_kinematics_batch(qlamd_context *ctx, const double *joint_position,
 } // extern "C"
 
 QLAMD_STAMPS_ACCESSOR(qlamd_debug_stamps)
+QLAMD_BLOCK_STAMPS_ACCESSOR(qlamd_debug_block_stamps)

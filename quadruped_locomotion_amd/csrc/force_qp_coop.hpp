@@ -33,6 +33,10 @@ namespace coop {
 // wavefronts -- three per SIMD -- fit a compute unit's 160 KB.)
 constexpr int kCoopLdsDoubles = 12 * 12;
 constexpr int kMaxRefinePasses = 8; // of a warm start whose set did not fit (force_qp_coop's refinement)
+#ifndef QLAMD_REFINE_AGAIN
+#define QLAMD_REFINE_AGAIN 1e-3
+#endif
+constexpr double kRefineAgain = QLAMD_REFINE_AGAIN; // a warm start's refinement passes again while a pass moved x by more than this
 constexpr int kDropSlot = 48, kZeroSlot = 60, kWarmSlot = 61; // (kWarmSlot: the update count of a warm start, an int)
 // rows of the wavefront's table of constraint normals ([row kind][lane]) the QP uses: 5, and 3 more with kTorque
 constexpr int kForceQpNrmRows = 5, kForceQpNrmRowsTorque = 8;
@@ -444,6 +448,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
   };
 
   int warm_updates = 0; // rank-one updates of the warm start (kWarm)
+  QL_BLOCK_STAMP(1);
   if constexpr (kWarm) {
     // ---- warm start: install the previous working set (rows of legs that still support), then drop negative multipliers
     constexpr mask_t kLegRows = (one_v<mask_t> << kKinds) - 1;
@@ -645,6 +650,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     if (lr == 0) reinterpret_cast<int *>(lds_row + kWarmSlot)[0] = warm_updates;
     warm_updates = 0;
   }
+  QL_BLOCK_STAMP(2);
   {
     // lanes that are not here (rows that have left with kStatusNotPd) count as finished: ballots never see them
     done_m = ~__builtin_amdgcn_ballot_w64(true);
@@ -885,11 +891,14 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
       static_for<kV>([&](auto K) { constexpr int k = K; fmac_bc<k, k == 0>(dx, rho, NsT[k]); });
       x += dx;
       if constexpr (kWarm) {
-        // A pass shrinks the error by the operators' relative drift.  A set that fitted leaves a first correction of the
-        // order of the drift itself (<= 4e-5 over 6.3 M cold steps): one pass, as for a cold start.  A set that did not can
-        // leave x far from the optimum of its final set; such a robot passes again until the correction is below 1e-4.
+        // A pass shrinks the error by the operators' relative drift (<= 1e-3: one pass takes the first correction of a cold
+        // start, <= 4e-5 over 6.3 M steps, to 4e-8).  A set that fitted leaves a first correction of up to a few 1e-4 when it
+        // was installed by rounds: one pass, as for a cold start.  A set that did not can leave x far from the optimum of its
+        // final set; such a robot passes again until the correction is below kRefineAgain = 1e-3 (what is left then is
+        // <= 1e-6 of it; with 1e-4, round 5's value, one static robot in three of the bench batch passed twice: 14.6 -> 13.9 us
+        // per step, the soak on trajectories with jumps -- 4.7 M steps -- the same 6e-8: profiles/r6/ab_refine_again.txt).
         const double moved = -row_min(-(__builtin_fabs(corr) + __builtin_fabs(dx)));
-        passes += (warm_updates > 0 && pass + 1 == passes && passes < kMaxRefinePasses && moved > 1e-4) ? 1 : 0;
+        passes += (warm_updates > 0 && pass + 1 == passes && passes < kMaxRefinePasses && moved > kRefineAgain) ? 1 : 0;
       }
     }
   }

@@ -187,23 +187,51 @@ struct LegStatePtrs {
   int32_t *status;
 };
 
-// the state machine of robot i, by one lane
-__device__ __forceinline__ void leg_state_robot(const LegStatePtrs &s, int index_quirk, int64_t i) {
-  LegStateRobot r;
-  // four flags per robot travel as one 32-bit word
-  const uint32_t sup = *reinterpret_cast<const uint32_t *>(s.support_leg + 4 * i);
+// Everything the state machine of robot i reads, fetched in one go (independent loads, one round trip): the four flags of a
+// kind travel as one 32-bit word.  Split from the machine itself so that the parser's blocks can issue these loads at their
+// very start -- they do not depend on the message -- and take the command fields of a well-formed message straight from the
+// record in LDS instead of reading them back from the arrays they have just written (two dependent memory round trips at the
+// tail of every block of the unpack launch: 12.2 -> 8.6 us without them, profiles/r5/tick_block_stamps.txt).
+struct LegStateIn {
+  uint32_t sup, fst_in, mm, mcur, con, lst, sto, sup_i;
+  double ph[4], jp[12], sj[12], ft[12];
+  uint8_t live;
+};
+__device__ __forceinline__ void leg_state_load(const LegStatePtrs &s, int64_t i, LegStateIn &in) {
+  in.sup = *reinterpret_cast<const uint32_t *>(s.support_leg + 4 * i);
   // (the whole tick hands in this tick's mode names instead of is_footstep: both words are loaded here with everything
   // else, merged below, and the modes in force are written back with the other results)
-  const uint32_t fst_in = *reinterpret_cast<const uint32_t *>((s.msg_mode ? s.support_leg : s.is_footstep) + 4 * i);
-  const uint32_t mm = *reinterpret_cast<const uint32_t *>((s.msg_mode ? s.msg_mode : s.support_leg) + 4 * i);
-  const uint32_t mcur = *reinterpret_cast<const uint32_t *>((s.msg_mode ? (const uint8_t *)s.leg_mode : s.support_leg) + 4 * i);
-  const uint32_t con = *reinterpret_cast<const uint32_t *>(s.contact + 4 * i);
-  const uint32_t lst = *reinterpret_cast<const uint32_t *>(s.limb_state + 4 * i);
-  const uint32_t sto = *reinterpret_cast<const uint32_t *>(s.store_flag + 4 * i);
+  in.fst_in = *reinterpret_cast<const uint32_t *>((s.msg_mode ? s.support_leg : s.is_footstep) + 4 * i);
+  in.mm = *reinterpret_cast<const uint32_t *>((s.msg_mode ? s.msg_mode : s.support_leg) + 4 * i);
+  in.mcur = *reinterpret_cast<const uint32_t *>((s.msg_mode ? (const uint8_t *)s.leg_mode : s.support_leg) + 4 * i);
+  in.con = *reinterpret_cast<const uint32_t *>(s.contact + 4 * i);
+  in.lst = *reinterpret_cast<const uint32_t *>(s.limb_state + 4 * i);
+  in.sto = *reinterpret_cast<const uint32_t *>(s.store_flag + 4 * i);
   const double2 p01 = *reinterpret_cast<const double2 *>(s.phase + 4 * i);
   const double2 p23 = *reinterpret_cast<const double2 *>(s.phase + 4 * i + 2);
-  const double ph[4] = {p01.x, p01.y, p23.x, p23.y};
-  uint32_t fst = fst_in, merged = 0;
+  in.ph[0] = p01.x; in.ph[1] = p01.y; in.ph[2] = p23.x; in.ph[3] = p23.y;
+  // every array the tick may touch is fetched up front (independent 16-byte loads, one round trip); what
+  // the state machine decides only selects which values are written back
+  {
+    const double2 *pj = reinterpret_cast<const double2 *>(s.joint_position + 12 * i);
+    const double2 *ps = reinterpret_cast<const double2 *>(s.stored_joint_position + 12 * i);
+    const double2 *pf = reinterpret_cast<const double2 *>(s.foot_target + 12 * i);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const double2 a = pj[k], b = ps[k], c = pf[k];
+      in.jp[2 * k] = a.x; in.jp[2 * k + 1] = a.y; in.sj[2 * k] = b.x; in.sj[2 * k + 1] = b.y; in.ft[2 * k] = c.x; in.ft[2 * k + 1] = c.y;
+    }
+  }
+  in.sup_i = *reinterpret_cast<const uint32_t *>(s.support + 4 * i);
+  in.live = s.live ? s.live[i] : (uint8_t)1;
+}
+
+// the state machine of robot i on what leg_state_load fetched, by one lane
+__device__ __forceinline__ void leg_state_run(const LegStatePtrs &s, int index_quirk, int64_t i, const LegStateIn &in) {
+  LegStateRobot r;
+  const uint32_t sup = in.sup, mm = in.mm, mcur = in.mcur, con = in.con, lst = in.lst, sto = in.sto;
+  const double *ph = in.ph, *jp = in.jp, *sj = in.sj, *ft = in.ft;
+  uint32_t fst = in.fst_in, merged = 0;
   if (s.msg_mode) {
     fst = 0;
 #pragma unroll
@@ -223,21 +251,8 @@ __device__ __forceinline__ void leg_state_robot(const LegStatePtrs &s, int index
     r.store_flag[l] = ((sto >> (8 * l)) & 0xFFu) != 0;
     r.phase[l] = ph[l];
   }
-  // every array the tick may touch is fetched up front (independent 16-byte loads, one round trip); what
-  // the state machine decides only selects which values are written back
-  double jp[12], sj[12], ft[12];
-  {
-    const double2 *pj = reinterpret_cast<const double2 *>(s.joint_position + 12 * i);
-    const double2 *ps = reinterpret_cast<const double2 *>(s.stored_joint_position + 12 * i);
-    const double2 *pf = reinterpret_cast<const double2 *>(s.foot_target + 12 * i);
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const double2 a = pj[k], b = ps[k], c = pf[k];
-      jp[2 * k] = a.x; jp[2 * k + 1] = a.y; sj[2 * k] = b.x; sj[2 * k + 1] = b.y; ft[2 * k] = c.x; ft[2 * k + 1] = c.y;
-    }
-  }
-  const uint32_t sup_i = *reinterpret_cast<const uint32_t *>(s.support + 4 * i);
-  if (s.live && !s.live[i]) {
+  const uint32_t sup_i = in.sup_i;
+  if (s.live && !in.live) {
     s.status[i] = QLAMD_STATUS_NO_COMMAND;
     return;
   }
@@ -266,6 +281,12 @@ __device__ __forceinline__ void leg_state_robot(const LegStatePtrs &s, int index
   *reinterpret_cast<uint32_t *>(s.support + 4 * i) = sup_o;
   *reinterpret_cast<uint32_t *>(s.code + 4 * i) = code_o;
   if (s.msg_mode) *reinterpret_cast<uint32_t *>(s.leg_mode + 4 * i) = merged;
+}
+
+__device__ __forceinline__ void leg_state_robot(const LegStatePtrs &s, int index_quirk, int64_t i) {
+  LegStateIn in;
+  leg_state_load(s, i, in);
+  leg_state_run(s, index_quirk, i, in);
 }
 
 __global__ __launch_bounds__(256) void leg_state_kernel(const LegStatePtrs s, int index_quirk, int64_t B) {
@@ -489,6 +510,11 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   QL_STAMP(20);
   QL_BLOCK_STAMP(0);
   const int64_t a = offsets[i0], b = offsets[i0 + n];
+  // the whole tick: what the state machine of my robot reads (lane m < n: robot i0 + m) is fetched NOW, with the block's first
+  // loads -- none of it depends on the message; the command fields among it are the command still in force, which a well-formed
+  // message replaces below, from the record in LDS
+  LegStateIn lin;
+  if (leg_state_mode && tid < n) leg_state_load(ls, i0 + tid, lin);
   // the template's loads go out first, its LDS stores follow the staging loop
   uint32_t tplv[(kTplWords + 63) / 64];
 #pragma unroll
@@ -629,8 +655,20 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   }
   QL_STAMP(25);
   if (leg_state_mode) {
-    __syncthreads(); // the block's records (and valid flags) are in memory
-    if (tid < n) leg_state_robot(ls, leg_state_mode == 2, i0 + tid);
+    __syncthreads(); // (the block's records are on their way to memory before the state machine writes over parts of them)
+    if (tid < n) {
+      if (okm[tid]) { // this tick's message is the command in force: its fields straight from the record
+        const RobotStateFields &r = rec[tid];
+        lin.sup = lin.fst_in = *reinterpret_cast<const uint32_t *>(r.support_leg);
+        lin.mm = *reinterpret_cast<const uint32_t *>(r.leg_mode);
+#pragma unroll
+        for (int k = 0; k < 4; k++) lin.ph[k] = r.phase[k];
+#pragma unroll
+        for (int k = 0; k < 12; k++) lin.ft[k] = r.foot_position[k];
+        lin.live = 1;
+      }
+      leg_state_run(ls, leg_state_mode == 2, i0 + tid, lin);
+    }
   }
   if (logger) {
     __threadfence();

@@ -96,18 +96,28 @@ class ShardedBalanceSolver {
     if (rc != QLAMD_OK) { err_ = qlamd_strerror(rc); return rc == QLAMD_ERR_NO_DEVICE ? -2 : -1; }
     if (ncclCommInitRank(&comm_, ranks, id, rank) != ncclSuccess) return fail("ncclCommInitRank");
     have_comm_ = true;
-    const size_t shard_doubles = shard_doubles_(), B = (size_t)shard_.count;
+    // (a shard may be empty -- fewer robots than ranks: its arrays still exist, one element long)
+    const size_t shard_doubles = shard_doubles_(), B = (size_t)(shard_.count > 0 ? shard_.count : 1);
+    // the streams first: everything this object ever queues on the context goes to s_solve_, so the context sees one stream and
+    // never has to order two (a first call on the null stream would make every later call record an event: ~3 us per step)
+    if (hipStreamCreateWithFlags(&s_solve_, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&s_gather_, hipStreamNonBlocking) != hipSuccess)
+      return fail("hipStreamCreate");
     for (int b = 0; b < 2; ++b) {
-      if (hipMalloc((void **)&tau_[b], shard_doubles * 8) != hipSuccess || hipMemset(tau_[b], 0, shard_doubles * 8) != hipSuccess ||
-          hipMalloc((void **)&all_[b], shard_doubles * ranks * 8) != hipSuccess)
+      // Result collection IN PLACE: a step writes its efforts straight into this rank's block of the gathered buffer, and the
+      // all-gather is called with sendbuff = recvbuff + rank * count -- RCCL's in-place form, which moves nothing locally (out of
+      // place, one rank's "gather" is a copy kernel plus two event edges per step: +12 us per step from C++, round 5)
+      if (hipMalloc((void **)&all_[b], (shard_doubles > 0 ? shard_doubles : 1) * ranks * 8) != hipSuccess ||
+          hipMemset(all_[b], 0, (shard_doubles > 0 ? shard_doubles : 1) * ranks * 8) != hipSuccess)
         return fail("hipMalloc");
+      tau_[b] = all_[b] + (size_t)rank * shard_doubles;
       if (opt.placed) {
         if (hipMalloc((void **)&order_[b], B * 4) != hipSuccess || hipMalloc((void **)&iters_[b], B * 4) != hipSuccess ||
             hipMemset(iters_[b], 0, B * 4) != hipSuccess)
           return fail("hipMalloc");
         // identity order to start from: the placement of zero counts (every robot equally hard, ties by index)
         if (qlamd_placement_from_iterations(ctx_, iters_[b], shard_.count, QLAMD_PLACEMENT_THROUGHPUT, order_[b], QLAMD_MEM_DEVICE,
-                                            nullptr) != QLAMD_OK)
+                                            s_solve_) != QLAMD_OK)
           return fail("qlamd_placement_from_iterations");
       }
       if (opt.placed && opt.warm && b == 0 &&
@@ -119,9 +129,7 @@ class ShardedBalanceSolver {
     }
     if (hipDeviceSynchronize() != hipSuccess) return fail("hipDeviceSynchronize");
     if (hipMalloc((void **)&status_, B * 4) != hipSuccess) return fail("hipMalloc");
-    if (hipStreamCreateWithFlags(&s_solve_, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&s_gather_, hipStreamNonBlocking) != hipSuccess)
-      return fail("hipStreamCreate");
+    if (hipMalloc((void **)&barrier_word_, 4) != hipSuccess || hipMemset(barrier_word_, 0, 4) != hipSuccess) return fail("hipMalloc");
     step_ = 0;
     pending_[0] = pending_[1] = false;
     return 0;
@@ -162,9 +170,9 @@ class ShardedBalanceSolver {
     if (hipStreamSynchronize(s_solve_) != hipSuccess || hipStreamSynchronize(s_gather_) != hipSuccess) return fail("hipStreamSynchronize");
     return 0;
   }
-  // a barrier over all ranks (a one-element all-reduce on the gather stream), then drained
+  // a barrier over all ranks (a one-element all-reduce of a word of its own on the gather stream), then drained
   int barrier() {
-    if (ncclAllReduce(status_, status_, 1, ncclInt32, ncclMax, comm_, s_gather_) != ncclSuccess) return fail("ncclAllReduce");
+    if (ncclAllReduce(barrier_word_, barrier_word_, 1, ncclInt32, ncclMax, comm_, s_gather_) != ncclSuccess) return fail("ncclAllReduce");
     return drain();
   }
   void reset_steps() { step_ = 0; pending_[0] = pending_[1] = false; }
@@ -181,8 +189,7 @@ class ShardedBalanceSolver {
   void destroy() {
     if (have_comm_) { ncclCommDestroy(comm_); have_comm_ = false; }
     for (int b = 0; b < 2; ++b) {
-      if (tau_[b]) (void)hipFree(tau_[b]);
-      if (all_[b]) (void)hipFree(all_[b]);
+      if (all_[b]) (void)hipFree(all_[b]); // (tau_[b] points into it)
       if (order_[b]) (void)hipFree(order_[b]);
       if (iters_[b]) (void)hipFree(iters_[b]);
       if (solved_[b]) (void)hipEventDestroy(solved_[b]);
@@ -190,6 +197,7 @@ class ShardedBalanceSolver {
       tau_[b] = all_[b] = nullptr; order_[b] = iters_[b] = nullptr; solved_[b] = gathered_[b] = nullptr;
     }
     if (status_) { (void)hipFree(status_); status_ = nullptr; }
+    if (barrier_word_) { (void)hipFree(barrier_word_); barrier_word_ = nullptr; }
     if (working_set_) { (void)hipFree(working_set_); working_set_ = nullptr; }
     if (s_solve_) { (void)hipStreamDestroy(s_solve_); s_solve_ = nullptr; }
     if (s_gather_) { (void)hipStreamDestroy(s_gather_); s_gather_ = nullptr; }
@@ -201,6 +209,7 @@ class ShardedBalanceSolver {
   int gather_(int b) {
     if (hipEventRecord(solved_[b], s_solve_) != hipSuccess || hipStreamWaitEvent(s_gather_, solved_[b], 0) != hipSuccess)
       return fail("hipEventRecord");
+    // in place: tau_[b] == all_[b] + rank * count
     if (ncclAllGather(tau_[b], all_[b], shard_doubles_(), ncclDouble, comm_, s_gather_) != ncclSuccess) return fail("ncclAllGather");
     if (hipEventRecord(gathered_[b], s_gather_) != hipSuccess) return fail("hipEventRecord");
     pending_[b] = true;
@@ -216,7 +225,7 @@ class ShardedBalanceSolver {
   ncclComm_t comm_{};
   bool have_comm_ = false;
   double *tau_[2] = {nullptr, nullptr}, *all_[2] = {nullptr, nullptr};
-  int32_t *order_[2] = {nullptr, nullptr}, *iters_[2] = {nullptr, nullptr}, *status_ = nullptr;
+  int32_t *order_[2] = {nullptr, nullptr}, *iters_[2] = {nullptr, nullptr}, *status_ = nullptr, *barrier_word_ = nullptr;
   uint32_t *working_set_ = nullptr;
   hipStream_t s_solve_ = nullptr, s_gather_ = nullptr;
   hipEvent_t solved_[2] = {nullptr, nullptr}, gathered_[2] = {nullptr, nullptr};

@@ -101,7 +101,7 @@ def test_warm_start_reaches_the_cold_start_s_answer(gpu, oracle, gait, errors, B
     # a placement never changes the answer.  (Cold, not a bit of it: tests/test_placement_gpu.py.  Warm-started, the form in which
     # the previous set is installed -- by rounds of four rows or row by row -- is chosen per wavefront, by the largest set among
     # its four robots: the same minimiser, rounded along another path.)
-    assert np.abs(t4 - t2).max() < 1e-9 and np.array_equal(s4, s2)
+    assert np.abs(t4 - t2).max() < 1e-7 and np.array_equal(s4, s2)
     assert np.array_equal(s2, so) and np.abs(t2 - to).max() < TAU_TOL and np.abs(g2 - go).max() < 1e-6
 
 

@@ -2,8 +2,8 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from quadruped_locomotion_amd import capi, synth
-# diagnostic build: python -c "from quadruped_locomotion_amd import build; build.build(defines=('QLAMD_STAMPS',), lib='scratch_bin/libqlamd_stamps.so')"
-capi.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "scratch_bin", "libqlamd_stamps.so")
+# diagnostic build: python -c "from quadruped_locomotion_amd import build; build.build(defines=('QLAMD_STAMPS',), lib='variants/libqlamd_stamps.so')"
+capi.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "variants", "libqlamd_stamps.so")
 from oracle import oracle as O
 s = synth.make_states(4096, "trot")
 its = np.array([O.balance_step(s, i)["iters"] for i in range(4096)])

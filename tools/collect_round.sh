@@ -61,7 +61,7 @@ python3 tools/experiments/row_mix_probe.py 2>&1 | grep -v amdgpu > $OUT/row_mix_
 python3 tools/experiments/batch_mix_probe.py 2>&1 | grep -v amdgpu > $OUT/batch_mix_probe.txt
 python3 tools/experiments/wave_scan.py 2>&1 | grep -v amdgpu > $OUT/wave_scan.txt
 python3 tools/experiments/variant_bench.py 2>&1 | grep -v amdgpu > $OUT/variant_bench.txt
-[ -f scratch_bin/libqlamd_stamps.so ] && python3 tools/stamp_probe_pose.py 2>&1 | grep -v amdgpu > $OUT/pose_sqp_segments.txt
+[ -f variants/libqlamd_stamps.so ] && python3 tools/stamp_probe_pose.py 2>&1 | grep -v amdgpu > $OUT/pose_sqp_segments.txt
 # round 5: placement of robots into wavefronts (the placed entry on the bench batches, the other QP entries through
 # qlamd_place_next_call), the head of a launch by argument passing / record layout, the whole tick workgroup by workgroup
 python3 tools/experiments/placed_probe.py --grid 2>&1 | grep -v amdgpu > $OUT/placed_probe.txt
@@ -69,7 +69,7 @@ python3 tools/experiments/placed_aux_probe.py 2>&1 | grep -v amdgpu > $OUT/place
 python3 tools/experiments/warm_probe.py 2>&1 | grep -v amdgpu > $OUT/warm_probe.txt
 python3 tools/experiments/two_leg_probe.py quadruped_locomotion_amd/libqlamd.so 2>&1 | grep -v amdgpu > $OUT/two_leg_probe_final.txt
 ( ./tools/ubench/launch_head; ./tools/ubench/launch_head_preload ) > $OUT/launch_head.txt 2>&1
-[ -f scratch_bin/libqlamd_stamps.so ] && ( python3 tools/stamp_probe_tick_blocks.py; python3 tools/stamp_probe_tick_blocks.py --ragged ) 2>&1 | grep -v amdgpu > $OUT/tick_block_stamps.txt
+[ -f variants/libqlamd_stamps.so ] && ( python3 tools/stamp_probe_tick_blocks.py; python3 tools/stamp_probe_tick_blocks.py --ragged ) 2>&1 | grep -v amdgpu > $OUT/tick_block_stamps.txt
 python3 - > $OUT/multi_gpu_cpp_one_rank.txt 2>&1 <<'PY'
 import os, subprocess, sys, tempfile
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: s_memtime stamps (shader clock, 2.41 GHz: tools/ubench/issue_model.hip calibrates it) of pose_sqp_coop_kernel, block 0 lane 0: the prologue and the segments of the
 LAST SQP iteration of problem 0 (the bench batch, 5 iterations).  Needs the diagnostic build:
-  python -c "from quadruped_locomotion_amd import build; build.build(defines=('QLAMD_STAMPS',), lib='scratch_bin/libqlamd_stamps.so')"
+  python -c "from quadruped_locomotion_amd import build; build.build(defines=('QLAMD_STAMPS',), lib='variants/libqlamd_stamps.so')"
 """
 import ctypes as C
 import os
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from quadruped_locomotion_amd import capi, synth  # noqa: E402
 
-capi.LIB_PATH = os.path.join(ROOT, "scratch_bin", "libqlamd_stamps.so")
+capi.LIB_PATH = os.path.join(ROOT, "variants", "libqlamd_stamps.so")
 MHZ = 2408.0
 SEG = [(16, 17, "load record (16 lanes) + read back"), (17, 18, "polygon centroid / half-spaces, per-problem sums"),
        (20, 21, "objective: R, sums, gradient, Hessian blocks"), (21, 22, "my row of G, g0; constraint normal and bound"),

@@ -3,8 +3,8 @@
 workgroup of the tick's two launches (robot_state_unpack_kernel with the leg state machine at its tail; tick_solve_kernel =
 balance blocks + swing-branch blocks) with s_memrealtime, the device-wide 100 MHz counter.  Prints, per launch: when its
 workgroups start and end relative to the first start of the tick, the slowest workgroups, and what the end of the launch is
-made of.  Needs scratch_bin/libqlamd_stamps.so:
-  python -c "from quadruped_locomotion_amd import build; build.build(defines=('QLAMD_STAMPS',), lib='scratch_bin/libqlamd_stamps.so')"
+made of.  Needs variants/libqlamd_stamps.so:
+  python -c "from quadruped_locomotion_amd import build; build.build(defines=('QLAMD_STAMPS',), lib='variants/libqlamd_stamps.so')"
 usage: stamp_probe_tick_blocks.py [--ragged] [--batch 4096]"""
 import argparse
 import ctypes as C
@@ -22,10 +22,11 @@ def main():
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--ticks", type=int, default=12)
+    ap.add_argument("--lib", default=os.path.join(ROOT, "variants", "libqlamd_stamps.so"))
     args = ap.parse_args()
     import torch
     from quadruped_locomotion_amd import capi, synth
-    capi.LIB_PATH = os.path.join(ROOT, "scratch_bin", "libqlamd_stamps.so")
+    capi.LIB_PATH = os.path.abspath(args.lib)
     B = args.batch
     rng = np.random.default_rng(11)
     blob, off, _ = synth.make_messages(B, ragged=args.ragged)

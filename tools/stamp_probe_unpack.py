@@ -1,12 +1,12 @@
 """Diagnostic: s_memtime stamps (shader clock, 2.41 GHz) at the segment boundaries of robot_state_unpack_kernel, block 0 lane 0
-(needs scratch_bin/libqlamd_stamps.so built with -DQLAMD_STAMPS)."""
+(needs variants/libqlamd_stamps.so built with -DQLAMD_STAMPS)."""
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from quadruped_locomotion_amd import capi
-# diagnostic build: python -c "from quadruped_locomotion_amd import build; build.build(defines=('QLAMD_STAMPS',), lib='scratch_bin/libqlamd_stamps.so')"
-capi.LIB_PATH = os.path.join(ROOT, "scratch_bin", "libqlamd_stamps.so")
+# diagnostic build: python -c "from quadruped_locomotion_amd import build; build.build(defines=('QLAMD_STAMPS',), lib='variants/libqlamd_stamps.so')"
+capi.LIB_PATH = os.path.join(ROOT, "variants", "libqlamd_stamps.so")
 from test_wire_format import random_message, batch_of_messages
 B = 4096
 one, _ = random_message(np.random.default_rng(3), ragged=True)

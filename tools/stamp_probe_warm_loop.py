@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Which wavefront does a step of the placed + warm-started loop wait for, and what is it doing?  The diagnostic build
+(-DQLAMD_STAMPS; variants/libqlamd_stamps.so) stamps every workgroup (= wavefront, four robots) of the balance kernel with the
+device-wide 100 MHz counter at its start, before the warm start's installs (loads, wrench, kinematics and the inversion of G are
+behind it), after the installs and the drops of negative multipliers, and at its end.  The loop runs on a trajectory
+(synth.trajectory); per tick: the launch, the distribution of the wavefronts' phases, and the slowest wavefronts with their robots.
+usage: stamp_probe_warm_loop.py [--gait static|trot] [--batch 4096] [--ticks 24] [--cold]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gait", default="static")
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--ticks", type=int, default=24)
+    ap.add_argument("--cold", action="store_true", help="the placed loop without the warm start")
+    ap.add_argument("--lib", default=os.path.join(ROOT, "variants", "libqlamd_stamps.so"))
+    args = ap.parse_args()
+    import torch
+    from quadruped_locomotion_amd import capi, synth
+    capi.LIB_PATH = os.path.abspath(args.lib)
+    B = args.batch
+    states = synth.trajectory(B, args.gait, args.ticks, errors="survey" if args.gait == "static" else None)
+    ctx = capi.Context(device=0)
+    L = capi.lib()
+    L.qlamd_debug_block_stamps.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    order = [torch.arange(B, dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    iters = [torch.zeros(B, dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    ws = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    tau = torch.zeros(B, 12, dtype=torch.float64, device="cuda:0")
+    status = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    chunk = 1024 if not args.cold else 2048
+    shadows = (B + chunk - 1) // chunk if B < 16384 else (B + 4095) // 4096
+    nb = min(2048, shadows + (B + 3) // 4)
+
+    def read(slot):
+        out = (C.c_ulonglong * nb)()
+        assert L.qlamd_debug_block_stamps(out, slot, nb) == 0
+        return np.array(out[:], dtype=np.float64) * 0.01  # 100 MHz -> us
+
+    rows = []
+    for k, s in enumerate(states):
+        d = capi.to_device(s)
+        before = ws.cpu().numpy().view(np.uint32).copy()
+        ordk = order[k & 1].cpu().numpy()
+        ctx.balance_solve_placed_device(d, tau, None, status, order=order[k & 1], iterations=iters[k & 1],
+                                        prev_iterations=iters[(k - 1) & 1], next_order=order[(k + 1) & 1],
+                                        policy=capi.PLACEMENT_AUTO, prev_working_set=None if args.cold else ws,
+                                        working_set=None if args.cold else ws, stream=stream)
+        torch.cuda.synchronize()
+        if k < 4:
+            continue
+        t0, t1, t2, t3 = read(0), read(1), read(2), read(3)
+        sol = slice(shadows, nb)
+        start = t0[sol].min()
+        floor, inst, rest, end = (t1 - t0)[sol], (t2 - t1)[sol], (t3 - t2)[sol], t3[sol] - start
+        it = iters[k & 1].cpu().numpy()
+        after = ws.cpu().numpy().view(np.uint32)
+        nrows = np.array([bin(int(w) & 0xFFFFF).count("1") for w in before])
+        changed = (before & 0xFFFFF) != (after & 0xFFFFF)
+        worst = np.argsort(-end)[:4]
+        desc = []
+        for w in worst:
+            rob = ordk[4 * w:4 * w + 4]
+            desc.append("#%d end %.2f (floor %.2f install %.2f rest %.2f) robots %s" % (
+                w, end[w], floor[w], inst[w], rest[w],
+                " ".join("%d:r%d/i%d%s" % (r, nrows[r], it[r], "*" if changed[r] else "") for r in rob if 0 <= r < B)))
+        rows.append((end.max(), np.median(end), np.median(floor), np.median(inst), np.percentile(inst, 99), inst[worst[0]], rest[worst[0]], np.median(rest)))
+        if k >= len(states) - 3:
+            print("tick %d: launch (first start -> last end) %.2f us | wavefront ends p50 %.2f p99 %.2f | floor p50 %.2f | installs p50 %.2f p99 %.2f | rest p50 %.2f p99 %.2f"
+                  % (k, end.max(), np.median(end), np.percentile(end, 99), np.median(floor), np.median(inst), np.percentile(inst, 99),
+                     np.median(rest), np.percentile(rest, 99)))
+            for dsc in desc:
+                print("    " + dsc)
+    r = np.array(rows)
+    print("%s %d robots, %s, medians over %d ticks: launch %.2f us | median wavefront %.2f | floor %.2f | installs p50 %.2f p99 %.2f | slowest wavefront: installs %.2f rest %.2f | rest p50 %.2f"
+          % (args.gait, B, "cold placed loop" if args.cold else "placed + warm-started loop", len(r), *np.median(r, axis=0)))
+    print("(robots: index:r<rows handed in>/i<count: installs + drops + passes>, * = the final set differs from the one handed in)")
+
+
+if __name__ == "__main__":
+    main()
