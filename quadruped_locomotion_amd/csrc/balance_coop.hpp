@@ -99,7 +99,11 @@ constexpr int kCoopNrmDoubles = 12 * 64; // 5 row kinds + parked Jacobian row (3
 // Returns whether this row's warm start was rejected (kWarm: the answer reached from the set handed in failed the final check of
 // force_qp_coop) -- coop_robot_checked() below then solves the robot again with `cold` set: the set handed in is ignored.
 // kThroughput (the 168-register form of the kernels): a warm start installs its rows one after the other, not by rounds
-template <bool kPerLeg, int kBlock = 64, bool kWarm = false, bool kParkInputs = false, bool kThroughput = false>
+// kSmallForm: the kernel carries the 6-variable form of the QP for wavefronts whose four robots stand on at most two legs (the
+// placed entries, whose sorted placement groups robots by class); without it (the plain entry: who shares a wavefront is an
+// accident of the batch order there, and the second form cost it 3-4 % on batches of robots on four legs) every wavefront
+// takes the 12-variable form, which gives a robot on two legs the same result bit for bit (its padding rows add exact zeros)
+template <bool kPerLeg, int kBlock = 64, bool kWarm = false, bool kParkInputs = false, bool kThroughput = false, bool kSmallForm = true>
 __device__ __forceinline__ bool coop_robot(const DeviceParams &P, const CoopPtrs &s, int64_t irobot, bool robot_live_in,
                                            double *lds_tab, double *lds_row, double *lds_nrm,
                                            double *__restrict__ tau_out,
@@ -414,12 +418,17 @@ __device__ __forceinline__ bool coop_robot(const DeviceParams &P, const CoopPtrs
     if constexpr (kWarm) Q.warm = permuted ? working_set_to_slots<5, unsigned>(warm_set, perm) : warm_set;
     status = force_qp_coop<false, kWarm, decltype(Legs)::value, !kThroughput>(Q, lds_row, lds_nrm, x, qp_iters, &final_set);
   };
-  int small_form = __builtin_amdgcn_readfirstlane(two_legs ? 1 : 0);
-  asm volatile("" : "+s"(small_form));
-  if (small_form != 0) solve(std::integral_constant<int, 2>{});
-  int large_form = __builtin_amdgcn_readfirstlane(1 - small_form);
-  asm volatile("" : "+s"(large_form));
-  if (large_form != 0) solve(std::integral_constant<int, 4>{});
+  if constexpr (kSmallForm) {
+    int small_form = __builtin_amdgcn_readfirstlane(two_legs ? 1 : 0);
+    asm volatile("" : "+s"(small_form));
+    if (small_form != 0) solve(std::integral_constant<int, 2>{});
+    int large_form = __builtin_amdgcn_readfirstlane(1 - small_form);
+    asm volatile("" : "+s"(large_form));
+    if (large_form != 0) solve(std::integral_constant<int, 4>{});
+  } else {
+    (void)two_legs;
+    solve(std::integral_constant<int, 4>{});
+  }
   const int2 parked = reinterpret_cast<const int2 *>(lds_nrm + 64 * 11)[(int)threadIdx.x & 63];
   const int64_t i = parked.x;
   const int aidx = parked.y & 15;

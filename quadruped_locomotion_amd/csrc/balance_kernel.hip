@@ -553,7 +553,7 @@ __global__ __launch_bounds__(64 * kCoopWaves, kMinWaves) void balance_coop_kerne
   // (inputs parked in LDS across the first form of the QP: the 168-register form solving cold -- no scratch then, 1-2 % on 65 536
   // to a million robots; the warm-started kernel is 3 % faster with them in registers and 20 bytes of scratch around the loop)
   {
-    const bool rejected = coop::coop_robot<kPerLeg, 64 * kCoopWaves, kWarm, kMinWaves == 3 && !kWarm, kMinWaves == 3>(
+    const bool rejected = coop::coop_robot<kPerLeg, 64 * kCoopWaves, kWarm, kMinWaves == 3 && !kWarm && kPlaced, kMinWaves == 3, kPlaced>(
         P, cp, i, live, tab, rows + row * coop::kCoopLdsDoubles, nrm + wave * coop::kCoopNrmDoubles, tau, grf, status);
     QL_BLOCK_STAMP(3);
     if constexpr (kWarm) {
