@@ -530,37 +530,41 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
         });
         static_for<kLegs>([&](auto K) {
           constexpr int k = K;
+          // (a lone wavefront pays per instruction, and a round is four of these: everything a leg without a row, or with a row
+          // that depends on the rows before it, must not do is done by ONE factor okf = 0 on its directions -- its z, r and
+          // step are then exact zeros all the way down -- instead of a select per quantity)
           const int kk = (int)((kinds >> (4 * k)) & 15u) - 1; // leg k's row of this round (-1: none)
           const double qk = quad_sum(npj * za[k]);            // on the lanes of leg m: n_m'z_k
           const double dk = bc<4 * k>(qk);
           // a row that depends on the rows installed before it is left out: z'n_p is then rounding noise, which with the entries
           // of H reaching 1 / w_reg = 1e4 means up to 1e-10, while an independent row has z'n_p >= |n|^2 / trace(G) ~ 1e-3
           const bool ok = kk >= 0 && dk > 1e-6;
-          const double zi = rcp_nr(sel(ok, dk, 1.0));
-          const double tw = sel(ok, -bc<4 * k>(sl) * zi, 0.0);
-          x = fma(tw, za[k], x);
-          u = fma(-tw, ra[k], u);
+          const double okf = sel(ok, 1.0, 0.0);
+          const double zi = rcp_nr1(sel(ok, dk, 1.0)) * okf;  // 1 / d_k, or 0
+          const double zk = za[k] * okf, rr = ra[k] * okf;
+          const double tw = -bc<4 * k>(sl) * zi;
+          x = fma(tw, zk, x);
+          u = fma(-tw, rr, u);
           sl = fma(tw, qk, sl);
           const int newlane = __ffs(~used & 0xFFFu) - 1;
           const bool newslot = ok && lr == newlane;
           const int pk = kKinds * k + kk;
-          vec = sel(ok, za[k] * zi, 0.0);
-          hc = sel(ok, -za[k], 0.0);
-          const double rk = sel(newslot, -1.0, ra[k]);
-          nc = sel(ok, -rk, 0.0);
+          vec = zk * zi;
+          hc = -zk;
+          const double rk = sel(newslot, -1.0, rr);
+          nc = -rk;
           u = sel(newslot, tw, u);
           idk = newslot ? pk : idk;
           used |= ok ? (1u << newlane) : 0u;
           act_mask |= ok ? (one << pk) : 0;
-          rnorm2 = sel(ok, vmax(rnorm2, dk), rnorm2);
+          rnorm2 = vmax(rnorm2, dk); // (a row left out has d_k <= 1e-6 < R_norm^2)
           q += ok ? 1 : 0;
-          warm_updates += ok ? 1 : 0;
           // the legs still to come: z_m -= z_k (n_m'z_k) / d_k, r_m -= r_k (n_m'z_k) / d_k (the new slot's own entry: + n_m'z_k / d_k)
           if constexpr (k + 1 < kLegs) {
-            const double cm = sel(ok, -qk * zi, 0.0);
+            const double cm = -qk * zi;
             static_for<kLegs - 1 - k>([&](auto M) {
               constexpr int m = k + 1 + M;
-              fmac_bc<4 * m, M == 0>(za[m], cm, za[k]);
+              fmac_bc<4 * m, M == 0>(za[m], cm, zk);
               fmac_bc<4 * m>(ra[m], cm, rk);
             });
           }
@@ -626,6 +630,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
         update_only();
       }
     }
+    if (by_rounds) warm_updates = q; // (installs only so far: one counter in the rounds)
     for (;;) { // at most q rounds: every round frees a slot and none is taken
       const bool slot = (used & lanebit) != 0u;
       const double umin = row_min(sel(slot, u, inf));

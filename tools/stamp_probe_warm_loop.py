@@ -74,6 +74,20 @@ def main():
             desc.append("#%d end %.2f (floor %.2f install %.2f rest %.2f) robots %s" % (
                 w, end[w], floor[w], inst[w], rest[w],
                 " ".join("%d:r%d/i%d%s" % (r, nrows[r], it[r], "*" if changed[r] else "") for r in rob if 0 <= r < B)))
+        if k == len(states) - 1 and not args.cold:
+            # what the rounds of the install hold: per wavefront and round, the legs for which some robot brings a row
+            per_leg = np.stack([[bin((int(w) >> (5 * l)) & 0x1F).count("1") for l in range(4)] for w in before])   # [B][4]
+            nw = (B + 3) // 4
+            hist = {}
+            for w in range(nw):
+                rob = [r for r in ordk[4 * w:4 * w + 4] if 0 <= r < B]
+                pl = per_leg[rob]                                   # [<=4][4]
+                big = (pl.sum(axis=1) >= 6).any()
+                legs = tuple(int((pl >= rnd + 1).any(axis=0).sum()) for rnd in range(3))
+                hist[(big, legs)] = hist.get((big, legs), 0) + 1
+            print("    rounds of the install (by rounds?, legs with a row in round 1 / 2 / 3): wavefronts")
+            for key, cnt in sorted(hist.items(), key=lambda kv: -kv[1])[:12]:
+                print("      %-5s %s: %d" % (key[0], key[1], cnt))
         rows.append((end.max(), np.median(end), np.median(floor), np.median(inst), np.percentile(inst, 99), inst[worst[0]], rest[worst[0]], np.median(rest)))
         if k >= len(states) - 3:
             print("tick %d: launch (first start -> last end) %.2f us | wavefront ends p50 %.2f p99 %.2f | floor p50 %.2f | installs p50 %.2f p99 %.2f | rest p50 %.2f p99 %.2f"
