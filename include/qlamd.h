@@ -742,6 +742,15 @@ typedef struct qlamd_tick_batch {
                                            with.  One more piece of state the controller keeps between ticks -- the reference
                                            keeps none because OOQP starts every solve from scratch; efforts agree with the
                                            cold start's to 1e-7 */
+  int32_t *placement_state;             /* [4][B] or NULL, QLAMD_MEM_DEVICE and more than 16 384 robots only (ignored otherwise): the
+                                           state of the placed loop of qlamd_balance_solve_placed_batch for the tick's balance
+                                           solve -- two placements and two arrays of iteration counts, used in turn; need not be
+                                           initialised.  From 16 384 robots up every SIMD holds several wavefronts and sorting the
+                                           robots by class and count is worth 30-40 % of the solve; below, on
+                                           states that move, a placement buys a tick nothing (profiles/r6/ab_retry_forms.txt).
+                                           The context remembers which tick of the loop comes next for the array it saw last: a
+                                           context that alternates between batches starts the loop over each time (slower, never
+                                           wrong).  Efforts are those of the unplaced tick bit for bit (cold) */
 } qlamd_tick_batch;
 
 size_t qlamd_tick_command_bytes(int64_t batch);

@@ -97,7 +97,7 @@ TICK_FIELDS = (("messages", np.uint8), ("offsets", np.int64), ("joint_position",
                ("limb_state", np.int8), ("store_flag", np.uint8), ("stored_joint_position", np.float64), ("leg_mode", np.uint8), ("support", np.uint8),
                ("pid_error_last", np.float64), ("pid_error_integral", np.float64), ("joint_effort", np.float64),
                ("leg_state_code", np.int8), ("status", np.int32), ("message_status", np.int32), ("command", np.uint8),
-               ("working_set", np.uint32))
+               ("working_set", np.uint32), ("placement_state", np.int32))
 
 
 class TickBatch(C.Structure):

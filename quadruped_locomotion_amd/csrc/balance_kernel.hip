@@ -708,6 +708,9 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
   ctx->place_sync = nullptr;
   ctx->placement_wait = 1u << 13;
   ctx->has_next_placement = false;
+  ctx->tick_place_state = nullptr;
+  ctx->tick_place_batch = 0;
+  ctx->tick_place_count = 0;
   ctx->on_failure = QLAMD_ON_FAILURE_ZERO;
   ctx->dynamics_form = QLAMD_DYNAMICS_AUTO;
   ctx->depth = 0;

@@ -31,6 +31,9 @@ struct qlamd_context {
                        // two more: event counters (kSyncGiveUps, kSyncWarmRetries)
   qlamd_placement next_placement; // qlamd_place_next_call: taken (and cleared) by the next QP entry that knows placements
   bool has_next_placement;
+  const void *tick_place_state;   // qlamd_tick_batch::placement_state of the last tick that had one, its batch and how many
+  int64_t tick_place_batch;       // ticks of the placed loop have run on it
+  int64_t tick_place_count;
   uint32_t *wire_tpl;  // two layout templates of robot_state_unpack_kernel (read one, write the other), or NULL
   int wire_flip;
   // HOST-memory mode staging (grown on demand)

@@ -1149,9 +1149,27 @@ int qlamd_full_tick_batch(qlamd_context *ctx, const qlamd_swing_params *swing, c
                          D(kCmdPos), D(kCmdQuat), D(kCmdLin), D(kCmdAng), d.support, nullptr};
     qlamd_placement wp;
     memset(&wp, 0, sizeof(wp));
-    wp.prev_working_set = wp.working_set = d.working_set; // in place
-    const bool warm = d.working_set && pick_rpw(ctx, batch) == 4; // (the one-lane kernels of the cross-check start cold)
-    rc = balance_impl(ctx, &sb, nullptr, live, 1, batch, d.joint_effort, nullptr, d.status, QLAMD_MEM_DEVICE, stream, warm ? &wp : nullptr);
+    const bool coop = pick_rpw(ctx, batch) == 4; // (the one-lane kernels of the cross-check know neither warm start nor placement)
+    const bool warm = d.working_set && coop;
+    if (warm) wp.prev_working_set = wp.working_set = d.working_set; // in place
+    const bool placed = io->placement_state && memory == QLAMD_MEM_DEVICE && coop;
+    if (placed) {
+      // the caller's loop of include/qlamd.h on the tick's own state: tick k runs in order[k & 1] (identity on the first tick),
+      // writes iters[k & 1] and makes order[(k + 1) & 1] from iters[(k - 1) & 1] (zeros on the first tick: the identity)
+      int32_t *ps = io->placement_state;
+      if (ctx->tick_place_state != ps || ctx->tick_place_batch != batch) {
+        ctx->tick_place_state = ps; ctx->tick_place_batch = batch; ctx->tick_place_count = 0;
+        if (hipMemsetAsync(ps + 2 * B, 0, 2 * B * sizeof(int32_t), st) != hipSuccess) return QLAMD_ERR_HIP;
+      }
+      const int64_t k = ctx->tick_place_count++;
+      wp.robot_order = k == 0 ? nullptr : ps + (k & 1) * B;
+      wp.iterations = ps + 2 * B + (k & 1) * B;
+      wp.prev_iterations = ps + 2 * B + ((k + 1) & 1) * B;
+      wp.next_robot_order = ps + ((k + 1) & 1) * B;
+      wp.policy = QLAMD_PLACEMENT_AUTO;
+    }
+    rc = balance_impl(ctx, &sb, nullptr, live, 1, batch, d.joint_effort, nullptr, d.status, QLAMD_MEM_DEVICE, stream,
+                      (warm || placed) ? &wp : nullptr);
     if (rc != QLAMD_OK) return rc;
     const qlamd_swing_batch sw{d.joint_position, d.joint_velocity, d.joint_velocity_oldest, D(kCmdFootP), D(kCmdFootV), d.support, nullptr};
     const qlamd_swing_branch_extra ex{d.base_orientation, D(kCmdJoint), d.leg_mode, d.pid_error_last, d.pid_error_integral};
