@@ -504,78 +504,6 @@ def bench_wholebody(args):
         **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
 
 
-def bench_full_tick(args):
-    """The plugin's whole tick for every robot: serialised /desired_robot_state message -> leg state machine -> balance
-    solve -> swing branch -> 12 efforts (qlamd_full_tick_batch).  Messages: one per robot; by default copies of one
-    message (one publisher's layout: the layout template of the unpack kernel hits from the second launch on, the
-    measured states still differ per robot); --ragged gives every message its own layout and payload (every message
-    is walked)."""
-    import numpy as np
-    import torch
-    from quadruped_locomotion_amd import capi, synth
-    B = args.batch
-    rng = np.random.default_rng(11)
-    blob, off, _ = synth.make_messages(B, ragged=args.ragged)
-    s = synth.make_states(B, "trot")
-    host = dict(messages=blob, offsets=off, joint_position=s["q"],
-                joint_velocity=rng.normal(scale=0.3, size=(B, 12)), joint_velocity_oldest=rng.normal(scale=0.3, size=(B, 12)),
-                base_position=s["base_pos"], base_orientation=s["base_quat"], base_linear_velocity=np.ascontiguousarray(s["base_linvel"]),
-                base_angular_velocity=np.ascontiguousarray(s["base_angvel"]), contact=rng.integers(0, 2, (B, 4)).astype(np.uint8),
-                limb_state=np.zeros((B, 4), np.int8), store_flag=np.zeros((B, 4), np.uint8), stored_joint_position=np.zeros((B, 12)),
-                leg_mode=np.zeros((B, 4), np.uint8), support=np.ones((B, 4), np.uint8), pid_error_last=np.zeros((B, 12)),
-                pid_error_integral=np.zeros((B, 12)), joint_effort=np.zeros((B, 12)), leg_state_code=np.zeros((B, 4), np.int8), status=np.full(B, -1, np.int32),
-                message_status=np.full(B, -1, np.int32), command=np.zeros(capi.tick_command_bytes(B), np.uint8))
-    warm = args.method == "warm"
-    if warm:  # the tick keeps every robot's working set between ticks and starts its balance solve from it
-        host["working_set"] = np.zeros(B, np.uint32)
-    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to("cuda:0") for k, v in host.items()}
-    devs = [dev]
-    if warm:
-        # odd ticks run on the measured states one control period later: the set always comes from OTHER states
-        s2 = synth.next_tick_states(s, 0.0025)
-        later = dict(dev)
-        for key, field in (("base_pos", "base_position"), ("base_quat", "base_orientation")):
-            later[field] = torch.from_numpy(np.ascontiguousarray(s2[key])).to("cuda:0")
-        devs.append(later)
-    ctx = capi.Context(device=0)
-    stream = torch.cuda.current_stream().cuda_stream
-    for k in range(max(args.warmup, 2)):
-        capi.full_tick(ctx, devs[k % len(devs)], 0.0025, memory=capi.MEM_DEVICE, stream=stream)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for k in range(args.steps):
-        capi.full_tick(ctx, devs[k % len(devs)], 0.0025, memory=capi.MEM_DEVICE, stream=stream)
-    e1.record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    tick_ms = e0.elapsed_time(e1) / args.steps
-    nbytes = int(off[-1])
-    # algorithmic bytes per robot: its message + measured state (q, qd, qd_oldest 288, base pose / twist 104, contact 4) +
-    # persistent state read and written (2 x (4 + 4 + 96 + 4 + 4 + 96 + 96)) + efforts 96 + codes / statuses 12
-    per = 288 + 104 + 4 + 2 * 304 + 96 + 12
-    algo = nbytes + per * B
-    achieved = algo / (tick_ms * 1e-3) / 1e9
-    print(json.dumps({
-        "metric": "whole control ticks/sec, message to efforts (SURVEY 8 rows a1 + f1 + f2, reported separately from the headline metric)",
-        "value": B * args.steps / elapsed, "unit": "ticks/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": "batch=%d robots, one serialised free_gait_msgs/RobotState (%d B on average, %s) per robot and tick, "
-                               "trot states: unpack -> leg state machine -> balance solve -> swing branch" %
-                               (B, nbytes // B, "ragged layouts" if args.ragged else "one layout") +
-                               ("; the balance solve warm-started from the working set the tick keeps (qlamd_tick_batch::working_set), "
-                                "odd ticks on the measured states one control period later" if warm else ""),
-                   "messages_ok": int((dev["message_status"] == 0).sum().item()), "solves_ok": int((dev["status"] == 0).sum().item())},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None,
-                     "kernel": ("two launches per tick (robot_state_unpack_kernel incl. the leg state machine; tick_solve_kernel = "
-                                "balance blocks + swing-branch blocks)") if B <= 16384 else
-                               "four launches per tick (unpack, leg state, balance, swing branch)",
-                     "kernel_ms": tick_ms, "algorithmic_bytes_per_launch": algo}}), flush=True)
-
-
 def selftest_launcher(args):
     """CPU-only check of what `--gpus N` does around the solve: ranks started by the same launcher, contiguous shards
     of the seeded generator, the all-gather layout and the max-over-ranks reduction, over gloo.  There is no solve
@@ -616,11 +544,9 @@ def main():
         sys.exit(launch_ranks(args))
     if args.selftest_launcher:
         return selftest_launcher(args)
-    if args.workload == "full_tick":
-        return bench_full_tick(args)
     if args.workload == "pose_sqp":
         return bench_pose_sqp(args)
-    if args.workload in ("wholebody", "wholebody_dynamics"):
+    if args.workload == "wholebody_dynamics":
         return bench_wholebody(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -630,7 +556,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # rank 0 at N = 1 only: the CPU baseline, in a pinned child process, BEFORE this process touches the GPU
     cpu = None
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and args.workload == "balance":
         try:
             cpu = cpu_baseline(args.gait, args.errors, args.batch, args.cpu_seconds)
         except Exception as e:  # the GPU measurement must not be lost to a failing host-side probe
@@ -1012,6 +938,18 @@ def main():
         for k in range(eager_steps):
             step_fn(k, stream)
         torch.cuda.synchronize()
+        if args.no_graph:   # eager launches (the counter passes of tools/collect_profiles.py): K steps between synchronisations
+            el, e0, e1 = [], torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for r in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                e0.record()
+                for k in range(args.steps):
+                    step_fn(r * args.steps + k, stream)
+                e1.record()
+                torch.cuda.synchronize()
+                el.append(time.perf_counter() - t0)
+            return float(np.median(el)), e0.elapsed_time(e1) / args.steps
         graphs = []
         for g in range(regions):
             side = torch.cuda.Stream()
@@ -1055,7 +993,7 @@ def main():
         K = args.steps
         if args.ticks:
             return max(1, args.ticks), max(1, -(-args.ticks // K))
-        return (K, 1) if K >= cap else (K * max(1, cap // K), max(1, cap // K))
+        return (cap, 1) if K >= cap else (K * max(1, cap // K), max(1, cap // K))
 
     def pose_sqp_entry(batch):
         """BASELINE configs[4] inside the headline line: batch pose optimisations, exactly 5 SQP iterations each, the K calls
@@ -1082,7 +1020,7 @@ def main():
         one serialised /desired_robot_state message (one publisher's layout; desired base state and support flags of the
         trajectory's tick) -> leg state machine -> balance solve -> swing branch -> 12 efforts, qlamd_full_tick_batch, the
         controller's state carried from tick to tick; cold, and with the working set the tick keeps (`warm`)."""
-        T, regions = ticks_for(60)
+        T, regions = ticks_for(60 if batch <= 16384 else 8)   # (a tick of 65 536 messages is 207 MB)
         states = synth.trajectory(batch, "trot", T)
         rng = np.random.default_rng(11)
         from quadruped_locomotion_amd import wire
@@ -1113,6 +1051,8 @@ def main():
                         message_status=np.full(batch, -1, np.int32), command=np.zeros(capi.tick_command_bytes(batch), np.uint8))
             if warm:
                 keep["working_set"] = np.zeros(batch, np.uint32)
+            if batch > 16384:   # the placed loop on the tick's own state (four launches per tick from here on)
+                keep["placement_state"] = np.zeros((4, batch), np.int32)
             keep = {k: torch.from_numpy(v).to(dev) for k, v in keep.items()}
             ios = [dict(pt, **keep) for pt in per_tick]
             tctx = capi.Context(device=local_rank)
@@ -1133,8 +1073,12 @@ def main():
                 "warm_rejected": tctx.counter(capi.COUNTER_WARM_RETRIES)}
             tctx.close()
         e = dict(out["warm"], unit="ticks/s", batch=batch, message_bytes=nbytes // batch, states_per_replay=args.steps, ticks=T,
-                 method="qlamd_full_tick_batch (unpack + leg state machine, then balance blocks + swing-branch blocks: two launches per "
-                        "tick), the balance solve warm-started from the working set the tick keeps (qlamd_tick_batch::working_set)",
+                 method=("qlamd_full_tick_batch (unpack + leg state machine, then balance blocks + swing-branch blocks: two launches per "
+                         "tick), the balance solve warm-started from the working set the tick keeps (qlamd_tick_batch::working_set)"
+                         if batch <= 16384 else
+                         "qlamd_full_tick_batch (four launches per tick: unpack, leg state machine, balance solve, swing branch), the "
+                         "balance solve in the placed loop the tick keeps the state of (qlamd_tick_batch::placement_state) and "
+                         "warm-started from the working set it keeps (::working_set)"),
                  cold_start=out["cold"], switched_per_tick=float(np.mean(synth.support_switches(states))) if T > 1 else 0.0)
         e["kernel_ms_note"] = "both launches of a tick (HIP events around K captured ticks)"
         return e
@@ -1179,6 +1123,22 @@ def main():
                            "-> 12 efforts), placed and warm-started through qlamd_place_next_call",
                     cold_start=out["cold"], switched_per_tick=float(np.mean(synth.support_switches(states))) if T > 1 else 0.0,
                     kernel_ms_note="solve launch + the placement's launches behind it (HIP events around K captured steps)")
+
+    if args.workload in ("full_tick", "wholebody"):
+        # side workloads on their own (reported separately from the headline metric): the same entries the default line carries
+        # in `also`, at the batch asked for
+        e = (full_tick_entry if args.workload == "full_tick" else wholebody_entry)(args.batch)
+        print(json.dumps({
+            "metric": ("whole control ticks/sec, message to efforts (SURVEY 8 rows a1 + f1 + f2" if args.workload == "full_tick" else
+                       "whole-body control steps/sec (SURVEY 8 row f4") + ", reported separately from the headline metric)",
+            "value": e["value"], "unit": e["unit"], "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": e["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic", "config": {"workload": e["method"], "robots_per_gpu": args.batch, "trot trajectory ticks": e["ticks"],
+                                            "switched_per_tick": e["switched_per_tick"], "all_status_ok": e["all_status_ok"]},
+            "roofline": {"bound": "hbm", "achieved": e["roofline_frac"] * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": e["roofline_frac"], "traffic": None, "kernel_ms": e["kernel_ms"], "kernel": e["kernel_ms_note"]},
+            "cold_start": e["cold_start"], "warm_rejected": e["warm_rejected"]}), flush=True)
+        return None
 
     B = args.batch
     method = args.method if not args.rpw else "plain"  # (the one-lane kernels of --rpw know neither placement nor warm start)

@@ -170,6 +170,42 @@ class ShardedBalanceSolver {
     if (hipStreamSynchronize(s_solve_) != hipSuccess || hipStreamSynchronize(s_gather_) != hipSuccess) return fail("hipStreamSynchronize");
     return 0;
   }
+
+  // K control steps as ONE hipGraph: the steps are queued exactly as step() queues them -- solves on one stream, the all-gathers
+  // on the other, joined by events -- while the solve stream is being captured, so that a replay costs the host one call instead
+  // of five per step (an eager step from C++ is host-bound: launch, event record, stream wait, all-gather call, event record:
+  // 38 us per step for a 27 us solve of 8192 robots, profiles/r6/multi_gpu_cpp_one_rank.txt).  `in` returns the states of step k
+  // (device pointers that stay valid and are re-read by every replay: a caller that steps a trajectory rewrites them between
+  // replays, or hands K different batches).  K should be even (the placed loop uses its two buffers in turn) and a multiple of
+  // gather_every.  RCCL's collectives are capturable; the context's own ordering state is left alone by captured calls
+  // (include/qlamd.h, "Threads and streams").  replay_captured() queues the graph on the solve stream; drain() waits for it.
+  template <class States>
+  int capture_steps(int K, bool with_gather, States in) {
+    if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+    reset_steps();
+    if (hipStreamBeginCapture(s_solve_, hipStreamCaptureModeThreadLocal) != hipSuccess) return fail("hipStreamBeginCapture");
+    int rc = 0;
+    for (int k = 0; k < K && rc == 0; ++k) rc = step(in(k), with_gather);
+    if (rc == 0) rc = finish_group(with_gather);
+    // join: the solve stream ends behind every gather still in flight
+    for (int b = 0; b < 2 && rc == 0; ++b)
+      if (pending_[b]) {
+        if (hipStreamWaitEvent(s_solve_, gathered_[b], 0) != hipSuccess) rc = fail("hipStreamWaitEvent");
+        pending_[b] = false;
+      }
+    hipGraph_t graph = nullptr;
+    if (hipStreamEndCapture(s_solve_, &graph) != hipSuccess || !graph) return rc != 0 ? rc : fail("hipStreamEndCapture");
+    if (rc == 0 && hipGraphInstantiate(&graph_exec_, graph, nullptr, nullptr, 0) != hipSuccess) rc = fail("hipGraphInstantiate");
+    (void)hipGraphDestroy(graph);
+    captured_steps_ = rc == 0 ? K : 0;
+    return rc;
+  }
+  int replay_captured() {
+    if (!graph_exec_) return fail("no captured steps");
+    if (hipGraphLaunch(graph_exec_, s_solve_) != hipSuccess) return fail("hipGraphLaunch");
+    return 0;
+  }
+  int captured_steps() const { return captured_steps_; }
   // a barrier over all ranks (a one-element all-reduce of a word of its own on the gather stream), then drained
   int barrier() {
     if (ncclAllReduce(barrier_word_, barrier_word_, 1, ncclInt32, ncclMax, comm_, s_gather_) != ncclSuccess) return fail("ncclAllReduce");
@@ -187,6 +223,7 @@ class ShardedBalanceSolver {
   const char *error() const { return err_; }
 
   void destroy() {
+    if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
     if (have_comm_) { ncclCommDestroy(comm_); have_comm_ = false; }
     for (int b = 0; b < 2; ++b) {
       if (all_[b]) (void)hipFree(all_[b]); // (tau_[b] points into it)
@@ -230,6 +267,8 @@ class ShardedBalanceSolver {
   hipStream_t s_solve_ = nullptr, s_gather_ = nullptr;
   hipEvent_t solved_[2] = {nullptr, nullptr}, gathered_[2] = {nullptr, nullptr};
   bool pending_[2] = {false, false};
+  hipGraphExec_t graph_exec_ = nullptr;
+  int captured_steps_ = 0;
   const char *err_ = "";
 };
 

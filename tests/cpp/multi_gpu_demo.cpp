@@ -3,7 +3,7 @@
 // efforts of all shards collected on every rank with ONE RCCL all-gather per control step or per G steps), without torch:
 // qlamd.h, the HIP runtime and rccl.h only.
 //
-//   multi_gpu_demo --states FILE --robots N [--rank R --ranks W --id-file F] [--steps K] [--out FILE] [--gather-every G] [--plain | --warm]
+//   multi_gpu_demo --states FILE --robots N [--ticks T] [--rank R --ranks W --id-file F] [--steps K] [--graph] [--out FILE] [--gather-every G] [--plain | --warm]
 //   multi_gpu_demo --selftest-sharding                       (no GPU: prints the shard of every rank for a few batch sizes)
 //   multi_gpu_demo --selftest-rendezvous --rank R --ranks W --id-file F
 //                                                            (no GPU, no RCCL call: the ranks exchange a 128-byte id through
@@ -71,6 +71,8 @@ int main(int argc, char **argv) {
   int rank = std::getenv("RANK") ? std::atoi(std::getenv("RANK")) : 0;
   int ranks = std::getenv("WORLD_SIZE") ? std::atoi(std::getenv("WORLD_SIZE")) : 1;
   int steps = 20;
+  int ticks = 1; // consecutive control ticks in --states (a trajectory: step k solves tick k % ticks)
+  bool graph = false; // the K steps captured into one hipGraph (ShardedBalanceSolver::capture_steps) and replayed
   bool rendezvous_only = false;
   qlamd::host::ShardedBalanceSolver::Options opt;
   for (int i = 1; i < argc; ++i) {
@@ -85,6 +87,8 @@ int main(int argc, char **argv) {
     else if (a == "--rank") rank = std::atoi(next());
     else if (a == "--ranks") ranks = std::atoi(next());
     else if (a == "--steps") steps = std::atoi(next());
+    else if (a == "--ticks") ticks = std::atoi(next());
+    else if (a == "--graph") graph = true;
     else if (a == "--gather-every") opt.gather_every = std::atoi(next());
     else if (a == "--plain") opt.placed = false;
     else if (a == "--warm") opt.warm = true;
@@ -111,31 +115,38 @@ int main(int argc, char **argv) {
   static const int kWidth[9] = {12, 3, 4, 3, 3, 3, 4, 3, 3};
   std::FILE *f = std::fopen(states_path.c_str(), "rb");
   if (!f) { std::fprintf(stderr, "cannot open %s\n", states_path.c_str()); return 2; }
-  double *dfield[9];
-  uint8_t *dsupport = nullptr;
+  // (--ticks T: the file holds T consecutive control ticks of the batch, tick after tick -- a trajectory, so that the placed /
+  // warm-started loop steps through states that move and its hints come from earlier ticks)
+  if (ticks < 1) ticks = 1;
+  std::vector<qlamd_state_batch> traj((size_t)ticks);
   int64_t offset = 0;
-  for (int k = 0; k < 9; ++k) {
-    std::vector<double> h((size_t)B * kWidth[k]);
-    std::fseek(f, (long)(offset + sh.first * kWidth[k] * 8), SEEK_SET);
-    if (std::fread(h.data(), 8, h.size(), f) != h.size()) { std::fprintf(stderr, "short read\n"); return 2; }
-    offset += robots * kWidth[k] * 8;
-    HIP_OK(hipMalloc((void **)&dfield[k], h.size() * 8));
-    HIP_OK(hipMemcpy(dfield[k], h.data(), h.size() * 8, hipMemcpyHostToDevice));
-  }
-  {
-    std::vector<uint8_t> h((size_t)B * 4);
-    std::fseek(f, (long)(offset + sh.first * 4), SEEK_SET);
-    if (std::fread(h.data(), 1, h.size(), f) != h.size()) { std::fprintf(stderr, "short read\n"); return 2; }
-    HIP_OK(hipMalloc((void **)&dsupport, h.size()));
-    HIP_OK(hipMemcpy(dsupport, h.data(), h.size(), hipMemcpyHostToDevice));
+  for (int t = 0; t < ticks; ++t) {
+    double *dfield[9];
+    uint8_t *dsupport = nullptr;
+    for (int k = 0; k < 9; ++k) {
+      std::vector<double> h((size_t)B * kWidth[k]);
+      std::fseek(f, (long)(offset + sh.first * kWidth[k] * 8), SEEK_SET);
+      if (std::fread(h.data(), 8, h.size(), f) != h.size()) { std::fprintf(stderr, "short read\n"); return 2; }
+      offset += robots * kWidth[k] * 8;
+      HIP_OK(hipMalloc((void **)&dfield[k], h.size() * 8 + 8));
+      HIP_OK(hipMemcpy(dfield[k], h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    }
+    {
+      std::vector<uint8_t> h((size_t)B * 4);
+      std::fseek(f, (long)(offset + sh.first * 4), SEEK_SET);
+      if (std::fread(h.data(), 1, h.size(), f) != h.size()) { std::fprintf(stderr, "short read\n"); return 2; }
+      offset += robots * 4;
+      HIP_OK(hipMalloc((void **)&dsupport, h.size() + 8));
+      HIP_OK(hipMemcpy(dsupport, h.data(), h.size(), hipMemcpyHostToDevice));
+    }
+    qlamd_state_batch &in = traj[(size_t)t];
+    std::memset(&in, 0, sizeof(in));
+    in.joint_position = dfield[0]; in.base_position = dfield[1]; in.base_orientation = dfield[2];
+    in.base_linear_velocity = dfield[3]; in.base_angular_velocity = dfield[4]; in.desired_position = dfield[5];
+    in.desired_orientation = dfield[6]; in.desired_linear_velocity = dfield[7]; in.desired_angular_velocity = dfield[8];
+    in.support_leg = dsupport;
   }
   std::fclose(f);
-  qlamd_state_batch in;
-  std::memset(&in, 0, sizeof(in));
-  in.joint_position = dfield[0]; in.base_position = dfield[1]; in.base_orientation = dfield[2];
-  in.base_linear_velocity = dfield[3]; in.base_angular_velocity = dfield[4]; in.desired_position = dfield[5];
-  in.desired_orientation = dfield[6]; in.desired_linear_velocity = dfield[7]; in.desired_angular_velocity = dfield[8];
-  in.support_leg = dsupport;
 
   // ---- the communicator id (rank 0 creates it, the others wait for the file), then the solver of this rank
   ncclUniqueId id;
@@ -153,9 +164,22 @@ int main(int argc, char **argv) {
     if (rc != 0) { std::fprintf(stderr, "init: %s\n", solver.error()); return rc == -2 ? 3 : 4; }
   }
   const auto run = [&](int nsteps, bool with_gather) -> int {
+    if (graph) { // capture once per (nsteps, with_gather), one untimed replay, then the replay that is timed
+      static int have_steps = -1, have_gather = -1;
+      if (have_steps != nsteps || have_gather != (int)with_gather) {
+        if (solver.capture_steps(nsteps, with_gather, [&](int k) -> const qlamd_state_batch & { return traj[(size_t)(k % ticks)]; }) != 0) {
+          std::fprintf(stderr, "capture: %s\n", solver.error());
+          return 4;
+        }
+        have_steps = nsteps; have_gather = (int)with_gather;
+        if (solver.replay_captured() != 0 || solver.drain() != 0) { std::fprintf(stderr, "replay: %s\n", solver.error()); return 4; }
+      }
+      if (solver.replay_captured() != 0 || solver.drain() != 0) { std::fprintf(stderr, "replay: %s\n", solver.error()); return 4; }
+      return 0;
+    }
     solver.reset_steps();
     for (int k = 0; k < nsteps; ++k)
-      if (solver.step(in, with_gather) != 0) { std::fprintf(stderr, "step: %s\n", solver.error()); return 4; }
+      if (solver.step(traj[(size_t)(k % ticks)], with_gather) != 0) { std::fprintf(stderr, "step: %s\n", solver.error()); return 4; }
     if (solver.finish_group(with_gather) != 0 || solver.drain() != 0) { std::fprintf(stderr, "drain: %s\n", solver.error()); return 4; }
     return 0;
   };
@@ -163,6 +187,7 @@ int main(int argc, char **argv) {
 
   double ms[2] = {0.0, 0.0};
   for (int with_gather = 1; with_gather >= 0; --with_gather) {
+    if (graph) { if (int rc = run(steps, with_gather != 0)) return rc; } // (untimed: captures the K steps and replays them once)
     if (solver.barrier() != 0) { std::fprintf(stderr, "barrier: %s\n", solver.error()); return 4; } // every rank starts together
     const auto w0 = std::chrono::steady_clock::now();
     if (int rc = run(steps, with_gather != 0)) return rc;
@@ -193,7 +218,8 @@ int main(int argc, char **argv) {
   for (int32_t v : hs) failed += v != QLAMD_STATUS_OK;
   std::printf("rank %d of %d device %d robots %lld+%lld steps %d gather_every %d %s : %.1f us/step with the all-gather, %.1f without, "
               "%lld robots with status != ok\n",
-              rank, ranks, device, (long long)sh.first, (long long)B, steps, G, opt.placed ? (opt.warm ? "placed+warm" : "placed") : "plain",
+              rank, ranks, device, (long long)sh.first, (long long)B, steps, G,
+              (std::string(opt.placed ? (opt.warm ? "placed+warm" : "placed") : "plain") + (graph ? " hipGraph" : "")).c_str(),
               1e3 * ms[1] / steps, 1e3 * ms[0] / steps, (long long)failed);
   solver.destroy();
   return 0;

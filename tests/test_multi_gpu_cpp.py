@@ -46,11 +46,13 @@ def run(*args, env_extra=None, timeout=300):
 
 
 def write_states(path, state):
-    """The global batch in the order of qlamd_state_batch, support flags last."""
+    """The global batch in the order of qlamd_state_batch, support flags last; a list of states: a trajectory, tick after tick
+    (the demo's --ticks)."""
     with open(path, "wb") as f:
-        for key, _field, k in FIELD_OF_KEY:
-            f.write(np.ascontiguousarray(state[key], dtype=np.float64).reshape(-1, k).tobytes())
-        f.write(np.ascontiguousarray(state["stance"], dtype=np.uint8).tobytes())
+        for st in (state if isinstance(state, (list, tuple)) else [state]):
+            for key, _field, k in FIELD_OF_KEY:
+                f.write(np.ascontiguousarray(st[key], dtype=np.float64).reshape(-1, k).tobytes())
+            f.write(np.ascontiguousarray(st["stance"], dtype=np.uint8).tobytes())
 
 
 @needs_hipcc
@@ -135,3 +137,20 @@ def test_one_rank_pipeline_equals_the_python_path(gpu, tmp_path, gather_every):
     assert p.returncode == 0, p.stdout + p.stderr
     assert "0 robots with status != ok" in p.stdout and "placed+warm" in p.stdout
     assert np.abs(np.fromfile(out, dtype=np.float64).reshape(B, 12) - got).max() < 1e-7
+    # a trajectory (--ticks): step k solves tick k % T, so the loop's hints come from earlier ticks; the last step's efforts
+    # are those of the last tick, whatever the method
+    T = 10
+    traj = synth.trajectory(B, "trot", T)
+    write_states(states, traj)
+    dl = capi.to_device(traj[-1])
+    ctx.balance_solve_device(dl, tau, None, status, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = tau.cpu().numpy()
+    # (--graph: the K steps captured into one hipGraph by ShardedBalanceSolver::capture_steps -- solves and in-place all-gathers on
+    # two captured streams -- and replayed: the same efforts)
+    for extra, tol in ((("--plain",), 0.0), ((), 0.0), (("--warm",), 1e-7), (("--graph",), 0.0), (("--graph", "--warm"), 1e-7)):
+        p = run("--states", states, "--robots", str(B), "--ticks", str(T), "--ranks", "1", "--rank", "0", "--steps", str(T),
+                "--gather-every", str(gather_every), "--out", out, *extra)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert "0 robots with status != ok" in p.stdout
+        assert np.abs(np.fromfile(out, dtype=np.float64).reshape(B, 12) - want).max() <= tol, extra

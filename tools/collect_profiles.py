@@ -29,20 +29,19 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = [
     # name, kernel substring, batch, bench.py arguments
-    # (+placed: bench.py's default method since round 5 -- every step one qlamd_balance_solve_placed_batch launch that also
-    # makes the next step's placement; the others: the plain entry, the headline of rounds 1-4)
-    ("static-survey+placed", "balance_coop_kernel", 4096, ["--gait", "static", "--errors", "survey", "--method", "placed"]),
-    ("trot+placed", "balance_coop_kernel", 4096, ["--gait", "trot", "--method", "placed"]),
-    ("trot+placed", "balance_coop_kernel", 8192, ["--gait", "trot", "--batch", "8192", "--method", "placed"]),
-    ("trot+placed", "balance_coop_kernel", 65536, ["--gait", "trot", "--batch", "65536", "--method", "placed"]),
+    # (+warm: bench.py's default method since round 6 -- the caller's placed + warm-started loop on a trajectory; +placed: the
+    # same steps with every QP started cold, round 5's method; no suffix: the plain entry, the headline of rounds 1-4)
     ("static-survey+warm", "balance_coop_kernel", 4096, ["--gait", "static", "--errors", "survey", "--method", "warm"]),
+    ("static-calm+warm", "balance_coop_kernel", 4096, ["--gait", "static", "--errors", "calm", "--method", "warm"]),
+    ("trot+warm", "balance_coop_kernel", 4096, ["--gait", "trot", "--method", "warm"]),
     ("trot+warm", "balance_coop_kernel", 8192, ["--gait", "trot", "--batch", "8192", "--method", "warm"]),
     ("trot+warm", "balance_coop_kernel", 65536, ["--gait", "trot", "--batch", "65536", "--method", "warm"]),
+    ("static-survey+placed", "balance_coop_kernel", 4096, ["--gait", "static", "--errors", "survey", "--method", "placed"]),
+    ("trot+placed", "balance_coop_kernel", 8192, ["--gait", "trot", "--batch", "8192", "--method", "placed"]),
+    ("trot+placed", "balance_coop_kernel", 65536, ["--gait", "trot", "--batch", "65536", "--method", "placed"]),
     ("static-survey", "balance_coop_kernel", 4096, ["--gait", "static", "--errors", "survey", "--method", "plain"]),
-    ("static-calm", "balance_coop_kernel", 4096, ["--gait", "static", "--errors", "calm", "--method", "plain"]),
     ("trot", "balance_coop_kernel", 4096, ["--gait", "trot", "--method", "plain"]),
     ("trot", "balance_coop_kernel", 65536, ["--gait", "trot", "--batch", "65536", "--method", "plain"]),
-    ("trot", "balance_coop_kernel", 8192, ["--gait", "trot", "--batch", "8192", "--method", "plain"]),
     ("pose_sqp", "pose_sqp_coop_kernel", 4096, ["--workload", "pose_sqp"]),
     ("wholebody-trot", "wholebody_solve_kernel", 4096, ["--workload", "wholebody", "--gait", "trot"]),
     ("wholebody_dynamics", "wholebody_dynamics_leg_kernel", 1048576, ["--workload", "wholebody_dynamics", "--batch", "1048576"]),
