@@ -10,6 +10,8 @@ from quadruped_locomotion_amd import capi, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 heur = sys.argv[3] if len(sys.argv) > 3 else "none"
+import os
+if os.environ.get("QLAMD_LIB"): capi.LIB_PATH = os.path.abspath(os.environ["QLAMD_LIB"])
 ctx = capi.Context()
 states = synth.trajectory(B, "trot", T)
 ws = torch.zeros(B, dtype=torch.int32, device="cuda:0")
