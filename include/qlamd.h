@@ -316,7 +316,12 @@ typedef struct qlamd_placement {
    * the library, 0 = not recorded) instead of the empty one, and its final working set goes to working_set [B] (0 for a robot
    * whose status is not QLAMD_STATUS_OK); either may be NULL; they may be ONE array, updated in place (a robot's set is read
    * and written by its own lanes only).  A robot whose support legs are not the recorded ones any more -- a trot entering or
-   * leaving double support -- starts cold: a stale set costs such a robot more than it saves.  Hand a robot the set it ended with on its previous
+   * leaving double support -- and a robot without a record (a word of zeros: its first step) has no set to start from: a stale
+   * one costs such a robot more than it saves.  With prev_working_set given it BUILDS one instead of adding a row a pass: by
+   * rounds, every leg's most violated row installed as an equality together with the other legs', up to three rounds, then on as
+   * after any warm start (four rows a round for the price of a pass and a half: the robots a launch of a trot waits for).
+   * With working_set alone (prev_working_set NULL) every robot starts from the empty set by the reference's method, bit for bit
+   * the plain entry's answer.  Hand a robot the set it ended with on its previous
    * control step (zeros to start with: a cold start).  At 400 Hz that is this
    * step's final set for 96 % of the robots of the bench batches: the rows are installed as equalities, slots whose
    * multiplier comes out negative are dropped, and the method of the reference continues from there -- a set that no longer

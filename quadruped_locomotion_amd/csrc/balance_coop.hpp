@@ -147,6 +147,7 @@ __device__ __forceinline__ bool coop_robot(const DeviceParams &P, const CoopPtrs
   double qj = s.q[12 * i_in + (comp ? myidx : 0)];
   const uint8_t alive = s.live ? s.live[i_in] : (uint8_t)1;
   unsigned warm_set = 0u;
+  bool build_set = false;
   if constexpr (kWarm) warm_set = (s.prev_working_set && !cold) ? s.prev_working_set[i_in] : 0u;
   double wr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; // externally supplied (F_B, T_B), if any: issued with the rest
   if (s.wrench) {
@@ -168,6 +169,10 @@ __device__ __forceinline__ bool coop_robot(const DeviceParams &P, const CoopPtrs
     // 3.4 (4 -> 2): profiles/r6/trajectory_stats.txt
     const unsigned from = (warm_set >> 20) & 0xFu;
     warm_set = (from != 0u && from != stance) ? 0u : (warm_set & 0xFFFFFu);
+    // ... and BUILDS a set by rounds instead of adding a row a pass (force_qp_coop.hpp, kGreedy), as does a robot on its first
+    // step (a word of zeros: no record).  A robot that simply ended its last step with no active row is neither: its empty set
+    // carries its support legs, and it goes on as the reference's method does.
+    build_set = s.prev_working_set != nullptr && !cold && from != stance;
   }
   // support legs first: the leg behind my slot, and what was loaded by leg goes to the lane of its slot
   const unsigned perm = slot_legs(stance);
@@ -415,6 +420,7 @@ __device__ __forceinline__ bool coop_robot(const DeviceParams &P, const CoopPtrs
     Q.mu = mu; Q.f_min = f_min;
     Q.on = on; Q.comp = comp; Q.nS = nS; Q.refine_passes = P.refine_passes;
     Q.warm = 0ull; Q.stance = stance_slots;
+    Q.build_set = build_set;
     if constexpr (kWarm) Q.warm = permuted ? working_set_to_slots<5, unsigned>(warm_set, perm) : warm_set;
     status = force_qp_coop<false, kWarm, decltype(Legs)::value, !kThroughput>(Q, lds_row, lds_nrm, x, qp_iters, &final_set);
   };

@@ -59,6 +59,8 @@ struct ForceQp {
   // by an earlier solve) and the stance legs as a bit mask (rows of other legs are left out of it)
   unsigned long long warm;
   unsigned stance;
+  bool build_set;                // kWarm: a robot without a set builds one by rounds (a caller that hands in sets); false: the
+                                 // method of the reference from the empty set, bit for bit the cold kernels' answer
 };
 
 // My row of G and my entry of g0 for the objective  |A f - F|^2_S + w_reg |f|^2  (A = [1 ... ; [r_leg]x ...], the
@@ -472,12 +474,23 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     // holds, a row on its own 0.40 us: the static bench batch -- 8 rows on average, up to 12 -- 15.5 -> 14.85 us by rounds, its
     // trot batches -- one to three rows on two legs -- 22.2 -> 23.2 us: profiles/r6/ab_install_forms.txt), row by row otherwise
     // and always in the throughput form of the kernels (!kRounds).  Wavefront-uniform: one scalar branch.
-    bool by_rounds = false;
+    // A robot WITHOUT a set -- its first step, or one whose support legs have just changed: the robots a launch of a trot waits
+    // for -- builds one by rounds as well (kGreedy): in every round each leg takes its most violated row at the current x, the
+    // round installs them as equalities, up to three rounds; negative multipliers are dropped below and the method of the
+    // reference runs from there as after any warm start (same guarantees, same final check).  Four rows a round at 0.95 us
+    // instead of one a pass at 0.65 us: a robot entering double support 9.5 passes -> three rounds and the passes that remain.
+#ifdef QLAMD_NO_GREEDY
+    constexpr bool kGreedy = false;   // (A/B builds)
+#else
+    constexpr bool kGreedy = kRounds && !kTorque;
+#endif
+    bool by_rounds = false, greedy = false;
     if constexpr (kRounds) {
       int nrows;
       if constexpr (kTorque) nrows = __popcll((unsigned long long)wm);
       else nrows = __popc((unsigned)wm);
-      by_rounds = __builtin_amdgcn_ballot_w64(nrows >= (kLegs == 4 ? 6 : 4)) != 0ull;
+      greedy = kGreedy && Q.build_set && wm == 0 && nS > 0;
+      by_rounds = __builtin_amdgcn_ballot_w64(nrows >= (kLegs == 4 ? 6 : 4) || greedy) != 0ull;
     }
     if (by_rounds) {
       // Installed a ROUND at a time: the next row of every leg together.  Every row touches the variables of one leg, so the
@@ -490,11 +503,36 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
       // profiles/r6/warm_install_probe.txt), twelve rows in 4.8 us; a round of four is 0.7 us and three rounds are the most there are.
       // A leg without a row in a round rides along with a zero normal and divisors biased to 1, like a ghost row of the loop.
       unsigned mine = (unsigned)((wm >> (kKinds * leg)) & kLegRows); // the rows of my leg still to install (lanes of a leg agree)
-      for (;;) {
-        if (__builtin_amdgcn_ballot_w64(mine != 0u) == 0ull) break;
-        const bool have = mine != 0u;
-        const int kind = have ? __ffs((int)mine) - 1 : 0;
+      const bool any_greedy = kGreedy && __builtin_amdgcn_ballot_w64(greedy) != 0ull; // (scalar)
+      // (the loop in two copies -- wavefronts with a robot that builds its set, and the others, whose rounds stay the straight
+      // code they were: folded into one loop the selection costs the static bench batch 0.25 us a step)
+      const auto rounds = [&](auto WithGreedy) {
+      constexpr bool kWithGreedy = decltype(WithGreedy)::value;
+      for (int round = 0;; round++) {
+        bool have = mine != 0u;
+        int kind = have ? __ffs((int)mine) - 1 : 0;
         mine &= mine - 1u;
+        if constexpr (kWithGreedy) {
+          // a robot that builds its set: the most violated row of my leg that is not in the set yet, by the keys of the
+          // selection (update_and_select) reduced over the quad instead of the row
+          if (round < 3) {
+            double s_min, s_fric, xg = x;
+            asm volatile("" : "+v"(xg)); // (not to be computed ahead of the branch, on the path of the wavefronts that build nothing)
+            slacks(xg, s_min, s_fric);
+            const mask_t avail = ~act_mask;
+            unsigned kf = __float_as_uint((float)s_fric), km = __float_as_uint((float)s_min);
+            kf = ((avail & maskf) != 0 && s_fric < 0.0) ? ((kf & ~kTagMask) | tagf) : 0u;
+            km = ((avail & maskm) != 0 && s_min < 0.0) ? ((km & ~kTagMask) | tagm) : 0u;
+            unsigned key = km > kf ? km : kf;
+            key = umax_dpp(key, std::integral_constant<int, 0xB1>{}); // quad_perm [1,0,3,2]
+            key = umax_dpp(key, std::integral_constant<int, 0x4E>{}); // quad_perm [2,3,0,1]
+            const bool ghave = greedy && (int)key < 0;
+            const int gkind = (key & 1u) ? 0 : (int)((key >> kTagBits) & 3u) + 1;
+            have = greedy ? ghave : have;
+            kind = greedy ? gkind : kind;
+          }
+        }
+        if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
         // component c of my leg's row and its offset: n'x - b >= 0 with b = f_min (kind 0), 0 (friction), and for the torque bounds
         // of joint k (kinds 5 + 2k upper, 6 + 2k lower) n = +-J[:,k], b = -(tau_max -+ tau0_k) -- held by the joint's lane
         double nv, bp;
@@ -570,6 +608,13 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
           }
           update_only();
         });
+      }
+      };
+      if constexpr (kGreedy) {
+        if (__builtin_expect(any_greedy, 0)) rounds(std::true_type{}); // (out of line: the common path stays contiguous)
+        else rounds(std::false_type{});
+      } else {
+        rounds(std::false_type{});
       }
     } else {
       // One row after the other (the throughput form of the kernels, which has no registers for a round's eight direction

@@ -407,7 +407,7 @@ __device__ __forceinline__ bool wholebody_robot(const DeviceParams &P, const coo
   Q.on = on; Q.comp = comp; Q.nS = nS; Q.refine_passes = P.refine_passes;
   Q.tq_up = W.tau_max - tau0; Q.tq_lo = W.tau_max + tau0;
   double x = 0.0;
-  Q.warm = 0ull; Q.stance = stance;
+  Q.warm = 0ull; Q.stance = stance; Q.build_set = false;
   if constexpr (kWarm) Q.warm = permuted ? working_set_to_slots<11, unsigned long long>(warm_set, perm) : warm_set;
   int qp_iters;
   unsigned long long final_set = 0ull;
