@@ -496,6 +496,13 @@ constexpr int kCoopWaves = 1;
 #ifndef QLAMD_THROUGHPUT_BATCH
 #define QLAMD_THROUGHPUT_BATCH 16384 // robots from which the three-wavefront form of the balance kernel runs
 #endif
+#ifndef QLAMD_THREE_WAVE_WARM_BATCH
+// ... of the warm-started kernel: later, because its two-wavefront form installs by rounds and lets robots without a set build
+// one by rounds, which the 168 registers of the other form have no room for (trot, placed + warm loop, us per step, two- against
+// three-wavefront form: 16 384 robots 30.0 / 32.6, 20 480: 33.6 / 34.3, 24 576: 37.9 / 37.1, 32 768: 45.6 / 42.8, 65 536:
+// 76.7 / 70.5 -- profiles/r6/ab_three_wave_threshold.txt)
+#define QLAMD_THREE_WAVE_WARM_BATCH 22528
+#endif
 // kMinWaves wavefronts per SIMD at least: 2 (at most 256 registers: the large-batch throughput halves without it) for the
 // latency form, 3 (at most 168 registers; 12 wavefronts x 13 056 bytes of LDS fit a compute unit) for the throughput form
 // that large batches take (QLAMD_THROUGHPUT_BATCH): two wavefronts of dependent instruction streams cannot fill a SIMD's
@@ -1018,7 +1025,7 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
                          ctx->d_params, s, batch, d_tau, d_grf, d_status);                                                   \
   } while (0)
       if (s.normals) QL_LAUNCH_COOP(true, 2);
-      else if (batch >= QLAMD_THROUGHPUT_BATCH) QL_LAUNCH_COOP(false, 3);
+      else if (batch >= (warm ? QLAMD_THREE_WAVE_WARM_BATCH : QLAMD_THROUGHPUT_BATCH)) QL_LAUNCH_COOP(false, 3);
       else QL_LAUNCH_COOP(false, 2);
 #undef QL_LAUNCH_COOP
       e = hipGetLastError();
