@@ -482,7 +482,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
 #ifdef QLAMD_NO_GREEDY
     constexpr bool kGreedy = false;   // (A/B builds)
 #else
-    constexpr bool kGreedy = kRounds && !kTorque;
+    constexpr bool kGreedy = kRounds;
 #endif
     bool by_rounds = false, greedy = false;
     if constexpr (kRounds) {
@@ -524,10 +524,19 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
             kf = ((avail & maskf) != 0 && s_fric < 0.0) ? ((kf & ~kTagMask) | tagf) : 0u;
             km = ((avail & maskm) != 0 && s_min < 0.0) ? ((km & ~kTagMask) | tagm) : 0u;
             unsigned key = km > kf ? km : kf;
+            if constexpr (kTorque) { // of the two bounds of a joint only the nearer one can be violated
+              const bool lower = s_lo < s_up;
+              const double s_t = lower ? s_lo : s_up;
+              unsigned kt = __float_as_uint((float)s_t);
+              kt = ((avail & (lower ? maskl : masku)) != 0 && s_t < 0.0) ? ((kt & ~kTagMask) | tagf | (lower ? 3u : 2u)) : 0u;
+              key = kt > key ? kt : key;
+            }
             key = umax_dpp(key, std::integral_constant<int, 0xB1>{}); // quad_perm [1,0,3,2]
             key = umax_dpp(key, std::integral_constant<int, 0x4E>{}); // quad_perm [2,3,0,1]
             const bool ghave = greedy && (int)key < 0;
-            const int gkind = (key & 1u) ? 0 : (int)((key >> kTagBits) & 3u) + 1;
+            const int cw = (int)((key >> kTagBits) & 3u); // the lane of my quad that watches the row
+            int gkind = (key & 1u) ? 0 : cw + 1;
+            if constexpr (kTorque) gkind = (key & 2u) ? 5 + 2 * cw + (int)(key & 1u) : gkind;
             have = greedy ? ghave : have;
             kind = greedy ? gkind : kind;
           }

@@ -328,6 +328,7 @@ __device__ __forceinline__ bool wholebody_robot(const DeviceParams &P, const coo
   const double qdd_raw = (s.qdd ? s.qdd : s.qd)[12 * i + jq];
   const uint32_t sm = *reinterpret_cast<const uint32_t *>(s.stance + 4 * i);
   unsigned long long warm_set = 0ull;
+  bool build_set = false;
   if constexpr (kWarm) warm_set = pp.prev_working_set ? pp.prev_working_set[i] : 0ull;
   double nWl[3] = {0.0, 0.0, 1.0};
   if (kPerLeg) { nWl[0] = s.normals[12 * i + 3 * leg]; nWl[1] = s.normals[12 * i + 3 * leg + 1]; nWl[2] = s.normals[12 * i + 3 * leg + 2]; }
@@ -339,6 +340,7 @@ __device__ __forceinline__ bool wholebody_robot(const DeviceParams &P, const coo
   if constexpr (kWarm) { // a set remembers the support legs it was reached with (bits 44..47); other legs now: a cold start (balance_coop.hpp)
     const unsigned from = (unsigned)(warm_set >> 44) & 0xFu;
     warm_set = (from != 0u && from != stance_legs) ? 0ull : (warm_set & ((1ull << 44) - 1ull));
+    build_set = pp.prev_working_set != nullptr && from != stance_legs; // (no record, or other legs: the set is built by rounds)
   }
   // support legs first (balance_coop.hpp): `leg` is my SLOT in the row, aleg the leg behind it; what was loaded by leg moves
   // to the lane of its slot
@@ -407,7 +409,7 @@ __device__ __forceinline__ bool wholebody_robot(const DeviceParams &P, const coo
   Q.on = on; Q.comp = comp; Q.nS = nS; Q.refine_passes = P.refine_passes;
   Q.tq_up = W.tau_max - tau0; Q.tq_lo = W.tau_max + tau0;
   double x = 0.0;
-  Q.warm = 0ull; Q.stance = stance; Q.build_set = false;
+  Q.warm = 0ull; Q.stance = stance; Q.build_set = build_set;
   if constexpr (kWarm) Q.warm = permuted ? working_set_to_slots<11, unsigned long long>(warm_set, perm) : warm_set;
   int qp_iters;
   unsigned long long final_set = 0ull;
