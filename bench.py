@@ -606,7 +606,7 @@ def main():
     trajectories = {}   # (gait, errors, batch, ticks, rank) -> (device-resident states of every tick, support switches per tick)
 
     def run_preset(gait, errors, with_gather, replays, second_without_gather, collect="rccl", every=1, batch=None,
-                   method="plain"):
+                   method="plain", records=False):
         """One workload preset on this rank's shard: warm-up, K steps captured as one hipGraph, `replays` timed samples.
         every: steps per collection; collect: "rccl" (all-gather) or "peer" (copies into the peers' buffers).
         Step k of the loop solves tick k % T of a T-tick trajectory of the shard's robots (synth.trajectory).  method "placed": the caller's loop of include/qlamd.h -- step k runs in order[k & 1], writes
@@ -623,11 +623,15 @@ def main():
         T = max(1, args.ticks) if args.ticks else (cap if K >= cap else K * max(1, cap // K))
         NG = max(1, -(-T // K)) if K > 0 else 1
         # rank r owns robots [r*B, (r+1)*B) of the global batch (contiguous shards)
-        key = (gait, errors, B, T, rank)
+        # records: the double fields of a robot in one 48-double record (QLAMD_OPT_STATE_LAYOUT = QLAMD_STATE_RECORDS) instead of
+        # one array per field -- what a permuted launch gathers in three lines instead of nine
+        key = (gait, errors, B, T, rank, records)
         if key not in trajectories:
             states = synth.trajectory(B, gait, T, offset=rank * B, errors=errors)
-            trajectories[key] = ([capi.to_device(st_, dev) for st_ in states], synth.support_switches(states + [states[0]]))
+            put = capi.to_device_records if records else capi.to_device
+            trajectories[key] = ([put(st_, dev) for st_ in states], synth.support_switches(states + [states[0]]))
         ds, switched = trajectories[key]   # (switched: T - 1 transitions of the trajectory, then the jump back to tick 0)
+        ctx.set_option(capi.OPT_STATE_LAYOUT, capi.STATE_RECORDS if records else capi.STATE_FIELDS)
         retries0, giveups0 = ctx.counter(capi.COUNTER_WARM_RETRIES), ctx.counter(capi.COUNTER_PLACEMENT_GIVE_UPS)
         placed, warm = method == "placed", method == "warm"
         orders = [torch.arange(B, dtype=torch.int32, device=dev) for _ in range(2)] if (placed or warm) else None
@@ -893,6 +897,7 @@ def main():
             # robots whose warm start was rejected and that were solved again cold inside the same launch (whole preset:
             # warm-up, settling and every timed replay included); with the fallback on none of them is ever reported
             res["trajectory"]["warm_rejected"] = ctx.counter(capi.COUNTER_WARM_RETRIES) - retries0
+        ctx.set_option(capi.OPT_STATE_LAYOUT, capi.STATE_FIELDS)
         return res
 
     def roofline_of(res, gait, errors):
@@ -1149,6 +1154,9 @@ def main():
     # the same preset by the other methods (every rank takes part: the preset's consensus steps are collectives)
     beside = ({m: run_preset(args.gait, args.errors, False, few, False, method=m) for m in others}
               if not (args.rpw or args.no_also) else {})
+    # ... and by the line's method on records instead of per-field arrays (the optional gather-friendly layout)
+    on_records = (run_preset(args.gait, args.errors, False, few, False, method=method, records=True)
+                  if not (args.rpw or args.no_also or method == "plain" or collective) else None)
     # The other presets and every other BASELINE config, same process (one GPU only; fewer samples each):
     #   static-calm, trot at the headline batch; trot_b8192 (one rank's shard of configs[3]) and trot_b65536 (its global
     #   batch on one GPU), each by the line's method with the other methods beside it; pose_sqp_b4096 (configs[4]).
@@ -1175,6 +1183,8 @@ def main():
             if args.gait == "trot" and bb == B:
                 continue
             also[name] = preset_entry("trot", "survey", bb, others)
+        if not args.rpw and method != "plain" and "trot_b65536" in also:
+            also["trot_b65536"]["records"] = brief(run_preset("trot", "survey", False, few, False, batch=65536, method=method, records=True))
         for name, fn in (("pose_sqp_b4096", pose_sqp_entry), ("full_tick_b4096", full_tick_entry), ("wholebody_trot_b4096", wholebody_entry)):
             try:
                 also[name] = fn(4096)
@@ -1277,6 +1287,10 @@ def main():
             line["valu_issue"] = valu
         for m, r in beside.items():
             line[OTHER_KEY[m]] = entry(r, args.gait, args.errors)
+        if on_records is not None:
+            line["records"] = dict(brief(on_records), note="the same steps with the nine double fields of a robot in one 48-double record "
+                                   "(QLAMD_OPT_STATE_LAYOUT = QLAMD_STATE_RECORDS, qlamd_state_record) instead of one array per field, the "
+                                   "layout of the reference's hardware interface that `value` is measured on")
         if scale_point is not None:
             line["scale_point"] = scale_point
         if also is not None:

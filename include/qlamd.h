@@ -145,6 +145,22 @@ typedef struct qlamd_state_batch {
                                          ros_balance_controller.cpp:378        */
 } qlamd_state_batch;
 
+/* The record of QLAMD_STATE_RECORDS (QLAMD_OPT_STATE_LAYOUT): the double fields of one robot, quaternions on 16-byte boundaries,
+ * 48 doubles = three 128-byte lines. */
+#define QLAMD_STATE_RECORD_DOUBLES 48
+typedef struct qlamd_state_record {
+  double joint_position[12];
+  double base_position[3], pad0;
+  double base_orientation[4];
+  double base_linear_velocity[3];
+  double base_angular_velocity[3];
+  double desired_position[3], pad1;
+  double desired_orientation[4];
+  double desired_linear_velocity[3];
+  double desired_angular_velocity[3];
+  double pad2[8];
+} qlamd_state_record;
+
 /* Create / destroy.  `device` is a HIP device ordinal.  `model` may be NULL
  * (reference robot).  Replaces RosBalanceController::init's construction of
  * ContactForceDistribution + VirtualModelController + State
@@ -203,12 +219,28 @@ int qlamd_set_robots_per_wave(qlamd_context *ctx, int robots_per_wave);
  *                          rejected.  0: the rejection is reported instead (the behaviour of version 0.5).  2: diagnostics --
  *                          every robot that ends a warm-started solve with a non-empty working set is treated as rejected and
  *                          solved a second time (how the tests reach the second attempt at will; rejections of their own are
- *                          rare: none in 9 M soaked control steps). */
+ *                          rare: none in 9 M soaked control steps).
+ *   QLAMD_OPT_STATE_LAYOUT   how the nine double fields of qlamd_state_batch lie in DEVICE memory for qlamd_balance_solve_batch /
+ *                          _placed_batch (lane-cooperative kernels only; the force-distribution entries, which read two of the
+ *                          fields, refuse the option with QLAMD_ERR_INVALID_ARGUMENT):
+ *                          QLAMD_STATE_FIELDS (default): one array [B][k] per field, as the reference's hardware interface
+ *                          hands them out (robot_state_interface.hpp:28-65).  QLAMD_STATE_RECORDS: one record of
+ *                          QLAMD_STATE_RECORD_DOUBLES doubles per robot (qlamd_state_record below) -- every field pointer of
+ *                          qlamd_state_batch then addresses the same [B] array of records at its field's offset
+ *                          (joint_position = &rec[0].joint_position[0], ...), field k of robot i at pointer + 48 i + k.  A
+ *                          launch in a placement gathers robots from all over the batch: three full 128-byte lines per robot
+ *                          instead of nine partially used ones (fetched bytes 2.44 -> 1.27 MB per 4096-robot launch, 38 -> 17
+ *                          MB at 65 536; 1 % of a launch at 4096 robots, 2.7 % at 65 536: profiles/r6/packed_record.txt).
+ *                          support_leg, surface_normal and virtual_wrench stay arrays of their own; host-buffer calls take
+ *                          per-field arrays whatever the option says. */
 #define QLAMD_OPT_ON_FAILURE 1
 #define QLAMD_OPT_REFINE_PASSES 2
 #define QLAMD_OPT_DYNAMICS_FORM 5
 #define QLAMD_OPT_PLACEMENT_WAIT 6
 #define QLAMD_OPT_WARM_FALLBACK 7
+#define QLAMD_OPT_STATE_LAYOUT 8
+#define QLAMD_STATE_FIELDS 0
+#define QLAMD_STATE_RECORDS 1
 #define QLAMD_ON_FAILURE_ZERO 0
 #define QLAMD_ON_FAILURE_KEEP 1
 #define QLAMD_DYNAMICS_AUTO 0

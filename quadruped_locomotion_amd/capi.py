@@ -808,6 +808,24 @@ def to_device(state, device="cuda:0"):
     return out
 
 
+def to_device_records(state, device="cuda:0"):
+    """numpy state dict -> dict of torch tensors for a context with OPT_STATE_LAYOUT = STATE_RECORDS: the nine double fields are
+    views into ONE [B][48] tensor of qlamd_state_record's (data_ptr() of a view = the field's first element of robot 0), the
+    support flags (and normals, if any) arrays of their own."""
+    import torch
+    B = state["q"].shape[0]
+    rec = np.zeros((B, STATE_RECORD_DOUBLES))
+    for k, o in STATE_RECORD_OFFSETS.items():
+        rec[:, o:o + state[k].shape[1]] = state[k]
+    t = torch.from_numpy(rec).to(device)
+    out = {k: t[:, o:] for k, o in STATE_RECORD_OFFSETS.items()}
+    out["_records"] = t
+    for k, v in state.items():
+        if k not in STATE_RECORD_OFFSETS:
+            out[k] = torch.from_numpy(np.ascontiguousarray(v)).to(device)
+    return out
+
+
 def default_wholebody_params():
     p = WholebodyParams()
     lib().qlamd_wholebody_default_params(C.byref(p))
@@ -877,7 +895,11 @@ def wholebody_dynamics_device(ctx, dstate, M, h, Jc, gravity=9.81, stream=None):
         raise QlamdError(rc, "qlamd_wholebody_dynamics_batch")
 
 
-OPT_ON_FAILURE, OPT_REFINE_PASSES, OPT_DYNAMICS_FORM, OPT_PLACEMENT_WAIT, OPT_WARM_FALLBACK = 1, 2, 5, 6, 7
+OPT_ON_FAILURE, OPT_REFINE_PASSES, OPT_DYNAMICS_FORM, OPT_PLACEMENT_WAIT, OPT_WARM_FALLBACK, OPT_STATE_LAYOUT = 1, 2, 5, 6, 7, 8
+STATE_FIELDS, STATE_RECORDS, STATE_RECORD_DOUBLES = 0, 1, 48
+# offsets (doubles) of the fields inside a qlamd_state_record (include/qlamd.h), by the keys of synth.make_states
+STATE_RECORD_OFFSETS = {"q": 0, "base_pos": 12, "base_quat": 16, "base_linvel": 20, "base_angvel": 23, "des_pos": 26, "des_quat": 30,
+                        "des_linvel": 34, "des_angvel": 37}
 COUNTER_PLACEMENT_GIVE_UPS, COUNTER_WARM_RETRIES = 0, 1
 DYNAMICS_AUTO, DYNAMICS_LEG, DYNAMICS_ROW = 0, 1, 2
 ON_FAILURE_ZERO, ON_FAILURE_KEEP = 0, 1

@@ -41,6 +41,7 @@ struct CoopPtrs {
   const uint32_t *prev_working_set;
   uint32_t *working_set;
   uint32_t *warm_retries; // the context's count of rejected warm starts (QLAMD_COUNTER_WARM_RETRIES), or NULL
+  int record_doubles;     // 0: one array per field; R: the double fields are records of R doubles (QLAMD_STATE_RECORDS)
 };
 
 // Support legs first.  The QP's variables are the contact forces of the legs that support; with the legs of a robot laid
@@ -129,22 +130,29 @@ __device__ __forceinline__ bool coop_robot(const DeviceParams &P, const CoopPtrs
     tabv[j] = P.legtab[idx < 4 * kTabPerLeg ? idx : 4 * kTabPerLeg - 1];
   }
   const int64_t i_in = irobot; // (below the QP the index comes back from LDS as `i`: one value less across the loop)
+  // Strides of the nine double fields, in doubles: their widths (12 / 4 / 3: one array per field, the layout of
+  // hardware_interface::RobotStateHandle::Data) or, with QLAMD_OPT_STATE_LAYOUT = QLAMD_STATE_RECORDS, one record length for all
+  // (every field pointer addresses the same [B][R] buffer at its field's offset): a permuted launch then touches three lines
+  // per robot instead of nine partially used ones (s.record_doubles, 0 = per-field arrays).  The support flags stay an array of
+  // their own (the shadow wavefronts read them too).
+  const int64_t kS12 = s.record_doubles ? s.record_doubles : 12, kS4 = s.record_doubles ? s.record_doubles : 4,
+                kS3 = s.record_doubles ? s.record_doubles : 3, kSB = 4;
   double quat[4], dquat[4], pos[3], linvel[3], angvel[3], dpos[3], dlinvel[3], dangvel[3];
   {
-    const double2 *a2 = reinterpret_cast<const double2 *>(s.quat + 4 * i_in);
-    const double2 *b2 = reinterpret_cast<const double2 *>(s.dquat + 4 * i_in);
+    const double2 *a2 = reinterpret_cast<const double2 *>(s.quat + kS4 * i_in);
+    const double2 *b2 = reinterpret_cast<const double2 *>(s.dquat + kS4 * i_in);
     double2 v = a2[0]; quat[0] = v.x; quat[1] = v.y;
     v = a2[1]; quat[2] = v.x; quat[3] = v.y;
     v = b2[0]; dquat[0] = v.x; dquat[1] = v.y;
     v = b2[1]; dquat[2] = v.x; dquat[3] = v.y;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      pos[k] = s.pos[3 * i_in + k]; linvel[k] = s.linvel[3 * i_in + k]; angvel[k] = s.angvel[3 * i_in + k];
-      dpos[k] = s.dpos[3 * i_in + k]; dlinvel[k] = s.dlinvel[3 * i_in + k]; dangvel[k] = s.dangvel[3 * i_in + k];
+      pos[k] = s.pos[kS3 * i_in + k]; linvel[k] = s.linvel[kS3 * i_in + k]; angvel[k] = s.angvel[kS3 * i_in + k];
+      dpos[k] = s.dpos[kS3 * i_in + k]; dlinvel[k] = s.dlinvel[kS3 * i_in + k]; dangvel[k] = s.dangvel[kS3 * i_in + k];
     }
   }
-  const uint32_t sm = *reinterpret_cast<const uint32_t *>(s.stance + 4 * i_in);
-  double qj = s.q[12 * i_in + (comp ? myidx : 0)];
+  const uint32_t sm = *reinterpret_cast<const uint32_t *>(s.stance + kSB * i_in);
+  double qj = s.q[kS12 * i_in + (comp ? myidx : 0)];
   const uint8_t alive = s.live ? s.live[i_in] : (uint8_t)1;
   unsigned warm_set = 0u;
   bool build_set = false;

@@ -30,6 +30,7 @@ struct StatePtrs {
   uint32_t *place_sync;             // two words, zero when the context is created: arrivals, state (their barrier)
   uint32_t place_wait;              // polls they wait for each other before they give up (QLAMD_OPT_PLACEMENT_WAIT)
   uint32_t *warm_retries;           // the context's count of rejected warm starts (kWarm instantiations)
+  int record_doubles;               // 0, or the record length of QLAMD_STATE_RECORDS (lane-cooperative kernels, device memory)
 };
 
 __device__ __forceinline__ void load_robot(const StatePtrs &s, int64_t i, RobotIn &in) {
@@ -482,7 +483,7 @@ __device__ __attribute__((noinline, noreturn)) void balance_cold_retry(const Bal
     ir = (inside && o >= 0 && o < a.B) ? o : a.B - 1;
   }
   const coop::CoopPtrs cold{a.s.q, a.s.pos, a.s.quat, a.s.linvel, a.s.angvel, a.s.dpos, a.s.dquat, a.s.dlinvel, a.s.dangvel, a.s.stance,
-                            a.s.normals, a.s.wrench, a.s.live, a.s.support_only, a.s.iterations, nullptr, nullptr, nullptr};
+                            a.s.normals, a.s.wrench, a.s.live, a.s.support_only, a.s.iterations, nullptr, nullptr, nullptr, a.s.record_doubles};
   (void)coop::coop_robot<kPerLeg, 64, false, kMinWaves == 3>(*a.Pp, cold, ir, rejected, tab, rows + row * coop::kCoopLdsDoubles, nrm, a.tau, a.grf, a.status);
   if (rejected && (threadIdx.x & 15) == 0 && a.s.working_set) a.s.working_set[ir] = 0u;
   __builtin_amdgcn_endpgm();
@@ -552,7 +553,8 @@ __global__ __launch_bounds__(64 * kCoopWaves, kMinWaves) void balance_coop_kerne
   }
   const coop::CoopPtrs cp{s.q, s.pos, s.quat, s.linvel, s.angvel, s.dpos, s.dquat, s.dlinvel, s.dangvel, s.stance,
                           s.normals, s.wrench, s.live, s.support_only, kPlaced ? s.iterations : nullptr,
-                          kWarm ? s.prev_working_set : nullptr, kWarm ? s.working_set : nullptr, kWarm ? s.warm_retries : nullptr};
+                          kWarm ? s.prev_working_set : nullptr, kWarm ? s.working_set : nullptr, kWarm ? s.warm_retries : nullptr,
+                          s.record_doubles};
 #ifdef QLAMD_STAMPS
 #pragma unroll 1
   for (int rep = 0; rep < 2; rep++) // second pass runs with a warm instruction cache
@@ -720,6 +722,7 @@ int qlamd_context_create(const qlamd_balance_params *params, const qlamd_robot_m
   ctx->tick_place_count = 0;
   ctx->on_failure = QLAMD_ON_FAILURE_ZERO;
   ctx->dynamics_form = QLAMD_DYNAMICS_AUTO;
+  ctx->state_record_doubles = 0;
   ctx->depth = 0;
   ctx->last_stream = nullptr;
   ctx->done_event = nullptr;
@@ -797,6 +800,10 @@ int qlamd_set_option(qlamd_context *ctx, int option, int value) {
     case QLAMD_OPT_PLACEMENT_WAIT:
       if (value < 0) return QLAMD_ERR_INVALID_ARGUMENT;
       ctx->placement_wait = (unsigned)value;
+      return QLAMD_OK;
+    case QLAMD_OPT_STATE_LAYOUT:
+      if (value != QLAMD_STATE_FIELDS && value != QLAMD_STATE_RECORDS) return QLAMD_ERR_INVALID_ARGUMENT;
+      ctx->state_record_doubles = value == QLAMD_STATE_RECORDS ? QLAMD_STATE_RECORD_DOUBLES : 0;
       return QLAMD_OK;
     case QLAMD_OPT_WARM_FALLBACK:
       if (value < 0 || value > 2) return QLAMD_ERR_INVALID_ARGUMENT;
@@ -990,6 +997,10 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
                   in->base_angular_velocity, in->desired_position, in->desired_orientation,
                   in->desired_linear_velocity, in->desired_angular_velocity, in->support_leg,
                   in->surface_normal, wrench, live, support_only, order, iterations, nullptr, nullptr, 0};
+    // records instead of per-field arrays: the lane-cooperative kernels only (and never with an external wrench, whose entry
+    // points the unused pose fields at joint_position)
+    if (ctx->state_record_doubles && (pick_rpw(ctx, batch) != 4 || wrench)) return QLAMD_ERR_INVALID_ARGUMENT;
+    s.record_doubles = ctx->state_record_doubles;
     s.prev_working_set = prev_ws;
     s.working_set = ws;
     s.warm_retries = (uint32_t *)ctx->place_sync + kSyncWarmRetries;

@@ -43,6 +43,7 @@ struct qlamd_context {
   size_t pinned_bytes;
   // options (qlamd_set_option): never read from the environment
   int on_failure, dynamics_form;
+  int state_record_doubles;  // QLAMD_OPT_STATE_LAYOUT: 0 = one array per field, else the record length in doubles
   unsigned placement_wait;   // QLAMD_OPT_PLACEMENT_WAIT: polls the shadow wavefronts of a placed launch wait for each other
   // one call at a time (include/qlamd.h, "Threads and streams"): owner thread and nesting depth of the call in
   // progress, and the stream of the previous call

@@ -82,6 +82,8 @@ def check_round6(d, steps):
     ft, wb = d["also"]["full_tick_b4096"], d["also"]["wholebody_trot_b4096"]
     assert ft["unit"] == "ticks/s" and ft["message_bytes"] > 3000 and 0.007 < ft["switched_per_tick"] < 0.016
     assert wb["unit"] == "whole-body control steps/s" and wb["warm_rejected"] == 0
+    assert d["records"]["all_status_ok"] is True and d["records"]["ms_per_step"] < 1.05 * d["ms_per_step"] and "qlamd_state_record" in d["records"]["note"]
+    assert d["also"]["trot_b65536"]["records"]["ms_per_step"] > 0
     sp = d["scale_point"]
     assert sp["robots_per_gpu"] == 8192 and sp["gait"] == "trot" and sp["n_gpus"] == d["n_gpus"] and sp["method"] == "warm"
     assert sp["value"] > 0 and sp["without_gather"] > 0 and "efficiency" in sp["definition"]

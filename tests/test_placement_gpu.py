@@ -372,3 +372,51 @@ def test_place_next_call_on_the_other_qp_entries(gpu):
     _ = whole()
     torch.cuda.synchronize()
     assert (it4.cpu().numpy() == -7).all()
+
+
+def test_records_instead_of_per_field_arrays(gpu):
+    """QLAMD_OPT_STATE_LAYOUT = QLAMD_STATE_RECORDS: the nine double fields of a robot in one 48-double record (every field pointer
+    of qlamd_state_batch into the same array of records): the same arithmetic on the same numbers -- efforts, forces, statuses,
+    iteration counts and working sets bit for bit those of the per-field arrays, plain, placed and warm-started, in the latency
+    and the throughput form; refused for the one-lane kernels and the force-distribution entries."""
+    capi, ctx, torch = gpu
+    stream = torch.cuda.current_stream().cuda_stream
+    for B, gait in ((4099, "static"), (4096, "trot"), (24001, "trot")):
+        s = synth.make_states(B, gait, errors="survey" if gait == "static" else None)
+        df, dr = capi.to_device(s), capi.to_device_records(s)
+        rng = np.random.default_rng(B)
+        order = torch.from_numpy(rng.permutation(B).astype(np.int32)).to("cuda:0")
+        out = {}
+        for layout, d in ((capi.STATE_FIELDS, df), (capi.STATE_RECORDS, dr)):
+            ctx.set_option(capi.OPT_STATE_LAYOUT, layout)
+            try:
+                res = []
+                tau, grf = torch.zeros(B, 12, dtype=torch.float64, device="cuda:0"), torch.zeros(B, 12, dtype=torch.float64, device="cuda:0")
+                st = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+                ctx.balance_solve_device(d, tau, grf, st, stream=stream)
+                torch.cuda.synchronize()
+                res += [tau.clone(), grf.clone(), st.clone()]
+                it, ws = torch.zeros(B, dtype=torch.int32, device="cuda:0"), torch.zeros(B, dtype=torch.int32, device="cuda:0")
+                for _ in range(2):   # cold through the warm kernel, then from its own sets, in a random placement
+                    ctx.balance_solve_placed_device(d, tau, grf, st, order=order, iterations=it, prev_working_set=ws, working_set=ws, stream=stream)
+                torch.cuda.synchronize()
+                res += [tau.clone(), grf.clone(), st.clone(), it.clone(), ws.clone()]
+                out[layout] = res
+            finally:
+                ctx.set_option(capi.OPT_STATE_LAYOUT, capi.STATE_FIELDS)
+        for a, b in zip(out[capi.STATE_FIELDS], out[capi.STATE_RECORDS]):
+            assert torch.equal(a, b), (B, gait)
+        assert (out[capi.STATE_RECORDS][2] == 0).all()
+    ctx.set_option(capi.OPT_STATE_LAYOUT, capi.STATE_RECORDS)
+    try:
+        ctx.set_robots_per_wave(64)
+        with pytest.raises(capi.QlamdError):
+            ctx.balance_solve_device(dr, tau, grf, st, stream=stream)
+        ctx.set_robots_per_wave(0)
+        w = torch.zeros(B, 6, dtype=torch.float64, device="cuda:0")
+        rc = capi.lib().qlamd_force_distribution_batch(ctx._h, dr["q"].data_ptr(), dr["base_quat"].data_ptr(), dr["stance"].data_ptr(), None,
+                                                       w.data_ptr(), B, tau.data_ptr(), grf.data_ptr(), st.data_ptr(), capi.MEM_DEVICE, None)
+        assert rc == capi.ERR_INVALID_ARGUMENT
+    finally:
+        ctx.set_robots_per_wave(0)
+        ctx.set_option(capi.OPT_STATE_LAYOUT, capi.STATE_FIELDS)
