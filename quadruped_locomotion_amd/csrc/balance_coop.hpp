@@ -202,7 +202,7 @@ __device__ __forceinline__ bool coop_robot(const DeviceParams &P, const CoopPtrs
   }
   __syncthreads();
 
-  QL_STAMP(1);
+  QL_STAMP(1); QL_QP_BLOCK_STAMP(4);
   // ---------------------------------------------------------------- wrench (replicated)
   double Rm[9], gB[3], b[6];
   double wr_d[3] = {0.0, 0.0, 0.0}, wr_dw = 1.0, wr_k = 2.0; // orientation error: vector part, scalar part, 2 alpha / sin(alpha)
@@ -375,7 +375,7 @@ __device__ __forceinline__ bool coop_robot(const DeviceParams &P, const CoopPtrs
     for (int k = 0; k < 6; k++) lds_tab[64 + 6 * (((int)threadIdx.x & 63) >> 4) + k] = b[k];
   }
 
-  QL_STAMP(3);
+  QL_STAMP(3); QL_QP_BLOCK_STAMP(5);
   // ---------------------------------------------------------------- friction pyramid of my leg
   double myn = 0.0, myt1 = 0.0, myt2 = 0.0; // component c of n, t1, t2 (base frame)
   double nb[3], t1[3], t2[3];               // the whole vectors of my leg

@@ -51,11 +51,22 @@ static __device__ unsigned long long g_stamps[64];
     if (blockIdx.x == 0 && threadIdx.x == 0)                                                \
       for (int k_ = 0; k_ < 8; k_++) ::qlamd::coop::g_stamps[16 + k_] = ql_acc_[k_];        \
   } while (0)
-// one stamp per WORKGROUP (slot = which event, up to four per unit; workgroups beyond kBlockStamps are not recorded):
+#else
+#define QLAMD_STAMPS_ACCESSOR(name)
+#define QL_STAMP(k)
+#define QL_SEG_DECL
+#define QL_SEG_START
+#define QL_SEG(k)
+#define QL_SEG_STORE
+#endif
+// -DQLAMD_BLOCK_STAMPS alone: the workgroup stamps without the segment stamps above, whose waits and scheduling barriers
+// make the solver 2.7 x slower -- a launch's phases at (nearly) the shipped kernel's own pace
+#if defined(QLAMD_STAMPS) || defined(QLAMD_BLOCK_STAMPS)
+// one stamp per WORKGROUP (slot = which event, up to eight per unit; workgroups beyond kBlockStamps are not recorded):
 // s_memrealtime, the 100 MHz counter that is one clock for the whole device (s_memtime counts per XCD), read back through
 // qlamd_debug_block_stamps_*.  Which workgroup a launch waits for, and what it was doing.
 constexpr int kBlockStamps = 2048;
-static __device__ unsigned long long g_block_stamps[4][kBlockStamps];
+static __device__ unsigned long long g_block_stamps[8][kBlockStamps];
 #define QLAMD_BLOCK_STAMPS_ACCESSOR(name)                                                                                \
   extern "C" int name(unsigned long long *out, int slot, int n) {                                                        \
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(::qlamd::coop::g_block_stamps), sizeof(unsigned long long) * n,           \
@@ -70,14 +81,8 @@ static __device__ unsigned long long g_block_stamps[4][kBlockStamps];
     if (threadIdx.x == 0 && blockIdx.x < ::qlamd::coop::kBlockStamps) ::qlamd::coop::g_block_stamps[slot][blockIdx.x] = t_; \
   } while (0)
 #else
-#define QLAMD_STAMPS_ACCESSOR(name)
 #define QLAMD_BLOCK_STAMPS_ACCESSOR(name)
 #define QL_BLOCK_STAMP(slot)
-#define QL_STAMP(k)
-#define QL_SEG_DECL
-#define QL_SEG_START
-#define QL_SEG(k)
-#define QL_SEG_STORE
 #endif
 
 template <int CTRL>

@@ -24,6 +24,11 @@
 #error "force_qp_coop.hpp needs IEEE inf / NaN semantics: do not build this translation unit with -ffast-math / -ffinite-math-only"
 #endif
 
+// the warm block's two workgroup stamps (tools/stamp_probe_warm_loop.py) belong to the balance kernel's unit; a unit with its
+// own use of slots 1 and 2 (the tick) defines QL_QP_BLOCK_STAMP away before including this file
+#ifndef QL_QP_BLOCK_STAMP
+#define QL_QP_BLOCK_STAMP(slot) QL_BLOCK_STAMP(slot)
+#endif
 namespace qlamd {
 namespace coop {
 
@@ -201,7 +206,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     x = (xa[0] + xa[1]) + xa[2];
   }
 
-  QL_STAMP(6);
+  QL_STAMP(6); QL_QP_BLOCK_STAMP(6);
   // ---------------------------------------------------------------- active-set loop
   // One pass of the loop = one outer iteration of the dual method for every live row: zero or more drops of a blocking
   // constraint (each a rank-one update of H and N*), then the add of the candidate (another one), with the selection of the
@@ -450,7 +455,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
   };
 
   int warm_updates = 0; // rank-one updates of the warm start (kWarm)
-  QL_BLOCK_STAMP(1);
+  QL_QP_BLOCK_STAMP(1);
   if constexpr (kWarm) {
     // ---- warm start: install the previous working set (rows of legs that still support), then drop negative multipliers
     constexpr mask_t kLegRows = (one_v<mask_t> << kKinds) - 1;
@@ -709,7 +714,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     if (lr == 0) reinterpret_cast<int *>(lds_row + kWarmSlot)[0] = warm_updates;
     warm_updates = 0;
   }
-  QL_BLOCK_STAMP(2);
+  QL_QP_BLOCK_STAMP(2);
   {
     // lanes that are not here (rows that have left with kStatusNotPd) count as finished: ballots never see them
     done_m = ~__builtin_amdgcn_ballot_w64(true);
@@ -905,7 +910,7 @@ __device__ __forceinline__ int force_qp_coop(const ForceQp &Q, double *lds_row, 
     if (ws_out) *ws_out = status == kStatusOk ? ((unsigned long long)hi << 32 | lo) : 0ull;
   }
 
-  QL_STAMP(7);
+  QL_STAMP(7); QL_QP_BLOCK_STAMP(7);
   // ---------------------------------------------------------------- refinement on the final working set
   // (a warm start that installed rows and dropped them all again ends with an empty set and operators that have drifted all
   // the same: it is refined like any other)

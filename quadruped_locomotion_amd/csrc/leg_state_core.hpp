@@ -31,53 +31,65 @@ struct LegStateRobot {
   bool capture[4], hold[4];            // stored <- measured joints / command <- stored joints
 };
 
+// Written as integer arithmetic on 0 / 1 predicates and small lookup words, not as the reference's nest of ifs: one lane runs a
+// robot's machine, and on the device a nest of ifs is a chain of ~100 short branches, bools are 64-bit lane masks in scalar
+// registers (about 1000 issue slots at the tail of every parser block of the whole tick, 2.3 us; profiles/r6/tick_block_phases.txt).
+// The comments name the branch of the reference each expression stands for.
 QL_HD void leg_state_machine(LegStateRobot &r, bool index_quirk) {
+  // per-leg predicates as bit masks (bit l = leg l): the contact loop picks them by its limb index
+  unsigned supm = 0u, footm = 0u, gt05 = 0u, gt02 = 0u, lt01 = 0u, touch = 0u, lsw = 0u;
+  QL_UNROLL for (int l = 0; l < 4; l++) {
+    supm |= (r.support_leg[l] ? 1u : 0u) << l;
+    footm |= (r.is_footstep[l] ? 1u : 0u) << l;
+    gt05 |= (r.phase[l] > 0.5 ? 1u : 0u) << l;
+    gt02 |= (r.phase[l] > 0.2 ? 1u : 0u) << l;
+    lt01 |= (r.phase[l] < 0.1 ? 1u : 0u) << l;
+    touch |= (r.contact[l] ? 1u : 0u) << l;
+    lsw |= ((unsigned)r.limb_state[l] & 0xFFu) << (8 * l); // limb states travel as int8 (LegStatePtrs): a byte each
+  }
+  const unsigned stay = index_quirk ? 0u : 1u;
   // the contact loop advances its limb index only at the end of a full pass (:1134); a `continue`
   // leaves it where it is, so the next contact lands on the same limb
-  int i = 0;
+  unsigned i = 0u;
   QL_UNROLL for (int c = 0; c < 4; c++) {
-    bool sup = false, foot = false;
-    double ph = 0.0;
-    int cur = 0;
-    QL_UNROLL for (int l = 0; l < 4; l++)
-      if (l == i) { sup = r.support_leg[l]; foot = r.is_footstep[l]; ph = r.phase[l]; cur = r.limb_state[l]; }
-    const bool touching = r.contact[c];
-    int next = cur;
-    bool advance = true;
-    if (!sup) { // desired SwingNormal, swing phase = ph
-      next = kLsSwingNormal;
-      if (!foot) advance = !index_quirk;
-      else if (ph > 0.5) { if (touching) next = kLsSwingEarlyTouchDown; }
-      else if (ph > 0.2) { if (touching) next = kLsSwingBumpedIntoObstacle; }
-    } else {    // desired StanceNormal, stance phase = ph
-      if (!foot) { next = kLsStanceNormal; advance = !index_quirk; }
-      else {
-        if (touching) next = kLsStanceNormal;
-        else if (ph < 0.1) next = kLsSwingLatelyTouchDown;
-        if (ph > 0.5 && !touching) next = kLsStanceLostContact;
-      }
-    }
-    QL_UNROLL for (int l = 0; l < 4; l++)
-      if (l == i) r.limb_state[l] = next;
-    if (advance) i++;
+    const unsigned sup = (supm >> i) & 1u, foot = (footm >> i) & 1u, g5 = (gt05 >> i) & 1u, g2 = (gt02 >> i) & 1u, l1 = (lt01 >> i) & 1u;
+    const unsigned t = (touch >> c) & 1u, cur = (lsw >> (8u * i)) & 0xFFu;
+    // desired SwingNormal (4), swing phase = ph: early touch-down (6) past half the swing, bumped into an obstacle (7) past a fifth
+    const unsigned ft = foot & t;
+    const unsigned nsw = (unsigned)kLsSwingNormal + 2u * (ft & g5) + 3u * (ft & (g5 ^ 1u) & g2);
+    // desired StanceNormal (1), stance phase = ph: in contact, or late touch-down (8) in the first tenth, lost contact (3) past half
+    const unsigned away = l1 ? (unsigned)kLsSwingLatelyTouchDown : cur;
+    const unsigned nfoot = t ? (unsigned)kLsStanceNormal : (g5 ? (unsigned)kLsStanceLostContact : away);
+    const unsigned nst = foot ? nfoot : (unsigned)kLsStanceNormal;
+    const unsigned next = sup ? nst : nsw;
+    lsw = (lsw & ~(0xFFu << (8u * i))) | (next << (8u * i));
+    i += foot | stay; // a leg without a footstep `continue`s
   }
+  // what update() (:234-380) does in each state, as lookup words indexed by the state (bit s / nibble s); states 2 and 5
+  // (StanceSlipping, SwingLateLiftOff) and anything out of range have no case there
+  constexpr unsigned kSupport = 1u << kLsInit | 1u << kLsStanceNormal | 1u << kLsSwingEarlyTouchDown;
+  constexpr unsigned kWritten = kSupport | 1u << kLsSwingNormal | 1u << kLsSwingBumpedIntoObstacle | 1u << kLsSwingLatelyTouchDown |
+                                1u << kLsStanceLostContact;
+  constexpr unsigned kLateOrLost = 1u << kLsSwingLatelyTouchDown | 1u << kLsStanceLostContact;
+  constexpr unsigned kClears = 1u << kLsSwingNormal | 1u << kLsStanceNormal; // store_flag <- false
+  // leg_state code + 1, three bits a state: StanceNormal 2, EarlyTouchDown 1, LatelyTouchDown 3, LostContact -1, else 0
+  constexpr unsigned long long kCode = 1ull << (3 * kLsInit) | 3ull << (3 * kLsStanceNormal) | 1ull << (3 * kLsStanceSlipping) |
+                                       0ull << (3 * kLsStanceLostContact) | 1ull << (3 * kLsSwingNormal) | 1ull << (3 * kLsSwingLateLiftOff) |
+                                       2ull << (3 * kLsSwingEarlyTouchDown) | 1ull << (3 * kLsSwingBumpedIntoObstacle) |
+                                       4ull << (3 * kLsSwingLatelyTouchDown);
   QL_UNROLL for (int l = 0; l < 4; l++) {
-    const int s = r.limb_state[l];
-    r.code[l] = 0; r.support_written[l] = true; r.support[l] = false;
-    r.nudge_bumped[l] = r.nudge_late[l] = r.capture[l] = r.hold[l] = false;
-    if (s == kLsSwingNormal) { r.store_flag[l] = false; }
-    else if (s == kLsStanceNormal) { r.support[l] = true; r.code[l] = 2; r.store_flag[l] = false; }
-    else if (s == kLsSwingEarlyTouchDown) { r.support[l] = true; r.code[l] = 1; }
-    else if (s == kLsSwingBumpedIntoObstacle) { r.nudge_bumped[l] = true; }
-    else if (s == kLsSwingLatelyTouchDown || s == kLsStanceLostContact) {
-      r.nudge_late[l] = s == kLsSwingLatelyTouchDown;
-      r.capture[l] = !r.store_flag[l];
-      r.hold[l] = r.store_flag[l];
-      r.store_flag[l] = true;
-      r.code[l] = s == kLsSwingLatelyTouchDown ? 3 : -1;
-    }
-    else if (s == kLsInit) { r.support[l] = true; }
-    else { r.support_written[l] = false; } // StanceSlipping / SwingLateLiftOff: no case in update()
+    const unsigned sb = (lsw >> (8 * l)) & 0xFFu;
+    r.limb_state[l] = (int)(signed char)sb;
+    const unsigned known = sb < 9u ? 1u : 0u, s = known ? sb : 2u; // out of range: like a state without a case
+    const unsigned late_or_lost = (kLateOrLost >> s) & 1u, stored = r.store_flag[l] ? 1u : 0u;
+    r.support[l] = (kSupport >> s) & 1u;
+    r.support_written[l] = (kWritten >> s) & 1u;
+    r.code[l] = (int)((kCode >> (3u * s)) & 7ull) - 1;
+    r.nudge_bumped[l] = s == (unsigned)kLsSwingBumpedIntoObstacle;
+    r.nudge_late[l] = s == (unsigned)kLsSwingLatelyTouchDown;
+    r.capture[l] = late_or_lost & (stored ^ 1u);
+    r.hold[l] = late_or_lost & stored;
+    r.store_flag[l] = (((kClears >> s) & 1u) ^ 1u) & (late_or_lost | stored);
   }
 }
 

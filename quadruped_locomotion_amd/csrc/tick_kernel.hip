@@ -1,6 +1,7 @@
 // HIP kernels (gfx950) of the steps either side of the balance solve in a control tick (rows a18, f1, f2, leg IK of
 // f4): swing-leg torque and swing branch, leg state machine, message unpacking, analytic leg IK, and the whole tick
 // composed of them; with their part of the C-ABI of include/qlamd.h.
+#define QL_QP_BLOCK_STAMP(slot) // slots 1 and 2 of this unit: the end of an unpack block, the start of a solve block
 #include "balance_coop.hpp"
 #include "swing_core.hpp"
 #include "leg_state_core.hpp"
@@ -426,49 +427,80 @@ __device__ __forceinline__ int wire_lds_skeleton(const LdsBytes &src, int64_t le
   return missing ? kWireMissingField : kWireOk;
 }
 
-// Pass 2: payload at the anchors, by the 16 lanes of the message's row.  The 77 doubles of a record are numbered in the
-// order of RobotStateFields (des_pos 0-2, des_quat 3-6, des_linvel 7-9, des_angvel 10-12, joint_command 13-24,
-// foot_position / velocity / acceleration 25-60, surface_normal 61-72, phase 73-76); lane lr takes entries lr, lr + 16, ...
-// All of a lane's reads are issued before its first store (a store into the record would otherwise fence the reads:
-// the record and the staged bytes are both LDS).  Lanes 0-3 also decode leg lr's mode name and support flag.
-__device__ __forceinline__ void wire_lds_extract_row(const LdsBytes &src, RobotStateFields &f, const uint32_t *an, int lr) {
-  double val[5];
-  bool put[5];
-#pragma unroll
-  for (int t = 0; t < 5; t++) {
-    const int e = lr + 16 * t;
-    uint32_t slot = kAnOdomPose, off = 0u;
-    bool ok = e < 77;
-    if (e < 3) { off = 8u * e; }                                                   // des_pos
-    else if (e < 7) { const int k = (e - 3 + 3) & 3; off = 24u + 8u * k; }          // des_quat (w,x,y,z) <- wire (x,y,z,w)
-    else if (e < 13) { off = 56u + 288u + 8u * (e - 7); }                          // des_linvel, des_angvel
-    else if (e < 25) { const int l = (e - 13) / 3, j = (e - 13) - 3 * l;           // joint_command
-      slot = kAnJointPos + l; off = 8u * j; ok = (uint32_t)j < an[kAnJointCnt + l]; }
-    else if (e < 61) { const int t9 = e - 25, arr = t9 / 12, r = t9 - 12 * arr, l = r / 3, j = r - 3 * l; // foot_* [arr][leg][j]
-      slot = kAnTarget + 3 * l + arr; off = 8u * j; ok = an[slot] != 0u; }
-    else if (e < 73) { const int l = (e - 61) / 3, j = (e - 61) - 3 * l; slot = kAnModeNormal + l; off = 8u * j; }
-    else { slot = kAnModeFlag + (e - 73 < 4 ? e - 73 : 0); off = 9u; }               // phase
-    put[t] = ok;
-    val[t] = src.f64(an[ok ? slot : (uint32_t)kAnOdomPose] + (ok ? off : 0u));
-  }
+// Pass 2: payload at the anchors, by the 16 lanes of the message's row, straight to the output arrays (robot i).  One step per
+// output array, lane lr = the array's entry lr of the robot (the four short ones of the base -- des_pos 0-2, des_quat 3-6,
+// des_linvel 7-9, des_angvel 10-12 -- share a step): which array a step reads for and stores to is known at compile time, a
+// lane's address in it is a constant plus 8 lr -- no per-entry dispatch on either side, and no trip through a record in LDS
+// (round 6; before: five entries lr + 16 t of a 77-entry record per lane, written to LDS and written out from there by ten
+// loops behind a barrier: extraction 1.4 + write-out 1.6 us of a block's 10).  In two halves, so that the reads can be issued
+// at the TEMPLATE's anchors together with the reads of the template check, before the check has decided (a row whose message
+// then turns out to have another layout reads again, at the anchors its walk found).
+struct WireRowAnchors { // the anchors lane lr of a row needs: leg l3 = lr / 3 of the 12-wide arrays, leg l4 = lr & 3 of the per-leg ones
+  uint32_t odom, joint, n_joint, t0, t1, t2, nrm, flag, name, n_name;
+};
+struct WireRowPayload {
+  double base, joint, t0, t1, t2, nrm, phase;
+  uint32_t w0, w1, w2;
+  uint8_t sup_byte;
+};
+// get(slot): anchor `slot` of the message (0 for a message without them)
+template <class Get>
+__device__ __forceinline__ WireRowAnchors wire_row_anchors(const Get &get, int lr) {
+  const int l3 = lr < 12 ? lr / 3 : 3, l4 = lr & 3;
+  return WireRowAnchors{get(kAnOdomPose), get(kAnJointPos + l3), get(kAnJointCnt + l3), get(kAnTarget + 3 * l3), get(kAnTarget + 3 * l3 + 1),
+                        get(kAnTarget + 3 * l3 + 2), get(kAnModeNormal + l3), get(kAnModeFlag + l4), get(kAnModeName + l4), get(kAnModeLen + l4)};
+}
+__device__ __forceinline__ WireRowPayload wire_row_read(const LdsBytes &src, const WireRowAnchors &a, int lr) {
+  const uint32_t j8 = 8u * (uint32_t)(lr - 3 * (lr / 3));
+  // base step: wire order of the pose is position, orientation (x, y, z, w) -> (w, x, y, z); the twist follows 288 bytes of covariance
+  const uint32_t off0 = lr < 3 ? 8u * lr : lr < 7 ? 24u + 8u * (lr & 3) : lr < 13 ? 56u + 288u + 8u * (lr - 7) : 0u;
+  WireRowPayload p;
+  p.base = src.f64(a.odom + off0);
+  p.joint = src.f64(a.joint + j8);
+  p.t0 = src.f64(a.t0 + j8); p.t1 = src.f64(a.t1 + j8); p.t2 = src.f64(a.t2 + j8);
+  p.nrm = src.f64(a.nrm + j8);
+  p.phase = src.f64(a.flag + 9u);
+  p.w0 = src.u32(a.name); p.w1 = src.u32(a.name + 4); p.w2 = src.u32(a.name + 8);
+  p.sup_byte = src.u8(a.flag);
+  return p;
+}
+// have: the message was walked (or matched the template) to its end -- otherwise every entry is the cleared record's 0.
+// write: a well-formed message, or the parse-only entry, which reports every record.  What the state machine at the block's
+// tail reads of the command (support flags, modes, phases, foot positions) is also left in the record f in LDS.
+__device__ __forceinline__ void wire_row_store(const WireRowPayload &p, const WireRowAnchors &a, RobotStateFields &f, int lr, bool have,
+                                               const RobotStateOutPtrs &out, int64_t i, bool write) {
+  const uint32_t j3 = (uint32_t)(lr - 3 * (lr / 3));
+  // "joint" 5, "leg_mode" 8, "cartesian" 9, "footstep" 8: compare 12 bytes read as three words against the literals
   int mode = kModeOther;
-  uint8_t sup = 0;
+  if (a.n_name == 5 && p.w0 == 0x6E696F6Au && (p.w1 & 0xFFu) == 0x74u) mode = kModeJoint;                      // "join" "t"
+  else if (a.n_name == 8 && p.w0 == 0x5F67656Cu && p.w1 == 0x65646F6Du) mode = kModeLegMode;                  // "leg_" "mode"
+  else if (a.n_name == 9 && p.w0 == 0x74726163u && p.w1 == 0x61697365u && (p.w2 & 0xFFu) == 0x6Eu) mode = kModeCartesian; // "cart" "esia" "n"
+  else if (a.n_name == 8 && p.w0 == 0x746F6F66u && p.w1 == 0x70657473u) mode = kModeFootstep;                 // "foot" "step"
+  mode = have ? mode : (int)kModeOther;
+  const uint8_t sup = have && p.sup_byte != 0;
+  const double e_base = have ? p.base : 0.0, e_joint = have && j3 < a.n_joint ? p.joint : 0.0, e_t0 = have && a.t0 != 0u ? p.t0 : 0.0,
+               e_t1 = have && a.t1 != 0u ? p.t1 : 0.0, e_t2 = have && a.t2 != 0u ? p.t2 : 0.0, e_nrm = have ? p.nrm : 0.0,
+               e_phase = have ? p.phase : 0.0;
+  const bool w12 = lr < 12;
+  if (w12) f.foot_position[lr] = e_t0;
+  if (lr < 4) { f.phase[lr] = e_phase; f.leg_mode[lr] = (uint8_t)mode; f.support_leg[lr] = sup; }
+  if (!write) return;
   {
-    const int l = lr & 3;
-    const uint32_t nm = an[kAnModeName + l], nl = an[kAnModeLen + l];
-    // "joint" 5, "leg_mode" 8, "cartesian" 9, "footstep" 8: compare 12 bytes read as three words against the literals
-    const uint32_t w0 = src.u32(nm), w1 = src.u32(nm + 4), w2 = src.u32(nm + 8);
-    if (nl == 5 && w0 == 0x6E696F6Au && (w1 & 0xFFu) == 0x74u) mode = kModeJoint;                    // "join" "t"
-    else if (nl == 8 && w0 == 0x5F67656Cu && w1 == 0x65646F6Du) mode = kModeLegMode;                // "leg_" "mode"
-    else if (nl == 9 && w0 == 0x74726163u && w1 == 0x61697365u && (w2 & 0xFFu) == 0x6Eu) mode = kModeCartesian; // "cart" "esia" "n"
-    else if (nl == 8 && w0 == 0x746F6F66u && w1 == 0x70657473u) mode = kModeFootstep;               // "foot" "step"
-    sup = src.u8(an[kAnModeFlag + l]) != 0;
+    double *b = lr < 3 ? out.des_pos : lr < 7 ? out.des_quat : lr < 10 ? out.des_linvel : out.des_angvel;
+    const int64_t k = lr < 3 ? 3 * i + lr : lr < 7 ? 4 * i + (lr - 3) : 3 * i + (lr < 10 ? lr - 7 : lr - 10);
+    if (lr < 13 && b) b[k] = e_base;
   }
-  double *rec = reinterpret_cast<double *>(&f);
-#pragma unroll
-  for (int t = 0; t < 5; t++)
-    if (put[t]) rec[lr + 16 * t] = val[t];
-  if (lr < 4) { f.leg_mode[lr] = (uint8_t)mode; f.support_leg[lr] = sup; }
+  const int64_t k12 = 12 * i + lr;
+  if (w12 && out.joint_command) out.joint_command[k12] = e_joint;
+  if (w12 && out.foot_position) out.foot_position[k12] = e_t0;
+  if (w12 && out.foot_velocity) out.foot_velocity[k12] = e_t1;
+  if (w12 && out.foot_acceleration) out.foot_acceleration[k12] = e_t2;
+  if (w12 && out.surface_normal) out.surface_normal[k12] = e_nrm;
+  if (lr < 4) {
+    if (out.phase) out.phase[4 * i + lr] = e_phase;
+    if (out.support_leg) out.support_leg[4 * i + lr] = sup;
+    if (out.leg_mode) out.leg_mode[4 * i + lr] = (uint8_t)mode;
+  }
 }
 
 constexpr int kWireMsgsPerBlock = 4;          // messages parsed per 64-lane block (one 16-lane row each)
@@ -488,6 +520,13 @@ constexpr int kTplValid = 0, kTplEnd = 1, kTplMissing = 2, kTplFields = 3, kTplA
 // in LDS and the whole block writes the records out.  Block 0 leaves the template for the next launch in tpl_out
 // (the layout of its first message if that one had to be walked, else the template it used).  Results never depend
 // on the template, only the time does: streams from one publisher keep one layout.
+// The kernel's parameters as they lie in its argument segment: the extraction and the state machine at a block's tail fetch
+// their pointers from there again (coop::kernel_arguments_again) -- 29 pointers kept in scalar registers from the block's first
+// instruction were spilled to vector lanes and read back one v_readlane at a time (141 of the tail's 850 instructions).
+struct UnpackArgs {
+  const uint8_t *messages; const int64_t *offsets; int64_t B; RobotStateOutPtrs o; int32_t *status; const uint32_t *tpl_in;
+  uint32_t *tpl_out; uint8_t *valid; LegStatePtrs ls; int leg_state_mode;
+};
 __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *__restrict__ messages,
                                                                 const int64_t *__restrict__ offsets, int64_t B,
                                                                 const RobotStateOutPtrs o, int32_t *__restrict__ status,
@@ -503,22 +542,31 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   __shared__ int okm[kWireMsgsPerBlock];
   __shared__ RobotStateFields rec[kWireMsgsPerBlock];
   __shared__ uint32_t anchors[kWireMsgsPerBlock][kAnCount];
-  __shared__ uint32_t tpl[kTplWords];
   const int tid = threadIdx.x;
   const int64_t i0 = (int64_t)blockIdx.x * kWireMsgsPerBlock;
   const int n = (int)((B - i0) < kWireMsgsPerBlock ? (B - i0) : kWireMsgsPerBlock);
   QL_STAMP(20);
   QL_BLOCK_STAMP(0);
   const int64_t a = offsets[i0], b = offsets[i0 + n];
+  const int row = tid >> 4, lr = tid & 15;
+  const bool mine = row < n;
+  // (my row's own pair of offsets with the block's: one round trip for all four)
+  const int64_t ma = offsets[i0 + (mine ? row : 0)], mb = offsets[i0 + (mine ? row : 0) + 1];
   // the whole tick: what the state machine of my robot reads (lane m < n: robot i0 + m) is fetched NOW, with the block's first
   // loads -- none of it depends on the message; the command fields among it are the command still in force, which a well-formed
   // message replaces below, from the record in LDS
   LegStateIn lin;
   if (leg_state_mode && tid < n) leg_state_load(ls, i0 + tid, lin);
-  // the template's loads go out first, its LDS stores follow the staging loop
-  uint32_t tplv[(kTplWords + 63) / 64];
+  // The template goes from memory straight into the registers of the lanes that use it, with the block's first loads: lane lr of
+  // every row checks length fields lr, lr + 16, ... (a (position, value) pair each) and carries anchors lr, lr + 16, lr + 32;
+  // the four header words are the same for everybody.  (Through LDS -- stored behind the staging loop, read back by the check --
+  // the check waited one more LDS round trip: 1.24 -> us, profiles/r6/tick_block_phases.txt.)
+  const uint32_t tpl_valid = tpl_in[kTplValid], tpl_end = tpl_in[kTplEnd], tpl_missing = tpl_in[kTplMissing], tnf = tpl_in[kTplFields];
+  uint2 pair[kTplMaxFields / 16];
 #pragma unroll
-  for (int j = 0; j < (kTplWords + 63) / 64; j++) tplv[j] = tpl_in[min(tid + 64 * j, kTplWords - 1)];
+  for (int t = 0; t < kTplMaxFields / 16; t++) { pair[t].x = tpl_in[kTplPairs + 2 * (lr + 16 * t)]; pair[t].y = tpl_in[kTplPairs + 2 * (lr + 16 * t) + 1]; }
+  // ... and the template's anchors of the slots this lane extracts for (wire_row_anchors)
+  const WireRowAnchors tpl_anchor = wire_row_anchors([&](int slot) { return tpl_in[kTplAnchors + slot]; }, lr);
   const uintptr_t src = (uintptr_t)(messages + a);
   const uintptr_t src_al = src & ~(uintptr_t)15;
   const int64_t lead = (int64_t)(src - src_al), nbytes = lead + (b - a);
@@ -552,50 +600,47 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
     const int64_t tail0 = full << 4;                 // last partial chunk byte by byte: never read past the blob
     if (tid < nbytes - tail0) ((uint8_t *)wire_lds)[tail0 + tid] = ((const uint8_t *)src_al)[tail0 + tid];
   }
-#pragma unroll
-  for (int j = 0; j < (kTplWords + 63) / 64; j++)
-    if (tid + 64 * j < kTplWords) tpl[tid + 64 * j] = tplv[j];
   // clear the records (fields a malformed message never reaches read as zero)
-  for (int w = tid; w < (int)(sizeof(rec) / 4); w += 64) ((uint32_t *)rec)[w] = 0u;
+  if (!staged)
+    for (int w = tid; w < (int)(sizeof(rec) / 4); w += 64) ((uint32_t *)rec)[w] = 0u;
   for (int w = tid; w < kWireMsgsPerBlock * kAnCount; w += 64) (&anchors[0][0])[w] = 0u;
   __syncthreads();
-  QL_STAMP(21);
-  const int row = tid >> 4, lr = tid & 15;
-  const bool mine = row < n;
-  const int64_t ma = offsets[i0 + (mine ? row : 0)], mb = offsets[i0 + (mine ? row : 0) + 1];
+  QL_STAMP(21); QL_BLOCK_STAMP(4);
   const bool sane = mine && !(ma < a || mb > b || mb < ma); // offsets not ascending: nothing to parse
   const LdsBytes msg{wire_lds, (uint32_t)(lead + (ma - a))};
   // ---- template check, 16 lanes per message
-  const uint32_t tnf = tpl[kTplFields];
-  bool same = sane && staged && tpl[kTplValid] == kTplMagic && tnf <= (uint32_t)kTplMaxFields &&
-              (mb - ma) <= 0x7FFFFFF0ll && (uint64_t)(mb - ma) >= (uint64_t)tpl[kTplEnd];
+  bool same = sane && staged && tpl_valid == kTplMagic && tnf <= (uint32_t)kTplMaxFields &&
+              (mb - ma) <= 0x7FFFFFF0ll && (uint64_t)(mb - ma) >= (uint64_t)tpl_end;
+  // the payload is read at the template's anchors together with the length fields of the check (one LDS round trip for both);
+  // a message that fails the check reads again below.  (A template's positions lie inside [0, end] and end <= my length was
+  // just checked; anything else reads at 0.)
+  WireRowAnchors anc = tpl_anchor;
+  {
+    const auto in = [&](uint32_t &v, bool position) { v = same ? (position ? min(v, tpl_end) : v) : 0u; };
+    in(anc.odom, true); in(anc.joint, true); in(anc.n_joint, false); in(anc.t0, true); in(anc.t1, true); in(anc.t2, true);
+    in(anc.nrm, true); in(anc.flag, true); in(anc.name, true); in(anc.n_name, false);
+  }
+  const LdsBytes spec{wire_lds, same ? msg.shift : 0u};
+  WireRowPayload pay;
   {
     // eight length fields per lane, all reads independent (positions inside the message: <= end <= length)
-    uint32_t at[kTplMaxFields / 16], want[kTplMaxFields / 16], got[kTplMaxFields / 16];
+    uint32_t got[kTplMaxFields / 16];
 #pragma unroll
-    for (int t = 0; t < kTplMaxFields / 16; t++) {
-      const uint32_t k = lr + 16u * t;
-      const bool on = same && k < tnf;
-      at[t] = on ? tpl[kTplPairs + 2 * k] : 0u;
-      want[t] = on ? tpl[kTplPairs + 2 * k + 1] : 0u;
-    }
+    for (int t = 0; t < kTplMaxFields / 16; t++) got[t] = spec.u32(same && lr + 16u * t < tnf ? min(pair[t].x, tpl_end) : 0u);
+    pay = wire_row_read(spec, anc, lr);
 #pragma unroll
-    for (int t = 0; t < kTplMaxFields / 16; t++) got[t] = msg.u32(same ? at[t] : 0u);
-#pragma unroll
-    for (int t = 0; t < kTplMaxFields / 16; t++) same = same && (lr + 16u * t >= tnf || got[t] == want[t]);
+    for (int t = 0; t < kTplMaxFields / 16; t++) same = same && (lr + 16u * t >= tnf || got[t] == pair[t].y);
   }
   const bool hit = ((unsigned)(__ballot(same) >> (tid & 48)) & 0xFFFFu) == 0xFFFFu;
-  if (hit)
-    for (int k = lr; k < kAnCount; k += 16) anchors[row][k] = tpl[kTplAnchors + k];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_s_waitcnt(0xC07F);
-  QL_STAMP(22);
+  QL_STAMP(22); QL_BLOCK_STAMP(5);
   uint32_t nf = 0u, end_pos = 0u;
   int st = kWireTruncated;
   const bool logger = blockIdx.x == 0 && row == 0; // this message's layout becomes the next launch's template
   if (lr == 0 && mine) {
     if (!sane) st = kWireTruncated;
-    else if (hit) st = tpl[kTplMissing] ? kWireMissingField : kWireOk;
+    else if (hit) st = tpl_missing ? kWireMissingField : kWireOk;
     else if (staged && logger) st = wire_lds_skeleton<true>(msg, mb - ma, anchors[row], tpl_out + kTplPairs, nf, end_pos);
     else if (staged) st = wire_lds_skeleton<false>(msg, mb - ma, anchors[row], nullptr, nf, end_pos);
     else st = robot_state_unpack(PlainBytes{messages + ma}, mb - ma, rec[row]);
@@ -606,7 +651,17 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_s_waitcnt(0xC07F);
   const int st_row = __shfl(st, 0, 16);
-  if (mine && sane && staged && st_row != kWireTruncated) wire_lds_extract_row(msg, rec[row], anchors[row], lr);
+  // a staged block's rows store their entries straight from the registers of the extraction (a malformed message of the
+  // parse-only entry: the cleared record); the record in LDS is for the state machine below and for a block that was not staged
+  if (mine && staged) {
+    const bool have = sane && st_row != kWireTruncated;
+    if (!hit) { // another layout (or no template yet): the anchors the walk left in LDS
+      const uint32_t *an = anchors[row];
+      anc = wire_row_anchors([&](int slot) { return have ? an[slot] : 0u; }, lr);
+      pay = wire_row_read(LdsBytes{wire_lds, have ? msg.shift : 0u}, anc, lr);
+    }
+    wire_row_store(pay, anc, rec[row], lr, have, coop::kernel_arguments_again<UnpackArgs>()->o, i0 + row, st_row == kWireOk || !valid);
+  }
   QL_STAMP(23);
   // ---- the template for the next launch (block 0, first message).  Its body goes out here; its valid word goes last,
   // behind a fence (a template is never valid before all of it is in memory) -- at the very END of the block's work, where
@@ -615,7 +670,7 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   if (logger) {
     const uint32_t nf0 = __shfl(nf, 0, 16), end0 = __shfl(end_pos, 0, 16);
     if (hit) {
-      tpl_valid_word = tpl[kTplValid]; // still in force: the body is copied below, by the whole block
+      tpl_valid_word = tpl_valid; // still in force: the body is copied below, by the whole block
     } else {
       // the walk has already left its (position, value) pairs in tpl_out; valid only if the message was well-formed
       const bool good = sane && staged && st_row != kWireTruncated && nf0 <= (uint32_t)kTplMaxFields;
@@ -629,13 +684,13 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   }
   if (blockIdx.x == 0 && __builtin_amdgcn_readfirstlane((int)hit) != 0) { // row 0 hit: all 64 lanes copy the template
     for (int k = tid; k < kTplWords; k += 64)
-      if (k != kTplValid) tpl_out[k] = tpl[k];
+      if (k != kTplValid) tpl_out[k] = tpl_in[k];
   }
   __syncthreads();
-  QL_STAMP(24);
+  QL_STAMP(24); QL_BLOCK_STAMP(6);
   // write-out: message m's k doubles of each field are contiguous in the output arrays
   const auto put = [&](double *dst, int width, size_t field_off) {
-    if (!dst) return;
+    if (!dst || staged) return;
     for (int e = tid; e < n * width; e += 64) {
       const int m = e / width, k2 = e - m * width;
       if (okm[m]) dst[(int64_t)width * i0 + e] = ((const double *)((const char *)&rec[m] + field_off))[k2];
@@ -648,12 +703,12 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   put(o.foot_velocity, 12, offsetof(RobotStateFields, foot_velocity));
   put(o.foot_acceleration, 12, offsetof(RobotStateFields, foot_acceleration));
   put(o.surface_normal, 12, offsetof(RobotStateFields, surface_normal)); put(o.phase, 4, offsetof(RobotStateFields, phase));
-  if (tid < 4 * n) {
+  if (tid < 4 * n && !staged) {
     const int m = tid >> 2, l = tid & 3;
     if (o.support_leg && okm[m]) o.support_leg[4 * i0 + tid] = rec[m].support_leg[l];
     if (o.leg_mode && okm[m]) o.leg_mode[4 * i0 + tid] = rec[m].leg_mode[l];
   }
-  QL_STAMP(25);
+  QL_STAMP(25); QL_BLOCK_STAMP(7);
   if (leg_state_mode) {
     __syncthreads(); // (the block's records are on their way to memory before the state machine writes over parts of them)
     if (tid < n) {
@@ -667,7 +722,7 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
         for (int k = 0; k < 12; k++) lin.ft[k] = r.foot_position[k];
         lin.live = 1;
       }
-      leg_state_run(ls, leg_state_mode == 2, i0 + tid, lin);
+      leg_state_run(coop::kernel_arguments_again<UnpackArgs>()->ls, leg_state_mode == 2, i0 + tid, lin);
     }
   }
   if (logger) {

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--ticks", type=int, default=24)
     ap.add_argument("--cold", action="store_true", help="the placed loop without the warm start")
+    ap.add_argument("--phases", action="store_true", help="all eight phase stamps (the build with -DQLAMD_BLOCK_STAMPS alone: near the shipped pace)")
     ap.add_argument("--lib", default=os.path.join(ROOT, "variants", "libqlamd_stamps.so"))
     args = ap.parse_args()
     import torch
@@ -62,6 +63,20 @@ def main():
         t0, t1, t2, t3 = read(0), read(1), read(2), read(3)
         sol = slice(shadows, nb)
         start = t0[sol].min()
+        if args.phases and k == len(states) - 1:
+            # every phase boundary of a wavefront: 0 start | 4 inputs loaded | 5 wrench, kinematics, Jacobians | 6 G inverted, x0 |
+            # 1 = start of the warm block | 2 installs and drops done | 7 active-set loop done | 3 refinement, torques, stores
+            names = ["first start -> my start", "loads", "wrench + kinematics", "G, inversion, x0", "(to the warm block)", "installs + drops",
+                     "active-set loop", "refinement + torques + stores"]
+            tt = [t0, read(4), read(5), read(6), t1, t2, read(7), t3]
+            slow = np.argsort(-(t3[sol] - start))[:8]
+            print("phases of the wavefronts of the last tick (us): p50 | p99 | mean over the 8 slowest wavefronts")
+            prev = np.full_like(t0[sol], start)
+            for nm, t in zip(names, tt):
+                seg = t[sol] - prev
+                print("   %-32s %6.2f %6.2f %6.2f" % (nm, np.median(seg), np.percentile(seg, 99), seg[slow].mean()))
+                prev = t[sol]
+            print("   %-32s %6.2f %6.2f %6.2f" % ("end (from the first start)", np.median(t3[sol] - start), np.percentile(t3[sol] - start, 99), (t3[sol] - start)[slow].mean()))
         floor, inst, rest, end = (t1 - t0)[sol], (t2 - t1)[sol], (t3 - t2)[sol], t3[sol] - start
         it = iters[k & 1].cpu().numpy()
         after = ws.cpu().numpy().view(np.uint32)
