@@ -505,6 +505,13 @@ __device__ __forceinline__ void wire_row_store(const WireRowPayload &p, const Wi
 
 constexpr int kWireMsgsPerBlock = 4;          // messages parsed per 64-lane block (one 16-lane row each)
 constexpr int kWireLdsBytes = 32 * 1024;      // staging window; longer runs are parsed straight from global memory
+// The window of a launch that is bound by throughput, not by a block's latency: 19 KB of LDS a block instead of 35, eight blocks
+// on a CU instead of four -- a tick of 65 536 robots 211 -> 186 us, of 16 384: 80 -> 71 (profiles/r6/README.md).  Four messages of up to 4 KB fit (a
+// reference message is 3.3 KB); for device buffers, whose sizes the host does not see, it is used from kWireSmallWindowBatch
+// messages on -- below that a CU holds four blocks at most anyway.  For host buffers the window is the smallest that holds
+// every block's run.
+constexpr int kWireLdsBytesSmall = 16 * 1024;
+constexpr int64_t kWireSmallWindowBatch = 8192;
 // Layout template: the (position, value) of every length field of one well-formed message plus the anchors its walk
 // produced.  A message whose length fields hold the template's values AT the template's positions has, by induction
 // along the walk, exactly the template's layout -- so its anchors are known without walking.
@@ -525,7 +532,7 @@ constexpr int kTplValid = 0, kTplEnd = 1, kTplMissing = 2, kTplFields = 3, kTplA
 // instruction were spilled to vector lanes and read back one v_readlane at a time (141 of the tail's 850 instructions).
 struct UnpackArgs {
   const uint8_t *messages; const int64_t *offsets; int64_t B; RobotStateOutPtrs o; int32_t *status; const uint32_t *tpl_in;
-  uint32_t *tpl_out; uint8_t *valid; LegStatePtrs ls; int leg_state_mode;
+  uint32_t *tpl_out; uint8_t *valid; LegStatePtrs ls; int leg_state_mode; int window_bytes;
 };
 __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *__restrict__ messages,
                                                                 const int64_t *__restrict__ offsets, int64_t B,
@@ -533,7 +540,7 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
                                                                 const uint32_t *__restrict__ tpl_in,
                                                                 uint32_t *__restrict__ tpl_out,
                                                                 uint8_t *__restrict__ valid, const LegStatePtrs ls,
-                                                                int leg_state_mode) {
+                                                                int leg_state_mode, int window_bytes) {
   // leg_state_mode (whole tick): 0 = parse only; 1 / 2 = the block also runs the leg state machine of its robots on the
   // command now in force (without / with the reference's index quirk): one launch and one memory round trip less per tick
   // valid != NULL (whole tick): the outputs are the per-robot command in force -- only a well-formed message
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   // The template goes from memory straight into the registers of the lanes that use it, with the block's first loads: lane lr of
   // every row checks length fields lr, lr + 16, ... (a (position, value) pair each) and carries anchors lr, lr + 16, lr + 32;
   // the four header words are the same for everybody.  (Through LDS -- stored behind the staging loop, read back by the check --
-  // the check waited one more LDS round trip: 1.24 -> us, profiles/r6/tick_block_phases.txt.)
+  // the check waited one more LDS round trip: 1.24 -> 0.84 us, profiles/r6/tick_block_phases.txt.)
   const uint32_t tpl_valid = tpl_in[kTplValid], tpl_end = tpl_in[kTplEnd], tpl_missing = tpl_in[kTplMissing], tnf = tpl_in[kTplFields];
   uint2 pair[kTplMaxFields / 16];
 #pragma unroll
@@ -570,7 +577,7 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   const uintptr_t src = (uintptr_t)(messages + a);
   const uintptr_t src_al = src & ~(uintptr_t)15;
   const int64_t lead = (int64_t)(src - src_al), nbytes = lead + (b - a);
-  const bool staged = nbytes + 16 <= kWireLdsBytes; // +16: u32 / f64 reads may touch the next two words
+  const bool staged = nbytes + 16 <= window_bytes; // +16: u32 / f64 reads may touch the next two words
   if (staged) {
     const int64_t full = nbytes >> 4;
     const uint4 *g = (const uint4 *)src_al;
@@ -968,9 +975,17 @@ static int unpack_impl(qlamd_context *ctx, const uint8_t *messages, const int64_
   const uint32_t *tpl_in = ctx->wire_tpl + kTplWords * ctx->wire_flip;
   uint32_t *tpl_out = ctx->wire_tpl + kTplWords * (ctx->wire_flip ^ 1);
   if (!captured) ctx->wire_flip ^= 1;
+  int window = batch >= kWireSmallWindowBatch ? kWireLdsBytesSmall : kWireLdsBytes;
+  if (memory == QLAMD_MEM_HOST) { // the host sees the offsets: the smaller window if every block's run fits it
+    window = kWireLdsBytesSmall;
+    for (int64_t i = 0; i < batch && window == kWireLdsBytesSmall; i += kWireMsgsPerBlock) {
+      const int64_t j = i + kWireMsgsPerBlock < batch ? i + kWireMsgsPerBlock : batch;
+      if (offsets[j] - offsets[i] + 32 > kWireLdsBytesSmall) window = kWireLdsBytes; // (+16 of alignment lead, +16 of overread)
+    }
+  }
   hipLaunchKernelGGL(robot_state_unpack_kernel, dim3((unsigned)((batch + kWireMsgsPerBlock - 1) / kWireMsgsPerBlock)),
-                     dim3(64), kWireLdsBytes, st, d_msg, d_off, batch, o, d_st, tpl_in, tpl_out, valid,
-                     ls ? *ls : LegStatePtrs{}, ls ? leg_state_mode : 0);
+                     dim3(64), window, st, d_msg, d_off, batch, o, d_st, tpl_in, tpl_out, valid,
+                     ls ? *ls : LegStatePtrs{}, ls ? leg_state_mode : 0, window);
   if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   if (memory == QLAMD_MEM_HOST) return sg.finish(st);
   return QLAMD_OK;

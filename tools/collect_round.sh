@@ -36,6 +36,12 @@ b full_tick_b65536 --workload full_tick --batch 65536 --steps 40
 b wholebody_trot_b4096 --workload wholebody --steps 100
 b wholebody_dynamics_b4096 --workload wholebody_dynamics --steps 100
 b wholebody_dynamics_b1048576 --workload wholebody_dynamics --batch 1048576 --steps 10
+# the kernels of a whole tick: one launch pair at 4096 robots, four launches (parser, state machine, placed balance step, swing branch) at 65 536
+for b in 4096 65536; do
+  ( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/tick_raw -o t -- python3 $GRAFT_REPO_ROOT/bench.py --workload full_tick --batch $b --steps 40 --no-cpu-baseline > /dev/null 2>&1 )
+  python3 tools/rocpd_kernels.py $(find $OUT/tick_raw -name "*_results.db" | head -1) $OUT/kernel_stats_full_tick_b$b.csv > /dev/null 2>&1
+  rm -rf $OUT/tick_raw
+done
 ( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/aux_raw -o aux -- python3 $GRAFT_REPO_ROOT/tools/aux_kernels.py > /dev/null 2>&1 )
 python3 tools/rocpd_kernels.py $(find $OUT/aux_raw -name "*_results.db" | head -1) $OUT/kernel_stats_aux_entries_b4096.csv > /dev/null 2>&1
 rm -rf $OUT/aux_raw
@@ -48,7 +54,8 @@ python3 tools/warm_install_probe.py 2>&1 | grep -v amdgpu > $OUT/warm_install_pr
 python3 tools/latency_b1.py 2>&1 | grep -v amdgpu > $OUT/host_buffer_latency.txt
 python3 tools/experiments/trajectory_stats.py 4096 60 2>&1 | grep -v amdgpu > $OUT/trajectory_stats_final.txt
 python3 tests/tools/soak_trajectory.py 65536 48 2>&1 | grep -v amdgpu > $OUT/soak_trajectory.txt
-[ -f variants/libqlamd_stamps.so ] && ( python3 tools/stamp_probe_warm_loop.py; python3 tools/stamp_probe_warm_loop.py --gait trot; python3 tools/stamp_probe_tick_blocks.py ) 2>&1 | grep -v amdgpu > $OUT/stamps_warm_loop_and_tick.txt
+# workgroup stamps at the shipped pace (-DQLAMD_BLOCK_STAMPS alone): the phases of the warm-started loop's wavefronts, of the tick's parser blocks
+[ -f variants/libqlamd_blockstamps.so ] && ( L=variants/libqlamd_blockstamps.so; python3 tools/stamp_probe_warm_loop.py --phases --lib $L; python3 tools/stamp_probe_warm_loop.py --phases --gait trot --lib $L; python3 tools/stamp_probe_warm_loop.py --phases --gait trot --cold --lib $L; python3 tools/stamp_probe_tick_blocks.py --lib $L; python3 tools/stamp_probe_tick_blocks.py --ragged --lib $L ) 2>&1 | grep -v amdgpu > $OUT/stamps_warm_loop_and_tick.txt
 python3 - > $OUT/multi_gpu_cpp_one_rank.txt 2>&1 <<'PY'
 import os, subprocess, sys, tempfile
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")

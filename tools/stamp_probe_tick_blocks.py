@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Which workgroup does the whole tick wait for?  The diagnostic build (-DQLAMD_STAMPS) stamps the start and the end of every
-workgroup of the tick's two launches (robot_state_unpack_kernel with the leg state machine at its tail; tick_solve_kernel =
-balance blocks + swing-branch blocks) with s_memrealtime, the device-wide 100 MHz counter.  Prints, per launch: when its
-workgroups start and end relative to the first start of the tick, the slowest workgroups, and what the end of the launch is
-made of.  Needs variants/libqlamd_stamps.so:
-  python -c "from quadruped_locomotion_amd import build; build.build(defines=('QLAMD_STAMPS',), lib='variants/libqlamd_stamps.so')"
+"""Which workgroup does the whole tick wait for?  The diagnostic build with workgroup stamps only (-DQLAMD_BLOCK_STAMPS: the
+kernels at nearly the shipped pace; -DQLAMD_STAMPS adds the segment stamps inside the solver, which make it 2.7 x slower) stamps
+the start and the end of every workgroup of the tick's two launches (robot_state_unpack_kernel with the leg state machine at its
+tail; tick_solve_kernel = balance blocks + swing-branch blocks) and the phase boundaries of the parser's blocks with s_memrealtime,
+the device-wide 100 MHz counter.  Prints, per launch: when its workgroups start and end relative to the first start of the tick,
+the slowest workgroups, what the end of the launch is made of, and the phases of a parser block.  Needs
+  python -c "from quadruped_locomotion_amd import build; build.build(defines=('QLAMD_BLOCK_STAMPS',), lib='variants/libqlamd_blockstamps.so')"
 usage: stamp_probe_tick_blocks.py [--ragged] [--batch 4096]"""
 import argparse
 import ctypes as C
@@ -22,7 +23,7 @@ def main():
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--ticks", type=int, default=12)
-    ap.add_argument("--lib", default=os.path.join(ROOT, "variants", "libqlamd_stamps.so"))
+    ap.add_argument("--lib", default=os.path.join(ROOT, "variants", "libqlamd_blockstamps.so"))
     args = ap.parse_args()
     import torch
     from quadruped_locomotion_amd import capi, synth

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Which wavefront does a step of the placed + warm-started loop wait for, and what is it doing?  The diagnostic build
-(-DQLAMD_STAMPS; variants/libqlamd_stamps.so) stamps every workgroup (= wavefront, four robots) of the balance kernel with the
+(-DQLAMD_BLOCK_STAMPS alone, variants/libqlamd_blockstamps.so: workgroup stamps at nearly the shipped pace; --lib
+variants/libqlamd_stamps.so for the build with the solver's segment stamps as well, 2.7 x slower) stamps every workgroup (= wavefront, four robots) of the balance kernel with the
 device-wide 100 MHz counter at its start, before the warm start's installs (loads, wrench, kinematics and the inversion of G are
 behind it), after the installs and the drops of negative multipliers, and at its end.  The loop runs on a trajectory
 (synth.trajectory); per tick: the launch, the distribution of the wavefronts' phases, and the slowest wavefronts with their robots.
@@ -23,7 +24,7 @@ def main():
     ap.add_argument("--ticks", type=int, default=24)
     ap.add_argument("--cold", action="store_true", help="the placed loop without the warm start")
     ap.add_argument("--phases", action="store_true", help="all eight phase stamps (the build with -DQLAMD_BLOCK_STAMPS alone: near the shipped pace)")
-    ap.add_argument("--lib", default=os.path.join(ROOT, "variants", "libqlamd_stamps.so"))
+    ap.add_argument("--lib", default=os.path.join(ROOT, "variants", "libqlamd_blockstamps.so"))
     args = ap.parse_args()
     import torch
     from quadruped_locomotion_amd import capi, synth
