@@ -734,6 +734,26 @@ def robot_state_unpack(ctx, messages, offsets, want=None):
     return out, st
 
 
+def robot_state_unpack_device(ctx, messages, offsets, stream=None):
+    """qlamd_robot_state_unpack_batch on device buffers (torch CUDA tensors: uint8 blob, int64 [B+1] offsets) ->
+    (dict of CUDA tensors, status tensor).  Asynchronous."""
+    import torch
+    B = offsets.numel() - 1
+    f, out = RobotStateFields(), {}
+    for name, w in ROBOT_STATE_FIELDS:
+        out[name] = torch.zeros(B, w, dtype=torch.float64, device=messages.device)
+        setattr(f, name, out[name].data_ptr())
+    for name in ("support_leg", "leg_mode"):
+        out[name] = torch.zeros(B, 4, dtype=torch.uint8, device=messages.device)
+        setattr(f, name, out[name].data_ptr())
+    st = torch.full((B,), -1, dtype=torch.int32, device=messages.device)
+    rc = lib().qlamd_robot_state_unpack_batch(ctx._h, messages.data_ptr(), offsets.data_ptr(), B, C.byref(f), st.data_ptr(), MEM_DEVICE,
+                                              C.c_void_p(stream) if stream else None)
+    if rc != OK:
+        raise QlamdError(rc, "qlamd_robot_state_unpack_batch")
+    return out, st
+
+
 def default_ik_params():
     p = IkParams()
     lib().qlamd_ik_default_params(C.byref(p))

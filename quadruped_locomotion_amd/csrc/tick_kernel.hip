@@ -650,7 +650,11 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
     else if (hit) st = tpl_missing ? kWireMissingField : kWireOk;
     else if (staged && logger) st = wire_lds_skeleton<true>(msg, mb - ma, anchors[row], tpl_out + kTplPairs, nf, end_pos);
     else if (staged) st = wire_lds_skeleton<false>(msg, mb - ma, anchors[row], nullptr, nf, end_pos);
-    else st = robot_state_unpack(PlainBytes{messages + ma}, mb - ma, rec[row]);
+    else {
+      st = robot_state_unpack(PlainBytes{messages + ma}, mb - ma, rec[row]);
+      if (st == kWireTruncated) // (the fields met before the end: a truncated message delivers the cleared record, as when staged)
+        for (int w = 0; w < (int)(sizeof(RobotStateFields) / 4); w++) ((uint32_t *)&rec[row])[w] = 0u;
+    }
     status[i0 + row] = st;
     okm[row] = (st == kWireOk || !valid) ? 1 : 0;
     if (valid && st == kWireOk) valid[i0 + row] = 1;

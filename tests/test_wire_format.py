@@ -13,7 +13,7 @@ MODES = ["joint", "leg_mode", "cartesian", "footstep", "LF_LEG", "", "footsteps"
 MODE_CODE = {"joint": 1, "leg_mode": 2, "cartesian": 3, "footstep": 4}
 
 
-def random_message(rng, ragged=True):
+def random_message(rng, ragged=True, pad=0):
     """A RobotState with random content; `ragged` varies string lengths and array counts so that every message has
     its own field offsets.  Returns (bytes, expected fields)."""
     exp = dict(des_pos=rng.normal(size=3), des_quat=rng.normal(size=4), des_linvel=rng.normal(size=3),
@@ -49,7 +49,7 @@ def random_message(rng, ragged=True):
             ignore_contact=int(rng.integers(0, 2)), ignore_for_pose_adaptation=int(rng.integers(0, 2)))
     q = exp["des_quat"]
     msg["base_pose"] = dict(
-        header=hdr(), child_frame_id=word(),
+        header=hdr(), child_frame_id=word() + "p" * pad,   # (pad: a long frame name, for messages of a chosen size)
         pose=dict(pose=dict(position=W.xyz(exp["des_pos"]), orientation=dict(x=q[1], y=q[2], z=q[3], w=q[0])),
                   covariance=list(rng.normal(size=36))),
         twist=dict(twist=dict(linear=W.xyz(exp["des_linvel"]), angular=W.xyz(exp["des_angvel"])), covariance=list(rng.normal(size=36))))
@@ -240,6 +240,52 @@ def test_device_unpack_truncated_and_corrupted_length_fields(oracle):
         else:
             assert all(not np.asarray(v[i]).any() for v in out.values())
     assert {0, 1} <= seen
+
+
+@pytest.mark.gpu
+def test_device_unpack_staging_windows(oracle):
+    """A block stages its four messages in LDS: in a 16 KB window when every block's run fits (host buffers) or from 8192
+    messages on (device buffers, whose sizes the host does not see), else in 32 KB; a run that does not fit its launch's window
+    is parsed from global memory.  All three ways in one batch, host and device buffers: the oracle's fields and statuses."""
+    import torch
+    from quadruped_locomotion_amd import capi
+    ctx = capi.Context()
+    rng = np.random.default_rng(31)
+    sizes = [0, 0, 0, 0, 2500, 2500, 2500, 2500, 7000, 7000, 7000, 7000, 0, 5000, 0, 0]  # runs of ~6, ~16, ~34, ~11 KB
+    raws = [random_message(rng, ragged=k % 2 == 0, pad=sizes[k % len(sizes)])[0] for k in range(64)]
+    raws[9] = raws[9][:100]                                                      # a truncated one inside a long run
+
+    def check(raws, out, st):
+        for i, r in enumerate(raws):
+            want, wst = oracle.robot_state_unpack(r)
+            assert st[i] == wst, i
+            if wst != 1:
+                same({k: v[i] for k, v in out.items()}, want)
+            else:
+                assert all(not np.asarray(v[i]).any() for v in out.values())
+
+    off = np.zeros(len(raws) + 1, np.int64)
+    off[1:] = np.cumsum([len(r) for r in raws])
+    assert max(off[4:] - off[:-4]) > 32 * 1024 and min(off[4::4] - off[:-4:4]) < 12 * 1024
+    out, st = capi.robot_state_unpack(ctx, b"".join(raws), off)                   # host buffers: the 32 KB window, one run beyond it
+    check(raws, out, st)
+    small = [r for r, s in zip(raws, [sizes[k % len(sizes)] for k in range(64)]) if s == 0]
+    off_s = np.zeros(len(small) + 1, np.int64)
+    off_s[1:] = np.cumsum([len(r) for r in small])
+    out, st = capi.robot_state_unpack(ctx, b"".join(small), off_s)               # host buffers, every run under 16 KB
+    check(small, out, st)
+    # device buffers, 8192 messages: the 16 KB window whatever the messages hold (the 64 above, repeated)
+    reps = 8192 // len(raws)
+    blob = torch.from_numpy(np.frombuffer(b"".join(raws) * reps, dtype=np.uint8).copy()).to("cuda:0")
+    off_d = np.concatenate([[0], np.cumsum(np.tile(np.diff(off), reps))]).astype(np.int64)
+    dout, dst = capi.robot_state_unpack_device(ctx, blob, torch.from_numpy(off_d).to("cuda:0"))
+    torch.cuda.synchronize()
+    hst = dst.cpu().numpy()
+    hout = {k: v.cpu().numpy() for k, v in dout.items()}
+    for rep in (0, reps // 2, reps - 1):
+        sl = slice(rep * len(raws), (rep + 1) * len(raws))
+        check(raws, {k: v[sl] for k, v in hout.items()}, hst[sl])
+    assert np.array_equal(hst, np.tile(hst[:len(raws)], reps))
 
 
 def test_package_writer_matches_the_schema_serialiser(oracle):
