@@ -15,9 +15,16 @@ TAU_TOL = 1e-6      # BASELINE north_star: joint torques within 1e-6
 PERSIST = ("limb_state", "store_flag", "stored_joint_position", "leg_mode", "support", "pid_error_last", "pid_error_integral")
 
 
-def make_tick_inputs(B, tick, truncated=()):
-    blob, off, _ = synth.make_messages(B, ragged=True, seed=synth.SEED + 100 + tick)
+def make_tick_inputs(B, tick, truncated=(), big=()):
+    blob, off, fields = synth.make_messages(B, ragged=True, seed=synth.SEED + 100 + tick)
     msgs = [bytes(blob[off[b]:off[b + 1]]) for b in range(B)]
+    name_of = {code: name for name, code in wire.MODE_CODE.items()}
+    for b in big:  # the same content behind a 9 KB frame name: a block of four of these is beyond the 32 KB staging window
+        f = {k: v[b] for k, v in fields.items() if k != "leg_mode"}
+        f["mode_name"] = [name_of.get(int(c), "") for c in fields["leg_mode"][b]]
+        layout = wire.random_layout(np.random.default_rng(b))
+        layout["frame_id"] = "f" * 9000
+        msgs[b] = wire.pack_robot_state(f, layout)
     for b in truncated:
         msgs[b] = msgs[b][:40 + 7 * (b % 50)]
     blob, off = wire.pack_batch(msgs)
@@ -96,7 +103,8 @@ def test_full_tick_matches_the_oracle_chain(oracle, memory, warm):
         # tick 0: robots 3, 77, 500 never got a well-formed message; they stay without one on tick 1 (3 and 77) ...
         # ticks 2, 3: robots 10..29 lose their message and run on the command stored before
         truncated = {0: (3, 77, 500), 1: (3, 77), 2: tuple(range(10, 30)) + (3,), 3: tuple(range(20, 30))}.get(tick, ())
-        msgs, tin = make_tick_inputs(B, tick, truncated)
+        # ticks 1 and 4: a block of messages too long to be staged in LDS (parsed from global memory), and a long one on its own
+        msgs, tin = make_tick_inputs(B, tick, truncated, big=(40, 41, 42, 43, 600) if tick in (1, 4) else ())
         if memory == "device":
             io = dict({k: torch.from_numpy(v).to("cuda:0") for k, v in tin.items()}, **keep)
             capi.full_tick(ctx, io, period, memory=capi.MEM_DEVICE)
