@@ -450,7 +450,17 @@ __device__ __forceinline__ WireRowAnchors wire_row_anchors(const Get &get, int l
   return WireRowAnchors{get(kAnOdomPose), get(kAnJointPos + l3), get(kAnJointCnt + l3), get(kAnTarget + 3 * l3), get(kAnTarget + 3 * l3 + 1),
                         get(kAnTarget + 3 * l3 + 2), get(kAnModeNormal + l3), get(kAnModeFlag + l4), get(kAnModeName + l4), get(kAnModeLen + l4)};
 }
-__device__ __forceinline__ WireRowPayload wire_row_read(const LdsBytes &src, const WireRowAnchors &a, int lr) {
+// Byte source in global memory: reads at any byte offset (the hardware takes unaligned global loads), every address clamped so
+// that the read stays inside the message.
+struct GlobalBytes {
+  const uint8_t *p;
+  uint32_t len; // >= 16
+  __device__ __forceinline__ uint32_t u32(uint32_t at) const { uint32_t v; __builtin_memcpy(&v, p + min(at, len - 4u), 4); return v; }
+  __device__ __forceinline__ uint8_t u8(uint32_t at) const { return p[min(at, len - 1u)]; }
+  __device__ __forceinline__ double f64(uint32_t at) const { double v; __builtin_memcpy(&v, p + min(at, len - 8u), 8); return v; }
+};
+template <class Bytes>
+__device__ __forceinline__ WireRowPayload wire_row_read(const Bytes &src, const WireRowAnchors &a, int lr) {
   const uint32_t j8 = 8u * (uint32_t)(lr - 3 * (lr / 3));
   // base step: wire order of the pose is position, orientation (x, y, z, w) -> (w, x, y, z); the twist follows 288 bytes of covariance
   const uint32_t off0 = lr < 3 ? 8u * lr : lr < 7 ? 24u + 8u * (lr & 3) : lr < 13 ? 56u + 288u + 8u * (lr - 7) : 0u;
@@ -546,7 +556,7 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   // valid != NULL (whole tick): the outputs are the per-robot command in force -- only a well-formed message
   // replaces a robot's record and sets valid[robot]; a malformed one leaves both as they are.
   extern __shared__ uint32_t wire_lds[];
-  __shared__ int okm[kWireMsgsPerBlock];
+  __shared__ int okm[kWireMsgsPerBlock], via_rec[kWireMsgsPerBlock];
   __shared__ RobotStateFields rec[kWireMsgsPerBlock];
   __shared__ uint32_t anchors[kWireMsgsPerBlock][kAnCount];
   const int tid = threadIdx.x;
@@ -574,10 +584,41 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   for (int t = 0; t < kTplMaxFields / 16; t++) { pair[t].x = tpl_in[kTplPairs + 2 * (lr + 16 * t)]; pair[t].y = tpl_in[kTplPairs + 2 * (lr + 16 * t) + 1]; }
   // ... and the template's anchors of the slots this lane extracts for (wire_row_anchors)
   const WireRowAnchors tpl_anchor = wire_row_anchors([&](int slot) { return tpl_in[kTplAnchors + slot]; }, lr);
+  const bool sane = mine && !(ma < a || mb > b || mb < ma); // offsets not ascending: nothing to parse
+  // ---- template check, 16 lanes per message, STRAIGHT FROM MEMORY (round 6): a message whose length fields hold the template's
+  // values at the template's positions needs nothing else of its bytes than the payload at the template's anchors -- so the lanes
+  // read exactly those, length fields and payload in one round trip, and a block whose four messages all match never stages
+  // anything (before: every block copied its messages into LDS first -- a second dependent round trip plus the LDS one of the
+  // check; a block 8.4 -> 7.6 us, the launch 10.0-10.7 -> 9.5: profiles/r6/tick_block_phases.txt).  Every address is clamped into the message: whatever a
+  // template holds, nothing outside the message is read.
+  bool same = sane && tpl_valid == kTplMagic && tnf <= (uint32_t)kTplMaxFields && (mb - ma) <= 0x7FFFFFF0ll &&
+              (uint64_t)(mb - ma) >= (uint64_t)tpl_end && tpl_end >= 16u;
+  WireRowAnchors anc = tpl_anchor;
+  {
+    const auto in = [&](uint32_t &v, bool position) { v = same ? (position ? min(v, tpl_end) : v) : 0u; };
+    in(anc.odom, true); in(anc.joint, true); in(anc.n_joint, false); in(anc.t0, true); in(anc.t1, true); in(anc.t2, true);
+    in(anc.nrm, true); in(anc.flag, true); in(anc.name, true); in(anc.n_name, false);
+  }
+  WireRowPayload pay{};
+  if (same) {
+    const GlobalBytes gsrc{messages + ma, (uint32_t)(mb - ma)};
+    // eight length fields per lane and the lane's share of the payload, all reads independent
+    uint32_t got[kTplMaxFields / 16];
+#pragma unroll
+    for (int t = 0; t < kTplMaxFields / 16; t++) got[t] = gsrc.u32(lr + 16u * t < tnf ? pair[t].x : 0u);
+    pay = wire_row_read(gsrc, anc, lr);
+#pragma unroll
+    for (int t = 0; t < kTplMaxFields / 16; t++) same = same && (lr + 16u * t >= tnf || got[t] == pair[t].y);
+  }
+  const bool hit = ((unsigned)(__ballot(same) >> (tid & 48)) & 0xFFFFu) == 0xFFFFu;
+  const bool all_hit = __ballot(mine && !hit) == 0ull; // (wavefront-uniform) nobody has to be walked: nothing is staged
+  QL_STAMP(21); QL_BLOCK_STAMP(4);
+  // ---- a block with a message of another layout (or no template yet): its messages are staged in LDS for the walk
   const uintptr_t src = (uintptr_t)(messages + a);
   const uintptr_t src_al = src & ~(uintptr_t)15;
   const int64_t lead = (int64_t)(src - src_al), nbytes = lead + (b - a);
-  const bool staged = nbytes + 16 <= window_bytes; // +16: u32 / f64 reads may touch the next two words
+  const bool staged = !all_hit && nbytes + 16 <= window_bytes; // +16: u32 / f64 reads may touch the next two words
+  if (!all_hit) {
   if (staged) {
     const int64_t full = nbytes >> 4;
     const uint4 *g = (const uint4 *)src_al;
@@ -612,35 +653,8 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
     for (int w = tid; w < (int)(sizeof(rec) / 4); w += 64) ((uint32_t *)rec)[w] = 0u;
   for (int w = tid; w < kWireMsgsPerBlock * kAnCount; w += 64) (&anchors[0][0])[w] = 0u;
   __syncthreads();
-  QL_STAMP(21); QL_BLOCK_STAMP(4);
-  const bool sane = mine && !(ma < a || mb > b || mb < ma); // offsets not ascending: nothing to parse
+  }
   const LdsBytes msg{wire_lds, (uint32_t)(lead + (ma - a))};
-  // ---- template check, 16 lanes per message
-  bool same = sane && staged && tpl_valid == kTplMagic && tnf <= (uint32_t)kTplMaxFields &&
-              (mb - ma) <= 0x7FFFFFF0ll && (uint64_t)(mb - ma) >= (uint64_t)tpl_end;
-  // the payload is read at the template's anchors together with the length fields of the check (one LDS round trip for both);
-  // a message that fails the check reads again below.  (A template's positions lie inside [0, end] and end <= my length was
-  // just checked; anything else reads at 0.)
-  WireRowAnchors anc = tpl_anchor;
-  {
-    const auto in = [&](uint32_t &v, bool position) { v = same ? (position ? min(v, tpl_end) : v) : 0u; };
-    in(anc.odom, true); in(anc.joint, true); in(anc.n_joint, false); in(anc.t0, true); in(anc.t1, true); in(anc.t2, true);
-    in(anc.nrm, true); in(anc.flag, true); in(anc.name, true); in(anc.n_name, false);
-  }
-  const LdsBytes spec{wire_lds, same ? msg.shift : 0u};
-  WireRowPayload pay;
-  {
-    // eight length fields per lane, all reads independent (positions inside the message: <= end <= length)
-    uint32_t got[kTplMaxFields / 16];
-#pragma unroll
-    for (int t = 0; t < kTplMaxFields / 16; t++) got[t] = spec.u32(same && lr + 16u * t < tnf ? min(pair[t].x, tpl_end) : 0u);
-    pay = wire_row_read(spec, anc, lr);
-#pragma unroll
-    for (int t = 0; t < kTplMaxFields / 16; t++) same = same && (lr + 16u * t >= tnf || got[t] == pair[t].y);
-  }
-  const bool hit = ((unsigned)(__ballot(same) >> (tid & 48)) & 0xFFFFu) == 0xFFFFu;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_s_waitcnt(0xC07F);
   QL_STAMP(22); QL_BLOCK_STAMP(5);
   uint32_t nf = 0u, end_pos = 0u;
   int st = kWireTruncated;
@@ -657,14 +671,15 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
     }
     status[i0 + row] = st;
     okm[row] = (st == kWireOk || !valid) ? 1 : 0;
+    via_rec[row] = (!hit && !staged && sane) ? okm[row] : 0; // parsed into the record by one lane: written out from there below
     if (valid && st == kWireOk) valid[i0 + row] = 1;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_s_waitcnt(0xC07F);
   const int st_row = __shfl(st, 0, 16);
-  // a staged block's rows store their entries straight from the registers of the extraction (a malformed message of the
-  // parse-only entry: the cleared record); the record in LDS is for the state machine below and for a block that was not staged
-  if (mine && staged) {
+  // a row stores its entries straight from the registers of the extraction (a malformed message of the parse-only entry: the
+  // cleared record); the record in LDS is for the state machine below and for a message parsed from global memory by one lane
+  if (mine && (hit || staged || !sane)) {
     const bool have = sane && st_row != kWireTruncated;
     if (!hit) { // another layout (or no template yet): the anchors the walk left in LDS
       const uint32_t *an = anchors[row];
@@ -701,10 +716,10 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   QL_STAMP(24); QL_BLOCK_STAMP(6);
   // write-out: message m's k doubles of each field are contiguous in the output arrays
   const auto put = [&](double *dst, int width, size_t field_off) {
-    if (!dst || staged) return;
+    if (!dst || staged || all_hit) return;
     for (int e = tid; e < n * width; e += 64) {
       const int m = e / width, k2 = e - m * width;
-      if (okm[m]) dst[(int64_t)width * i0 + e] = ((const double *)((const char *)&rec[m] + field_off))[k2];
+      if (via_rec[m]) dst[(int64_t)width * i0 + e] = ((const double *)((const char *)&rec[m] + field_off))[k2];
     }
   };
   put(o.des_pos, 3, offsetof(RobotStateFields, des_pos)); put(o.des_quat, 4, offsetof(RobotStateFields, des_quat));
@@ -714,10 +729,10 @@ __global__ __launch_bounds__(64) void robot_state_unpack_kernel(const uint8_t *_
   put(o.foot_velocity, 12, offsetof(RobotStateFields, foot_velocity));
   put(o.foot_acceleration, 12, offsetof(RobotStateFields, foot_acceleration));
   put(o.surface_normal, 12, offsetof(RobotStateFields, surface_normal)); put(o.phase, 4, offsetof(RobotStateFields, phase));
-  if (tid < 4 * n && !staged) {
+  if (tid < 4 * n && !staged && !all_hit) {
     const int m = tid >> 2, l = tid & 3;
-    if (o.support_leg && okm[m]) o.support_leg[4 * i0 + tid] = rec[m].support_leg[l];
-    if (o.leg_mode && okm[m]) o.leg_mode[4 * i0 + tid] = rec[m].leg_mode[l];
+    if (o.support_leg && via_rec[m]) o.support_leg[4 * i0 + tid] = rec[m].support_leg[l];
+    if (o.leg_mode && via_rec[m]) o.leg_mode[4 * i0 + tid] = rec[m].leg_mode[l];
   }
   QL_STAMP(25); QL_BLOCK_STAMP(7);
   if (leg_state_mode) {
