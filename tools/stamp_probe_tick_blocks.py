@@ -63,11 +63,12 @@ def main():
         ss, se = read(2, n_bal + n_swing), read(3, n_bal + n_swing)
         t0 = us.min()
         if tick == args.ticks - 1:
-            # the unpack blocks' phases (slots 4-7: staged in LDS | template checked | payload extracted | records written out)
-            prev, names = us, ["offsets -> messages staged in LDS", "template check", "extraction (+ barrier)", "write-out", "state machine, end"]
+            # the unpack blocks' phases (slots 4-7: template checked against memory | staged, if a message missed | walked, stored | written out)
+            prev, names = us, ["offsets, template -> fields from memory", "staging in LDS (a miss in the block)", "status, walk of a miss, stores",
+                               "write-out of rows parsed by one lane", "state machine, end"]
             print("phases of the unpack blocks of the last tick (us): p50 | p99")
             for nm, t in zip(names, [read(4, n_unpack), read(5, n_unpack), read(6, n_unpack), read(7, n_unpack), ue]):
-                print("   %-36s %6.2f %6.2f" % (nm, np.median(t - prev), np.percentile(t - prev, 99)))
+                print("   %-40s %6.2f %6.2f" % (nm, np.median(t - prev), np.percentile(t - prev, 99)))
                 prev = t
         summary.append((e0.elapsed_time(e1) * 1e3, ue.max() - t0, ss.min() - t0, se.max() - t0, se[:n_bal].max() - t0, se[n_bal:].max() - t0))
     print("%d robots, %s, %d ticks; times in us from the first workgroup start of the tick (s_memrealtime, 10 ns steps); HIP events around the tick: median %.1f us"
