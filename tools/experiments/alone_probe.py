@@ -84,6 +84,15 @@ def main():
     u0, u3 = read(0, n2), read(3, n2)
     dur2 = (u3 - u0)[:len(robots)]
     launch_b = u3.max() - u0.min()
+    # (c) the same robots alone, started cold (the reference's method from the empty set): what a race of the two starts would give
+    for rep in range(3):
+        ctx.balance_solve_placed_device(d, tau, None, status, order=o2, iterations=it2, policy=capi.PLACEMENT_AUTO, stream=stream)
+        torch.cuda.synchronize()
+    c0, c3 = read(0, n2), read(3, n2)
+    dur3 = (c3 - c0)[:len(robots)]
+    best = np.minimum(dur2, dur3)
+    print("alone, the loop's start: slowest %.2f us | alone, cold: slowest %.2f | the better start of each robot: slowest %.2f (the loop's start wins for %d of %d)"
+          % (dur2.max(), dur3.max(), best.max(), int((dur2 <= dur3).sum()), len(robots)))
     print("%s, %d robots, last of %d ticks: launch %.2f us in the loop's placement, %.2f with the %d robots of the %d slowest wavefronts alone (and %d robots left out)"
           % (args.gait, B, len(states), launch_a, launch_b, len(robots), K, len(rest) - room))
     print("wavefront: duration | its robots: iterations -> duration alone")
