@@ -639,12 +639,14 @@ def main():
         wset = torch.zeros(B, dtype=torch.int32, device=dev) if warm else None   # working sets: one array, in place
 
         def solve(k, out, st):
-            if warm:
+            if warm and os.environ.get("QLAMD_BENCH_WARM_UNPLACED") == "1":   # (experiment: the warm start in batch order)
+                ctx.balance_solve_placed_device(ds[k % T], out, None, status, iterations=its[k & 1], prev_working_set=wset, working_set=wset, stream=st)
+            elif warm:
                 # the placed loop, and every robot's active-set loop starts from its final working set of the step before
                 # (include/qlamd.h: both halves of the hint a 400 Hz caller has)
                 ctx.balance_solve_placed_device(ds[k % T], out, None, status, order=orders[k & 1], iterations=its[k & 1],
                                                 prev_iterations=its[(k - 1) & 1], next_order=orders[(k + 1) & 1],
-                                                policy=capi.PLACEMENT_AUTO,
+                                                policy=int(os.environ.get("QLAMD_BENCH_POLICY", capi.PLACEMENT_AUTO)),
                                                 prev_working_set=wset, working_set=wset, stream=st)
             elif placed:
                 ctx.balance_solve_placed_device(ds[k % T], out, None, status, order=orders[k & 1], iterations=its[k & 1],
@@ -1229,7 +1231,10 @@ def main():
                  "minimiser is unique: efforts are those of the cold start to the solver's accuracy and within 1e-6 of the oracle's "
                  "on every tick (tests/test_trajectory_gpu.py); iteration counts are no longer QuadProg++'s.  `cold_start` = the "
                  "same steps with every QP started from the empty working set (the placed loop, the headline of round 5), "
-                 "`unplaced` = through qlamd_balance_solve_batch (robot s in slot s, the headline of rounds 1-4)"),
+                 "`unplaced` = through qlamd_balance_solve_batch (robot s in slot s, the headline of rounds 1-4).  The placement's "
+                 "policy is QLAMD_PLACEMENT_AUTO: with a warm start that is NO placement up to 4096 robots (the launch itself leaves "
+                 "the identity as the next order: a warm-started launch lasts as long as its slowest robot, whoever its neighbours "
+                 "are) and the throughput policy above (profiles/r6/ab_warm_policies.txt)"),
         "placed": ("every step is ONE launch of qlamd_balance_solve_placed_batch: it solves all robots, each from the empty working set, "
                    "in the placement that the previous step's launch made from the iteration counts of the step before it, writes its "
                    "own counts, and makes the next step's placement with extra wavefronts of its own; results bit for bit those of "

@@ -328,7 +328,16 @@ int qlamd_force_distribution_batch(qlamd_context *ctx, const double *joint_posit
  *                               solves 6-variable QPs (the support legs sit in front of the row: every product of a pass
  *                               and the inversion of G half as long; 9-11 % on batches of such robots), and a sorted
  *                               placement that ignores the class would mix them
- *   QLAMD_PLACEMENT_AUTO        by batch size (latency below 16 384 robots)
+ *   QLAMD_PLACEMENT_NONE        the batch order: next_robot_order is the identity (written by the launch itself, no extra
+ *                               wavefronts) -- for a caller's loop that keeps its shape when no placement pays
+ *   QLAMD_PLACEMENT_AUTO        without a warm start: latency below 16 384 robots, throughput from there.  With one
+ *                               (prev_working_set / working_set below): NONE up to 4096 robots, THROUGHPUT above -- a
+ *                               warm-started launch of a few thousand robots lasts as long as its slowest ROBOT (its three
+ *                               neighbours in the wavefront cost it 0.3 us), so a placement buys nothing while every wavefront
+ *                               has a SIMD to itself, and the latency policy, which starts the hard robots together, puts two
+ *                               slow wavefronts on one SIMD once there are two a SIMD (the loop on trajectories, us per step,
+ *                               latency / throughput / none: 8192 trot robots 25.5 / 23.3 / 23.8, 12 288: 31.5 / 26.5 / 29.1,
+ *                               4096 static 14.7 / 14.7 / 14.4: profiles/r6/ab_warm_policies.txt)
  * A placement computed from stale or wrong hints costs time, never correctness.  Not available with
  * qlamd_set_robots_per_wave(16 | 64) (QLAMD_ERR_INVALID_ARGUMENT): one lane is one robot there and nothing is shared.
  * Other arguments as qlamd_balance_solve_batch / qlamd_force_distribution_batch; the arrays of `placement` live in the
@@ -336,6 +345,7 @@ int qlamd_force_distribution_batch(qlamd_context *ctx, const double *joint_posit
 #define QLAMD_PLACEMENT_AUTO 0
 #define QLAMD_PLACEMENT_LATENCY 1
 #define QLAMD_PLACEMENT_THROUGHPUT 2
+#define QLAMD_PLACEMENT_NONE 3
 typedef struct qlamd_placement {
   const int32_t *robot_order;
   int32_t *iterations;

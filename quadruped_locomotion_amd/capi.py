@@ -923,7 +923,7 @@ STATE_RECORD_OFFSETS = {"q": 0, "base_pos": 12, "base_quat": 16, "base_linvel": 
 COUNTER_PLACEMENT_GIVE_UPS, COUNTER_WARM_RETRIES = 0, 1
 DYNAMICS_AUTO, DYNAMICS_LEG, DYNAMICS_ROW = 0, 1, 2
 ON_FAILURE_ZERO, ON_FAILURE_KEEP = 0, 1
-PLACEMENT_AUTO, PLACEMENT_LATENCY, PLACEMENT_THROUGHPUT = 0, 1, 2
+PLACEMENT_AUTO, PLACEMENT_LATENCY, PLACEMENT_THROUGHPUT, PLACEMENT_NONE = 0, 1, 2, 3
 STATUS_NO_COMMAND = 4
 STATUS_DEPENDENT_EQUALITY = 5
 

@@ -31,6 +31,7 @@ struct StatePtrs {
   uint32_t place_wait;              // polls they wait for each other before they give up (QLAMD_OPT_PLACEMENT_WAIT)
   uint32_t *warm_retries;           // the context's count of rejected warm starts (kWarm instantiations)
   int record_doubles;               // 0, or the record length of QLAMD_STATE_RECORDS (lane-cooperative kernels, device memory)
+  int32_t *identity_out;            // [B] or NULL: QLAMD_PLACEMENT_NONE -- every slot writes its own index here (the next call's order)
 };
 
 __device__ __forceinline__ void load_robot(const StatePtrs &s, int64_t i, RobotIn &in) {
@@ -545,6 +546,7 @@ __global__ __launch_bounds__(64 * kCoopWaves, kMinWaves) void balance_coop_kerne
   bool live = i < B;
   if (!live) i = B - 1;
   if constexpr (kPlaced) {
+    if (s.identity_out && live && (threadIdx.x & 15) == 0) s.identity_out[i] = (int32_t)i; // (QLAMD_PLACEMENT_NONE: the batch order)
     if (s.order) {
       const int64_t o = s.order[i];
       live = live && o >= 0 && o < B;
@@ -867,12 +869,36 @@ bool throughput_policy(int policy, int64_t batch) {
   return policy == QLAMD_PLACEMENT_THROUGHPUT || (policy == QLAMD_PLACEMENT_AUTO && batch >= QLAMD_THROUGHPUT_BATCH);
 }
 bool valid_policy(int policy) {
-  return policy == QLAMD_PLACEMENT_AUTO || policy == QLAMD_PLACEMENT_LATENCY || policy == QLAMD_PLACEMENT_THROUGHPUT;
+  return policy == QLAMD_PLACEMENT_AUTO || policy == QLAMD_PLACEMENT_LATENCY || policy == QLAMD_PLACEMENT_THROUGHPUT ||
+         policy == QLAMD_PLACEMENT_NONE;
+}
+// What QLAMD_PLACEMENT_AUTO means for a call.  Without a warm start: the latency policy below QLAMD_THROUGHPUT_BATCH robots, the
+// throughput policy from there.  With one (measured on trajectories, profiles/r6/ab_warm_policies.txt: us per step of the loop,
+// latency / throughput / no placement): 4096 robots static 14.7 / 14.7 / 14.4, trot 19.9 / 19.7 / 19.6; 8192: 20.8 / 20.0 / 19.1
+// and 25.5 / 23.3 / 23.8; 12 288: 25.7 / 25.3 / 25.0 and 31.5 / 26.5 / 29.1 -- a warm-started launch lasts as long as its
+// slowest ROBOT (alone_probe.txt), so who shares a wavefront with whom no longer matters while every wavefront has a SIMD to
+// itself, and the latency policy, which starts the hard robots together, puts two slow wavefronts on one SIMD as soon as there
+// are two a SIMD: no placement up to QLAMD_WARM_UNPLACED_BATCH robots, the throughput policy (with its support classes) above.
+#ifndef QLAMD_WARM_UNPLACED_BATCH
+#define QLAMD_WARM_UNPLACED_BATCH 4096
+#endif
+int effective_policy(int policy, int64_t batch, bool warm) {
+  if (policy != QLAMD_PLACEMENT_AUTO) return policy;
+  if (warm) return batch <= QLAMD_WARM_UNPLACED_BATCH ? QLAMD_PLACEMENT_NONE : QLAMD_PLACEMENT_THROUGHPUT;
+  return batch >= QLAMD_THROUGHPUT_BATCH ? QLAMD_PLACEMENT_THROUGHPUT : QLAMD_PLACEMENT_LATENCY;
+}
+__global__ void identity_order_kernel(int32_t *order, int64_t B) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < B) order[i] = (int32_t)i;
 }
 } // namespace
 
 int qlamd::rt::placement_launch(qlamd_context *ctx, const int32_t *d_iterations, int64_t batch, int policy, int32_t *d_order,
                                 hipStream_t st) {
+  if (policy == QLAMD_PLACEMENT_NONE) { // the batch order
+    hipLaunchKernelGGL(identity_order_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, d_order, batch);
+    return hipGetLastError() == hipSuccess ? QLAMD_OK : QLAMD_ERR_HIP;
+  }
   return launch_placement(ctx, d_iterations, batch, throughput_policy(policy, batch) ? 1 : 0, d_order, st);
 }
 
@@ -886,12 +912,12 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
   const int32_t *prev_iterations = pl ? pl->prev_iterations : nullptr;
   int32_t *next_order = pl ? pl->next_robot_order : nullptr;
   if ((prev_iterations != nullptr) != (next_order != nullptr)) return QLAMD_ERR_INVALID_ARGUMENT;
-  if (next_order && pl->policy != QLAMD_PLACEMENT_AUTO && pl->policy != QLAMD_PLACEMENT_LATENCY && pl->policy != QLAMD_PLACEMENT_THROUGHPUT)
-    return QLAMD_ERR_INVALID_ARGUMENT;
+  if (next_order && !valid_policy(pl->policy)) return QLAMD_ERR_INVALID_ARGUMENT;
   if (next_order && (next_order == order || prev_iterations == iterations)) return QLAMD_ERR_INVALID_ARGUMENT; // read and written by one launch
   const uint32_t *prev_ws = pl ? pl->prev_working_set : nullptr;
   uint32_t *ws = pl ? pl->working_set : nullptr;
   const bool warm = prev_ws || ws;
+  const int policy = next_order ? effective_policy(pl->policy, batch, warm) : QLAMD_PLACEMENT_NONE;
   if (warm && memory != QLAMD_MEM_DEVICE) return QLAMD_ERR_INVALID_ARGUMENT; // (a host-buffer call is bound by its copies)
   // (prev_ws == ws is fine: a robot's set is read and written by its own 16 lanes only -- updated in place)
   const bool placed = order || iterations || next_order || warm;
@@ -1007,10 +1033,12 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
     // the next launch's placement: by extra wavefronts in front of this launch
     const int chunk = batch >= QLAMD_THROUGHPUT_BATCH ? kShadowChunkLarge : (warm ? kShadowChunkWarm : kShadowChunkCold);
     const int64_t shadows = (batch + chunk - 1) / chunk;
-    if (next_order && shadows <= kShadowMaxBlocks && pick_rpw(ctx, batch) == 4) {
+    if (next_order && policy == QLAMD_PLACEMENT_NONE) {
+      s.identity_out = next_order; // (written by the slots themselves: no shadow wavefronts)
+    } else if (next_order && shadows <= kShadowMaxBlocks && pick_rpw(ctx, batch) == 4) {
       s.prev_iterations = prev_iterations;
       s.next_order = next_order;
-      s.place_throughput = throughput_policy(pl->policy, batch) ? 1 : 0;
+      s.place_throughput = policy == QLAMD_PLACEMENT_THROUGHPUT ? 1 : 0;
       s.shadow_blocks = (int)shadows;
       s.shadow_chunk = chunk;
       s.place_hist = (uint32_t *)ctx->place_ws;
@@ -1046,8 +1074,8 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
     default: e = launch_balance<64>(ctx, s, batch, d_tau, d_grf, d_status, st); break;
   }
   if (e != hipSuccess) return QLAMD_ERR_HIP;
-  if (next_order && memory == QLAMD_MEM_DEVICE && !s.shadow_blocks) { // more robots than the shadow wavefronts take: launches of their own
-    const int rc = launch_placement(ctx, prev_iterations, batch, throughput_policy(pl->policy, batch) ? 1 : 0, next_order, st, s.stance);
+  if (next_order && memory == QLAMD_MEM_DEVICE && !s.shadow_blocks && policy != QLAMD_PLACEMENT_NONE) { // more robots than the shadow wavefronts take: launches of their own
+    const int rc = launch_placement(ctx, prev_iterations, batch, policy == QLAMD_PLACEMENT_THROUGHPUT ? 1 : 0, next_order, st, s.stance);
     if (rc != QLAMD_OK) return rc;
   }
 
@@ -1069,7 +1097,7 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
     if (hipStreamSynchronize(st) != hipSuccess) return QLAMD_ERR_HIP;
   }
   if (next_order && memory == QLAMD_MEM_HOST)
-    return qlamd_placement_from_iterations(ctx, prev_iterations, batch, pl->policy, next_order, QLAMD_MEM_HOST, stream);
+    return qlamd_placement_from_iterations(ctx, prev_iterations, batch, policy, next_order, QLAMD_MEM_HOST, stream);
   return QLAMD_OK;
 }
 
@@ -1130,10 +1158,19 @@ int qlamd_place_next_call(qlamd_context *ctx, const qlamd_placement *placement) 
 int qlamd_placement_from_iterations(qlamd_context *ctx, const int32_t *iterations, int64_t batch, int policy,
                                     int32_t *robot_order, int memory, void *stream) {
   if (!ctx || !iterations || !robot_order || batch < 0 || batch > INT32_MAX) return QLAMD_ERR_INVALID_ARGUMENT;
-  if (policy != QLAMD_PLACEMENT_AUTO && policy != QLAMD_PLACEMENT_LATENCY && policy != QLAMD_PLACEMENT_THROUGHPUT)
-    return QLAMD_ERR_INVALID_ARGUMENT;
+  if (!valid_policy(policy)) return QLAMD_ERR_INVALID_ARGUMENT;
   if (memory != QLAMD_MEM_DEVICE && memory != QLAMD_MEM_HOST) return QLAMD_ERR_INVALID_ARGUMENT;
   if (batch == 0) return QLAMD_OK;
+  if (policy == QLAMD_PLACEMENT_NONE) { // the batch order
+    if (memory == QLAMD_MEM_HOST) {
+      for (int64_t i = 0; i < batch; i++) robot_order[i] = (int32_t)i;
+      return QLAMD_OK;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
+    QL_ENTER(ctx, (hipStream_t)stream);
+    hipLaunchKernelGGL(identity_order_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, robot_order, batch);
+    return hipGetLastError() == hipSuccess ? QLAMD_OK : QLAMD_ERR_HIP;
+  }
   if (hipSetDevice(ctx->device) != hipSuccess) return QLAMD_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
   QL_ENTER(ctx, st);

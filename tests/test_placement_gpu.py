@@ -420,3 +420,47 @@ def test_records_instead_of_per_field_arrays(gpu):
     finally:
         ctx.set_robots_per_wave(0)
         ctx.set_option(capi.OPT_STATE_LAYOUT, capi.STATE_FIELDS)
+
+
+def test_no_placement_and_what_auto_means_with_a_warm_start(gpu):
+    """QLAMD_PLACEMENT_NONE leaves the identity in next_robot_order (written by the solving launch itself, or by
+    qlamd_placement_from_iterations).  QLAMD_PLACEMENT_AUTO with a warm start: no placement up to 4096 robots, the throughput
+    policy above (include/qlamd.h); without one: latency below 16 384 robots as before.  Results do not depend on any of it."""
+    capi, ctx, torch = gpu
+    dev = "cuda:0"
+    for B in (4096, 6144):
+        s = synth.make_states(B, "trot")
+        d = capi.to_device(s)
+        ident = np.arange(B, dtype=np.int32)
+        prev = torch.from_numpy(np.random.default_rng(B).integers(1, 20, B).astype(np.int32)).to(dev)
+        out = {}
+        for name, policy, warm in (("none", capi.PLACEMENT_NONE, False), ("auto cold", capi.PLACEMENT_AUTO, False),
+                                   ("auto warm", capi.PLACEMENT_AUTO, True), ("throughput warm", capi.PLACEMENT_THROUGHPUT, True)):
+            tau = torch.zeros(B, 12, dtype=torch.float64, device=dev)
+            st = torch.full((B,), -1, dtype=torch.int32, device=dev)
+            it = torch.zeros(B, dtype=torch.int32, device=dev)
+            nxt = torch.full((B,), -7, dtype=torch.int32, device=dev)
+            ws = torch.zeros(B, dtype=torch.int32, device=dev) if warm else None
+            ctx.balance_solve_placed_device(d, tau, None, st, iterations=it, prev_iterations=prev, next_order=nxt, policy=policy,
+                                            prev_working_set=ws, working_set=ws)
+            torch.cuda.synchronize()
+            assert (st.cpu().numpy() == 0).all()
+            out[name] = (tau.cpu().numpy(), nxt.cpu().numpy())
+            assert sorted(out[name][1].tolist()) == ident.tolist(), name               # always a permutation
+        assert np.array_equal(out["none"][1], ident)
+        assert not np.array_equal(out["auto cold"][1], ident)                         # the latency policy, from the counts
+        if B <= 4096:
+            assert np.array_equal(out["auto warm"][1], ident)
+        else:
+            assert np.array_equal(out["auto warm"][1], out["throughput warm"][1]) and not np.array_equal(out["auto warm"][1], ident)
+        assert np.abs(out["none"][0] - out["auto cold"][0]).max() == 0.0              # the cold kernels: bit for bit
+        assert np.abs(out["auto warm"][0] - out["none"][0]).max() < 1e-7
+        # the placement entry on its own
+        o = torch.full((B,), -7, dtype=torch.int32, device=dev)
+        rc = capi.lib().qlamd_placement_from_iterations(ctx._h, prev.data_ptr(), B, capi.PLACEMENT_NONE, o.data_ptr(), capi.MEM_DEVICE, None)
+        torch.cuda.synchronize()
+        assert rc == 0 and np.array_equal(o.cpu().numpy(), ident)
+        ho = np.full(B, -7, np.int32)
+        hp = prev.cpu().numpy()
+        rc = capi.lib().qlamd_placement_from_iterations(ctx._h, hp.ctypes.data, B, capi.PLACEMENT_NONE, ho.ctypes.data, capi.MEM_HOST, None)
+        assert rc == 0 and np.array_equal(ho, ident)

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--ticks", type=int, default=24)
     ap.add_argument("--cold", action="store_true", help="the placed loop without the warm start")
+    ap.add_argument("--unplaced", action="store_true", help="the warm start without a placement: batch order, no shadow wavefronts")
     ap.add_argument("--phases", action="store_true", help="all eight phase stamps (the build with -DQLAMD_BLOCK_STAMPS alone: near the shipped pace)")
     ap.add_argument("--lib", default=os.path.join(ROOT, "variants", "libqlamd_blockstamps.so"))
     args = ap.parse_args()
@@ -42,6 +43,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     chunk = 1024 if not args.cold else 2048
     shadows = (B + chunk - 1) // chunk if B < 16384 else (B + 4095) // 4096
+    if args.unplaced:
+        shadows = 0
     nb = min(2048, shadows + (B + 3) // 4)
 
     def read(slot):
@@ -54,10 +57,14 @@ def main():
         d = capi.to_device(s)
         before = ws.cpu().numpy().view(np.uint32).copy()
         ordk = order[k & 1].cpu().numpy()
-        ctx.balance_solve_placed_device(d, tau, None, status, order=order[k & 1], iterations=iters[k & 1],
-                                        prev_iterations=iters[(k - 1) & 1], next_order=order[(k + 1) & 1],
-                                        policy=capi.PLACEMENT_AUTO, prev_working_set=None if args.cold else ws,
-                                        working_set=None if args.cold else ws, stream=stream)
+        if args.unplaced:
+            ctx.balance_solve_placed_device(d, tau, None, status, iterations=iters[k & 1], prev_working_set=None if args.cold else ws,
+                                            working_set=None if args.cold else ws, stream=stream)
+        else:
+            ctx.balance_solve_placed_device(d, tau, None, status, order=order[k & 1], iterations=iters[k & 1],
+                                            prev_iterations=iters[(k - 1) & 1], next_order=order[(k + 1) & 1],
+                                            policy=capi.PLACEMENT_AUTO, prev_working_set=None if args.cold else ws,
+                                            working_set=None if args.cold else ws, stream=stream)
         torch.cuda.synchronize()
         if k < 4:
             continue
