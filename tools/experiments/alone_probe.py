@@ -47,7 +47,7 @@ def main():
 
     for k, s in enumerate(states[:-1]):
         ctx.balance_solve_placed_device(capi.to_device(s), tau, None, status, order=order[k & 1], iterations=iters[k & 1],
-                                        prev_iterations=iters[(k - 1) & 1], next_order=order[(k + 1) & 1], policy=capi.PLACEMENT_AUTO,
+                                        prev_iterations=iters[(k - 1) & 1], next_order=order[(k + 1) & 1], policy=capi.PLACEMENT_LATENCY,
                                         prev_working_set=ws, working_set=ws, stream=stream)
     torch.cuda.synchronize()
     k = len(states) - 1
@@ -58,7 +58,7 @@ def main():
     ws_out = torch.zeros_like(ws)
     for rep in range(3):
         ctx.balance_solve_placed_device(d, tau, None, status, order=order[k & 1], iterations=iters[k & 1], prev_iterations=iters[(k - 1) & 1],
-                                        next_order=order[(k + 1) & 1], policy=capi.PLACEMENT_AUTO, prev_working_set=ws0, working_set=ws_out,
+                                        next_order=order[(k + 1) & 1], policy=capi.PLACEMENT_LATENCY, prev_working_set=ws0, working_set=ws_out,
                                         stream=stream)
         torch.cuda.synchronize()
     n = min(2048, shadows + nw)

@@ -43,8 +43,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     chunk = 1024 if not args.cold else 2048
     shadows = (B + chunk - 1) // chunk if B < 16384 else (B + 4095) // 4096
-    if args.unplaced:
-        shadows = 0
+    if args.unplaced or (not args.cold and B <= 4096):
+        shadows = 0   # (QLAMD_PLACEMENT_AUTO with a warm start: no placement up to 4096 robots -- no shadow wavefronts)
     nb = min(2048, shadows + (B + 3) // 4)
 
     def read(slot):
