@@ -1109,7 +1109,8 @@ def main():
 
             def step(k, st_, wctx=wctx, orders=orders, its=its, wsets=wsets, warm=warm):
                 pl = capi.Placement(orders[k & 1].data_ptr(), its[k & 1].data_ptr(), its[(k - 1) & 1].data_ptr(), orders[(k + 1) & 1].data_ptr(),
-                                    capi.PLACEMENT_AUTO, wsets.data_ptr() if warm else None, wsets.data_ptr() if warm else None)
+                                    int(os.environ.get("QLAMD_BENCH_WB_POLICY", capi.PLACEMENT_AUTO)) if warm else capi.PLACEMENT_AUTO,
+                                    wsets.data_ptr() if warm else None, wsets.data_ptr() if warm else None)
                 rc = capi.lib().qlamd_place_next_call(wctx._h, C.byref(pl))
                 if rc != 0:
                     raise capi.QlamdError(rc, "qlamd_place_next_call")

@@ -211,6 +211,7 @@ struct PlacePtrs {
   const unsigned long long *prev_working_set;
   unsigned long long *working_set;
   uint32_t *warm_retries; // the context's count of rejected warm starts, or NULL
+  int32_t *identity_out = nullptr; // QLAMD_PLACEMENT_NONE with a warm start: every slot writes its own index here (the next call's order)
 };
 #ifdef __HIPCC__
 // problem index of slot `slot` (row slot % 4 of wavefront slot / 4); live = the slot holds a problem (an order entry
@@ -218,6 +219,7 @@ struct PlacePtrs {
 __device__ __forceinline__ int64_t placed_index(const PlacePtrs &pp, int64_t slot, int64_t B, bool &live) {
   live = slot < B;
   int64_t i = live ? slot : B - 1;
+  if (pp.identity_out && live && (threadIdx.x & 15) == 0) pp.identity_out[slot] = (int32_t)slot;
   if (pp.order) {
     const int64_t o = pp.order[i];
     live = live && o >= 0 && o < B;
@@ -241,6 +243,15 @@ inline int take_placement(qlamd_context *ctx, int memory, int64_t batch, PlacePt
   pp->prev_working_set = reinterpret_cast<const unsigned long long *>(pl.prev_working_set);
   pp->working_set = reinterpret_cast<unsigned long long *>(pl.working_set);
   *next = pl;
+  // QLAMD_PLACEMENT_AUTO with a warm start (the whole-body step): no placement up to 4096 problems, the throughput policy above --
+  // include/qlamd.h; with no placement the solving launch writes the identity itself and nothing is launched behind it (the
+  // placement's two launches were 5 of the 23 us of a warm-started whole-body step of 4096 robots)
+  if (pl.next_robot_order && pl.policy == QLAMD_PLACEMENT_AUTO && (pl.prev_working_set || pl.working_set))
+    next->policy = batch <= 4096 ? QLAMD_PLACEMENT_NONE : QLAMD_PLACEMENT_THROUGHPUT;
+  if (pl.next_robot_order && next->policy == QLAMD_PLACEMENT_NONE && (pl.prev_working_set || pl.working_set)) {
+    pp->identity_out = pl.next_robot_order;
+    next->next_robot_order = nullptr;
+  }
   return QLAMD_OK;
 }
 inline int finish_placement(qlamd_context *ctx, const qlamd_placement &pl, int64_t batch, hipStream_t st) {

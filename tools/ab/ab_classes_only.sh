@@ -1,3 +1,5 @@
+# (the define was a three-line experiment in placement_wave's key_of of csrc/balance_kernel.hip -- "if (B < 16384u) key = 0u;" behind
+# QLAMD_PLACE_CLASSES_ONLY -- not kept in the source: profiles/r6/ab_warm_policies.txt has what it measured)
 cd "${GRAFT_REPO_ROOT:-.}"
 run() { lib=$1; shift; python tools/experiments/bench_with_lib.py "$lib" --no-cpu-baseline --no-also --steps 100 --warmup 10 "$@" 2>/dev/null | python -c "
 import json,sys
