@@ -546,7 +546,9 @@ __global__ __launch_bounds__(64 * kCoopWaves, kMinWaves) void balance_coop_kerne
   bool live = i < B;
   if (!live) i = B - 1;
   if constexpr (kPlaced) {
-    if (s.identity_out && live && (threadIdx.x & 15) == 0) s.identity_out[i] = (int32_t)i; // (QLAMD_PLACEMENT_NONE: the batch order)
+    if constexpr (kMinWaves == 2) { // (QLAMD_PLACEMENT_NONE: the batch order; the 168-register form has no register for it -- a launch of its own there)
+      if (s.identity_out && live && (threadIdx.x & 15) == 0) s.identity_out[i] = (int32_t)i;
+    }
     if (s.order) {
       const int64_t o = s.order[i];
       live = live && o >= 0 && o < B;
@@ -1033,8 +1035,9 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
     // the next launch's placement: by extra wavefronts in front of this launch
     const int chunk = batch >= QLAMD_THROUGHPUT_BATCH ? kShadowChunkLarge : (warm ? kShadowChunkWarm : kShadowChunkCold);
     const int64_t shadows = (batch + chunk - 1) / chunk;
+    const bool three_wave_form = !in->surface_normal && batch >= (warm ? QLAMD_THREE_WAVE_WARM_BATCH : QLAMD_THROUGHPUT_BATCH);
     if (next_order && policy == QLAMD_PLACEMENT_NONE) {
-      s.identity_out = next_order; // (written by the slots themselves: no shadow wavefronts)
+      if (!three_wave_form) s.identity_out = next_order; // (written by the slots themselves: no shadow wavefronts)
     } else if (next_order && shadows <= kShadowMaxBlocks && pick_rpw(ctx, batch) == 4) {
       s.prev_iterations = prev_iterations;
       s.next_order = next_order;
@@ -1074,6 +1077,10 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
     default: e = launch_balance<64>(ctx, s, batch, d_tau, d_grf, d_status, st); break;
   }
   if (e != hipSuccess) return QLAMD_ERR_HIP;
+  if (next_order && memory == QLAMD_MEM_DEVICE && policy == QLAMD_PLACEMENT_NONE && !s.identity_out) {
+    hipLaunchKernelGGL(identity_order_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, next_order, batch);
+    if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
+  }
   if (next_order && memory == QLAMD_MEM_DEVICE && !s.shadow_blocks && policy != QLAMD_PLACEMENT_NONE) { // more robots than the shadow wavefronts take: launches of their own
     const int rc = launch_placement(ctx, prev_iterations, batch, policy == QLAMD_PLACEMENT_THROUGHPUT ? 1 : 0, next_order, st, s.stance);
     if (rc != QLAMD_OK) return rc;

@@ -428,7 +428,7 @@ def test_no_placement_and_what_auto_means_with_a_warm_start(gpu):
     policy above (include/qlamd.h); without one: latency below 16 384 robots as before.  Results do not depend on any of it."""
     capi, ctx, torch = gpu
     dev = "cuda:0"
-    for B in (4096, 6144):
+    for B in (4096, 6144, 20000):   # (20 000 without a warm start: the 168-register form, whose identity order is a launch of its own)
         s = synth.make_states(B, "trot")
         d = capi.to_device(s)
         ident = np.arange(B, dtype=np.int32)
