@@ -833,6 +833,12 @@ def main():
             km = np.zeros(n)
             for r in range(n):
                 el[r], km[r] = sample()
+                # A sample takes two replays (the timed one, the one between HIP events): with an even number NG of regions the
+                # timed samples would visit every other region of the trajectory only -- and the one behind the jump back to tick 0
+                # three times in eleven.  One more untimed replay makes the stride 3: every region in turn (all ranks alike).
+                if graphs is not None and NG > 1 and NG % 2 == 0 and NG % 3 != 0:
+                    replay()
+                    fence()
             if collective:  # a sample lasts as long as its slowest rank
                 t = torch.from_numpy(el).to(dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
