@@ -21,7 +21,8 @@ struct StatePtrs {
   int32_t *iterations;  // [B] or NULL: outer iterations of each robot's QP
   // the placement of the NEXT launch, made by extra wavefronts in the shadow of this one (placement_wave below)
   const int32_t *prev_iterations; // [B]: the counts it is made from (the previous launch's `iterations`)
-  int32_t *next_order;            // [B] or NULL: where it goes
+  int32_t *next_order;            // [B] or NULL: where it goes.  With shadow_blocks == 0: QLAMD_PLACEMENT_NONE -- every slot writes its own
+                                  // index here (no field of its own: one more pointer in the arguments cost the 168-register form 1 % at 65 536 robots)
   int place_throughput;           // policy: 0 latency, 1 throughput
   const uint32_t *prev_working_set; // [B] or NULL: warm start (kWarm instantiations)
   uint32_t *working_set;            // [B] or NULL
@@ -31,7 +32,6 @@ struct StatePtrs {
   uint32_t place_wait;              // polls they wait for each other before they give up (QLAMD_OPT_PLACEMENT_WAIT)
   uint32_t *warm_retries;           // the context's count of rejected warm starts (kWarm instantiations)
   int record_doubles;               // 0, or the record length of QLAMD_STATE_RECORDS (lane-cooperative kernels, device memory)
-  int32_t *identity_out;            // [B] or NULL: QLAMD_PLACEMENT_NONE -- every slot writes its own index here (the next call's order)
 };
 
 __device__ __forceinline__ void load_robot(const StatePtrs &s, int64_t i, RobotIn &in) {
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64 * kCoopWaves, kMinWaves) void balance_coop_kerne
   if (!live) i = B - 1;
   if constexpr (kPlaced) {
     if constexpr (kMinWaves == 2) { // (QLAMD_PLACEMENT_NONE: the batch order; the 168-register form has no register for it -- a launch of its own there)
-      if (s.identity_out && live && (threadIdx.x & 15) == 0) s.identity_out[i] = (int32_t)i;
+      if (s.shadow_blocks == 0 && s.next_order && live && (threadIdx.x & 15) == 0) s.next_order[i] = (int32_t)i;
     }
     if (s.order) {
       const int64_t o = s.order[i];
@@ -1037,7 +1037,7 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
     const int64_t shadows = (batch + chunk - 1) / chunk;
     const bool three_wave_form = !in->surface_normal && batch >= (warm ? QLAMD_THREE_WAVE_WARM_BATCH : QLAMD_THROUGHPUT_BATCH);
     if (next_order && policy == QLAMD_PLACEMENT_NONE) {
-      if (!three_wave_form) s.identity_out = next_order; // (written by the slots themselves: no shadow wavefronts)
+      if (!three_wave_form) s.next_order = next_order; // (shadow_blocks stays 0: written by the slots themselves)
     } else if (next_order && shadows <= kShadowMaxBlocks && pick_rpw(ctx, batch) == 4) {
       s.prev_iterations = prev_iterations;
       s.next_order = next_order;
@@ -1077,7 +1077,7 @@ int qlamd::rt::balance_impl(qlamd_context *ctx, const qlamd_state_batch *in_user
     default: e = launch_balance<64>(ctx, s, batch, d_tau, d_grf, d_status, st); break;
   }
   if (e != hipSuccess) return QLAMD_ERR_HIP;
-  if (next_order && memory == QLAMD_MEM_DEVICE && policy == QLAMD_PLACEMENT_NONE && !s.identity_out) {
+  if (next_order && memory == QLAMD_MEM_DEVICE && policy == QLAMD_PLACEMENT_NONE && !s.next_order) {
     hipLaunchKernelGGL(identity_order_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, next_order, batch);
     if (hipGetLastError() != hipSuccess) return QLAMD_ERR_HIP;
   }
